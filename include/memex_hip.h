@@ -1,0 +1,205 @@
+/*
+ * memex_hip.h -- C ABI of libmemex_hip.so: the MI355X (gfx950) embedding + vector-search path
+ * that drops in under memex's `VectorStore` trait and `SentenceEmbedder` actor.
+ *
+ * The reference (spyglass-search/memex, Rust) has no FFI layer; the seam is the Rust surface of
+ * lib/libmemex.  Every entry point below names the reference item it replaces (paths relative to
+ * the reference root).  INTEGRATION.md shows the ~100-line Rust shim (`extern "C"` block +
+ * `impl VectorStore for HipFlatStore`) a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns MX_OK (0) or a negative mx_status; mx_last_error() is thread-local.
+ *   - nothing aborts or throws across this boundary (contrast: the reference panics at
+ *     storage/local.rs:83 and :31).
+ *   - the caller owns every input buffer (copied/consumed before return) and every output buffer.
+ *   - handles are safe to use from several threads; calls on one handle are serialised inside.
+ *   - "_device" variants take pointers into the HBM of the handle's device (for callers that keep
+ *     data resident: the encoder output feeding mx_index_add_device, benchmarks, multi-GPU merge).
+ */
+#ifndef MEMEX_HIP_H
+#define MEMEX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: map 1:1 onto VectorStoreError (lib/libmemex/src/storage/mod.rs:31-48) and
+ *      EmbeddingError (lib/libmemex/src/llm/embedding.rs:11-16) in the Rust shim ------------- */
+typedef enum mx_status {
+    MX_OK = 0,
+    MX_EINVAL = -1,       /* bad argument                    -> InsertionError / SearchError      */
+    MX_EDEVICE = -2,      /* HIP runtime / no device         -> ConnectionError / SetupError      */
+    MX_EINSERT = -3,      /* insert failed                   -> InsertionError                    */
+    MX_ESEARCH = -4,      /* search failed                   -> SearchError / EncodingFailure     */
+    MX_EIO = -5,          /* save / load / delete files      -> FileIOError / SaveError           */
+    MX_EUNSUPPORTED = -6, /* unsupported config              -> Unsupported / SetupError          */
+    MX_ENOMEM = -7        /* host or device allocation       -> InsertionError / SetupError       */
+} mx_status;
+
+const char *mx_last_error(void); /* thread-local message of the last failing call on this thread */
+const char *mx_version(void);
+int mx_device_count(int *n_devices);
+
+/* =====================================================================================
+ * Flat cosine index  (replaces HnswStore, lib/libmemex/src/storage/local.rs:21-166)
+ * ===================================================================================== */
+typedef struct mx_index mx_index;
+
+/*
+ * Open (or attach to) the GPU-resident index registered under `key`.
+ * Replaces HnswStore::new / the per-request construction in get_vector_storage
+ * (storage/mod.rs:95-121, storage/local.rs:95-108): callers there build a store per request, so
+ * a second open of the same key returns the SAME resident index (ref-counted, O(1)).
+ * key == NULL or "" creates a private, unregistered index.  dim >= 1 (any; rows are padded
+ * internally).  device = HIP device ordinal.
+ */
+int mx_index_open(const char *key, int dim, int device, mx_index **out);
+void mx_index_close(mx_index *idx); /* drops one reference; frees HBM when the last one goes */
+
+int mx_index_dim(mx_index *idx, int *dim);
+int mx_index_size(mx_index *idx, uint64_t *n_rows); /* = _id_map.len(), storage/local.rs:63 */
+int mx_index_reserve(mx_index *idx, uint64_t n_rows); /* pre-size HBM (optional)             */
+
+/*
+ * Row-sharding support: ids returned by search are
+ * `id_offset + local_row + 1`.  Default 0 = the reference's dense 1-based ids.
+ */
+int mx_index_set_id_offset(mx_index *idx, uint64_t id_offset);
+
+/*
+ * Append n rows ([n, dim] row-major f32).  Replaces HnswStore::insert / bulk_insert
+ * (storage/local.rs:55-69): ids are dense, 1-based, in insertion order; *first_id receives the id
+ * of rows[0] (later rows follow consecutively).  Non-finite values are rejected (MX_EINVAL) and
+ * nothing is inserted.  Unlike the reference there is no save-per-insert (local.rs:67); call
+ * mx_index_save.
+ */
+int mx_index_add(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_id);
+int mx_index_add_device(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *first_id);
+
+/* Replaces HnswStore::delete_all (storage/local.rs:34-53): drops every row, ids restart at 1.
+ * (Removing the persisted files is mx_index_remove_files; the shim calls both.) */
+int mx_index_clear(mx_index *idx);
+
+/*
+ * Top-k cosine search.  Replaces HnswStore::search (storage/local.rs:71-91) + hnsw_rs DistCosine:
+ *   dist  = max(0, 1 - sum_f64(fl32(q_i*c_i)) / sqrt(sum_f64(fl32(q_i^2)) * sum_f64(fl32(c_i^2)))) as f32
+ *           (0 when either norm is 0)
+ *   score = 1.0f - (1.0f / (1.0f / dist))                                  (local.rs:86)
+ * Results per query are ordered by (dist ascending, id ascending) -- exact brute force, so recall
+ * is 1 by construction.  Outputs are row-major [B, k]; n_found[b] = min(k, size); unused slots
+ * hold id 0 / score 0 / dist +inf.  `dists` may be NULL.  B > 1 is an extension (the trait is
+ * single-query); B is processed in batches of 256.
+ */
+int mx_index_search(mx_index *idx, const float *queries, int B, int k, uint64_t *ids, float *scores,
+                    float *dists, int32_t *n_found);
+int mx_index_search_device(mx_index *idx, const float *d_queries, int B, int k, uint64_t *d_ids,
+                           float *d_scores, float *d_dists, int32_t *d_n_found);
+
+/* Search strategy (testing / diagnostics).  AUTO = bf16-MFMA streaming scan that certifies a
+ * candidate superset, exact f64 rescoring of the candidates, per-query fallback to EXACT when a
+ * candidate buffer overflows.  EXACT = f64 arithmetic on every row (slow, always available). */
+enum { MX_SEARCH_AUTO = 0, MX_SEARCH_EXACT = 1 };
+int mx_index_set_search_mode(mx_index *idx, int mode);
+
+/*
+ * Persistence.  Replaces HnswStore::save / load / has_store (storage/local.rs:110-165).  Files in
+ * `dir`: `vectors.mxflat` (header + raw f32 rows).  The string-id map `vectors.meta.json`
+ * (local.rs:19,156-163) stays on the Rust side unchanged.
+ */
+int mx_index_save(mx_index *idx, const char *dir);
+int mx_index_load(mx_index *idx, const char *dir); /* replaces current contents */
+int mx_index_has_store(const char *dir, int *exists);
+int mx_index_store_info(const char *dir, int *dim, uint64_t *n_rows); /* header of vectors.mxflat */
+int mx_index_remove_files(const char *dir);        /* the file half of delete_all, local.rs:36-46 */
+
+/* Counters for the bench / roofline report (cumulative since open or last reset). */
+typedef struct mx_index_stats {
+    uint64_t searches;          /* query batches served                                   */
+    uint64_t queries;           /* queries served                                          */
+    uint64_t fallback_queries;  /* queries answered by the EXACT path after an overflow    */
+    uint64_t scan_launches;     /* launches of the main streaming-scan kernel              */
+    uint64_t scan_bytes;        /* algorithmic bytes those launches covered: rows*dim_pad*4 */
+    double scan_ms;             /* HIP-event time of those launches (profiling on)         */
+    uint64_t candidates;        /* candidates exactly rescored                             */
+    double max_abs_err;         /* profiling only: max |approx - exact| cosine on candidates */
+} mx_index_stats;
+int mx_index_set_profiling(mx_index *idx, int on); /* record HIP events around the scan kernel */
+int mx_index_get_stats(mx_index *idx, mx_index_stats *out);
+int mx_index_reset_stats(mx_index *idx);
+
+/*
+ * Multi-GPU merge: after an RCCL all-gather of per-shard results
+ * ([G, B, k] ids + dists, each shard list ordered), produce the global top-k ordered by
+ * (dist, id) and the scores.  Pointers are device pointers on `device`.
+ */
+int mx_topk_merge_device(int device, const uint64_t *d_ids, const float *d_dists, int G, int B, int k,
+                         uint64_t *d_out_ids, float *d_out_dists, float *d_out_scores);
+
+/* =====================================================================================
+ * Sentence encoder  (replaces the rust-bert model owned by SentenceEmbedder::runner,
+ * lib/libmemex/src/llm/embedding.rs:94-135; `model.encode(&segments)` at :109)
+ * ===================================================================================== */
+typedef struct mx_encoder mx_encoder;
+
+enum { MX_POOL_MEAN = 0, MX_POOL_CLS = 1 };
+
+typedef struct mx_encoder_cfg {
+    int32_t layers;     /* 6  (all-MiniLM-L6-v2) / 12 (all-MiniLM-L12-v2, bge-base-en)      */
+    int32_t hidden;     /* 384 / 768; multiple of 64                                         */
+    int32_t heads;      /* 12; hidden/heads must be 32 or 64                                 */
+    int32_t ffn;        /* 1536 / 3072; multiple of 64                                       */
+    int32_t vocab;      /* 30522                                                              */
+    int32_t max_pos;    /* 512                                                                */
+    int32_t type_vocab; /* 2                                                                  */
+    float ln_eps;       /* 1e-12                                                              */
+    int32_t pooling;    /* MX_POOL_MEAN (MiniLM) | MX_POOL_CLS (bge)                          */
+    int32_t normalize;  /* 1 = L2-normalise the pooled vector                                 */
+} mx_encoder_cfg;
+
+/*
+ * Weight blob: f32, little-endian, tensors concatenated in this order (HF BertModel names,
+ * Linear weights [out, in]):
+ *   embeddings.word_embeddings.weight [vocab,H]; embeddings.position_embeddings.weight [max_pos,H];
+ *   embeddings.token_type_embeddings.weight [type_vocab,H]; embeddings.LayerNorm.{weight,bias} [H];
+ *   then per layer l: attention.self.{query,key,value}.{weight [H,H], bias [H]} (q,k,v in turn);
+ *   attention.output.dense.{weight [H,H], bias}; attention.output.LayerNorm.{weight,bias};
+ *   intermediate.dense.{weight [F,H], bias [F]}; output.dense.{weight [H,F], bias [H]};
+ *   output.LayerNorm.{weight,bias}.
+ * mx_encoder_weight_bytes() gives the exact size.  memex_amd/weights.py packs it from a
+ * state-dict / safetensors file.
+ */
+size_t mx_encoder_weight_bytes(const mx_encoder_cfg *cfg);
+
+/* Replaces SentenceEmbeddingsBuilder::remote(..).create_model() (embedding.rs:99-100). */
+int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nbytes, int device,
+                      mx_encoder **out);
+void mx_encoder_destroy(mx_encoder *enc);
+
+/*
+ * Replaces model.encode(&segments) (embedding.rs:109) after tokenisation: ids [B, S] row-major
+ * ([CLS] .. [SEP] already added, padded with anything past lens[b]); lens[b] in [1, S];
+ * out [B, hidden] f32 (pooled, L2-normalised when cfg.normalize).  bf16 MFMA arithmetic with f32
+ * accumulation; agrees with the f32 CPU path to |delta cosine| <= 1e-3 (north_star tolerance).
+ */
+int mx_encoder_encode(mx_encoder *enc, const int32_t *ids, const int32_t *lens, int B, int S, float *out);
+int mx_encoder_encode_device(mx_encoder *enc, const int32_t *d_ids, const int32_t *d_lens, int B, int S,
+                             float *d_out);
+
+typedef struct mx_encoder_stats {
+    uint64_t calls;
+    uint64_t sequences;
+    uint64_t tokens;   /* non-padding tokens processed */
+    double flops;      /* algorithmic flops: tokens * L * (8H^2 + 4HF) + attention 4*S_b*H per token */
+    double gpu_ms;     /* HIP-event time (profiling on) */
+} mx_encoder_stats;
+int mx_encoder_set_profiling(mx_encoder *enc, int on);
+int mx_encoder_get_stats(mx_encoder *enc, mx_encoder_stats *out);
+int mx_encoder_reset_stats(mx_encoder *enc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEMEX_HIP_H */

@@ -1,0 +1,149 @@
+"""ctypes binding of ``libmemex_hip.so`` (C ABI: ``include/memex_hip.h``).
+
+There is deliberately no CPU fallback: if the shared library is missing or a call fails, this
+module raises.  ``build()`` compiles the library in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmemex_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MX_OK = 0
+MX_EINVAL, MX_EDEVICE, MX_EINSERT, MX_ESEARCH, MX_EIO, MX_EUNSUPPORTED, MX_ENOMEM = -1, -2, -3, -4, -5, -6, -7
+MX_SEARCH_AUTO, MX_SEARCH_EXACT = 0, 1
+MX_POOL_MEAN, MX_POOL_CLS = 0, 1
+
+# every symbol include/memex_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "mx_last_error", "mx_version", "mx_device_count",
+    "mx_index_open", "mx_index_close", "mx_index_dim", "mx_index_size", "mx_index_reserve",
+    "mx_index_set_id_offset", "mx_index_add", "mx_index_add_device", "mx_index_clear",
+    "mx_index_search", "mx_index_search_device", "mx_index_set_search_mode",
+    "mx_index_save", "mx_index_load", "mx_index_has_store", "mx_index_store_info", "mx_index_remove_files",
+    "mx_index_set_profiling", "mx_index_get_stats", "mx_index_reset_stats", "mx_topk_merge_device",
+    "mx_encoder_weight_bytes", "mx_encoder_create", "mx_encoder_destroy", "mx_encoder_encode",
+    "mx_encoder_encode_device", "mx_encoder_set_profiling", "mx_encoder_get_stats",
+    "mx_encoder_reset_stats",
+]
+
+
+class MemexHipError(RuntimeError):
+    """A C-ABI call returned a negative mx_status."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[mx_status {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class IndexStats(ctypes.Structure):
+    _fields_ = [("searches", ctypes.c_uint64), ("queries", ctypes.c_uint64),
+                ("fallback_queries", ctypes.c_uint64), ("scan_launches", ctypes.c_uint64),
+                ("scan_bytes", ctypes.c_uint64), ("scan_ms", ctypes.c_double),
+                ("candidates", ctypes.c_uint64), ("max_abs_err", ctypes.c_double)]
+
+
+class EncoderCfg(ctypes.Structure):
+    _fields_ = [("layers", ctypes.c_int32), ("hidden", ctypes.c_int32), ("heads", ctypes.c_int32),
+                ("ffn", ctypes.c_int32), ("vocab", ctypes.c_int32), ("max_pos", ctypes.c_int32),
+                ("type_vocab", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("pooling", ctypes.c_int32),
+                ("normalize", ctypes.c_int32)]
+
+
+class EncoderStats(ctypes.Structure):
+    _fields_ = [("calls", ctypes.c_uint64), ("sequences", ctypes.c_uint64), ("tokens", ctypes.c_uint64),
+                ("flops", ctypes.c_double), ("gpu_ms", ctypes.c_double)]
+
+
+def build(force: bool = False) -> str:
+    """Compile libmemex_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j8", "-s"]
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(args)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("build did not produce " + LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def _declare(L: ctypes.CDLL) -> None:
+    vp, i32, u64, cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p
+    P = ctypes.POINTER
+    L.mx_last_error.restype = cp
+    L.mx_last_error.argtypes = []
+    L.mx_version.restype = cp
+    L.mx_version.argtypes = []
+    sig = {
+        "mx_device_count": [P(i32)],
+        "mx_index_open": [cp, i32, i32, P(vp)],
+        "mx_index_dim": [vp, P(i32)],
+        "mx_index_size": [vp, P(u64)],
+        "mx_index_reserve": [vp, u64],
+        "mx_index_set_id_offset": [vp, u64],
+        "mx_index_add": [vp, vp, u64, P(u64)],
+        "mx_index_add_device": [vp, vp, u64, P(u64)],
+        "mx_index_clear": [vp],
+        "mx_index_search": [vp, vp, i32, i32, vp, vp, vp, vp],
+        "mx_index_search_device": [vp, vp, i32, i32, vp, vp, vp, vp],
+        "mx_index_set_search_mode": [vp, i32],
+        "mx_index_save": [vp, cp],
+        "mx_index_load": [vp, cp],
+        "mx_index_has_store": [cp, P(i32)],
+        "mx_index_store_info": [cp, P(i32), P(u64)],
+        "mx_index_remove_files": [cp],
+        "mx_index_set_profiling": [vp, i32],
+        "mx_index_get_stats": [vp, P(IndexStats)],
+        "mx_index_reset_stats": [vp],
+        "mx_topk_merge_device": [i32, vp, vp, i32, i32, i32, vp, vp, vp],
+        "mx_encoder_create": [P(EncoderCfg), vp, ctypes.c_size_t, i32, P(vp)],
+        "mx_encoder_encode": [vp, vp, vp, i32, i32, vp],
+        "mx_encoder_encode_device": [vp, vp, vp, i32, i32, vp],
+        "mx_encoder_set_profiling": [vp, i32],
+        "mx_encoder_get_stats": [vp, P(EncoderStats)],
+        "mx_encoder_reset_stats": [vp],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(L, name)
+        fn.restype = i32
+        fn.argtypes = argtypes
+    L.mx_index_close.restype = None
+    L.mx_index_close.argtypes = [vp]
+    L.mx_encoder_destroy.restype = None
+    L.mx_encoder_destroy.argtypes = [vp]
+    L.mx_encoder_weight_bytes.restype = ctypes.c_size_t
+    L.mx_encoder_weight_bytes.argtypes = [P(EncoderCfg)]
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library.  Raises (never falls back) when it is absent."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise MemexHipError(MX_EDEVICE, f"{LIB_PATH} is missing: run memex_amd.build() "
+                                                "(python -c 'import __graft_entry__ as g; g.build()')")
+            L = ctypes.CDLL(LIB_PATH)
+            _declare(L)
+            _lib = L
+        return _lib
+
+
+def check(rc: int) -> None:
+    if rc != MX_OK:
+        raise MemexHipError(rc, lib().mx_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    rc = lib().mx_device_count(ctypes.byref(n))
+    return n.value if rc == MX_OK else 0

@@ -1,0 +1,153 @@
+"""Thin object wrapper over the ``mx_index_*`` C ABI (include/memex_hip.h).
+
+``FlatIndex`` is the GPU-resident exact cosine index that stands in for memex's ``HnswStore``
+(reference lib/libmemex/src/storage/local.rs:21-166).  Host arrays are NumPy; the ``*_device``
+methods take anything exposing ``data_ptr()`` (torch tensors already in HBM).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import IndexStats, check, lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class FlatIndex:
+    def __init__(self, dim: int, key: str | None = None, device: int = 0):
+        h = ctypes.c_void_p()
+        check(lib().mx_index_open(key.encode() if key else None, int(dim), int(device), ctypes.byref(h)))
+        self._h = h
+        self.dim = int(dim)
+        self.device = int(device)
+        self.key = key
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().mx_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __len__(self) -> int:
+        n = ctypes.c_uint64(0)
+        check(lib().mx_index_size(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    # -- configuration -------------------------------------------------------------------
+    def reserve(self, n_rows: int) -> None:
+        check(lib().mx_index_reserve(self._h, int(n_rows)))
+
+    def set_id_offset(self, off: int) -> None:
+        check(lib().mx_index_set_id_offset(self._h, int(off)))
+
+    def set_search_mode(self, mode: int) -> None:
+        check(lib().mx_index_set_search_mode(self._h, int(mode)))
+
+    def set_profiling(self, on: bool) -> None:
+        check(lib().mx_index_set_profiling(self._h, 1 if on else 0))
+
+    def stats(self) -> IndexStats:
+        s = IndexStats()
+        check(lib().mx_index_get_stats(self._h, ctypes.byref(s)))
+        return s
+
+    def reset_stats(self) -> None:
+        check(lib().mx_index_reset_stats(self._h))
+
+    # -- mutation ------------------------------------------------------------------------
+    def add(self, rows) -> int:
+        """Append rows [n, dim]; returns the (1-based) id of the first one."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim == 1:
+            rows = rows[None, :]
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise _lib.MemexHipError(_lib.MX_EINVAL, f"expected [n, {self.dim}] rows, got {rows.shape}")
+        first = ctypes.c_uint64(0)
+        check(lib().mx_index_add(self._h, _ptr(rows), rows.shape[0], ctypes.byref(first)))
+        return int(first.value)
+
+    def add_device(self, t) -> int:
+        """Append rows held in HBM (contiguous f32 [n, dim] tensor on this index's device)."""
+        n = int(t.shape[0])
+        first = ctypes.c_uint64(0)
+        check(lib().mx_index_add_device(self._h, ctypes.c_void_p(t.data_ptr()), n, ctypes.byref(first)))
+        return int(first.value)
+
+    def clear(self) -> None:
+        check(lib().mx_index_clear(self._h))
+
+    # -- search --------------------------------------------------------------------------
+    def search(self, queries, k: int):
+        """-> (ids u64 [B,k], scores f32 [B,k], dists f32 [B,k], n_found i32 [B])."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise _lib.MemexHipError(_lib.MX_EINVAL, f"expected [B, {self.dim}] queries, got {q.shape}")
+        B = q.shape[0]
+        ids = np.zeros((B, k), dtype=np.uint64)
+        scores = np.zeros((B, k), dtype=np.float32)
+        dists = np.zeros((B, k), dtype=np.float32)
+        nf = np.zeros(B, dtype=np.int32)
+        check(lib().mx_index_search(self._h, _ptr(q), B, int(k), _ptr(ids), _ptr(scores), _ptr(dists), _ptr(nf)))
+        return ids, scores, dists, nf
+
+    def search_device(self, q, k: int, ids, scores, dists, n_found) -> None:
+        """All arguments are device tensors: q f32 [B,dim]; ids i64/u64 [B,k]; scores, dists f32 [B,k];
+        n_found i32 [B].  Blocks until the results are in HBM."""
+        B = int(q.shape[0])
+        check(lib().mx_index_search_device(self._h, ctypes.c_void_p(q.data_ptr()), B, int(k),
+                                           ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(scores.data_ptr()),
+                                           ctypes.c_void_p(dists.data_ptr()) if dists is not None else None,
+                                           ctypes.c_void_p(n_found.data_ptr())))
+
+    # -- persistence ---------------------------------------------------------------------
+    def save(self, directory: str) -> None:
+        check(lib().mx_index_save(self._h, str(directory).encode()))
+
+    def load(self, directory: str) -> None:
+        check(lib().mx_index_load(self._h, str(directory).encode()))
+
+    @staticmethod
+    def has_store(directory: str) -> bool:
+        e = ctypes.c_int(0)
+        check(lib().mx_index_has_store(str(directory).encode(), ctypes.byref(e)))
+        return bool(e.value)
+
+    @staticmethod
+    def store_info(directory: str):
+        """-> (dim, n_rows) of the persisted vector file."""
+        d = ctypes.c_int(0)
+        n = ctypes.c_uint64(0)
+        check(lib().mx_index_store_info(str(directory).encode(), ctypes.byref(d), ctypes.byref(n)))
+        return int(d.value), int(n.value)
+
+    @staticmethod
+    def remove_files(directory: str) -> None:
+        check(lib().mx_index_remove_files(str(directory).encode()))
+
+
+def merge_topk_device(device: int, ids, dists, out_ids, out_dists, out_scores) -> None:
+    """ids/dists: device tensors [G,B,k] (gathered shard results) -> [B,k] global top-k."""
+    G, B, k = (int(x) for x in ids.shape)
+    check(lib().mx_topk_merge_device(int(device), ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(dists.data_ptr()),
+                                     G, B, k, ctypes.c_void_p(out_ids.data_ptr()),
+                                     ctypes.c_void_p(out_dists.data_ptr()),
+                                     ctypes.c_void_p(out_scores.data_ptr()) if out_scores is not None else None))
