@@ -14,10 +14,11 @@ constexpr int kScanWaves = 8;
 constexpr int kTileRows = 32;      // one 32x32x16 MFMA A-operand worth of corpus rows
 constexpr int kChunkFloats = 128;  // k-chunk: 32 rows x 128 f32 = one 16 KiB LDS slot
 constexpr int kSlotBytes = kTileRows * kChunkFloats * 4;
-constexpr int kNumSlots = 9;       // LDS ring: 9 x 16 KiB = 144 KiB
-constexpr int kPrefetch = 8;       // slots in flight ahead of the consumer (= kNumSlots - 1)
+constexpr int kNumSlots = 8;       // f32 LDS ring: 8 x 16 KiB = 128 KiB, all of it in flight
+constexpr int kPrefetch = 8;
 constexpr int kScaleRing = 16;     // per-tile 1/|c| vectors (128 B each)
-constexpr int kScanLdsBytes = kNumSlots * kSlotBytes + kScaleRing * kTileRows * 4;
+// ring + two padded bf16 tiles (32 rows x 272 B) + scale ring
+constexpr int kScanLdsBytes = kNumSlots * kSlotBytes + 2 * kTileRows * (kChunkFloats * 2 + 16) + kScaleRing * kTileRows * 4;
 constexpr int kMaxKC = 6;          // k-chunks per row the MFMA scan supports (dim_pad <= 768)
 
 constexpr int kMaxBatch = 256;     // queries per scan pass (8 waves x 32 MFMA columns)

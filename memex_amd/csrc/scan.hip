@@ -3,19 +3,33 @@
 // Replaces the graph walk of `self.hnsw.search(vec, limit, 32)`
 // (reference lib/libmemex/src/storage/local.rs:76) with an exhaustive pass over the corpus.
 //
-// One persistent 512-thread workgroup per CU streams 32-row x 128-float "slots" (16 KiB) of the
-// f32 corpus straight into LDS with buffer_load...lds (LDS-DMA, nt policy, no VGPR staging), nine
-// slots deep.  Each of the 8 waves owns 32 of the (<=256) queries as register-resident bf16 MFMA
-// B-fragments; corpus fragments are read from LDS as f32, converted to bf16 in registers and fed
-// to v_mfma_f32_32x32x16_bf16 (A = 32 corpus rows, B = 32 queries), so every lane ends a tile with
-// 16 corpus-row scores of ONE query.  Scores are scaled by 1/|c| and compared against that query's
-// pass threshold; the (rare) survivors are appended to a lane-private buffer in HBM.  No top-k
-// bookkeeping, no atomics and no cross-lane traffic sit on the streaming path.
+// One persistent 512-thread workgroup per CU.  Data path per 32-row x 128-float "slot" (16 KiB):
+//   1. buffer_load ... lds (LDS-DMA, nt policy, no VGPR staging) streams the f32 slot into an
+//      8-deep LDS ring.  Wave w DMAs rows 4w..4w+3 and is the ONLY reader of those rows, so the
+//      ring needs no barrier: a counted s_waitcnt vmcnt covers it.
+//   2. each wave converts its 4 rows to bf16 once (2 ds_read_b128 + 4 v_cvt_pk_bf16_f32 +
+//      1 ds_write_b128 per lane) into a padded, double-buffered bf16 tile shared by the workgroup.
+//   3. after one s_barrier, all 8 waves read MFMA A-fragments (32 corpus rows x 16 k) from the bf16
+//      tile with immediate-offset ds_read_b128 and run v_mfma_f32_32x32x16_bf16 against their own
+//      32 queries, held as register-resident B-fragments for the whole launch.
+// Steps 2 (slot j+1) and 3 (slot j) are independent and interleave.
+// With A = corpus rows and B = queries every lane ends a tile holding 16 corpus-row scores of ONE
+// query: scale by 1/|c|, compare with that query's pass threshold, append the (rare) survivors to
+// a lane-private buffer in HBM.  No top-k bookkeeping, atomics or cross-lane traffic on the
+// streaming path.
 //
-// Algorithmic bytes: rows * ds * 4 per launch (+ rows*4 for 1/|c|); MFMA work 2*256*rows*ds flop.
-// Bound: HBM.  Approximate scores are within kApproxErr of the exact cosine;
-// exactness of the final answer is restored by index_kernels.hip (pool select + f64 rescoring).
+// Algorithmic bytes: rows * ds * 4 per launch (+ rows*4 for 1/|c|); MFMA work 2*256*rows*ds flop
+// (512 MFMA cycles per SIMD per slot vs ~1250 cycles of HBM time per slot per CU: HBM-bound).
+// Approximate scores are within kApproxErr of the exact cosine; exactness of the final answer is
+// restored by index_kernels.hip (pool select + f64 rescoring).
 #include "index_kernels.h"
+
+// Ablation switch for scripts/scan_ubench.hip only (0 = production kernel):
+//   1 = DMA + waits + LDS reads of the conversion pass, 2 = + bf16 conversion and tile writes,
+//   3 = + fragment reads (no MFMA)
+#ifndef MX_SCAN_ABLATE
+#define MX_SCAN_ABLATE 0
+#endif
 
 namespace mx {
 
@@ -27,15 +41,21 @@ typedef __attribute__((address_space(3))) void lds_void;
 #define MX_LDS_DMA16(rsrc, ldsptr, voff, soff, aux) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lds_void *)(ldsptr), 16, (voff), (soff), 0, (aux))
 
+constexpr int kTilePitch = kChunkFloats * 2 + 16;          // bf16 tile row pitch: 272 B (odd # of 16-B slots)
+constexpr int kTileBytes = kTileRows * kTilePitch;         // 8704 B
+constexpr uint32_t kTileOff = kNumSlots * kSlotBytes;      // two bf16 tiles after the ring
+constexpr uint32_t kScaleOff = kTileOff + 2 * kTileBytes;  // per-tile 1/|c| ring
+static_assert(kScaleOff + kScaleRing * kTileRows * 4 == kScanLdsBytes, "LDS layout");
+static_assert(kPrefetch == kNumSlots && kNumSlots == 8, "waits below assume an 8-slot ring, all in flight");
+
 template <int KC, int TAG>
 __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr uint32_t kScaleOff = kNumSlots * kSlotBytes;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 31;  // MFMA row (corpus row in tile) for A reads; query column for B/D
+    const int m = lane & 31;  // MFMA: corpus row of the A fragment / query column of B and D
     const int h = lane >> 5;
 
     // ---- register-resident query fragments (B operand), loaded once per launch
@@ -55,11 +75,14 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     const uint32_t rowbytes = p.ds * 4;
 
     // ---- LDS-DMA lane constants.  Piece P (1 KiB) of a slot = rows 2P, 2P+1 x 512 B; wave w
-    // issues pieces 2w and 2w+1.  LDS image is lane-linear, so the bank swizzle lives in the
-    // SOURCE address: physical 16-B chunk pc of row r holds logical chunk pc ^ (r & 15).
-    const int r0 = 4 * wave + h, r1 = r0 + 2;
-    const uint32_t voff0 = (uint32_t)r0 * rowbytes + (uint32_t)(((lane & 31) ^ (r0 & 15)) << 4);
-    const uint32_t voff1 = (uint32_t)r1 * rowbytes + (uint32_t)(((lane & 31) ^ (r1 & 15)) << 4);
+    // issues pieces 2w, 2w+1 (rows 4w..4w+3).  The LDS image is lane-linear, so the layout the
+    // conversion pass wants -- even 16-B chunks in the first 256 B of a row, odd chunks in the
+    // second -- is produced by permuting the SOURCE address: physical chunk pc <- logical chunk
+    // ((pc & 15) << 1) | (pc >> 4).
+    const int pc = lane & 31;
+    const uint32_t lchunk = (uint32_t)(((pc & 15) << 1) | (pc >> 4));
+    const uint32_t voff0 = (uint32_t)(4 * wave + h) * rowbytes + (lchunk << 4);
+    const uint32_t voff1 = voff0 + 2u * rowbytes;
 
     uint32_t nx = 0, nx_ti = 0, nx_kc = 0, nx_rp = 0;  // next slot to issue (all wave-uniform)
     auto issue_next = [&]() {
@@ -85,17 +108,44 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         if (++nx_rp == kNumSlots) nx_rp = 0;
     };
 
-#pragma unroll 1
-    for (int i = 0; i < kPrefetch; ++i) issue_next();
+    // conversion pass of the slot at ring position rp into bf16 tile tb: this wave's own 4 rows.
+    // lane -> row 4w + (lane>>4), floats [8*(lane&15), +8) = physical chunks (lane&15), 16+(lane&15)
+    const uint32_t cv_src = (uint32_t)wave * 2048u + (uint32_t)(lane >> 4) * 512u + (uint32_t)(lane & 15) * 16u;
+    const uint32_t cv_dst = kTileOff + (uint32_t)(4 * wave + (lane >> 4)) * kTilePitch + (uint32_t)(lane & 15) * 16u;
+    auto convert = [&](uint32_t rp, uint32_t tb) {
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(smem + rp * kSlotBytes + cv_src);
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(smem + rp * kSlotBytes + cv_src + 256);
+#if MX_SCAN_ABLATE == 1
+        asm volatile("" ::"v"(lo), "v"(hi));
+        (void)tb;
+#else
+        bf16x8 a;
+        a[0] = (__bf16)lo[0]; a[1] = (__bf16)lo[1]; a[2] = (__bf16)lo[2]; a[3] = (__bf16)lo[3];
+        a[4] = (__bf16)hi[0]; a[5] = (__bf16)hi[1]; a[6] = (__bf16)hi[2]; a[7] = (__bf16)hi[3];
+        *reinterpret_cast<bf16x8 *>(smem + cv_dst + tb * kTileBytes) = a;
+#endif
+    };
 
-    // A-fragment read address: row m, logical chunk (ks*4 + h*2 + e) -> physical chunk ^ (m & 15)
-    const uint32_t lane_lds = (uint32_t)m * 512u + (uint32_t)((((h << 1) ^ (m & 15))) << 4);
+    // A-fragment read base: row m, bf16 [8h, 8h+8) of k-step ks at + ks*32 (immediate offsets)
+    const uint32_t frag_base = kTileOff + (uint32_t)m * kTilePitch + (uint32_t)h * 16u;
 
     Cand *mybuf = p.lane_buf + ((size_t)blockIdx.x * kScanThreads + tid) * kLaneCap;
     uint32_t cnt = 0;
     uint32_t ovf = 0;
-    uint32_t rp = 0, j = 0;
 
+    // ---- prologue: fill the ring, convert slot 0
+#pragma unroll 1
+    for (int i = 0; i < kNumSlots; ++i) issue_next();
+    if (total > 0) {
+        if (total >= (uint32_t)kNumSlots)
+            asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // 7 newer slots x 2 ops may stay in flight
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        convert(0, 0);
+    }
+
+    uint32_t rp = 0;  // ring position of slot j
+    uint32_t j = 0;
 #pragma unroll 1
     for (uint32_t ti = 0; ti < nT; ++ti) {
         f32x16 acc;
@@ -104,25 +154,58 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
 
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc, ++j) {
-            // slot j has landed once at most the 2*(kPrefetch-1) newer DMA ops are outstanding
-            if (total - 1 - j >= (uint32_t)(kPrefetch - 1))
-                asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            // Issued so far: slots 0 .. j+7.  Slot j+1 (converted below) has landed once at most
+            // the 6 newer slots (12 DMA ops) are outstanding; near the end just drain.
+            // lgkmcnt(0): this wave's bf16 tile writes of the previous iteration are done before
+            // it arrives at the barrier.
+            if (j + (uint32_t)kNumSlots <= total)
+                asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
             else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // every wave's pieces landed; slot j-1 is free
-            issue_next();                  // refill the ring position slot j-1 occupied
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // One barrier per slot: tile j&1 (written last iteration) is complete and visible;
+            // tile (j+1)&1 (read last iteration) is free to overwrite.
+            __builtin_amdgcn_s_barrier();
+            const uint32_t rp1 = (rp + 1 == (uint32_t)kNumSlots) ? 0 : rp + 1;
+            const bool more = j + 1 < total;
 
-            const uint32_t lb = rp * kSlotBytes + lane_lds;
+            // (a) every LDS read of this iteration up front: the slot's 8 A-fragments and the two
+            //     f32 chunks of the conversion pass -> one LDS latency per slot
+            const uint32_t fb = frag_base + (j & 1) * kTileBytes;
+            bf16x8 a[8];
+#if MX_SCAN_ABLATE == 0 || MX_SCAN_ABLATE == 3
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) a[ks] = *reinterpret_cast<const bf16x8 *>(smem + fb + ks * 32);
+#endif
+            f32x4 lo, hi;
+            if (more) {
+                lo = *reinterpret_cast<const f32x4 *>(smem + rp1 * kSlotBytes + cv_src);
+                hi = *reinterpret_cast<const f32x4 *>(smem + rp1 * kSlotBytes + cv_src + 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (b) DMA issue (scalar address math) under the LDS latency: slot j+8 -> ring
+            //     position of slot j, which this wave finished converting last iteration
+            issue_next();
+            __builtin_amdgcn_sched_barrier(0);
+            // (c) MFMAs; the VALU/LDS-write tail of the conversion pass sits between them
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(smem + (lb ^ (uint32_t)((ks * 4 + 0) << 4)));
-                const f32x4 hi = *reinterpret_cast<const f32x4 *>(smem + (lb ^ (uint32_t)((ks * 4 + 1) << 4)));
-                bf16x8 a;
-                a[0] = (__bf16)lo[0]; a[1] = (__bf16)lo[1]; a[2] = (__bf16)lo[2]; a[3] = (__bf16)lo[3];
-                a[4] = (__bf16)hi[0]; a[5] = (__bf16)hi[1]; a[6] = (__bf16)hi[2]; a[7] = (__bf16)hi[3];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kc * 8 + ks], acc, 0, 0, 0);
+#if MX_SCAN_ABLATE == 3
+                asm volatile("" ::"v"(a[ks]));
+#elif MX_SCAN_ABLATE == 0
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], qf[kc * 8 + ks], acc, 0, 0, 0);
+#endif
+                if (ks == 3 && more) {
+#if MX_SCAN_ABLATE == 1
+                    asm volatile("" ::"v"(lo), "v"(hi));
+#else
+                    bf16x8 c;
+                    c[0] = (__bf16)lo[0]; c[1] = (__bf16)lo[1]; c[2] = (__bf16)lo[2]; c[3] = (__bf16)lo[3];
+                    c[4] = (__bf16)hi[0]; c[5] = (__bf16)hi[1]; c[6] = (__bf16)hi[2]; c[7] = (__bf16)hi[3];
+                    *reinterpret_cast<bf16x8 *>(smem + cv_dst + ((j + 1) & 1) * kTileBytes) = c;
+#endif
+                }
             }
-            if (++rp == kNumSlots) rp = 0;
+            rp = rp1;
         }
 
         // ---- tile epilogue: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*h
