@@ -1,0 +1,68 @@
+"""C-ABI checks that need no GPU: the library builds, loads, exports every symbol the header
+declares, and fails loudly (never falls back) when no device is present."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "memex_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_surface():
+    fns = header_functions()
+    for must in ("mx_index_open", "mx_index_add", "mx_index_search", "mx_index_clear", "mx_index_save",
+                 "mx_index_load", "mx_encoder_create", "mx_encoder_encode", "mx_topk_merge_device", "mx_last_error"):
+        assert must in fns
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    from memex_amd import _lib
+    missing = [f for f in header_functions() if not hasattr(lib_built, f)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == header_functions()      # the python binding tracks the header
+
+
+def test_version_and_error_slot(lib_built):
+    assert b"gfx950" in lib_built.mx_version()
+    assert lib_built.mx_last_error() is not None
+
+
+def test_argument_validation_without_device(lib_built):
+    from memex_amd import _lib
+    h = ctypes.c_void_p()
+    assert lib_built.mx_index_open(None, 0, 0, ctypes.byref(h)) == _lib.MX_EINVAL      # dim < 1
+    assert lib_built.mx_index_open(None, 3, 0, None) == _lib.MX_EINVAL                 # null out
+    assert lib_built.mx_index_size(None, None) == _lib.MX_EINVAL
+    assert lib_built.mx_index_search(None, None, 1, 1, None, None, None, None) == _lib.MX_ESEARCH
+    e = ctypes.c_int(-1)
+    assert lib_built.mx_index_has_store(b"/nonexistent-dir", ctypes.byref(e)) == 0 and e.value == 0
+    assert lib_built.mx_index_load(None, b"/x") == _lib.MX_EINVAL
+
+
+def test_no_cpu_fallback(lib_built):
+    """Without a GPU the product path must raise -- not silently compute on the host."""
+    from memex_amd import _lib
+    from memex_amd.index import FlatIndex
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present; the negative check only makes sense on the CPU box")
+    with pytest.raises(_lib.MemexHipError) as ei:
+        FlatIndex(3)
+    assert ei.value.code == _lib.MX_EDEVICE
+
+
+def test_product_code_does_not_import_the_oracle():
+    """oracle/ is test infrastructure: nothing under memex_amd/ may import, load or link it."""
+    pkg = os.path.join(ROOT, "memex_amd")
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|libmxoracle|cosine_oracle|mxo_", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not pat.search(text), f"{os.path.join(dirpath, f)} reaches into oracle/"

@@ -1,0 +1,52 @@
+"""Host-side logic that needs no GPU: URI factory, error mapping, stage planning, sharding."""
+import numpy as np
+import pytest
+
+from memex_amd import storage
+from memex_amd.sharded import partition
+
+
+def test_get_vector_storage_rejects_unknown_schemes(tmp_path):
+    # reference: storage/mod.rs:99-102,134-136 -> VectorStoreError::Unsupported
+    for uri in ("", "not a uri", "qdrant://x", "opensearch+https://admin:admin@localhost:9200", "file:///tmp/x"):
+        with pytest.raises(storage.Unsupported):
+            storage.get_vector_storage(uri, "c")
+
+
+def test_vector_data_fields_match_reference():
+    v = storage.VectorData(_id="a", document_id="d", text="t", vector=[0.0], segment_id=3)
+    assert (v._id, v.document_id, v.text, v.segment_id) == ("a", "d", "t", 3)   # mod.rs:17-28
+
+
+def test_store_without_rows_needs_no_device(tmp_path):
+    s = storage.HipFlatStore.new(str(tmp_path))
+    assert s.search([0.1, 0.2], 3) == []                 # empty store: nothing to search, no GPU touched
+    with pytest.raises(NotImplementedError):
+        s.delete("x")                                    # reference: unimplemented!() (local.rs:29-32)
+    assert not storage.HipFlatStore.has_store(str(tmp_path))
+    s.save()
+    assert storage.HipFlatStore.has_store(str(tmp_path))   # vectors.meta.json exists (local.rs:110-113)
+    s2 = storage.HipFlatStore.load(str(tmp_path))
+    assert s2._id_map == {}
+    s.delete_all()
+    assert not storage.HipFlatStore.has_store(str(tmp_path))
+
+
+def test_load_errors_map_to_reference_variants(tmp_path):
+    with pytest.raises(storage.FileIOError):
+        storage.HipFlatStore.load(str(tmp_path / "missing"))
+    (tmp_path / storage.META_FILE).write_text("{not json")
+    with pytest.raises(storage.SerdeError):
+        storage.HipFlatStore.load(str(tmp_path))
+    (tmp_path / storage.META_FILE).write_text('{"1": "a"}')      # ids but no vector file
+    with pytest.raises(storage.FileIOError):
+        storage.HipFlatStore.load(str(tmp_path))
+
+
+def test_partition_covers_all_rows():
+    for n, w in ((10_000_000, 8), (10, 3), (7, 8), (0, 2)):
+        p = partition(n, w)
+        assert p[0][0] == 0 and p[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(p, p[1:]))
+        sizes = [b - a for a, b in p]
+        assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,266 @@
+"""GPU parity of the HIP flat index (through the C ABI) against the oracle.
+
+The first three tests are the reference's own tests restated on `HipFlatStore`
+(lib/libmemex/src/storage/local.rs:201-242: test_hnsw, test_save_load, test_delete_all).
+Bar: ids, dists and scores bit-exact (integer / f32-bit equality) against the oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from conftest import bits  # noqa: E402
+
+
+def test_data():
+    from memex_amd.storage import VectorData
+    # local.rs:175-199
+    return [VectorData(_id="test-one", document_id="test-one", text="", segment_id=0, vector=[0.0, 0.1, 0.2]),
+            VectorData(_id="test-two", document_id="test-two", text="", segment_id=0, vector=[0.1, 0.1, 0.1]),
+            VectorData(_id="test-three", document_id="test-three", text="", segment_id=0, vector=[0.3, 0.2, 0.1])]
+
+
+def test_hnsw(tmp_path, lib_built):
+    from memex_amd.storage import HipFlatStore
+    store = HipFlatStore.new(str(tmp_path))
+    store.bulk_insert(test_data())
+    results = store.search([0.1, 0.1, 0.1], 3)
+    assert len(results) == 3
+    doc_id, _ = results[0]
+    assert doc_id == "test-two"                                   # the reference's assertion (local.rs:211-212)
+    assert [r[0] for r in results] == ["test-two", "test-three", "test-one"]
+    np.testing.assert_array_equal(np.float32([r[1] for r in results]), np.float32([1.0, 0.9258201, 0.7745967]))
+    store.delete_all()
+
+
+def test_save_load(tmp_path, lib_built):
+    from memex_amd.storage import HipFlatStore
+    store = HipFlatStore.new(str(tmp_path / "vectortest"))
+    store.bulk_insert(test_data())
+    store.save()
+    loaded = HipFlatStore.load(str(tmp_path / "vectortest"))
+    assert len(loaded._id_map) == len(store._id_map)              # local.rs:224-225
+    assert loaded.search([0.1, 0.1, 0.1], 3) == store.search([0.1, 0.1, 0.1], 3)
+    store.delete_all()
+
+
+def test_delete_all(tmp_path, lib_built):
+    from memex_amd import storage
+    store = storage.HipFlatStore.new(str(tmp_path))
+    store.bulk_insert(test_data())
+    store.save()
+    store.delete_all()
+    assert not store._id_map                                      # local.rs:237
+    assert len(store._index) == 0                                 # get_nb_point() == 0 (local.rs:238)
+    with pytest.raises(storage.VectorStoreError):
+        storage.HipFlatStore.load(str(tmp_path))                  # load fails: files removed (local.rs:240-241)
+    store.insert(test_data()[0])
+    assert list(store._id_map) == [1]                             # ids restart at 1 (local.rs:50,63)
+
+
+def test_get_vector_storage_roundtrip(tmp_path, lib_built):
+    from memex_amd.storage import get_vector_storage
+    vs = get_vector_storage(f"hnsw://{tmp_path}", "test")          # the reference's URI scheme, served from HBM
+    vs.add_vectors(test_data())
+    vs.client.save()
+    vs2 = get_vector_storage(f"hip://{tmp_path}", "test")
+    assert [r[0] for r in vs2.search([0.3, 0.2, 0.1], 2)] == ["test-three", "test-two"]
+    vs2.delete_collection()
+    assert vs2.search([0.3, 0.2, 0.1], 2) == []
+
+
+def _check(idx, X, Q, k, oracle, id_offset=0):
+    ids, sc, di, nf = idx.search(Q, k)
+    oi, od, os_, onf = oracle.search(X, Q, k, id_offset=id_offset)
+    np.testing.assert_array_equal(ids, oi)
+    np.testing.assert_array_equal(bits(di), bits(od))
+    np.testing.assert_array_equal(bits(sc), bits(os_))
+    np.testing.assert_array_equal(nf, onf)
+
+
+@pytest.mark.parametrize("n,d,B,k,seed", [
+    (3, 3, 1, 3, 0), (100, 3, 4, 10, 1), (1000, 384, 16, 10, 2), (5000, 100, 33, 7, 3),
+    (20000, 768, 256, 10, 4), (100000, 384, 256, 10, 5), (100000, 384, 300, 10, 6),
+    (300000, 384, 64, 100, 7), (9000, 384, 5, 1, 8), (40000, 640, 20, 10, 9), (12345, 1, 4, 5, 10),
+    (2000, 1000, 3, 10, 11),
+])
+def test_parity_random(n, d, B, k, seed, oracle, lib_built):
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    Q = rng.standard_normal((B, d), dtype=np.float32)
+    with FlatIndex(d) as idx:
+        assert idx.add(X) == 1 and len(idx) == n
+        _check(idx, X, Q, k, oracle)
+
+
+def test_parity_golden_fixtures(oracle, lib_built):
+    """HIP path vs the committed golden outputs (tests/golden/search_golden.npz)."""
+    from memex_amd.index import FlatIndex
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "search_golden.npz"))
+    for name in [k[:-4] for k in g.files if k.endswith("_ids")]:
+        n, d, B, k, seed = (int(x) for x in g[name + "_cfg"])
+        rng = np.random.default_rng(seed)
+        X = rng.standard_normal((n, d), dtype=np.float32)
+        Q = rng.standard_normal((B, d), dtype=np.float32)
+        with FlatIndex(d) as idx:
+            idx.add(X)
+            ids, sc, di, _ = idx.search(Q, k)
+        np.testing.assert_array_equal(ids, g[name + "_ids"])
+        np.testing.assert_array_equal(bits(di), bits(g[name + "_dists"]))
+        np.testing.assert_array_equal(bits(sc), bits(g[name + "_scores"]))
+
+
+def test_exact_mode_parity(oracle, lib_built):
+    from memex_amd import _lib
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((30000, 384), dtype=np.float32)
+    Q = rng.standard_normal((6, 384), dtype=np.float32)
+    with FlatIndex(384) as idx:
+        idx.add(X)
+        idx.set_search_mode(_lib.MX_SEARCH_EXACT)
+        _check(idx, X, Q, 10, oracle)
+        _check(idx, X, Q, 300, oracle)
+
+
+def test_edge_zero_rows_zero_query_duplicates(oracle, lib_built):
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(22)
+    X = rng.standard_normal((50000, 384), dtype=np.float32)
+    Q = rng.standard_normal((8, 384), dtype=np.float32)
+    X[5] = 0
+    X[-1] = 0                       # zero-norm rows: dist 0 to everything (DistCosine else-branch)
+    Q[1] = 0                        # zero-norm query: every dist 0, ties by id
+    X[25000:25040] = X[7]           # exact duplicates
+    X[300] = X[7] * 2.0             # same direction, different length
+    Q[0] = X[7] * 3.0
+    Q[2] = -X[9]                    # dist ~2 to row 9
+    with FlatIndex(384) as idx:
+        idx.add(X)
+        _check(idx, X, Q, 10, oracle)
+        _check(idx, X, Q, 64, oracle)
+        assert idx.stats().fallback_queries == 0
+
+
+def test_overflow_falls_back_to_exact_and_stays_bit_exact(oracle, lib_built):
+    """More near-identical rows than the candidate buffers hold: the AUTO path must detect it and
+    re-answer on the EXACT path, still bit-exact (lowest ids among the ties win)."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(23)
+    X = rng.standard_normal((60000, 384), dtype=np.float32)
+    X[20000:26000] = X[11]
+    Q = rng.standard_normal((4, 384), dtype=np.float32)
+    Q[0] = X[11]
+    with FlatIndex(384) as idx:
+        idx.add(X)
+        _check(idx, X, Q, 10, oracle)
+        assert idx.stats().fallback_queries >= 1
+
+
+def test_incremental_adds_ids_offsets_and_clear(oracle, lib_built):
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(24)
+    X = rng.standard_normal((7000, 384), dtype=np.float32)
+    Q = rng.standard_normal((5, 384), dtype=np.float32)
+    with FlatIndex(384) as idx:
+        assert idx.add(X[:1]) == 1
+        assert idx.add(X[1:4097]) == 2                   # forces a capacity growth with live rows
+        assert idx.add(X[4097:]) == 4098
+        _check(idx, X, Q, 10, oracle)
+        idx.set_id_offset(1_000_000)
+        _check(idx, X, Q, 10, oracle, id_offset=1_000_000)
+        idx.set_id_offset(0)
+        idx.clear()
+        assert len(idx) == 0
+        ids, _, _, nf = idx.search(Q, 3)
+        assert not ids.any() and not nf.any()
+        assert idx.add(X[:10]) == 1                      # ids restart at 1 (local.rs:50,63)
+        _check(idx, X[:10], Q, 20, oracle)
+
+
+def test_rejects_non_finite_rows(lib_built):
+    from memex_amd import _lib
+    from memex_amd.index import FlatIndex
+    with FlatIndex(4) as idx:
+        idx.add(np.ones((3, 4), dtype=np.float32))
+        bad = np.ones((2, 4), dtype=np.float32)
+        bad[1, 2] = np.nan
+        with pytest.raises(_lib.MemexHipError) as ei:
+            idx.add(bad)
+        assert ei.value.code == _lib.MX_EINVAL and len(idx) == 3
+
+
+def test_out_of_range_norms_use_exact_path(oracle, lib_built):
+    """Rows with extreme norms are outside the bf16 filter's certified range -> EXACT path, same bits."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(25)
+    X = rng.standard_normal((3000, 64), dtype=np.float32)
+    X[10] *= 1e-22
+    X[11] *= 1e18
+    Q = rng.standard_normal((3, 64), dtype=np.float32)
+    Q[0] = X[10]
+    with FlatIndex(64) as idx:
+        idx.add(X)
+        _check(idx, X, Q, 10, oracle)
+
+
+def test_registry_shares_one_resident_index(lib_built):
+    """Callers build a store per request (reference handlers.rs:61-63): same key -> same HBM index."""
+    from memex_amd.index import FlatIndex
+    a = FlatIndex(8, key="collection-x")
+    b = FlatIndex(8, key="collection-x")
+    a.add(np.eye(8, dtype=np.float32))
+    assert len(b) == 8
+    a.close()
+    assert len(b) == 8                                   # still alive through b's reference
+    ids, _, _, _ = b.search(np.eye(8, dtype=np.float32)[3], 1)
+    assert ids[0, 0] == 4
+    b.close()
+
+
+def test_approximation_error_bound_holds(lib_built):
+    """The exactness argument needs |bf16 score - exact cosine| <= kApproxErr (0.0081)."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(26)
+    for d, scale in ((3, 1.0), (16, 1.0), (384, 1.0), (384, 50.0), (768, 1e-3)):
+        X = (rng.standard_normal((20000, d)) * scale).astype(np.float32)
+        Q = rng.standard_normal((32, d), dtype=np.float32)
+        with FlatIndex(d) as idx:
+            idx.set_profiling(True)
+            idx.add(X)
+            idx.search(Q, 10)
+            assert idx.stats().max_abs_err <= 0.0081
+
+
+def test_multi_shard_merge_equals_unsharded(oracle, lib_built):
+    """Two shard indexes with global id offsets + the HIP merge kernel == one big index."""
+    import torch
+    from memex_amd.index import FlatIndex, merge_topk_device
+    rng = np.random.default_rng(27)
+    X = rng.standard_normal((30001, 384), dtype=np.float32)
+    X[14990:15010] = X[4]
+    Q = rng.standard_normal((9, 384), dtype=np.float32)
+    Q[0] = X[4]
+    k = 10
+    cuts = [(0, 15000), (15000, 30001)]
+    g_ids = torch.zeros((2, 9, k), dtype=torch.int64, device="cuda")
+    g_d = torch.zeros((2, 9, k), dtype=torch.float32, device="cuda")
+    for s, (a, b) in enumerate(cuts):
+        with FlatIndex(384) as idx:
+            idx.set_id_offset(a)
+            idx.add(X[a:b])
+            ids, _, di, _ = idx.search(Q, k)
+            g_ids[s] = torch.from_numpy(ids.astype(np.int64)).cuda()
+            g_d[s] = torch.from_numpy(di).cuda()
+    m_ids = torch.zeros((9, k), dtype=torch.int64, device="cuda")
+    m_d = torch.zeros((9, k), dtype=torch.float32, device="cuda")
+    m_s = torch.zeros((9, k), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    merge_topk_device(0, g_ids, g_d, m_ids, m_d, m_s)
+    oi, od, os_, _ = oracle.search(X, Q, k)
+    np.testing.assert_array_equal(m_ids.cpu().numpy().astype(np.uint64), oi)
+    np.testing.assert_array_equal(bits(m_d.cpu().numpy()), bits(od))
+    np.testing.assert_array_equal(bits(m_s.cpu().numpy()), bits(os_))
