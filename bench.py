@@ -77,6 +77,20 @@ def cpu_baseline(dim: int, batch: int, k: int, rows_total: int, target_s: float)
     }
 
 
+def traffic_from_profile(rows_total: int, dim: int, world: int):
+    """HBM bytes per launch of the scan kernel from the committed PMC pass (profiles/, FETCH_SIZE x2
+    gfx950 correction + WRITE_SIZE, separate --pmc runs).  bench.py cannot collect PMCs itself, so
+    this is only reported when the committed profile matches the workload being run."""
+    path = os.path.join(ROOT, "profiles", "r1_scan_traffic.json")
+    if world != 1 or rows_total != 10_000_000 or dim != 384 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return float(json.load(f)["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     import torch
@@ -219,7 +233,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "bytes_per_launch": st.scan_bytes / max(1, st.scan_launches),
                 "ms_per_launch": st.scan_ms / max(1, st.scan_launches),
-                "traffic": None,
+                "traffic": traffic_from_profile(rows_total, a.dim, world),
             },
         }
         if world == 1 and not a.no_cpu_baseline:

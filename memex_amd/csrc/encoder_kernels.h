@@ -1,0 +1,68 @@
+// encoder_kernels.h -- device-side contract of the sentence encoder (kernels in
+// encoder_kernels.hip, host logic in encoder.hip).
+//
+// Token layout: sequences are packed back to back ("varlen"), each sequence start aligned to 8
+// tokens so that 16-byte vector accesses along the token axis stay aligned; the packed length is
+// padded to a multiple of 128 rows (GEMM tile height).  Rows that belong to no sequence hold
+// finite garbage and are never read by attention (masked by length) or pooling.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mx {
+
+typedef __bf16 bf16_t;
+
+constexpr int kSeqAlign = 8;     // sequence start alignment (tokens)
+constexpr int kRowPad = 128;     // packed token count is padded to this (GEMM BM)
+
+enum GemmEpilogue {
+    EPI_BIAS = 0,         // out = bf16(acc + bias)
+    EPI_BIAS_GELU = 1,    // out = bf16(gelu_erf(acc + bias))
+    EPI_QKV = 2,          // N = 3H: q (scaled) and k token-major, v feature-major (transposed)
+    EPI_BIAS_RES_LN = 3,  // out = bf16(LayerNorm(acc + bias + residual))   (BN == N == hidden)
+};
+
+struct GemmParams {
+    const bf16_t *a;      // [M, K] activations, row pitch lda (elements)
+    int lda;
+    const bf16_t *w;      // [N, K] weights (nn.Linear layout), row pitch K
+    const float *bias;    // [N]
+    int m, n, k;          // m multiple of 128 (or 64 for the 768-wide LN variant), n multiple of 384, k of 64
+    bf16_t *out;          // EPI_BIAS/GELU/LN: [M, N] pitch ldo;  EPI_QKV: q [M, H]
+    int ldo;
+    bf16_t *out_k;        // EPI_QKV: k [M, H]
+    bf16_t *out_vt;       // EPI_QKV: v^T [H, ldvt]
+    int ldvt;
+    int hidden;           // EPI_QKV: H
+    float qscale;         // EPI_QKV: multiplies q (1/sqrt(d_head) * log2(e))
+    const bf16_t *res;    // EPI_BIAS_RES_LN: residual [M, N] pitch ldres
+    int ldres;
+    const float *gamma;   // EPI_BIAS_RES_LN
+    const float *beta;
+    float eps;
+};
+
+hipError_t encoder_kernels_setup();
+hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p);
+
+// token maps from sequence lengths: cu[b] (aligned starts), tok_seq / tok_pos for every packed row
+hipError_t launch_token_map(hipStream_t s, const int32_t *lens, int B, int S, int32_t *cu, int32_t *tok_seq,
+                            int32_t *tok_pos, int t_pad);
+
+// x[t] = LayerNorm(word[id] + pos[p] + type[0])
+hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32_t *tok_seq, const int32_t *tok_pos,
+                           int t_pad, int hidden, const float *word, const float *pos, const float *type0,
+                           const float *gamma, const float *beta, float eps, int vocab, bf16_t *x);
+
+// softmax(q k^T + mask) v per (sequence, head); q is pre-scaled by 1/sqrt(d)*log2(e)
+hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt,
+                            const int32_t *cu, const int32_t *lens, int B, int max_len, int heads, int d_head,
+                            int hidden, bf16_t *ctx);
+
+// masked mean (or CLS) over tokens + optional L2 normalise -> out [B, H] f32
+hipError_t launch_pool(hipStream_t s, const bf16_t *x, const int32_t *cu, const int32_t *lens, int B, int hidden,
+                       int pooling_cls, int normalize, float *out);
+
+}  // namespace mx

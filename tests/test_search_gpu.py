@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 from conftest import bits  # noqa: E402
 
 
-def test_data():
+def _test_data():
     from memex_amd.storage import VectorData
     # local.rs:175-199
     return [VectorData(_id="test-one", document_id="test-one", text="", segment_id=0, vector=[0.0, 0.1, 0.2]),
@@ -25,7 +25,7 @@ def test_data():
 def test_hnsw(tmp_path, lib_built):
     from memex_amd.storage import HipFlatStore
     store = HipFlatStore.new(str(tmp_path))
-    store.bulk_insert(test_data())
+    store.bulk_insert(_test_data())
     results = store.search([0.1, 0.1, 0.1], 3)
     assert len(results) == 3
     doc_id, _ = results[0]
@@ -38,7 +38,7 @@ def test_hnsw(tmp_path, lib_built):
 def test_save_load(tmp_path, lib_built):
     from memex_amd.storage import HipFlatStore
     store = HipFlatStore.new(str(tmp_path / "vectortest"))
-    store.bulk_insert(test_data())
+    store.bulk_insert(_test_data())
     store.save()
     loaded = HipFlatStore.load(str(tmp_path / "vectortest"))
     assert len(loaded._id_map) == len(store._id_map)              # local.rs:224-225
@@ -49,21 +49,21 @@ def test_save_load(tmp_path, lib_built):
 def test_delete_all(tmp_path, lib_built):
     from memex_amd import storage
     store = storage.HipFlatStore.new(str(tmp_path))
-    store.bulk_insert(test_data())
+    store.bulk_insert(_test_data())
     store.save()
     store.delete_all()
     assert not store._id_map                                      # local.rs:237
     assert len(store._index) == 0                                 # get_nb_point() == 0 (local.rs:238)
     with pytest.raises(storage.VectorStoreError):
         storage.HipFlatStore.load(str(tmp_path))                  # load fails: files removed (local.rs:240-241)
-    store.insert(test_data()[0])
+    store.insert(_test_data()[0])
     assert list(store._id_map) == [1]                             # ids restart at 1 (local.rs:50,63)
 
 
 def test_get_vector_storage_roundtrip(tmp_path, lib_built):
     from memex_amd.storage import get_vector_storage
     vs = get_vector_storage(f"hnsw://{tmp_path}", "test")          # the reference's URI scheme, served from HBM
-    vs.add_vectors(test_data())
+    vs.add_vectors(_test_data())
     vs.client.save()
     vs2 = get_vector_storage(f"hip://{tmp_path}", "test")
     assert [r[0] for r in vs2.search([0.3, 0.2, 0.1], 2)] == ["test-three", "test-two"]
