@@ -1,14 +1,390 @@
-// encoder.hip -- placeholder while the index path is brought up; replaced by the MFMA encoder.
+// encoder.hip -- host logic of the sentence encoder behind the C ABI (include/memex_hip.h).
+//
+// Stands in for the rust-bert model that memex's embedder thread owns
+// (reference lib/libmemex/src/llm/embedding.rs:94-135): `create_model()` (:99-100) becomes
+// mx_encoder_create, `model.encode(&segments)` (:109) becomes mx_encoder_encode after host-side
+// tokenisation.  One handle = one device + one HIP stream; use it from one thread at a time
+// (the reference confines the model to a dedicated thread too, embedding.rs:98).
+//
+// Per call: sequences are packed back to back (no padding FLOPs), then
+//   embed+LN -> L x { QKV GEMM -> attention -> out-proj GEMM(+res+LN) -> FFN1 GEMM(+GELU)
+//                     -> FFN2 GEMM(+res+LN) } -> pool (+L2 normalise)
+// with bf16 activations/weights, f32 accumulation and f32 LayerNorm/softmax/GELU.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "encoder_kernels.h"
 #include "mx_common.h"
+
 using namespace mx;
-struct mx_encoder { int dummy; };
-extern "C" {
-size_t mx_encoder_weight_bytes(const mx_encoder_cfg *) { return 0; }
-int mx_encoder_create(const mx_encoder_cfg *, const void *, size_t, int, mx_encoder **) { return fail(MX_EUNSUPPORTED, "encoder not built yet"); }
-void mx_encoder_destroy(mx_encoder *) {}
-int mx_encoder_encode(mx_encoder *, const int32_t *, const int32_t *, int, int, float *) { return fail(MX_EUNSUPPORTED, "encoder not built yet"); }
-int mx_encoder_encode_device(mx_encoder *, const int32_t *, const int32_t *, int, int, float *) { return fail(MX_EUNSUPPORTED, "encoder not built yet"); }
-int mx_encoder_set_profiling(mx_encoder *, int) { return fail(MX_EUNSUPPORTED, "encoder not built yet"); }
-int mx_encoder_get_stats(mx_encoder *, mx_encoder_stats *) { return fail(MX_EUNSUPPORTED, "encoder not built yet"); }
-int mx_encoder_reset_stats(mx_encoder *) { return fail(MX_EUNSUPPORTED, "encoder not built yet"); }
+
+namespace {
+
+inline uint16_t f32_to_bf16(float f) {  // round to nearest even
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
 }
+
+struct Layer {
+    bf16_t *wqkv = nullptr;  // [3H, H]
+    float *bqkv = nullptr;   // [3H]
+    bf16_t *wo = nullptr;    // [H, H]
+    float *bo = nullptr, *ln1g = nullptr, *ln1b = nullptr;
+    bf16_t *wi = nullptr;    // [F, H]
+    float *bi = nullptr;
+    bf16_t *wo2 = nullptr;   // [H, F]
+    float *bo2 = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+
+std::once_flag g_enc_once;
+hipError_t g_enc_setup = hipSuccess;
+
+}  // namespace
+
+struct mx_encoder {
+    mx_encoder_cfg cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::vector<void *> allocs;  // every weight buffer (freed on destroy)
+    float *word = nullptr, *pos = nullptr, *type0 = nullptr, *eg = nullptr, *eb = nullptr;
+    std::vector<Layer> layers;
+    // workspace (grown on demand)
+    int ws_rows = 0, ws_seqs = 0, ws_ids = 0;
+    bf16_t *x = nullptr, *x1 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *hbuf = nullptr;
+    int32_t *cu = nullptr, *tok_seq = nullptr, *tok_pos = nullptr, *lens_dev = nullptr, *ids_dev = nullptr;
+    float *out_dev = nullptr;
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    mx_encoder_stats stats{};
+};
+
+namespace {
+
+int upload_f32(mx_encoder *e, const float *src, size_t n, float **dst) {
+    MX_HIP(hipMalloc(dst, n * sizeof(float)));
+    e->allocs.push_back(*dst);
+    MX_HIP(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return MX_OK;
+}
+
+int upload_bf16(mx_encoder *e, const float *src, size_t n, bf16_t **dst) {
+    std::vector<uint16_t> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16(src[i]);
+    MX_HIP(hipMalloc(dst, n * sizeof(uint16_t)));
+    e->allocs.push_back(*dst);
+    MX_HIP(hipMemcpy(*dst, tmp.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return MX_OK;
+}
+
+void free_ws(mx_encoder *e) {
+    void *ptrs[] = {e->x, e->x1, e->q, e->k, e->vt, e->ctx, e->hbuf, e->tok_seq, e->tok_pos};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    e->x = e->x1 = e->q = e->k = e->vt = e->ctx = e->hbuf = nullptr;
+    e->tok_seq = e->tok_pos = nullptr;
+    e->ws_rows = 0;
+}
+
+int ensure_ws(mx_encoder *e, int rows, int seqs, int n_ids) {
+    const int H = e->cfg.hidden, F = e->cfg.ffn;
+    if (rows > e->ws_rows) {
+        free_ws(e);
+        const size_t r = (size_t)rows;
+        bf16_t **bufs[] = {&e->x, &e->x1, &e->q, &e->k, &e->vt, &e->ctx};
+        for (bf16_t **b : bufs) {
+            MX_HIP(hipMalloc(b, r * H * sizeof(uint16_t)));
+            MX_HIP(hipMemsetAsync(*b, 0, r * H * sizeof(uint16_t), e->stream));
+        }
+        MX_HIP(hipMalloc(&e->hbuf, r * F * sizeof(uint16_t)));
+        MX_HIP(hipMemsetAsync(e->hbuf, 0, r * F * sizeof(uint16_t), e->stream));
+        MX_HIP(hipMalloc(&e->tok_seq, r * sizeof(int32_t)));
+        MX_HIP(hipMalloc(&e->tok_pos, r * sizeof(int32_t)));
+        e->ws_rows = rows;
+    }
+    if (seqs > e->ws_seqs) {
+        if (e->cu) (void)hipFree(e->cu);
+        if (e->lens_dev) (void)hipFree(e->lens_dev);
+        if (e->out_dev) (void)hipFree(e->out_dev);
+        e->cu = nullptr; e->lens_dev = nullptr; e->out_dev = nullptr;
+        e->ws_seqs = 0;
+        MX_HIP(hipMalloc(&e->cu, ((size_t)seqs + 1) * sizeof(int32_t)));
+        MX_HIP(hipMalloc(&e->lens_dev, (size_t)seqs * sizeof(int32_t)));
+        MX_HIP(hipMalloc(&e->out_dev, (size_t)seqs * H * sizeof(float)));
+        e->ws_seqs = seqs;
+    }
+    if (n_ids > e->ws_ids) {
+        if (e->ids_dev) (void)hipFree(e->ids_dev);
+        e->ids_dev = nullptr;
+        e->ws_ids = 0;
+        MX_HIP(hipMalloc(&e->ids_dev, (size_t)n_ids * sizeof(int32_t)));
+        e->ws_ids = n_ids;
+    }
+    return MX_OK;
+}
+
+constexpr int kMaxSeqsPerPass = 1024;
+constexpr int kMaxRowsPerPass = 1 << 17;  // packed rows per pass (131072): bounds the workspace
+
+// one pass: sequences [0, B) with device ids [B,S] (row pitch S) and HOST lens; output d_out [B,H]
+int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const int32_t *d_lens, int B, int S,
+                float *d_out) {
+    const mx_encoder_cfg &c = e->cfg;
+    const int H = c.hidden, F = c.ffn, heads = c.heads, dh = H / heads;
+    long rows = 0;
+    int max_len = 1;
+    double attn_flops = 0.0;
+    uint64_t tokens = 0;
+    for (int b = 0; b < B; ++b) {
+        const int l = std::min(std::max(h_lens[b], 1), S);
+        rows += (l + kSeqAlign - 1) / kSeqAlign * kSeqAlign;
+        max_len = std::max(max_len, l);
+        tokens += (uint64_t)l;
+        attn_flops += 4.0 * (double)l * (double)l * H;
+    }
+    const int t_pad = (int)round_up((uint64_t)rows + 32, kRowPad);
+    int rc = ensure_ws(e, t_pad, B, 0);
+    if (rc != MX_OK) return rc;
+    hipStream_t st = e->stream;
+    if (e->profiling) MX_HIP(hipEventRecord(e->ev0, st));
+    MX_HIP(launch_token_map(st, d_lens, B, S, e->cu, e->tok_seq, e->tok_pos, t_pad));
+    MX_HIP(launch_embed_ln(st, d_ids, S, e->tok_seq, e->tok_pos, t_pad, H, e->word, e->pos, e->type0, e->eg, e->eb,
+                           c.ln_eps, c.vocab, e->x));
+    const float qscale = (float)(1.4426950408889634 / std::sqrt((double)dh));
+    for (const Layer &L : e->layers) {
+        GemmParams g{};
+        g.a = e->x; g.lda = H; g.w = L.wqkv; g.bias = L.bqkv; g.m = t_pad; g.n = 3 * H; g.k = H;
+        g.out = e->q; g.out_k = e->k; g.out_vt = e->vt; g.ldo = H; g.ldvt = t_pad; g.hidden = H; g.qscale = qscale;
+        MX_HIP(launch_gemm(st, EPI_QKV, g));
+        MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->cu, d_lens, B, max_len, heads, dh, H, e->ctx));
+        GemmParams o{};
+        o.a = e->ctx; o.lda = H; o.w = L.wo; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = H;
+        o.out = e->x1; o.ldo = H; o.res = e->x; o.ldres = H; o.gamma = L.ln1g; o.beta = L.ln1b; o.eps = c.ln_eps;
+        MX_HIP(launch_gemm(st, EPI_BIAS_RES_LN, o));
+        GemmParams f1{};
+        f1.a = e->x1; f1.lda = H; f1.w = L.wi; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = H;
+        f1.out = e->hbuf; f1.ldo = F;
+        MX_HIP(launch_gemm(st, EPI_BIAS_GELU, f1));
+        GemmParams f2{};
+        f2.a = e->hbuf; f2.lda = F; f2.w = L.wo2; f2.bias = L.bo2; f2.m = t_pad; f2.n = H; f2.k = F;
+        f2.out = e->x; f2.ldo = H; f2.res = e->x1; f2.ldres = H; f2.gamma = L.ln2g; f2.beta = L.ln2b; f2.eps = c.ln_eps;
+        MX_HIP(launch_gemm(st, EPI_BIAS_RES_LN, f2));
+    }
+    MX_HIP(launch_pool(st, e->x, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
+    if (e->profiling) MX_HIP(hipEventRecord(e->ev1, st));
+    MX_HIP(hipStreamSynchronize(st));
+    if (e->profiling) {
+        float ms = 0.f;
+        MX_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->stats.gpu_ms += ms;
+    }
+    e->stats.sequences += (uint64_t)B;
+    e->stats.tokens += tokens;
+    e->stats.flops += (double)c.layers * ((double)tokens * (8.0 * H * H + 4.0 * (double)H * F) + attn_flops);
+    return MX_OK;
+}
+
+// splits a batch into passes bounded by kMaxSeqsPerPass / kMaxRowsPerPass
+int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const int32_t *d_lens, int B, int S,
+               float *d_out) {
+    for (int b = 0; b < B; ++b)
+        if (h_lens[b] < 1 || h_lens[b] > S) return fail(MX_EINVAL, "lens[%d] = %d outside [1, %d]", b, h_lens[b], S);
+    int b0 = 0;
+    while (b0 < B) {
+        int nb = 0;
+        long rows = 0;
+        while (b0 + nb < B && nb < kMaxSeqsPerPass) {
+            const int l = std::min(std::max(h_lens[b0 + nb], 1), S);
+            const long r = (l + kSeqAlign - 1) / kSeqAlign * kSeqAlign;
+            if (nb > 0 && rows + r > kMaxRowsPerPass) break;
+            rows += r;
+            ++nb;
+        }
+        int rc = encode_pass(e, d_ids + (size_t)b0 * S, h_lens + b0, d_lens + b0, nb, S,
+                             d_out + (size_t)b0 * e->cfg.hidden);
+        if (rc != MX_OK) return rc;
+        b0 += nb;
+    }
+    e->stats.calls += 1;
+    return MX_OK;
+}
+
+int check_cfg(const mx_encoder_cfg *c) {
+    if (!c) return fail(MX_EINVAL, "cfg is null");
+    if (c->layers < 1 || c->layers > 48) return fail(MX_EUNSUPPORTED, "layers %d", c->layers);
+    if (c->hidden != 384 && c->hidden != 768)
+        return fail(MX_EUNSUPPORTED, "hidden %d: the fused LayerNorm GEMM is built for 384 and 768", c->hidden);
+    if (c->heads < 1 || c->hidden % c->heads) return fail(MX_EINVAL, "heads %d does not divide hidden", c->heads);
+    const int dh = c->hidden / c->heads;
+    if (dh != 32 && dh != 64) return fail(MX_EUNSUPPORTED, "head dim %d (need 32 or 64)", dh);
+    if (c->ffn < 384 || c->ffn % 384) return fail(MX_EUNSUPPORTED, "ffn %d must be a multiple of 384", c->ffn);
+    if (c->vocab < 1 || c->max_pos < 1 || c->max_pos > 512 || c->type_vocab < 1)
+        return fail(MX_EINVAL, "vocab/max_pos/type_vocab out of range (max_pos <= 512)");
+    if (c->pooling != MX_POOL_MEAN && c->pooling != MX_POOL_CLS) return fail(MX_EINVAL, "pooling %d", c->pooling);
+    if (!(c->ln_eps >= 0.0f)) return fail(MX_EINVAL, "ln_eps");
+    return MX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mx_encoder_weight_bytes(const mx_encoder_cfg *c) {
+    if (!c) return 0;
+    const size_t H = (size_t)c->hidden, F = (size_t)c->ffn;
+    size_t n = ((size_t)c->vocab + c->max_pos + c->type_vocab) * H + 2 * H;
+    n += (size_t)c->layers * (3 * (H * H + H) + (H * H + H) + 2 * H + (F * H + F) + (H * F + H) + 2 * H);
+    return n * sizeof(float);
+}
+
+int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nbytes, int device, mx_encoder **out) {
+    if (!out) return fail(MX_EINVAL, "out is null");
+    *out = nullptr;
+    int rc = check_cfg(cfg);
+    if (rc != MX_OK) return rc;
+    if (!weights) return fail(MX_EINVAL, "weights is null");
+    if (nbytes != mx_encoder_weight_bytes(cfg))
+        return fail(MX_EINVAL, "weight blob is %zu bytes, config needs %zu", nbytes, mx_encoder_weight_bytes(cfg));
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0)
+        return fail(MX_EDEVICE, "no HIP device available (%s)", he == hipSuccess ? "count 0" : hipGetErrorString(he));
+    if (device < 0 || device >= ndev) return fail(MX_EDEVICE, "device %d out of range (have %d)", device, ndev);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
+    std::call_once(g_enc_once, [] { g_enc_setup = encoder_kernels_setup(); });
+    if (g_enc_setup != hipSuccess)
+        return fail(MX_EDEVICE, "encoder kernel setup failed: %s", hipGetErrorString(g_enc_setup));
+
+    mx_encoder *e = new mx_encoder();
+    e->cfg = *cfg;
+    e->device = device;
+    auto bail = [&](int code) {
+        mx_encoder_destroy(e);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess)
+        return bail(fail(MX_EDEVICE, "stream/event creation failed"));
+
+    const size_t H = (size_t)cfg->hidden, F = (size_t)cfg->ffn;
+    const float *p = static_cast<const float *>(weights);
+    auto take = [&](size_t n) {
+        const float *r = p;
+        p += n;
+        return r;
+    };
+#define MX_TRY(x)                      \
+    do {                               \
+        int _rc = (x);                 \
+        if (_rc != MX_OK) return bail(_rc); \
+    } while (0)
+    MX_TRY(upload_f32(e, take((size_t)cfg->vocab * H), (size_t)cfg->vocab * H, &e->word));
+    MX_TRY(upload_f32(e, take((size_t)cfg->max_pos * H), (size_t)cfg->max_pos * H, &e->pos));
+    {
+        const float *ty = take((size_t)cfg->type_vocab * H);
+        MX_TRY(upload_f32(e, ty, H, &e->type0));  // token_type 0 only (single-segment inputs)
+    }
+    MX_TRY(upload_f32(e, take(H), H, &e->eg));
+    MX_TRY(upload_f32(e, take(H), H, &e->eb));
+    e->layers.resize(cfg->layers);
+    for (Layer &L : e->layers) {
+        std::vector<float> wqkv(3 * H * H), bqkv(3 * H);
+        for (int part = 0; part < 3; ++part) {
+            memcpy(wqkv.data() + part * H * H, take(H * H), H * H * sizeof(float));
+            memcpy(bqkv.data() + part * H, take(H), H * sizeof(float));
+        }
+        MX_TRY(upload_bf16(e, wqkv.data(), 3 * H * H, &L.wqkv));
+        MX_TRY(upload_f32(e, bqkv.data(), 3 * H, &L.bqkv));
+        MX_TRY(upload_bf16(e, take(H * H), H * H, &L.wo));
+        MX_TRY(upload_f32(e, take(H), H, &L.bo));
+        MX_TRY(upload_f32(e, take(H), H, &L.ln1g));
+        MX_TRY(upload_f32(e, take(H), H, &L.ln1b));
+        MX_TRY(upload_bf16(e, take(F * H), F * H, &L.wi));
+        MX_TRY(upload_f32(e, take(F), F, &L.bi));
+        MX_TRY(upload_bf16(e, take(H * F), H * F, &L.wo2));
+        MX_TRY(upload_f32(e, take(H), H, &L.bo2));
+        MX_TRY(upload_f32(e, take(H), H, &L.ln2g));
+        MX_TRY(upload_f32(e, take(H), H, &L.ln2b));
+    }
+#undef MX_TRY
+    *out = e;
+    return MX_OK;
+}
+
+void mx_encoder_destroy(mx_encoder *e) {
+    if (!e) return;
+    DeviceGuard g(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void *p : e->allocs) (void)hipFree(p);
+    free_ws(e);
+    void *ptrs[] = {e->cu, e->lens_dev, e->ids_dev, e->out_dev};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+static int check_call(mx_encoder *e, const void *ids, const void *lens, int B, int S, const void *out) {
+    if (!e) return fail(MX_ESEARCH, "null encoder");
+    if (B < 0 || S < 1) return fail(MX_EINVAL, "bad batch shape B=%d S=%d", B, S);
+    if (S > e->cfg.max_pos) return fail(MX_EINVAL, "S=%d exceeds max_pos=%d", S, e->cfg.max_pos);
+    if (B > 0 && (!ids || !lens || !out)) return fail(MX_EINVAL, "null argument");
+    return MX_OK;
+}
+
+int mx_encoder_encode_device(mx_encoder *e, const int32_t *d_ids, const int32_t *d_lens, int B, int S, float *d_out) {
+    int rc = check_call(e, d_ids, d_lens, B, S, d_out);
+    if (rc != MX_OK || B == 0) return rc;
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    std::vector<int32_t> h_lens((size_t)B);
+    MX_HIP(hipMemcpy(h_lens.data(), d_lens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return encode_all(e, d_ids, h_lens.data(), d_lens, B, S, d_out);
+}
+
+int mx_encoder_encode(mx_encoder *e, const int32_t *ids, const int32_t *lens, int B, int S, float *out) {
+    int rc = check_call(e, ids, lens, B, S, out);
+    if (rc != MX_OK || B == 0) return rc;
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    rc = ensure_ws(e, 0, B, B * S);
+    if (rc != MX_OK) return rc;
+    MX_HIP(hipMemcpyAsync(e->ids_dev, ids, (size_t)B * S * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    MX_HIP(hipMemcpyAsync(e->lens_dev, lens, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    rc = encode_all(e, e->ids_dev, lens, e->lens_dev, B, S, e->out_dev);
+    if (rc != MX_OK) return rc;
+    MX_HIP(hipMemcpy(out, e->out_dev, (size_t)B * e->cfg.hidden * sizeof(float), hipMemcpyDeviceToHost));
+    return MX_OK;
+}
+
+int mx_encoder_set_profiling(mx_encoder *e, int on) {
+    if (!e) return fail(MX_EINVAL, "null encoder");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->profiling = on != 0;
+    return MX_OK;
+}
+
+int mx_encoder_get_stats(mx_encoder *e, mx_encoder_stats *out) {
+    if (!e || !out) return fail(MX_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    *out = e->stats;
+    return MX_OK;
+}
+
+int mx_encoder_reset_stats(mx_encoder *e) {
+    if (!e) return fail(MX_EINVAL, "null encoder");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->stats = mx_encoder_stats{};
+    return MX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+"""Encoder configurations and weight packing for ``mx_encoder_create``.
+
+The blob layout (f32, HF ``BertModel`` tensor names, Linear weights ``[out, in]``) is documented in
+``include/memex_hip.h``.  ``pack_weights`` accepts any mapping name -> array (a torch ``state_dict``
+with or without the ``bert.`` prefix, a safetensors file via :func:`load_safetensors`);
+``synthetic_weights`` produces seeded weights of the real shapes -- pretrained checkpoints are not
+reachable offline, so parity work and benchmarks run on these.
+
+Reference: the model zoo is selected by ``EmbeddingsModelType`` / ``ModelConfig``
+(lib/libmemex/src/llm/embedding.rs:25-73); the default is all-MiniLM-L12-v2.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+from typing import Dict, List, Mapping, Tuple
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class EncoderConfig:
+    layers: int
+    hidden: int
+    heads: int
+    ffn: int
+    vocab: int = 30522
+    max_pos: int = 512
+    type_vocab: int = 2
+    ln_eps: float = 1e-12
+    pooling: str = "mean"      # "mean" (MiniLM) | "cls" (bge)
+    normalize: bool = True
+    max_seq_length: int = 256  # sentence_bert_config.json truncation
+
+    def as_dict(self) -> dict:
+        return asdict(self)
+
+
+ALL_MINILM_L6_V2 = EncoderConfig(layers=6, hidden=384, heads=12, ffn=1536, max_seq_length=256)
+ALL_MINILM_L12_V2 = EncoderConfig(layers=12, hidden=384, heads=12, ffn=1536, max_seq_length=128)
+BGE_BASE_EN = EncoderConfig(layers=12, hidden=768, heads=12, ffn=3072, pooling="cls", max_seq_length=512)
+
+
+def tensor_order(cfg: EncoderConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    H, F = cfg.hidden, cfg.ffn
+    out = [("embeddings.word_embeddings.weight", (cfg.vocab, H)),
+           ("embeddings.position_embeddings.weight", (cfg.max_pos, H)),
+           ("embeddings.token_type_embeddings.weight", (cfg.type_vocab, H)),
+           ("embeddings.LayerNorm.weight", (H,)), ("embeddings.LayerNorm.bias", (H,))]
+    for l in range(cfg.layers):
+        p = f"encoder.layer.{l}."
+        for n in ("query", "key", "value"):
+            out += [(p + f"attention.self.{n}.weight", (H, H)), (p + f"attention.self.{n}.bias", (H,))]
+        out += [(p + "attention.output.dense.weight", (H, H)), (p + "attention.output.dense.bias", (H,)),
+                (p + "attention.output.LayerNorm.weight", (H,)), (p + "attention.output.LayerNorm.bias", (H,)),
+                (p + "intermediate.dense.weight", (F, H)), (p + "intermediate.dense.bias", (F,)),
+                (p + "output.dense.weight", (H, F)), (p + "output.dense.bias", (H,)),
+                (p + "output.LayerNorm.weight", (H,)), (p + "output.LayerNorm.bias", (H,))]
+    return out
+
+
+def pack_weights(state: Mapping[str, object], cfg: EncoderConfig) -> np.ndarray:
+    """-> contiguous f32 blob in the order ``mx_encoder_create`` expects."""
+    parts = []
+    for name, shape in tensor_order(cfg):
+        t = None
+        for key in (name, "bert." + name, "0.auto_model." + name, "model." + name):
+            if key in state:
+                t = state[key]
+                break
+        if t is None:
+            raise KeyError(f"weight '{name}' missing")
+        a = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+        a = np.asarray(a, dtype=np.float32)
+        if tuple(a.shape) != shape:
+            raise ValueError(f"{name}: shape {a.shape}, expected {shape}")
+        parts.append(a.reshape(-1))
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+def synthetic_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded weights with the real shapes (BERT-style init scales; LayerNorm near identity)."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in tensor_order(cfg):
+        if name.endswith("LayerNorm.weight"):
+            a = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith("LayerNorm.bias"):
+            a = 0.05 * rng.standard_normal(shape)
+        elif name.endswith(".bias"):
+            a = 0.02 * rng.standard_normal(shape)
+        elif "embeddings" in name:
+            a = 0.05 * rng.standard_normal(shape)
+        else:
+            a = rng.standard_normal(shape) * (1.0 / np.sqrt(shape[1]))  # keeps activations O(1)
+        out[name] = a.astype(np.float32)
+    return out
+
+
+def load_safetensors(path: str) -> Dict[str, np.ndarray]:
+    from safetensors.numpy import load_file
+    return load_file(path)
