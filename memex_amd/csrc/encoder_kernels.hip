@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vector (HIP's uint4 struct defeats SROA)
 
 // ---------------------------------------------------------------------------------------------
 // K2: GEMM  C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue)
@@ -55,18 +56,24 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
     const int m0 = blockIdx.x * G::BM;
     const int n0 = blockIdx.y * G::BN;
 
+    // kernel-argument fields used inside the staging lambdas are copied to locals first: capturing
+    // the by-value struct by reference makes hipcc materialise it in scratch memory
+    const bf16_t *const pa = p.a;
+    const bf16_t *const pw = p.w;
+    const int lda = p.lda, kdim = p.k;
+
     constexpr int NA = (G::BM * G::CPR + 511) / 512;
     constexpr int NW = (G::BN * G::CPR + 511) / 512;
-    uint4 ra[NA], rw[NW];
+    u32x4 ra[NA], rw[NW];
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&ra, &rw, pa, pw, lda, kdim, m0, n0, tid](int kt) __attribute__((always_inline)) {
         const int k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = tid + i * 512;
             if (c < G::BM * G::CPR) {
                 const int row = c / G::CPR, cc = c % G::CPR;
-                ra[i] = *reinterpret_cast<const uint4 *>(p.a + (size_t)(m0 + row) * p.lda + k0 + cc * 8);
+                ra[i] = *reinterpret_cast<const u32x4 *>(pa + (size_t)(m0 + row) * lda + k0 + cc * 8);
             }
         }
 #pragma unroll
@@ -74,22 +81,22 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
             const int c = tid + i * 512;
             if (c < G::BN * G::CPR) {
                 const int row = c / G::CPR, cc = c % G::CPR;
-                rw[i] = *reinterpret_cast<const uint4 *>(p.w + (size_t)(n0 + row) * p.k + k0 + cc * 8);
+                rw[i] = *reinterpret_cast<const u32x4 *>(pw + (size_t)(n0 + row) * kdim + k0 + cc * 8);
             }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&ra, &rw, tid](int buf) __attribute__((always_inline)) {
         char *sa = smem + buf * G::STAGE;
         char *sw = sa + G::BM * G::P;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = tid + i * 512;
-            if (c < G::BM * G::CPR) *reinterpret_cast<uint4 *>(sa + (c / G::CPR) * G::P + (c % G::CPR) * 16) = ra[i];
+            if (c < G::BM * G::CPR) *reinterpret_cast<u32x4 *>(sa + (c / G::CPR) * G::P + (c % G::CPR) * 16) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int c = tid + i * 512;
-            if (c < G::BN * G::CPR) *reinterpret_cast<uint4 *>(sw + (c / G::CPR) * G::P + (c % G::CPR) * 16) = rw[i];
+            if (c < G::BN * G::CPR) *reinterpret_cast<u32x4 *>(sw + (c / G::CPR) * G::P + (c % G::CPR) * 16) = rw[i];
         }
     };
 
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = p.k / BK;
+    const int nk = kdim / BK;
     load_tile(0);
     store_tile(0);
     __syncthreads();
