@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--recall-queries", type=int, default=4, help="queries re-answered on the EXACT path")
+    ap.add_argument("--ingest-chunks", type=int, default=4096, help="512-token chunks per GPU for the ingest leg (0 = skip)")
     return ap.parse_args()
 
 
@@ -62,7 +63,7 @@ def cpu_baseline(dim: int, batch: int, k: int, rows_total: int, target_s: float)
     t0 = time.perf_counter()
     orc.search(x, q, k)
     dt = max(time.perf_counter() - t0, 1e-4)
-    rows = int(min(max(cal_rows * target_s / dt, cal_rows), 400_000))
+    rows = int(min(max(cal_rows * target_s / dt, cal_rows), 1_600_000))
     x = rng.standard_normal((rows, dim), dtype=np.float32)
     t0 = time.perf_counter()
     orc.search(x, q, k)
@@ -74,6 +75,81 @@ def cpu_baseline(dim: int, batch: int, k: int, rows_total: int, target_s: float)
         "cores": cores,
         "kind": "port",
         "sample": f"{batch} queries x {rows} rows x {dim}-d in {dt:.2f}s, scaled linearly to {rows_total} rows",
+    }
+
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
+
+
+def encoder_cpu_baseline(cfg, chunks: int = 16):
+    """libtorch CPU f32 forward of the same architecture (transformers.BertModel eager, all host
+    threads): the closest available proxy for rust-bert's `model.encode` (embedding.rs:109), which
+    drives the same operator library through tch.  Bounded sample."""
+    try:
+        import torch
+        from transformers import BertConfig, BertModel
+        hc = BertConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
+                        num_attention_heads=cfg.heads, intermediate_size=cfg.ffn, max_position_embeddings=cfg.max_pos)
+        m = BertModel(hc, add_pooling_layer=False).eval()
+        ids = torch.randint(1000, cfg.vocab, (chunks, 512))
+        with torch.no_grad():
+            m(input_ids=ids[:2])
+            t0 = time.perf_counter()
+            m(input_ids=ids)
+            dt = time.perf_counter() - t0
+        return {"value": chunks / dt, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{chunks} x 512-token chunks, transformers.BertModel f32 eager on CPU, {dt:.2f}s"}
+    except Exception as e:  # the baseline is optional; never fail the bench for it
+        return {"error": repr(e)}
+
+
+def ingest_leg(chunks: int, dev: int, world: int, cpu_too: bool = True):
+    """BASELINE.json configs[4] shape: 512-token chunks, all-MiniLM-L6-v2 architecture with seeded
+    synthetic weights (no checkpoints offline), bf16 MFMA encoder, data-parallel replicas (no
+    collective).  Reported next to the headline metric; not part of `value`."""
+    import torch
+    import torch.distributed as dist
+    from memex_amd import weights as W
+    from memex_amd.encoder import Encoder
+
+    cfg = W.ALL_MINILM_L6_V2
+    enc = Encoder(cfg, W.synthetic_weights(cfg, 0), device=dev)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    ids = torch.randint(1000, cfg.vocab, (chunks, 512), device="cuda", dtype=torch.int32, generator=g)
+    lens = torch.full((chunks,), 512, device="cuda", dtype=torch.int32)
+    out = torch.zeros((chunks, cfg.hidden), device="cuda")
+    torch.cuda.synchronize()
+    enc.encode_device(ids[:256], lens[:256], out[:256])  # warm-up
+    enc.reset_stats()
+    enc.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        enc.encode_device(ids, lens, out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = enc.stats()
+    enc.close()
+    tf = st.flops / (st.gpu_ms / 1e3) / 1e12 if st.gpu_ms > 0 else 0.0
+    cpu = None
+    if world == 1 and cpu_too:
+        cpu = encoder_cpu_baseline(cfg)
+    return {
+        "cpu_baseline": cpu,
+        "metric": "ingest chunks/sec (512-token chunks, all-MiniLM-L6-v2 shape, bf16 MFMA)",
+        "value": chunks * reps * world / dt,
+        "unit": "chunks/s",
+        "chunks_per_gpu": chunks * reps,
+        "gflop_per_chunk": st.flops / max(1, st.sequences) / 1e9,
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / MFMA_PEAK_TFLOPS, "note": "rank-0 GPU time by HIP events on the encoder stream"},
     }
 
 
@@ -201,6 +277,7 @@ def main():
             recall_exact_order = None
     if world > 1:
         dist.barrier()
+    ingest = ingest_leg(a.ingest_chunks, dev, world, not a.no_cpu_baseline) if a.ingest_chunks > 0 else None
 
     if rank == 0:
         scan_s = st.scan_ms / 1e3
@@ -236,6 +313,8 @@ def main():
                 "traffic": traffic_from_profile(rows_total, a.dim, world),
             },
         }
+        if ingest is not None:
+            out["ingest"] = ingest
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.dim, a.batch, k, rows_total, a.cpu_seconds)
         print(json.dumps(out), flush=True)
