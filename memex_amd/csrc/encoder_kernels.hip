@@ -13,6 +13,7 @@
 #include "encoder_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace mx {
 
@@ -24,83 +25,111 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vecto
 
 // ---------------------------------------------------------------------------------------------
 // K2: GEMM  C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue)
-//   workgroup = 8 waves as WM x WN; wave tile 64 x 96 = 2 x 3 MFMA 32x32 tiles (96 acc VGPRs,
-//   6 MFMAs per 5 fragment reads).  Tiles are staged global -> registers -> LDS (padded rows:
-//   pitch = BK*2+16 bytes keeps ds_read_b128 fragment reads conflict-free), double buffered with
-//   one barrier per k-tile; the next k-tile's global loads are in flight during the MFMAs.
+//   workgroup = WM x WN waves, wave tile 64 (m) x 96 (n) = 2 x 3 MFMA 32x32x16 tiles (96 acc VGPRs,
+//   6 MFMAs per 5 fragment reads).  Tiles are small enough for 2-3 workgroups per CU so that one
+//   workgroup's prologue / epilogue overlaps another's MFMAs (K is only 384..3072 here).
+//   Staging: global -> registers -> LDS, rows padded to BK*2+16 bytes (conflict-free
+//   ds_read_b128 fragment reads), double buffered, one barrier per k-tile, next tile's global
+//   loads in flight during the MFMAs.
+//   Operand roles: by default the WEIGHT fragment is the MFMA A operand and the activation
+//   fragment the B operand, i.e. the wave accumulates C^T tiles: a lane then owns one output row m
+//   and 4 consecutive output columns n per register group -> the epilogue packs 4 bf16 into one
+//   ds_write_b64 of the row-major output tile.  The V third of the QKV projection wants the
+//   transposed (feature-major) output and uses the opposite roles for the same reason.
+//   Epilogue: registers -> bf16 tile in LDS -> 16-byte coalesced copy-out (+ residual + LayerNorm).
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int BK>
+template <int WM, int WN, int BK, int S>
 struct GemmGeom {
+    static_assert(BK == 32, "staging layout below is written for 64-byte (BK = 32) rows");
+    static constexpr int NT = 64 * WM * WN;               // threads
+    static constexpr int NWAVE = WM * WN;
     static constexpr int BM = 64 * WM;
     static constexpr int BN = 96 * WN;
-    static constexpr int P = BK * 2 + 16;                 // staged row pitch (bytes)
-    static constexpr int STAGE = (BM + BN) * P;           // one stage: A rows then W rows
-    static constexpr int PO = BN * 2 + 16;                // output tile pitch, row-major
-    static constexpr int POT = BM * 2 + 16;               // output tile pitch, transposed (v^T)
+    static constexpr int ROWS = BM + BN;                  // staged rows per k-tile: A rows then W rows
+    static constexpr int STAGE = ROWS * BK * 2;           // bytes per stage (unpadded, lane-linear DMA image)
+    static constexpr int PIECES = ROWS / 16;              // 1 KiB DMA pieces (16 rows x 64 B) per stage
+    static constexpr int PPW = (PIECES + NWAVE - 1) / NWAVE;  // pieces each wave issues per k-tile
+    static constexpr int PO = BN * 2 + 16;                // output tile pitch, row-major [m][n]
+    static constexpr int POT = BM * 2 + 16;               // output tile pitch, feature-major [n][m]
     static constexpr int OUT_BYTES = (BM * PO > BN * POT) ? BM * PO : BN * POT;
-    static constexpr int LDS = (2 * STAGE > OUT_BYTES) ? 2 * STAGE : OUT_BYTES;
-    static constexpr int CPR = BK * 2 / 16;               // 16-B chunks per staged row
+    static constexpr int LDS = (S * STAGE > OUT_BYTES) ? S * STAGE : OUT_BYTES;
+    static_assert(ROWS % 16 == 0, "piece split");
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf to ~1.5e-7 absolute (Abramowitz-Stegun 7.1.26): the result is rounded to bf16 (2^-9) anyway
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erfv = x < 0.0f ? -e : e;
+    return 0.5f * x * (1.0f + erfv);
+}
 
-template <int EPI, int WM, int WN, int BK>
-__global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
-    using G = GemmGeom<WM, WN, BK>;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <int EPI, int WM, int WN, int BK, int S>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) {
+    using G = GemmGeom<WM, WN, BK, S>;
+    constexpr int NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * G::BM;
-    const int n0 = blockIdx.y * G::BN;
-
-    // kernel-argument fields used inside the staging lambdas are copied to locals first: capturing
-    // the by-value struct by reference makes hipcc materialise it in scratch memory
-    const bf16_t *const pa = p.a;
-    const bf16_t *const pw = p.w;
-    const int lda = p.lda, kdim = p.k;
-
-    constexpr int NA = (G::BM * G::CPR + 511) / 512;
-    constexpr int NW = (G::BN * G::CPR + 511) / 512;
-    u32x4 ra[NA], rw[NW];
-
-    auto load_tile = [&ra, &rw, pa, pw, lda, kdim, m0, n0, tid](int kt) __attribute__((always_inline)) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int c = tid + i * 512;
-            if (c < G::BM * G::CPR) {
-                const int row = c / G::CPR, cc = c % G::CPR;
-                ra[i] = *reinterpret_cast<const u32x4 *>(pa + (size_t)(m0 + row) * lda + k0 + cc * 8);
-            }
+    // 1-D grid, XCD-aware order: workgroup b runs on XCD b%8 (observed dispatch rule, speed only).
+    // Within an XCD consecutive workgroups walk the n-tiles of one m-tile, so the activation rows
+    // they share are fetched into that XCD's L2 once.
+    const int n_tiles = p.n / G::BN, m_tiles = p.m / G::BM;
+    int m_idx, n_idx;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+        const int full = (m_tiles / 8) * 8;  // m-tiles covered by the XCD-interleaved part
+        if (b < full * n_tiles) {
+            m_idx = (q / n_tiles) * 8 + xcd;
+            n_idx = q % n_tiles;
+        } else {  // tail (m_tiles % 8 m-tiles): plain order
+            const int r = b - full * n_tiles;
+            m_idx = full + r / n_tiles;
+            n_idx = r % n_tiles;
         }
+    }
+    const int m0 = m_idx * G::BM;
+    const int n0 = n_idx * G::BN;
+    const int kdim = p.k;
+    const int nk = kdim / BK;
+
+    // ---- staging by LDS-DMA (global_load_lds_dwordx4): stage = ROWS x 64 B, lane-linear.
+    // Piece P = rows 16P..16P+15; lane l -> row 16P + (l>>2), physical 16-B chunk l&3.  Bank
+    // conflicts of the fragment reads are removed by permuting the SOURCE chunk:
+    // physical chunk pc holds logical chunk pc ^ ((row>>2)&3).
+    const char *src[G::PPW];   // per-lane source address of each of this wave's pieces at k = 0
+    uint32_t dst[G::PPW];      // wave-uniform LDS offset of the piece inside a stage
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int c = tid + i * 512;
-            if (c < G::BN * G::CPR) {
-                const int row = c / G::CPR, cc = c % G::CPR;
-                rw[i] = *reinterpret_cast<const u32x4 *>(pw + (size_t)(n0 + row) * kdim + k0 + cc * 8);
-            }
-        }
+    for (int i = 0; i < G::PPW; ++i) {
+        int piece = wave + i * G::NWAVE;
+        piece = piece < G::PIECES ? piece : G::PIECES - 1;  // surplus issues re-load the last piece
+        const int row = piece * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        const bf16_t *base = row < G::BM ? p.a + (size_t)(m0 + row) * p.lda : p.w + (size_t)(n0 + row - G::BM) * kdim;
+        src[i] = reinterpret_cast<const char *>(base + c * 8);
+        dst[i] = (uint32_t)piece * 1024u;
+    }
+    auto issue_tile = [&](int kt) __attribute__((always_inline)) {
+        const uint32_t sbase = (uint32_t)(kt % S) * G::STAGE;
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src[i] + (size_t)kt * (BK * 2)),
+                                             (lds_void_t *)(smem + __builtin_amdgcn_readfirstlane(sbase + dst[i])), 16, 0, 0);
     };
-    auto store_tile = [&ra, &rw, tid](int buf) __attribute__((always_inline)) {
-        char *sa = smem + buf * G::STAGE;
-        char *sw = sa + G::BM * G::P;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int c = tid + i * 512;
-            if (c < G::BM * G::CPR) *reinterpret_cast<u32x4 *>(sa + (c / G::CPR) * G::P + (c % G::CPR) * 16) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int c = tid + i * 512;
-            if (c < G::BN * G::CPR) *reinterpret_cast<u32x4 *>(sw + (c / G::CPR) * G::P + (c % G::CPR) * 16) = rw[i];
-        }
-    };
 
-    f32x16 acc[2][3];
+    int part = 0;
+    if (EPI == EPI_QKV) part = n0 / p.hidden;  // block-uniform: BN divides hidden
+    const bool feature_major = (EPI == EPI_QKV) && part == 2;
+
+    f32x16 acc[2][3];  // [i: 32-row m block][j: 32-col n block]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -108,79 +137,108 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = kdim / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    const int a_off = (wm * 64 + l31) * G::P + h * 16;
-    const int w_off = G::BM * G::P + (wn * 96 + l31) * G::P + h * 16;
+    // fragment read offsets: row (.. + l31), logical chunk (2*ks + h) -> physical ^ ((l31>>2)&3)
+    const uint32_t sw0 = (uint32_t)((h ^ ((l31 >> 2) & 3)) << 4), sw1 = sw0 ^ 32u;
+    const uint32_t a_row = (uint32_t)(wm * 64 + l31) * (BK * 2);
+    const uint32_t w_row = (uint32_t)(G::BM + wn * 96 + l31) * (BK * 2);
+
+#pragma unroll 1
+    for (int kt = 0; kt < S - 1 && kt < nk; ++kt) issue_tile(kt);
+#pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const char *st = smem + (kt & 1) * G::STAGE;
+        // tile kt has landed once at most the (S-2) newer tiles' pieces of this wave are in flight
+        if (kt + S - 2 < nk) {
+            if (G::PPW * (S - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (G::PPW * (S - 2) == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt landed; stage (kt-1)%S is free
+        if (kt + S - 1 < nk) issue_tile(kt + S - 1);
+        const char *st = smem + (kt % S) * G::STAGE;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+            const uint32_t sw = ks == 0 ? sw0 : sw1;
             bf16x8 af[2], bf[3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(st + a_off + i * 32 * G::P + ks * 32);
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(st + a_row + i * 32 * (BK * 2) + sw);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const bf16x8 *>(st + w_off + j * 32 * G::P + ks * 32);
+            for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const bf16x8 *>(st + w_row + j * 32 * (BK * 2) + sw);
+            if (feature_major) {  // D[m][n]: lane owns column n, 4 consecutive rows m per group
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            } else {              // D^T[n][m]: lane owns row m, 4 consecutive columns n per group
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // all waves are done with the ring: its space becomes the output tile
+
+    // ---- epilogue pass 1: registers -> bf16 tile in LDS (staging buffers are free now).
+    // 32x32 D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    if (feature_major) {
+        // col = n (one bias per lane), rows = m: write [n][m .. m+3] as one 8-byte store
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = wn * 96 + j * 32 + l31;
+            const float b = p.bias[n0 + col];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int row0 = wm * 64 + i * 32 + 8 * rg + 4 * h;
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(acc[i][j][rg * 4 + e] + b);
+                    *reinterpret_cast<bf16x4 *>(smem + col * G::POT + row0 * 2) = pk;
+                }
         }
-        if (kt + 1 < nk) store_tile((kt + 1) & 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue pass 1: registers -> bf16 tile in LDS (staging buffers are free now)
-    // D layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    int part = 0;
-    if (EPI == EPI_QKV) part = n0 / p.hidden;  // block-uniform: BN divides hidden
-    const bool transposed = (EPI == EPI_QKV) && part == 2;
-    const float oscale = (EPI == EPI_QKV && part == 0) ? p.qscale : 1.0f;
+    } else {
+        // col = m (this lane's output row), rows = n: write [m][n .. n+3] as one 8-byte store
+        const float oscale = (EPI == EPI_QKV && part == 0) ? p.qscale : 1.0f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int col = wn * 96 + j * 32 + l31;
-        const float b = p.bias[n0 + col];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int row0 = wm * 64 + i * 32 + 8 * rg + 4 * h;
-                float v[4];
+                const int nloc = wn * 96 + j * 32 + 8 * rg + 4 * h;
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + nloc);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][rg * 4 + e] + b;
-                    if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
-                    v[e] = t * oscale;
-                }
-                if (transposed) {
+                for (int i = 0; i < 2; ++i) {
+                    const int mrow = wm * 64 + i * 32 + l31;
                     bf16x4 pk;
-                    pk[0] = (__bf16)v[0]; pk[1] = (__bf16)v[1]; pk[2] = (__bf16)v[2]; pk[3] = (__bf16)v[3];
-                    *reinterpret_cast<bf16x4 *>(smem + col * G::POT + row0 * 2) = pk;
-                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        *reinterpret_cast<__bf16 *>(smem + (row0 + e) * G::PO + col * 2) = (__bf16)v[e];
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[i][j][rg * 4 + e] + b4[e];
+                        if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
+                        pk[e] = (__bf16)(t * oscale);
+                    }
+                    *reinterpret_cast<bf16x4 *>(smem + mrow * G::PO + nloc * 2) = pk;
                 }
             }
-        }
     }
     __syncthreads();
 
     // ---- epilogue pass 2: coalesced 16-byte copy-out (+ residual + LayerNorm)
     if (EPI == EPI_BIAS_RES_LN) {
-        constexpr int TPR = 512 / G::BM;           // threads per row
+        constexpr int TPR = NT / G::BM;            // threads per row
         constexpr int CPT = G::BN / TPR / 8;       // 16-B chunks per thread
-        static_assert(G::BN % (TPR * 8) == 0, "row split");
+        static_assert(G::BN % (TPR * 8) == 0 && NT % G::BM == 0, "row split");
         const int row = tid / TPR, prt = tid % TPR;
         float y[CPT * 8];
         float sum = 0.0f;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            const int col = (prt * CPT + c) * 8;
+            // interleave the threads of a row chunk-wise: consecutive threads read consecutive 16 B
+            const int col = (c * TPR + prt) * 8;
             const bf16x8 o = *reinterpret_cast<const bf16x8 *>(smem + row * G::PO + col * 2);
             const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res + (size_t)(m0 + row) * p.ldres + n0 + col);
 #pragma unroll
@@ -203,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
         const float rstd = 1.0f / sqrtf(sq / (float)G::BN + p.eps);
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            const int col = (prt * CPT + c) * 8;
+            const int col = (c * TPR + prt) * 8;
             const f32x4 g0 = *reinterpret_cast<const f32x4 *>(p.gamma + n0 + col);
             const f32x4 g1 = *reinterpret_cast<const f32x4 *>(p.gamma + n0 + col + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p.beta + n0 + col);
@@ -216,13 +274,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
             }
             *reinterpret_cast<bf16x8 *>(p.out + (size_t)(m0 + row) * p.ldo + n0 + col) = o;
         }
-    } else if (transposed) {
+    } else if (feature_major) {
         constexpr int CPF = G::BM / 8;  // chunks per feature row
         const int nloc = n0 - 2 * p.hidden;
-        for (int c = tid; c < G::BN * CPF; c += 512) {
+        for (int c = tid; c < G::BN * CPF; c += NT) {
             const int f = c / CPF, tc = c % CPF;
-            const uint4 v = *reinterpret_cast<const uint4 *>(smem + f * G::POT + tc * 16);
-            *reinterpret_cast<uint4 *>(p.out_vt + (size_t)(nloc + f) * p.ldvt + m0 + tc * 8) = v;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + f * G::POT + tc * 16);
+            *reinterpret_cast<u32x4 *>(p.out_vt + (size_t)(nloc + f) * p.ldvt + m0 + tc * 8) = v;
         }
     } else {
         constexpr int CPO = G::BN / 8;  // chunks per output row
@@ -232,37 +290,40 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
             dst = part == 0 ? p.out : p.out_k;
             nloc = n0 - part * p.hidden;
         }
-        for (int c = tid; c < G::BM * CPO; c += 512) {
+        for (int c = tid; c < G::BM * CPO; c += NT) {
             const int row = c / CPO, cc = c % CPO;
-            const uint4 v = *reinterpret_cast<const uint4 *>(smem + row * G::PO + cc * 16);
-            *reinterpret_cast<uint4 *>(dst + (size_t)(m0 + row) * p.ldo + nloc + cc * 8) = v;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + row * G::PO + cc * 16);
+            *reinterpret_cast<u32x4 *>(dst + (size_t)(m0 + row) * p.ldo + nloc + cc * 8) = v;
         }
     }
 }
 
-template <int EPI, int WM, int WN, int BK>
+template <int EPI, int WM, int WN, int BK, int S>
 static hipError_t gemm_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<EPI, WM, WN, BK>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, GemmGeom<WM, WN, BK>::LDS);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<EPI, WM, WN, BK, S>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GemmGeom<WM, WN, BK, S>::LDS);
 }
 
-template <int EPI, int WM, int WN, int BK>
+template <int EPI, int WM, int WN, int BK, int S>
 static hipError_t gemm_go(hipStream_t s, const GemmParams &p) {
-    using G = GemmGeom<WM, WN, BK>;
+    using G = GemmGeom<WM, WN, BK, S>;
     if (p.m % G::BM || p.n % G::BN || p.k % BK) return hipErrorInvalidValue;
-    dim3 grid(p.m / G::BM, p.n / G::BN);
-    hipLaunchKernelGGL((gemm_kernel<EPI, WM, WN, BK>), grid, dim3(512), G::LDS, s, p);
+    if (EPI == EPI_QKV && p.hidden % G::BN) return hipErrorInvalidValue;
+    dim3 grid((p.m / G::BM) * (p.n / G::BN));
+    hipLaunchKernelGGL((gemm_kernel<EPI, WM, WN, BK, S>), grid, dim3(G::NT), G::LDS, s, p);
     return hipGetLastError();
 }
 
+// tile configurations: 128 x 384 (8 waves, 4-stage 32 KiB ring) everywhere the row is 384-wide or the
+// epilogue is row-independent; 64 x 768 (8 waves, 3-stage 52 KiB ring) for the 768-wide LayerNorm
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
     switch (epi) {
-        case EPI_BIAS: return gemm_go<EPI_BIAS, 2, 4, 64>(s, p);
-        case EPI_BIAS_GELU: return gemm_go<EPI_BIAS_GELU, 2, 4, 64>(s, p);
-        case EPI_QKV: return gemm_go<EPI_QKV, 2, 4, 64>(s, p);
+        case EPI_BIAS: return gemm_go<EPI_BIAS, 2, 4, 32, 4>(s, p);
+        case EPI_BIAS_GELU: return gemm_go<EPI_BIAS_GELU, 2, 4, 32, 4>(s, p);
+        case EPI_QKV: return gemm_go<EPI_QKV, 2, 4, 32, 4>(s, p);
         case EPI_BIAS_RES_LN:
-            if (p.n == 384) return gemm_go<EPI_BIAS_RES_LN, 2, 4, 64>(s, p);
-            if (p.n == 768) return gemm_go<EPI_BIAS_RES_LN, 1, 8, 32>(s, p);
+            if (p.n == 384) return gemm_go<EPI_BIAS_RES_LN, 2, 4, 32, 4>(s, p);
+            if (p.n == 768) return gemm_go<EPI_BIAS_RES_LN, 1, 8, 32, 3>(s, p);
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
@@ -570,11 +631,11 @@ hipError_t launch_pool(hipStream_t s, const bf16_t *x, const int32_t *cu, const 
 
 hipError_t encoder_kernels_setup() {
     hipError_t e;
-    if ((e = gemm_attr<EPI_BIAS, 2, 4, 64>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_BIAS_GELU, 2, 4, 64>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_QKV, 2, 4, 64>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_BIAS_RES_LN, 2, 4, 64>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_BIAS_RES_LN, 1, 8, 32>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS, 2, 4, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS_GELU, 2, 4, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_QKV, 2, 4, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS_RES_LN, 2, 4, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS_RES_LN, 1, 8, 32, 3>()) != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<32>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(512, 32));
     if (e != hipSuccess) return e;
