@@ -426,22 +426,34 @@ hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: attention.  grid = (query blocks of 128, heads, sequences); 4 waves x 32 queries.
+// K3: attention.  grid = (query blocks of 256, heads, sequences); 8 waves x 32 queries.
 // The whole K ([keys][d]) and V^T ([d][keys]) of the (sequence, head) sit in LDS.  Scores are
 // computed TRANSPOSED (A = 32 keys, B = 32 queries) so that a lane owns one query: the running
 // max / sum and the rescale factor are lane-local, P converts to the PV B-operand without any
 // cross-lane movement, and O^T = V^T P^T accumulates with the query still in the lane.
+// At d = 32 the kernel is softmax(VALU)-bound by construction (128 MFMA flops per score), so the
+// VALU work per score is kept minimal: raw v_exp_f32, masking only in the tail key block, the
+// O/l rescale only when some lane's running max actually grew.
+// V^T tile key order: inside every 16-key group the two middle 4-key groups are swapped
+// ([0-3, 8-11, 4-7, 12-15]) -- exactly the keys a lane's P registers hold for one k16 step -- so a
+// PV A-fragment is ONE ds_read_b128.
 // ---------------------------------------------------------------------------------------------
+constexpr int kAttnWaves = 8;
+constexpr int kAttnQ = kAttnWaves * 32;  // queries per workgroup
+
 template <int D>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k,
-                                                        const bf16_t *__restrict__ vt, int ldvt,
-                                                        const int32_t *__restrict__ cu, const int32_t *__restrict__ lens,
-                                                        int hidden, bf16_t *__restrict__ ctx) {
+__global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(const bf16_t *__restrict__ q,
+                                                                    const bf16_t *__restrict__ k,
+                                                                    const bf16_t *__restrict__ vt, int ldvt,
+                                                                    const int32_t *__restrict__ cu,
+                                                                    const int32_t *__restrict__ lens, int hidden,
+                                                                    bf16_t *__restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = kAttnWaves * 64;
     constexpr int KP = D * 2 + 16;  // K row pitch (bytes)
     const int b = blockIdx.z, hd = blockIdx.y, qb = blockIdx.x;
     const int len = lens[b];
-    if (qb * 128 >= len) return;
+    if (qb * kAttnQ >= len) return;
     const int tok0 = cu[b];
     const int sb = (len + 31) / 32 * 32;  // keys rounded to MFMA blocks
     const int VP = sb * 2 + 16;           // V^T row pitch (bytes)
@@ -449,32 +461,34 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
     char *vs = smem + (size_t)sb * KP;
     const int tid = threadIdx.x;
 
-    // ---- stage K (rows >= len zero-filled) and V^T (keys >= len zero-filled)
+    // ---- stage K (rows >= len zero-filled) and V^T (keys >= len zero-filled, permuted key order)
     constexpr int KC = D * 2 / 16;
-    for (int c = tid; c < sb * KC; c += 256) {
+    for (int c = tid; c < sb * KC; c += NT) {
         const int row = c / KC, cc = c % KC;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < len) v = *reinterpret_cast<const uint4 *>(k + (size_t)(tok0 + row) * hidden + hd * D + cc * 8);
-        *reinterpret_cast<uint4 *>(ks + row * KP + cc * 16) = v;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < len) v = *reinterpret_cast<const u32x4 *>(k + (size_t)(tok0 + row) * hidden + hd * D + cc * 8);
+        *reinterpret_cast<u32x4 *>(ks + row * KP + cc * 16) = v;
     }
     const int vc = sb / 8;
-    for (int c = tid; c < D * vc; c += 256) {
-        const int f = c / vc, kc = c % vc;
-        uint4 v = *reinterpret_cast<const uint4 *>(vt + (size_t)(hd * D + f) * ldvt + tok0 + kc * 8);
+    for (int c = tid; c < D * vc; c += NT) {
+        const int f = c / vc, kc = c % vc;  // 8 keys 8kc .. 8kc+7 of feature f
+        bf16x8 t = *reinterpret_cast<const bf16x8 *>(vt + (size_t)(hd * D + f) * ldvt + tok0 + kc * 8);
         if (kc * 8 + 8 > len) {  // mask the tail so that 0 * garbage can never be NaN
-            bf16x8 t = *reinterpret_cast<bf16x8 *>(&v);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (kc * 8 + e >= len) t[e] = (__bf16)0.0f;
-            v = *reinterpret_cast<uint4 *>(&t);
         }
-        *reinterpret_cast<uint4 *>(vs + f * VP + kc * 16) = v;
+        // 4-key groups g = 2*(kc&1), 2*(kc&1)+1 of the 16-key block kc>>1 -> physical (0,2) / (1,3)
+        char *dstrow = vs + f * VP + (kc >> 1) * 32;
+        bf16x4 lo = {t[0], t[1], t[2], t[3]}, hi = {t[4], t[5], t[6], t[7]};
+        *reinterpret_cast<bf16x4 *>(dstrow + (kc & 1) * 8) = lo;
+        *reinterpret_cast<bf16x4 *>(dstrow + 16 + (kc & 1) * 8) = hi;
     }
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int q0 = qb * 128 + wave * 32;
+    const int q0 = qb * kAttnQ + wave * 32;
     if (q0 >= len) return;
     const int qi = q0 + l31;
 
@@ -495,8 +509,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
     float m_run = -1e30f, l_run = 0.0f;
+    const int nkb = sb / 32;
+    const int full_blocks = len / 32;  // key blocks without padding keys
 
-    for (int kb = 0; kb < sb / 32; ++kb) {
+    for (int kb = 0; kb < nkb; ++kb) {
         // S^T tile: rows = keys kb*32 + (r&3) + 8*(r>>2) + 4h, col = query l31
         f32x16 sc;
 #pragma unroll
@@ -506,29 +522,36 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(ks + (kb * 32 + l31) * KP + s * 32 + h * 16);
             sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
         }
-        float bm = -1e30f;
+        if (kb >= full_blocks) {  // wave-uniform: only the last block can hold padding keys
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            sc[r] = key < len ? sc[r] : -1e30f;  // reference: additive -10000 mask == exclusion in f32
-            bm = fmaxf(bm, sc[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                sc[r] = key < len ? sc[r] : -1e30f;  // reference: additive -10000 mask == exclusion in f32
+            }
         }
+        float bm = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+#pragma unroll
+        for (int r = 4; r < 16; r += 4) bm = fmaxf(bm, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
         bm = fmaxf(bm, __shfl_xor(bm, 32));
-        const float m_new = fmaxf(m_run, bm);
-        const float alpha = exp2f(m_run - m_new);
+        if (__builtin_amdgcn_ballot_w64(bm > m_run) != 0) {  // some query's max grew: rescale (rare later on)
+            const float m_new = fmaxf(m_run, bm);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
         float ps = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sc[r] = exp2f(sc[r] - m_new);
+            sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_run);
             ps += sc[r];
         }
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-        // O^T += V^T P^T: k16 step s uses this lane's p[8s .. 8s+7] = keys 16s + 8(i>>2) + 4h + (i&3)
+        l_run += ps;
+        // O^T += V^T P^T: k16 step s uses this lane's p[8s .. 8s+7] = keys 16s + 8(i>>2) + 4h + (i&3),
+        // stored contiguously in the permuted V^T tile at physical key offset 16s + 8h
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 pf;
@@ -536,12 +559,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s + e];
 #pragma unroll
             for (int t = 0; t < D / 32; ++t) {
-                const char *vrow = vs + (t * 32 + l31) * VP + (kb * 32 + 16 * s + 4 * h) * 2;
-                const bf16x4 v0 = *reinterpret_cast<const bf16x4 *>(vrow);
-                const bf16x4 v1 = *reinterpret_cast<const bf16x4 *>(vrow + 16);
-                bf16x8 vf;
-                vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-                vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(vs + (t * 32 + l31) * VP + (kb * 32 + 16 * s + 8 * h) * 2);
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
             }
         }
@@ -572,12 +590,12 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
                             const int32_t *cu, const int32_t *lens, int B, int max_len, int heads, int d_head,
                             int hidden, bf16_t *ctx) {
     if (max_len > 512 || max_len < 1) return hipErrorInvalidValue;
-    dim3 grid((max_len + 127) / 128, heads, B);
+    dim3 grid((max_len + kAttnQ - 1) / kAttnQ, heads, B);
     const size_t lds = attn_lds(max_len, d_head);
     if (d_head == 32)
-        hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx);
+        hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx);
     else if (d_head == 64)
-        hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx);
+        hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -586,46 +604,52 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
 // ---------------------------------------------------------------------------------------------
 // K5: pooling + L2 normalise
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool_kernel(const bf16_t *__restrict__ x, const int32_t *__restrict__ cu,
-                                                   const int32_t *__restrict__ lens, int hidden, int pooling_cls,
-                                                   int normalize, float *__restrict__ out) {
-    __shared__ float s_red[4];
+__global__ __launch_bounds__(1024) void pool_kernel(const bf16_t *__restrict__ x, const int32_t *__restrict__ cu,
+                                                    const int32_t *__restrict__ lens, int hidden, int pooling_cls,
+                                                    int normalize, float *__restrict__ out) {
+    // 1024 threads = hidden/8 column chunks (16-byte loads) x token stripes; partial sums meet in LDS
+    __shared__ float s_part[8192];  // [stripe][hidden] partial sums (deterministic reduction order)
+    __shared__ float s_red[16];
     const int b = blockIdx.x;
     const int tok0 = cu[b];
-    const int len = lens[b];
+    const int len = pooling_cls ? 1 : lens[b];
     const int tid = threadIdx.x;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};  // hidden <= 1024
-    const int per = (hidden + 255) / 256;
-    for (int i = 0; i < per; ++i) {
-        const int c = tid + i * 256;
-        if (c >= hidden) break;
-        float acc = 0.0f;
-        if (pooling_cls) {
-            acc = (float)x[(size_t)tok0 * hidden + c];
-        } else {
-            for (int t = 0; t < len; ++t) acc += (float)x[(size_t)(tok0 + t) * hidden + c];
-            acc = acc / fmaxf((float)len, 1e-9f);  // sum(h*m) / clamp(sum(m), 1e-9)
+    const int nch = hidden / 8;              // column chunks (48 or 96)
+    const int stripes = 1024 / nch;          // token stripes
+    const int ch = tid % nch, st = tid / nch;
+    if (st < stripes) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = st; t < len; t += stripes) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + (size_t)(tok0 + t) * hidden + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
         }
-        v[i] = acc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_part[st * hidden + ch * 8 + e] = a[e];
     }
-    float ss = 0.0f;
-    for (int i = 0; i < per; ++i) ss += v[i] * v[i];
+    __syncthreads();
+    const float denom = pooling_cls ? 1.0f : fmaxf((float)len, 1e-9f);  // sum(h*m) / clamp(sum(m), 1e-9)
+    float v = 0.0f, ss = 0.0f;
+    if (tid < hidden) {
+        for (int i = 0; i < stripes; ++i) v += s_part[i * hidden + tid];
+        v = v / denom;
+        ss = v * v;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     if ((tid & 63) == 0) s_red[tid >> 6] = ss;
     __syncthreads();
-    const float nrm = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
-    const float sc = normalize ? 1.0f / fmaxf(nrm, 1e-12f) : 1.0f;
-    for (int i = 0; i < per; ++i) {
-        const int c = tid + i * 256;
-        if (c < hidden) out[(size_t)b * hidden + c] = v[i] * sc;
-    }
+    float tot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += s_red[i];
+    const float sc = normalize ? 1.0f / fmaxf(sqrtf(tot), 1e-12f) : 1.0f;
+    if (tid < hidden) out[(size_t)b * hidden + tid] = v * sc;
 }
 
 hipError_t launch_pool(hipStream_t s, const bf16_t *x, const int32_t *cu, const int32_t *lens, int B, int hidden,
                        int pooling_cls, int normalize, float *out) {
-    if (hidden > 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(256), 0, s, x, cu, lens, hidden, pooling_cls, normalize, out);
+    if (hidden > 1024 || hidden % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(1024), 0, s, x, cu, lens, hidden, pooling_cls, normalize, out);
     return hipGetLastError();
 }
 
