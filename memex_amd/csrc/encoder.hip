@@ -12,7 +12,6 @@
 // with bf16 activations/weights, f32 accumulation and f32 LayerNorm/softmax/GELU.
 #include <algorithm>
 #include <cmath>
-#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -131,10 +130,9 @@ int ensure_ws(mx_encoder *e, int rows, int seqs, int n_ids) {
 }
 
 constexpr int kMaxSeqsPerPass = 1024;
-static int max_rows_per_pass() {  // packed rows per pass: bounds the workspace (experiment switch)
-    static const int v = getenv("MX_ENC_ROWS") ? atoi(getenv("MX_ENC_ROWS")) : (1 << 17);
-    return v;
-}
+// packed rows per pass (131072): bounds the workspace; measured: larger passes are faster (fixed
+// per-pass costs), smaller ones do not help (the GEMMs are not bandwidth-bound)
+constexpr int kMaxRowsPerPass = 1 << 17;
 
 // one pass: sequences [0, B) with device ids [B,S] (row pitch S) and HOST lens; output d_out [B,H]
 int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const int32_t *d_lens, int B, int S,
@@ -206,7 +204,7 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
         while (b0 + nb < B && nb < kMaxSeqsPerPass) {
             const int l = std::min(std::max(h_lens[b0 + nb], 1), S);
             const long r = (l + kSeqAlign - 1) / kSeqAlign * kSeqAlign;
-            if (nb > 0 && rows + r > max_rows_per_pass()) break;
+            if (nb > 0 && rows + r > kMaxRowsPerPass) break;
             rows += r;
             ++nb;
         }

@@ -13,7 +13,6 @@
 #include "encoder_kernels.h"
 
 #include <cmath>
-#include <cstdlib>
 
 namespace mx {
 
@@ -148,8 +147,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most the (S-2) newer tiles' pieces of this wave are in flight
         if (kt + S - 2 < nk) {
-            if (G::PPW * (S - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (G::PPW * (S - 2) == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            constexpr int kInFlight = G::PPW * (S - 2);  // DMA ops of newer tiles that may stay outstanding
+            if (kInFlight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (kInFlight == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (kInFlight == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if (kInFlight == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (kInFlight == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
