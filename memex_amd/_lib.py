@@ -124,11 +124,28 @@ def _declare(L: ctypes.CDLL) -> None:
     L.mx_encoder_weight_bytes.argtypes = [P(EncoderCfg)]
 
 
+def _load_torch_runtime_first() -> None:
+    """PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 (ROCm 7.0) while
+    libmemex_hip.so links the system ROCm runtime.  Both coexist in one process (device memory is
+    process-wide), but only when torch's copies are loaded FIRST: with the opposite order torch's
+    lazy CUDA init later reports "No HIP GPUs are available".  So, in processes where torch is
+    installed, import it before dlopen()ing our library.  Processes without torch (the Rust host)
+    are unaffected."""
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+
+
 def lib() -> ctypes.CDLL:
     """The loaded library.  Raises (never falls back) when it is absent."""
     global _lib
     with _lock:
         if _lib is None:
+            _load_torch_runtime_first()
             if not os.path.exists(LIB_PATH):
                 raise MemexHipError(MX_EDEVICE, f"{LIB_PATH} is missing: run memex_amd.build() "
                                                 "(python -c 'import __graft_entry__ as g; g.build()')")

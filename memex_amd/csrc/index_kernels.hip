@@ -102,18 +102,19 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
                                                            double *__restrict__ qnorm2, float *__restrict__ theta,
                                                            uint32_t *__restrict__ overflow,
                                                            uint32_t *__restrict__ pool_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    float *s_row = reinterpret_cast<float *>(psm);  // [d] this query (coalesced load; the chain reads LDS)
     __shared__ float s_inv;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const bool live = b < B;
+    for (int i = tid; i < d; i += 256) s_row[i] = live ? q[(size_t)b * d + i] : 0.0f;
+    __syncthreads();
     if (tid == 0) {
         double na = 0.0;
-        if (live) {
-            const float *row = q + (size_t)b * d;
-            for (int i = 0; i < d; ++i) {  // sequential, f32 products: DistCosine's query-norm chain
-                const float v = row[i];
-                na += (double)__fmul_rn(v, v);
-            }
+        for (int i = 0; i < d; ++i) {  // sequential, f32 products: DistCosine's query-norm chain
+            const float v = s_row[i];
+            na += (double)__fmul_rn(v, v);
         }
         qnorm2[b] = na;
         const bool usable = live && na > 0.0 && isfinite(na);
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
     const int ksteps = ds / 16;
     const int w = b >> 5, col = b & 31;
     for (int dim = tid; dim < ds; dim += 256) {
-        const float v = (live && dim < d) ? q[(size_t)b * d + dim] : 0.0f;
+        const float v = dim < d ? s_row[dim] : 0.0f;
         qpad[(size_t)b * ds + dim] = v;
         // MFMA 32x32x16 B-operand: lane l holds B[k = 8*(l>>5)+i][n = l&31]
         const int ks = dim >> 4, hh = (dim >> 3) & 1, i = dim & 7;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
 
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag, float *qpad,
                                double *qnorm2, float *theta, uint32_t *overflow, uint32_t *pool_cnt) {
-    hipLaunchKernelGGL(prep_queries_kernel, dim3(kMaxBatch), dim3(256), 0, s, q, B, d, ds, (__bf16 *)qfrag, qpad,
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(kMaxBatch), dim3(256), sizeof(float) * (size_t)d, s, q, B, d, ds, (__bf16 *)qfrag, qpad,
                        qnorm2, theta, overflow, pool_cnt);
     return hipGetLastError();
 }
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void update_kernel(int k, int nwg, const Cand 
                                                      Cand *pool_out, uint32_t *pool_cnt, float *theta,
                                                      uint32_t *overflow) {
     __shared__ uint32_t s_cnt;
-    __shared__ uint32_t s_red[4];
+    __shared__ uint32_t s_sel[2][4];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     Cand *pin = pool_in + (size_t)q * kPoolCap;
@@ -162,20 +163,34 @@ __global__ __launch_bounds__(256) void update_kernel(int k, int nwg, const Cand 
     if (tid == 0) s_cnt = m_old;
     __syncthreads();
 
-    // ---- gather: scan workgroup w kept this query's candidates in lanes L0 and L0+32 of wave q/32
+    // ---- gather: scan workgroup w kept this query's candidates in lanes L0 and L0+32 of wave q/32.
+    // All loads of a lane buffer are issued before the first store (16-byte vectors, 2 entries each):
+    // a load-store-load chain through HBM latency is what made this kernel slow.
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     for (int w = tid; w < nwg; w += 256) {
         const uint32_t l0 = (uint32_t)w * kScanThreads + (uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31);
+        const uint32_t c0 = lane_cnt[l0], c1 = lane_cnt[l0 + 32];
         for (int half = 0; half < 2; ++half) {
-            const uint32_t l = l0 + 32u * half;
-            const uint32_t c = lane_cnt[l];
+            const uint32_t c = half ? c1 : c0;
             if (c == 0) continue;
             const uint32_t pos = atomicAdd(&s_cnt, c);
-            const Cand *src = lane_buf + (size_t)l * kLaneCap;
-            for (uint32_t e = 0; e < c; ++e) {
-                if (pos + e < (uint32_t)kPoolCap) {
-                    Cand cd = src[e];
-                    if (!(cd.score == cd.score)) cd.score = 2.0f;  // NaN = zero-norm row: rank first
-                    pin[pos + e] = cd;
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(lane_buf + (size_t)(l0 + 32u * half) * kLaneCap);
+            u32x4 v[kLaneCap / 2];
+#pragma unroll
+            for (int e = 0; e < kLaneCap / 2; ++e)
+                if ((uint32_t)(2 * e) < c) v[e] = src[e];
+#pragma unroll
+            for (int e = 0; e < kLaneCap / 2; ++e) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const uint32_t i = 2 * e + hh;
+                    if (i < c && pos + i < (uint32_t)kPoolCap) {
+                        Cand cd;
+                        cd.score = __uint_as_float(v[e][2 * hh]);
+                        cd.row = v[e][2 * hh + 1];
+                        if (!(cd.score == cd.score)) cd.score = 2.0f;  // NaN = zero-norm row: rank first
+                        pin[pos + i] = cd;
+                    }
                 }
             }
         }
@@ -209,15 +224,47 @@ __global__ __launch_bounds__(256) void update_kernel(int k, int nwg, const Cand 
     float th_new = th_old;
     uint32_t keep_key = 0;  // keep everything
     if (m >= (uint32_t)k && k > 0 && th_old != INFINITY) {
-        // k-th largest key, MSB-first
-        uint32_t prefix = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t trial = prefix | (1u << bit);
-            uint32_t c = 0;
+        // k-th largest key.  Only the bits below the highest bit in which the keys differ need a
+        // decision; counts are wave ballots + popcounts (scalar), one LDS exchange and one barrier
+        // per bit.
+        uint32_t kmax = 0, kmin = 0xffffffffu;
 #pragma unroll
-            for (int e = 0; e < kPer; ++e) c += (e < per && key[e] >= trial) ? 1u : 0u;
-            c = block_sum_256(c, s_red);
-            if (c >= (uint32_t)k) prefix = trial;
+        for (int e = 0; e < kPer; ++e)
+            if (e < per && row[e] != 0xffffffffu) {
+                kmax = key[e] > kmax ? key[e] : kmax;
+                kmin = key[e] < kmin ? key[e] : kmin;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t a = __shfl_xor(kmax, o), b = __shfl_xor(kmin, o);
+            kmax = a > kmax ? a : kmax;
+            kmin = b < kmin ? b : kmin;
+        }
+        if ((tid & 63) == 0) {
+            s_sel[0][tid >> 6] = kmax;
+            s_sel[1][tid >> 6] = kmin;
+        }
+        __syncthreads();
+        kmax = max(max(s_sel[0][0], s_sel[0][1]), max(s_sel[0][2], s_sel[0][3]));
+        kmin = min(min(s_sel[1][0], s_sel[1][1]), min(s_sel[1][2], s_sel[1][3]));
+        __syncthreads();
+        const uint32_t diff = kmax ^ kmin;
+        uint32_t prefix = kmax;
+        if (diff != 0) {
+            const int top = 31 - __clz((int)diff);
+            prefix = top == 31 ? 0u : (kmax & ~((2u << top) - 1u));  // bits above `top` are common
+            for (int bit = top; bit >= 0; --bit) {
+                const uint32_t trial = prefix | (1u << bit);
+                uint32_t c = 0;
+#pragma unroll
+                for (int e = 0; e < kPer; ++e)
+                    if (e < per) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(key[e] >= trial));
+                uint32_t *slot = s_sel[bit & 1];
+                if ((tid & 63) == 0) slot[tid >> 6] = c;
+                __syncthreads();  // slots alternate per bit, so one barrier per bit suffices
+                c = slot[0] + slot[1] + slot[2] + slot[3];
+                if (c >= (uint32_t)k) prefix = trial;
+            }
         }
         const float kth = key_f32(prefix);
         th_new = kth - kMargin;
