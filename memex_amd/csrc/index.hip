@@ -58,6 +58,8 @@ struct Scratch {
     uint64_t *sel_state = nullptr;  // [4 + ksel]
     int ksel = 0;
     float *max_err = nullptr;
+    uint32_t *host_flags = nullptr;  // pinned: [overflow 256 | pool_cnt 256], one async D2H per batch
+    uint32_t *dev_flags = nullptr;   // device: same layout (overflow and pool_cnt live back to back)
     bool ready = false;
 };
 
@@ -101,7 +103,8 @@ int free_index(mx_index *idx) {
     };
     F(idx->x); F(idx->scale); F(idx->flags);
     Scratch &s = idx->s;
-    F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.overflow); F(s.pool_cnt); F(s.pool[0]); F(s.pool[1]);
+    F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.dev_flags); F(s.pool[0]); F(s.pool[1]);
+    if (s.host_flags) (void)hipHostFree(s.host_flags);
     F(s.lane_buf); F(s.lane_cnt); F(s.qstage); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
     F(s.exact_keys); F(s.sel_state); F(s.max_err);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
@@ -119,8 +122,10 @@ int ensure_scratch(mx_index *idx) {
     MX_HIP(hipMalloc(&s.qpad, (size_t)kMaxBatch * ds * 4));
     MX_HIP(hipMalloc(&s.qnorm2, kMaxBatch * sizeof(double)));
     MX_HIP(hipMalloc(&s.theta, kMaxBatch * sizeof(float)));
-    MX_HIP(hipMalloc(&s.overflow, kMaxBatch * sizeof(uint32_t)));
-    MX_HIP(hipMalloc(&s.pool_cnt, kMaxBatch * sizeof(uint32_t)));
+    MX_HIP(hipMalloc(&s.dev_flags, 2 * kMaxBatch * sizeof(uint32_t)));
+    s.overflow = s.dev_flags;
+    s.pool_cnt = s.dev_flags + kMaxBatch;
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.host_flags), 2 * kMaxBatch * sizeof(uint32_t), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) MX_HIP(hipMalloc(&s.pool[i], (size_t)kMaxBatch * kPoolCap * sizeof(Cand)));
     MX_HIP(hipMalloc(&s.lane_buf, (size_t)idx->nwg * kScanThreads * kLaneCap * sizeof(Cand)));
     MX_HIP(hipMalloc(&s.lane_cnt, (size_t)idx->nwg * kScanThreads * sizeof(uint32_t)));
@@ -295,10 +300,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                             s.pool[cur], s.pool_cnt, s.overflow, d_ids, d_scores, d_dists, d_nfound,
                             idx->profiling ? s.max_err : nullptr));
         if (fast) {
-            uint32_t ovf[kMaxBatch];
-            uint32_t cnt[kMaxBatch];
-            MX_HIP(hipMemcpyAsync(ovf, s.overflow, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, st));
-            MX_HIP(hipMemcpyAsync(cnt, s.pool_cnt, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, st));
+            const uint32_t *ovf = s.host_flags, *cnt = s.host_flags + kMaxBatch;
+            MX_HIP(hipMemcpyAsync(s.host_flags, s.dev_flags, 2 * kMaxBatch * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             MX_HIP(hipStreamSynchronize(st));
             for (int b = 0; b < B; ++b) {
                 if (ovf[b]) redo.push_back(b);
@@ -324,11 +327,6 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         float ms = 0.f;
         MX_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
         idx->stats.scan_ms += ms;
-    }
-    if (idx->profiling) {
-        float e = 0.f;
-        MX_HIP(hipMemcpy(&e, s.max_err, sizeof(float), hipMemcpyDeviceToHost));
-        idx->stats.max_abs_err = std::max(idx->stats.max_abs_err, (double)e);
     }
     idx->stats.searches += 1;
     idx->stats.queries += (uint64_t)B;
@@ -561,6 +559,12 @@ int mx_index_set_profiling(mx_index *idx, int on) {
 int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
     if (!idx || !out) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->s.max_err) {  // device-side running maximum (profiling mode); fetched on demand
+        DeviceGuard g(idx->device);
+        float e = 0.f;
+        MX_HIP(hipMemcpy(&e, idx->s.max_err, sizeof(float), hipMemcpyDeviceToHost));
+        idx->stats.max_abs_err = std::max(idx->stats.max_abs_err, (double)e);
+    }
     *out = idx->stats;
     return MX_OK;
 }
