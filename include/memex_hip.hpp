@@ -1,0 +1,479 @@
+// memex_hip.hpp -- header-only C++17 host mirror of memex's Rust surface over the C ABI
+// (memex_hip.h).  The reference is compiled code (Rust); with no Rust toolchain in the build image
+// this is the host side a compiled caller links against, with the reference's names, argument
+// meaning and error behaviour:
+//
+//   reference (lib/libmemex/src)                         here (namespace memex)
+//   storage/mod.rs:17-28   VectorData                    VectorData
+//   storage/mod.rs:31-48   VectorStoreError (8 variants) VectorStoreError{kind(), what()}
+//   storage/mod.rs:55-66   trait VectorStore             class VectorStore (abstract)
+//   storage/local.rs:21-166 HnswStore                    class HipFlatStore (exact GPU search)
+//   storage/mod.rs:69-93   VectorStorage (Arc<Mutex<..>>) class VectorStorage
+//   storage/mod.rs:95-139  get_vector_storage            get_vector_storage (hnsw:// and hip://)
+//   llm/embedding.rs:11-22 EmbeddingError / Result       EmbeddingError, EmbeddingResult
+//   llm/embedding.rs:58-73 ModelConfig                   ModelConfig (L12-v2, 256, 86)
+//   llm/embedding.rs:78-152 SentenceEmbedder             SentenceEmbedder::spawn/encode/encode_single
+//   llm/embedding.rs:155-198 segment_text                segment_text (stand-in tokenizer, see below)
+//
+// The reference's async fns are blocking calls here (the C ABI is synchronous); the Rust shim in
+// INTEGRATION.md wraps them in `async fn` again.
+#pragma once
+#include <sys/stat.h>
+
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <deque>
+#include <fstream>
+#include <functional>
+#include <future>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "memex_hip.h"
+
+namespace memex {
+
+// ---- storage/mod.rs -----------------------------------------------------------------------------
+struct VectorData {  // mod.rs:17-28
+    std::string _id, document_id, text;
+    std::vector<float> vector;
+    size_t segment_id = 0;
+};
+
+class VectorStoreError : public std::runtime_error {  // mod.rs:31-48
+  public:
+    enum Kind { ConnectionError, DeleteError, FileIOError, InsertionError, SearchError, SerdeError, SaveError, Unsupported };
+    VectorStoreError(Kind k, const std::string &m) : std::runtime_error(m), kind_(k) {}
+    Kind kind() const { return kind_; }
+
+  private:
+    Kind kind_;
+};
+
+inline VectorStoreError from_status(int rc, VectorStoreError::Kind dflt) {
+    const std::string msg = mx_last_error() ? mx_last_error() : "";
+    switch (rc) {
+        case MX_EDEVICE: return {VectorStoreError::ConnectionError, msg};
+        case MX_ESEARCH: return {VectorStoreError::SearchError, msg};
+        case MX_EIO: return {VectorStoreError::FileIOError, msg};
+        case MX_EUNSUPPORTED: return {VectorStoreError::Unsupported, msg};
+        default: return {dflt, msg};
+    }
+}
+
+using VectorSearchResult = std::pair<std::string, float>;  // (doc_id, score), mod.rs:51
+
+class VectorStore {  // mod.rs:55-66
+  public:
+    virtual ~VectorStore() = default;
+    virtual void delete_(const std::string &id) = 0;
+    virtual void delete_all() = 0;
+    virtual void bulk_insert(const std::vector<VectorData> &data) = 0;
+    virtual void insert(const VectorData &data) = 0;
+    virtual std::vector<VectorSearchResult> search(const std::vector<float> &vec, size_t limit) = 0;
+};
+
+// ---- storage/local.rs ---------------------------------------------------------------------------
+constexpr const char *META_FILE = "vectors.meta.json";  // local.rs:19
+
+class HipFlatStore : public VectorStore {
+  public:
+    std::string storage_path;
+    std::map<size_t, std::string> _id_map;  // local.rs:24 (usize -> _id)
+
+    explicit HipFlatStore(const std::string &path, int device = 0) : storage_path(path), device_(device) {}  // ::new, local.rs:95
+    ~HipFlatStore() override {
+        if (idx_) mx_index_close(idx_);
+    }
+    HipFlatStore(const HipFlatStore &) = delete;
+    HipFlatStore &operator=(const HipFlatStore &) = delete;
+
+    static bool has_store(const std::string &path) {  // local.rs:110-113
+        struct stat sb;
+        return stat((path + "/" + META_FILE).c_str(), &sb) == 0;
+    }
+
+    static std::unique_ptr<HipFlatStore> load(const std::string &path, int device = 0) {  // local.rs:115-141
+        std::ifstream f(path + "/" + META_FILE);
+        if (!f) throw VectorStoreError(VectorStoreError::FileIOError, "cannot open " + path + "/" + META_FILE);
+        std::stringstream ss;
+        ss << f.rdbuf();
+        auto store = std::make_unique<HipFlatStore>(path, device);
+        store->_id_map = parse_id_map(ss.str());
+        if (!store->_id_map.empty()) {
+            int dim = 0;
+            uint64_t n = 0;
+            int rc = mx_index_store_info(path.c_str(), &dim, &n);
+            if (rc != MX_OK) throw from_status(rc, VectorStoreError::FileIOError);
+            store->open(dim);
+            rc = mx_index_load(store->idx_, path.c_str());
+            if (rc != MX_OK) throw from_status(rc, VectorStoreError::FileIOError);
+            if (n != store->_id_map.size()) throw VectorStoreError(VectorStoreError::FileIOError, "vector / id count mismatch");
+        }
+        return store;
+    }
+
+    void save(const std::string &path_in = "") {  // local.rs:143-165
+        const std::string path = path_in.empty() ? storage_path : path_in;
+        mkdir(path.c_str(), 0755);
+        if (idx_) {
+            int rc = mx_index_save(idx_, path.c_str());
+            if (rc != MX_OK) throw VectorStoreError(VectorStoreError::SaveError, mx_last_error());
+        }
+        std::ofstream f(path + "/" + META_FILE);
+        if (!f) throw VectorStoreError(VectorStoreError::FileIOError, "cannot write " + path + "/" + META_FILE);
+        f << "{";
+        bool first = true;
+        for (auto &kv : _id_map) {
+            f << (first ? "" : ",") << "\"" << kv.first << "\":\"" << escape(kv.second) << "\"";
+            first = false;
+        }
+        f << "}";
+    }
+
+    void delete_(const std::string &) override {  // local.rs:29-32: unimplemented!()
+        throw std::logic_error("Currently removing a single point is not supported");
+    }
+
+    void delete_all() override {  // local.rs:34-53
+        std::remove((storage_path + "/" + META_FILE).c_str());
+        if (mx_index_remove_files(storage_path.c_str()) != MX_OK) throw VectorStoreError(VectorStoreError::DeleteError, mx_last_error());
+        if (idx_ && mx_index_clear(idx_) != MX_OK) throw VectorStoreError(VectorStoreError::DeleteError, mx_last_error());
+        _id_map.clear();
+    }
+
+    void bulk_insert(const std::vector<VectorData> &data) override {  // local.rs:55-60, one transfer
+        if (data.empty()) return;
+        const size_t d = data[0].vector.size();
+        if (!idx_) open((int)d);
+        std::vector<float> flat;
+        flat.reserve(data.size() * d);
+        for (auto &v : data) {
+            if (v.vector.size() != (size_t)dim_) throw VectorStoreError(VectorStoreError::InsertionError, "vector dimension mismatch");
+            flat.insert(flat.end(), v.vector.begin(), v.vector.end());
+        }
+        uint64_t first = 0;
+        int rc = mx_index_add(idx_, flat.data(), data.size(), &first);
+        if (rc != MX_OK) throw from_status(rc, VectorStoreError::InsertionError);
+        for (size_t i = 0; i < data.size(); ++i) _id_map[(size_t)first + i] = data[i]._id;  // next_id = len + 1 (local.rs:63)
+    }
+
+    void insert(const VectorData &data) override { bulk_insert({data}); }  // local.rs:62-69 (no save-per-insert)
+
+    std::vector<VectorSearchResult> search(const std::vector<float> &vec, size_t limit) override {  // local.rs:71-91
+        std::vector<VectorSearchResult> out;
+        if (!idx_ || limit == 0) return out;
+        if (vec.size() != (size_t)dim_) throw VectorStoreError(VectorStoreError::SearchError, "query dimension mismatch");
+        std::vector<uint64_t> ids(limit);
+        std::vector<float> scores(limit);
+        int32_t nf = 0;
+        int rc = mx_index_search(idx_, vec.data(), 1, (int)limit, ids.data(), scores.data(), nullptr, &nf);
+        if (rc != MX_OK) throw from_status(rc, VectorStoreError::SearchError);
+        for (int j = 0; j < nf; ++j) {
+            auto it = _id_map.find((size_t)ids[j]);
+            if (it == _id_map.end())  // local.rs:80-83 panics; we raise
+                throw VectorStoreError(VectorStoreError::SearchError, "Internal inconsistency. Id from vector store not mapped.");
+            out.emplace_back(it->second, scores[j]);
+        }
+        return out;
+    }
+
+    uint64_t nb_point() const {  // hnsw.get_nb_point() in the reference's test (local.rs:238)
+        uint64_t n = 0;
+        if (idx_) mx_index_size(idx_, &n);
+        return n;
+    }
+
+  private:
+    int device_ = 0, dim_ = 0;
+    mx_index *idx_ = nullptr;
+
+    void open(int dim) {
+        int rc = mx_index_open(nullptr, dim, device_, &idx_);
+        if (rc != MX_OK) throw from_status(rc, VectorStoreError::ConnectionError);
+        dim_ = dim;
+    }
+    static std::string escape(const std::string &s) {
+        std::string o;
+        for (char c : s) {
+            if (c == '"' || c == '\\') o += '\\';
+            o += c;
+        }
+        return o;
+    }
+    // {"<usize>":"<id>", ...} as written by serde_json for HashMap<usize,String> (local.rs:156-163)
+    static std::map<size_t, std::string> parse_id_map(const std::string &s) {
+        std::map<size_t, std::string> m;
+        size_t i = s.find('{');
+        if (i == std::string::npos) throw VectorStoreError(VectorStoreError::SerdeError, "expected a JSON object");
+        auto read_str = [&](std::string &out) {
+            while (i < s.size() && s[i] != '"') {
+                if (s[i] == '}') return false;
+                ++i;
+            }
+            if (i >= s.size()) throw VectorStoreError(VectorStoreError::SerdeError, "unterminated JSON");
+            ++i;
+            out.clear();
+            while (i < s.size() && s[i] != '"') {
+                if (s[i] == '\\' && i + 1 < s.size()) ++i;
+                out += s[i++];
+            }
+            if (i >= s.size()) throw VectorStoreError(VectorStoreError::SerdeError, "unterminated string");
+            ++i;
+            return true;
+        };
+        ++i;
+        std::string k, v;
+        while (read_str(k)) {
+            if (!read_str(v)) throw VectorStoreError(VectorStoreError::SerdeError, "missing value");
+            try {
+                m[(size_t)std::stoull(k)] = v;
+            } catch (const std::exception &) {
+                throw VectorStoreError(VectorStoreError::SerdeError, "non-numeric key " + k);
+            }
+        }
+        return m;
+    }
+};
+
+class VectorStorage {  // mod.rs:69-93
+  public:
+    explicit VectorStorage(std::shared_ptr<VectorStore> c) : client(std::move(c)) {}
+    std::shared_ptr<VectorStore> client;
+    void add_vectors(const std::vector<VectorData> &points) {
+        std::lock_guard<std::mutex> lk(*mu_);
+        client->bulk_insert(points);
+    }
+    void delete_collection() {
+        std::lock_guard<std::mutex> lk(*mu_);
+        client->delete_all();
+    }
+    std::vector<VectorSearchResult> search(const std::vector<float> &query, size_t limit) {
+        std::lock_guard<std::mutex> lk(*mu_);
+        return client->search(query, limit);
+    }
+
+  private:
+    std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
+};
+
+inline VectorStorage get_vector_storage(const std::string &uri, const std::string &collection, int device = 0) {  // mod.rs:95-139
+    const size_t p = uri.find("://");
+    if (p == std::string::npos || p == 0) throw VectorStoreError(VectorStoreError::Unsupported, uri);
+    const std::string scheme = uri.substr(0, p);
+    if (scheme == "hnsw" || scheme == "hip") {  // the reference's file backend, now served from HBM
+        const std::string storage = uri.substr(p + 3) + "/" + collection;
+        std::string partial;
+        for (size_t i = 0; i <= storage.size(); ++i)  // create_dir_all
+            if (i == storage.size() || storage[i] == '/') {
+                if (!partial.empty()) mkdir(partial.c_str(), 0755);
+                if (i < storage.size()) partial += '/';
+            } else {
+                partial += storage[i];
+            }
+        std::shared_ptr<VectorStore> store;
+        if (HipFlatStore::has_store(storage)) store = HipFlatStore::load(storage, device);
+        else store = std::make_shared<HipFlatStore>(storage, device);
+        return VectorStorage(store);
+    }
+    throw VectorStoreError(VectorStoreError::Unsupported, uri);  // opensearch+https is a remote client: out of scope
+}
+
+// ---- llm/embedding.rs ---------------------------------------------------------------------------
+class EmbeddingError : public std::runtime_error {  // embedding.rs:11-16
+  public:
+    enum Kind { EncodingFailure, SetupError };
+    EmbeddingError(Kind k, const std::string &m) : std::runtime_error(m), kind_(k) {}
+    Kind kind() const { return kind_; }
+
+  private:
+    Kind kind_;
+};
+
+struct EmbeddingResult {  // embedding.rs:19-22
+    std::string content;
+    std::vector<float> vector;
+};
+
+enum class EmbeddingsModelType {  // embedding.rs:25-33
+    DistiluseBaseMultilingualCased, BertBaseNliMeanTokens, AllMiniLmL12V2, AllMiniLmL6V2, AllDistilrobertaV1,
+    ParaphraseAlbertSmallV2, SentenceT5Base
+};
+
+struct ModelConfig {  // embedding.rs:58-73
+    EmbeddingsModelType model = EmbeddingsModelType::AllMiniLmL12V2;
+    size_t max_length = 256;
+    size_t stride = 86;
+};
+
+// STAND-IN tokenizer (the pretrained WordPiece vocabulary is not obtainable offline; a native
+// WordPiece segmenter is SURVEY.md section 8 row f-1): lower-case, whitespace split, CRC-32 hash into
+// [1000, vocab); [PAD]=0, [CLS]=101, [SEP]=102; windowing arithmetic as tokenizers 0.14.
+struct WhitespaceHashTokenizer {
+    int vocab = 30522;
+    static std::vector<std::string> words(const std::string &text) {
+        std::vector<std::string> w;
+        std::string cur;
+        for (unsigned char c : text) {
+            if (std::isspace(c)) {
+                if (!cur.empty()) w.push_back(cur), cur.clear();
+            } else {
+                cur += (char)std::tolower(c);
+            }
+        }
+        if (!cur.empty()) w.push_back(cur);
+        return w;
+    }
+    static uint32_t crc32(const std::string &s) {
+        uint32_t c = 0xffffffffu;
+        for (unsigned char ch : s) {
+            c ^= ch;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+        }
+        return ~c;
+    }
+    int word_id(const std::string &w) const { return 1000 + (int)(crc32(w) % (uint32_t)(vocab - 1000)); }
+    std::vector<std::string> windows(const std::string &text, size_t max_length, size_t stride) const {
+        const auto ws = words(text);
+        std::vector<std::string> out;
+        if (ws.empty()) return {""};
+        const size_t step = max_length - stride;  // each overflow window starts max_length - stride later
+        for (size_t start = 0;; start += step) {
+            std::string seg;
+            for (size_t i = start; i < ws.size() && i < start + max_length; ++i) seg += (i > start ? " " : "") + ws[i];
+            out.push_back(seg);
+            if (start + max_length >= ws.size()) break;
+        }
+        return out;
+    }
+    void encode_batch(const std::vector<std::string> &texts, size_t max_seq_length, std::vector<int32_t> &ids,
+                      std::vector<int32_t> &lens, int &S) const {
+        std::vector<std::vector<int32_t>> rows;
+        S = 0;
+        for (auto &t : texts) {
+            std::vector<int32_t> r{101};
+            for (auto &w : words(t)) {
+                if (r.size() + 1 >= max_seq_length) break;
+                r.push_back(word_id(w));
+            }
+            r.push_back(102);
+            S = std::max<int>(S, (int)r.size());
+            rows.push_back(std::move(r));
+        }
+        ids.assign(rows.size() * (size_t)S, 0);
+        lens.clear();
+        for (size_t i = 0; i < rows.size(); ++i) {
+            std::copy(rows[i].begin(), rows[i].end(), ids.begin() + i * S);
+            lens.push_back((int32_t)rows[i].size());
+        }
+    }
+};
+
+inline std::vector<std::string> segment_text(const ModelConfig &mc, const std::string &text) {  // embedding.rs:155-198
+    if (mc.model != EmbeddingsModelType::AllMiniLmL12V2 && mc.model != EmbeddingsModelType::AllMiniLmL6V2 &&
+        mc.model != EmbeddingsModelType::AllDistilrobertaV1)
+        throw EmbeddingError(EmbeddingError::SetupError, "Model not supported yet");  // :160
+    return WhitespaceHashTokenizer{}.windows(text, mc.max_length, mc.stride);
+}
+
+// The actor of embedding.rs:78-152: a dedicated thread owns the encoder; callers post
+// (text, segment?, reply) messages on a queue bounded at 100 (sync_channel(100), :87).
+class SentenceEmbedder {
+  public:
+    // `weights`: f32 blob in the order documented in memex_hip.h for `cfg`.
+    static std::pair<std::thread, std::shared_ptr<SentenceEmbedder>> spawn(const ModelConfig &mc, const mx_encoder_cfg &cfg,
+                                                                           std::vector<float> weights, size_t max_seq_length,
+                                                                           int device = 0) {
+        auto self = std::shared_ptr<SentenceEmbedder>(new SentenceEmbedder());
+        std::promise<std::string> ready;
+        auto fut = ready.get_future();
+        std::thread th([self, mc, cfg, w = std::move(weights), max_seq_length, device, pr = std::move(ready)]() mutable {
+            self->runner(mc, cfg, w, max_seq_length, device, pr);
+        });
+        const std::string err = fut.get();
+        if (!err.empty()) {
+            th.join();
+            throw EmbeddingError(EmbeddingError::SetupError, err);
+        }
+        return {std::move(th), self};
+    }
+    std::vector<EmbeddingResult> encode(const std::string &text) { return call(text, true); }  // :138-142
+    std::optional<EmbeddingResult> encode_single(const std::string &text) {                   // :146-151
+        auto r = call(text, false);
+        if (r.empty()) return std::nullopt;
+        return r.back();
+    }
+    void shutdown() { post({"", false, nullptr, true}); }
+
+  private:
+    struct Msg {
+        std::string text;
+        bool segment;
+        std::shared_ptr<std::promise<std::vector<EmbeddingResult>>> reply;
+        bool stop = false;
+    };
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Msg> q_;
+
+    void post(Msg m) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return q_.size() < 100; });
+        q_.push_back(std::move(m));
+        cv_.notify_all();
+    }
+    std::vector<EmbeddingResult> call(const std::string &text, bool segment) {
+        auto pr = std::make_shared<std::promise<std::vector<EmbeddingResult>>>();
+        auto fut = pr->get_future();
+        post({text, segment, pr});
+        return fut.get();
+    }
+    void runner(const ModelConfig &mc, const mx_encoder_cfg &cfg, const std::vector<float> &w, size_t max_seq_length, int device,
+                std::promise<std::string> &ready) {
+        mx_encoder *enc = nullptr;
+        int rc = mx_encoder_create(&cfg, w.data(), w.size() * sizeof(float), device, &enc);  // create_model(), :99-100
+        if (rc != MX_OK) {
+            ready.set_value(mx_last_error());
+            return;
+        }
+        ready.set_value("");
+        WhitespaceHashTokenizer tok{cfg.vocab};
+        for (;;) {
+            Msg m;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return !q_.empty(); });
+                m = std::move(q_.front());
+                q_.pop_front();
+                cv_.notify_all();
+            }
+            if (m.stop) break;
+            try {
+                const auto segments = m.segment ? segment_text(mc, m.text) : std::vector<std::string>{m.text};  // :103-107
+                std::vector<int32_t> ids, lens;
+                int S = 0;
+                tok.encode_batch(segments, max_seq_length, ids, lens, S);
+                std::vector<float> out(segments.size() * (size_t)cfg.hidden);
+                rc = mx_encoder_encode(enc, ids.data(), lens.data(), (int)segments.size(), S, out.data());  // model.encode, :109
+                if (rc != MX_OK) throw EmbeddingError(EmbeddingError::EncodingFailure, mx_last_error());
+                std::vector<EmbeddingResult> res;
+                for (size_t i = 0; i < segments.size(); ++i)
+                    res.push_back({segments[i], std::vector<float>(out.begin() + i * cfg.hidden, out.begin() + (i + 1) * cfg.hidden)});
+                m.reply->set_value(std::move(res));
+            } catch (...) {
+                m.reply->set_exception(std::current_exception());
+            }
+        }
+        mx_encoder_destroy(enc);
+    }
+};
+
+}  // namespace memex

@@ -46,8 +46,8 @@ struct ScanParams {
     uint32_t tile_begin;     // tile range of this stage
     uint32_t tile_end;
     uint32_t ds;             // floats per stored row
-    Cand *lane_buf;          // [nwg][512][kLaneCap]
-    uint32_t *lane_cnt;      // [nwg][512]
+    Cand *lane_buf;          // [512][nwg][kLaneCap]  (thread-in-workgroup major)
+    uint32_t *lane_cnt;      // [512][nwg]
     uint32_t *overflow;      // [256]
 };
 

@@ -168,13 +168,15 @@ __global__ __launch_bounds__(256) void update_kernel(int k, int nwg, const Cand 
     // a load-store-load chain through HBM latency is what made this kernel slow.
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     for (int w = tid; w < nwg; w += 256) {
-        const uint32_t l0 = (uint32_t)w * kScanThreads + (uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31);
-        const uint32_t c0 = lane_cnt[l0], c1 = lane_cnt[l0 + 32];
+        // [thread-in-workgroup][workgroup] layout (scan.hip): consecutive threads read consecutive words
+        const uint32_t t0 = (uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31);
+        const uint32_t l0 = t0 * (uint32_t)nwg + (uint32_t)w, l1 = (t0 + 32) * (uint32_t)nwg + (uint32_t)w;
+        const uint32_t c0 = lane_cnt[l0], c1 = lane_cnt[l1];
         for (int half = 0; half < 2; ++half) {
             const uint32_t c = half ? c1 : c0;
             if (c == 0) continue;
             const uint32_t pos = atomicAdd(&s_cnt, c);
-            const u32x4 *src = reinterpret_cast<const u32x4 *>(lane_buf + (size_t)(l0 + 32u * half) * kLaneCap);
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(lane_buf + (size_t)(half ? l1 : l0) * kLaneCap);
             u32x4 v[kLaneCap / 2];
 #pragma unroll
             for (int e = 0; e < kLaneCap / 2; ++e)
@@ -315,7 +317,8 @@ __device__ __forceinline__ float exact_dist_row(const float *__restrict__ qv, co
     // sequential f64 accumulation of f32 products, element order 0..d-1 (zero padding adds +0.0)
     double dot = 0.0, nb = 0.0;
     const float4 *r4 = reinterpret_cast<const float4 *>(row);
-    for (int i = 0; i < ds / 4; ++i) {
+#pragma unroll 8
+    for (int i = 0; i < ds / 4; ++i) {  // ds is a multiple of 128: 8 independent loads in flight per trip
         const float4 c = r4[i];
         const float4 a = *reinterpret_cast<const float4 *>(qv + 4 * i);
         dot += (double)__fmul_rn(a.x, c.x); nb += (double)__fmul_rn(c.x, c.x);

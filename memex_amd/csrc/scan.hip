@@ -129,7 +129,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     // A-fragment read base: row m, bf16 [8h, 8h+8) of k-step ks at + ks*32 (immediate offsets)
     const uint32_t frag_base = kTileOff + (uint32_t)m * kTilePitch + (uint32_t)h * 16u;
 
-    Cand *mybuf = p.lane_buf + ((size_t)blockIdx.x * kScanThreads + tid) * kLaneCap;
+    // lane buffers are laid out [thread-in-workgroup][workgroup]: everything one query ever receives
+    // (2 lanes x all workgroups) is contiguous for the gather in update_kernel
+    Cand *mybuf = p.lane_buf + ((size_t)tid * gridDim.x + blockIdx.x) * kLaneCap;
     uint32_t cnt = 0;
     uint32_t ovf = 0;
 
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         }
     }
 
-    p.lane_cnt[(size_t)blockIdx.x * kScanThreads + tid] = cnt;
+    p.lane_cnt[(size_t)tid * gridDim.x + blockIdx.x] = cnt;
     if (ovf) p.overflow[wave * 32 + m] = 1;
 }
 

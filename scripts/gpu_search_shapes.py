@@ -1,0 +1,29 @@
+"""Search throughput on other shapes (not a test): d=768 (cfg 4 per-GPU shard), B=1, k=100."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from memex_amd.index import FlatIndex
+def run(n, d, B, k, steps=10):
+    idx = FlatIndex(d); idx.reserve(n)
+    g = torch.Generator(device="cuda")
+    for b0 in range(0, n, 1_000_000):
+        g.manual_seed(b0)
+        x = torch.randn((min(1_000_000, n - b0), d), device="cuda", generator=g); torch.cuda.synchronize()
+        idx.add_device(x); del x
+    q = torch.randn((B, d), device="cuda", generator=g)
+    ids = torch.zeros((B, k), dtype=torch.int64, device="cuda"); sc = torch.zeros((B, k), device="cuda"); di = torch.zeros((B, k), device="cuda"); nf = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2): idx.search_device(q, k, ids, sc, di, nf)
+    idx.reset_stats(); idx.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps): idx.search_device(q, k, ids, sc, di, nf)
+    dt = (time.perf_counter() - t0) / steps
+    st = idx.stats()
+    print(f"n={n} d={d} B={B} k={k}: {dt*1e3:.3f} ms/step {B/dt:.0f} QPS scan {st.scan_bytes/max(st.scan_ms,1e-9)/1e6:.0f} GB/s fallback={st.fallback_queries} cand/q={st.candidates/max(1,st.queries):.0f}")
+    idx.close()
+run(10_000_000, 768, 256, 10, 6)
+run(10_000_000, 384, 1, 10)
+run(10_000_000, 384, 32, 10)
+run(10_000_000, 384, 256, 100)
+run(1_000_000, 384, 256, 10)
+run(100_000, 384, 256, 10, 30)

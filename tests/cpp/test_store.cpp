@@ -1,0 +1,146 @@
+// C++ restatement of the reference's own storage tests (lib/libmemex/src/storage/local.rs:168-243)
+// against memex::HipFlatStore (include/memex_hip.hpp over the C ABI), plus the embedder actor.
+// Built and run by tests/test_cpp_host.py.  Exit code 0 = all passed.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+
+#include "memex_hip.hpp"
+
+using namespace memex;
+
+#define CHECK(c)                                                              \
+    do {                                                                      \
+        if (!(c)) {                                                           \
+            std::fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); \
+            std::exit(1);                                                     \
+        }                                                                     \
+    } while (0)
+
+static std::vector<VectorData> test_data() {  // local.rs:175-199
+    return {{"test-one", "test-one", "", {0.0f, 0.1f, 0.2f}, 0},
+            {"test-two", "test-two", "", {0.1f, 0.1f, 0.1f}, 0},
+            {"test-three", "test-three", "", {0.3f, 0.2f, 0.1f}, 0}};
+}
+
+static void test_hnsw(const std::string &tmp) {  // local.rs:201-214
+    HipFlatStore store(tmp + "/a");
+    store.bulk_insert(test_data());
+    auto results = store.search({0.1f, 0.1f, 0.1f}, 3);
+    CHECK(results.size() == 3);
+    CHECK(results[0].first == "test-two");  // the reference's assertion
+    CHECK(results[1].first == "test-three" && results[2].first == "test-one");
+    CHECK(results[0].second == 1.0f && results[1].second == 0.9258201f && results[2].second == 0.7745967f);
+    store.delete_all();
+}
+
+static void test_save_load(const std::string &tmp) {  // local.rs:216-227
+    HipFlatStore store(tmp + "/vectortest");
+    store.bulk_insert(test_data());
+    store.save();
+    auto loaded = HipFlatStore::load(tmp + "/vectortest");
+    CHECK(loaded->_id_map.size() == store._id_map.size());
+    auto a = loaded->search({0.1f, 0.1f, 0.1f}, 3), b = store.search({0.1f, 0.1f, 0.1f}, 3);
+    CHECK(a == b);
+    store.delete_all();
+}
+
+static void test_delete_all(const std::string &tmp) {  // local.rs:229-242
+    HipFlatStore store(tmp + "/d");
+    store.bulk_insert(test_data());
+    store.save();
+    store.delete_all();
+    CHECK(store._id_map.empty());
+    CHECK(store.nb_point() == 0);
+    bool failed = false;
+    try {
+        HipFlatStore::load(tmp + "/d");
+    } catch (const VectorStoreError &) {
+        failed = true;
+    }
+    CHECK(failed);  // load fails: files removed
+    store.insert(test_data()[0]);
+    CHECK(store._id_map.size() == 1 && store._id_map.begin()->first == 1);  // ids restart at 1
+}
+
+static void test_factory_and_errors(const std::string &tmp) {  // mod.rs:95-139
+    auto vs = get_vector_storage("hnsw://" + tmp + "/coll", "test");
+    vs.add_vectors(test_data());
+    std::dynamic_pointer_cast<HipFlatStore>(vs.client)->save();
+    auto vs2 = get_vector_storage("hip://" + tmp + "/coll", "test");
+    auto r = vs2.search({0.3f, 0.2f, 0.1f}, 2);
+    CHECK(r.size() == 2 && r[0].first == "test-three" && r[1].first == "test-two");
+    vs2.delete_collection();
+    CHECK(vs2.search({0.3f, 0.2f, 0.1f}, 2).empty());
+    for (const char *bad : {"", "not a uri", "qdrant://x", "opensearch+https://admin@localhost:9200"}) {
+        bool unsupported = false;
+        try {
+            get_vector_storage(bad, "c");
+        } catch (const VectorStoreError &e) {
+            unsupported = e.kind() == VectorStoreError::Unsupported;
+        }
+        CHECK(unsupported);
+    }
+    HipFlatStore s(tmp + "/e");
+    bool threw = false;
+    try {
+        s.delete_("x");
+    } catch (const std::logic_error &) {
+        threw = true;
+    }
+    CHECK(threw);  // unimplemented!() in the reference
+    s.insert({"a", "a", "", {1.0f, 0.0f}, 0});
+    bool dim_err = false;
+    try {
+        s.insert({"b", "b", "", {1.0f, 0.0f, 0.0f}, 0});
+    } catch (const VectorStoreError &e) {
+        dim_err = e.kind() == VectorStoreError::InsertionError;
+    }
+    CHECK(dim_err);
+}
+
+static void test_embedder_actor() {  // embedding.rs:78-152 with a seeded 1-layer MiniLM-shaped encoder
+    mx_encoder_cfg cfg{1, 384, 12, 1536, 30522, 512, 2, 1e-12f, MX_POOL_MEAN, 1};
+    const size_t n = mx_encoder_weight_bytes(&cfg) / sizeof(float);
+    std::vector<float> w(n);
+    std::mt19937 rng(5);
+    std::normal_distribution<float> nd(0.0f, 0.04f);
+    for (auto &x : w) x = nd(rng);
+    auto [th, emb] = SentenceEmbedder::spawn(ModelConfig{}, cfg, std::move(w), 128);
+    std::string doc;
+    for (int i = 0; i < 600; ++i) doc += "w" + std::to_string(i % 97) + " ";
+    auto segs = emb->encode(doc);
+    CHECK(segs.size() == 4);  // 600 tokens, windows of 256 advancing by 170
+    for (auto &s : segs) {
+        double nn = 0;
+        for (float v : s.vector) nn += (double)v * v;
+        CHECK(s.vector.size() == 384 && std::fabs(nn - 1.0) < 1e-3);
+    }
+    auto one = emb->encode_single("w1 w2 w3");
+    CHECK(one.has_value() && one->content == "w1 w2 w3");
+    auto again = emb->encode_single("w1 w2 w3");
+    CHECK(again->vector == one->vector);
+    bool gate = false;
+    try {
+        segment_text(ModelConfig{EmbeddingsModelType::SentenceT5Base, 256, 86}, "x");
+    } catch (const EmbeddingError &e) {
+        gate = e.kind() == EmbeddingError::SetupError;
+    }
+    CHECK(gate);
+    emb->shutdown();
+    th.join();
+}
+
+int main(int argc, char **argv) {
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp/memex_cpp_test";
+    mkdir(tmp.c_str(), 0755);
+    test_hnsw(tmp);
+    test_save_load(tmp);
+    test_delete_all(tmp);
+    test_factory_and_errors(tmp);
+    test_embedder_actor();
+    std::printf("OK 5 tests\n");
+    return 0;
+}

@@ -1,0 +1,30 @@
+"""The C++ host mirror (include/memex_hip.hpp) -- the reference is compiled code, so the host side
+above the C ABI exists in C++ too.  CPU: it compiles against the header and links the library.
+GPU: tests/cpp/test_store.cpp restates the reference's own tests (storage/local.rs:168-243)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path, lib_built):
+    exe = str(tmp_path / "test_store")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_store.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "memex_amd"), "-lmemex_hip", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "memex_amd")])
+    return exe
+
+
+def test_cpp_mirror_compiles_and_links(tmp_path, lib_built):
+    assert os.path.exists(_build(tmp_path, lib_built))
+
+
+@pytest.mark.gpu
+def test_cpp_reference_tests(tmp_path, lib_built):
+    exe = _build(tmp_path, lib_built)
+    r = subprocess.run([exe, str(tmp_path / "work")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK 5 tests" in r.stdout
