@@ -199,6 +199,36 @@ int mx_encoder_set_profiling(mx_encoder *enc, int on);
 int mx_encoder_get_stats(mx_encoder *enc, mx_encoder_stats *out);
 int mx_encoder_reset_stats(mx_encoder *enc);
 
+/* =====================================================================================
+ * WordPiece tokenizer + sliding-window segmenter (host code; replaces the `tokenizers` crate
+ * calls of segment_text, lib/libmemex/src/llm/embedding.rs:155-198, and the tokenisation rust-bert
+ * performs inside model.encode, embedding.rs:109)
+ * ===================================================================================== */
+typedef struct mx_tokenizer mx_tokenizer;
+
+/* vocab: BERT vocab.txt (one token per line; needs [PAD] [UNK] [CLS] [SEP]).  lowercase = 1 for
+ * the uncased MiniLM / bge models.  Replaces Tokenizer::from_pretrained (embedding.rs:163). */
+int mx_tokenizer_create(const char *vocab_path, int lowercase, mx_tokenizer **out);
+int mx_tokenizer_create_from_memory(const char *vocab, size_t nbytes, int lowercase, mx_tokenizer **out);
+void mx_tokenizer_destroy(mx_tokenizer *tok);
+int mx_tokenizer_vocab_size(mx_tokenizer *tok, int *n);
+
+/* tokenizer.encode(text, add_special_tokens) (embedding.rs:181).  *n = number of ids produced
+ * (may exceed cap: only the first cap are written). */
+int mx_tokenizer_encode(mx_tokenizer *tok, const char *text, int add_special_tokens, int32_t *ids, int cap, int *n);
+/* tokenizer.decode(ids, skip_special_tokens) (embedding.rs:182,189); *nbytes includes the NUL. */
+int mx_tokenizer_decode(mx_tokenizer *tok, const int32_t *ids, int n, int skip_special_tokens, char *out, size_t cap,
+                        size_t *nbytes);
+/* segment_text (embedding.rs:155-198): windows of max_length tokens starting every
+ * max_length - stride tokens, each decoded back to text (first window also gets " ' " -> "'").
+ * out receives the segments as consecutive NUL-terminated strings; *nbytes = total bytes. */
+int mx_tokenizer_segment(mx_tokenizer *tok, const char *text, int max_length, int stride, char *out, size_t cap,
+                         size_t *nbytes, int *n_segments);
+/* Batch for mx_encoder_encode: [CLS] .. [SEP], truncated to max_seq_length, padded with [PAD] to
+ * row pitch s_cap; lens[b] = tokens incl. specials; *S = longest row (<= s_cap or MX_EINVAL). */
+int mx_tokenizer_encode_batch(mx_tokenizer *tok, const char *const *texts, int B, int max_seq_length, int32_t *ids,
+                              int s_cap, int32_t *lens, int *S);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,8 @@ EXPORTS = [
     "mx_encoder_weight_bytes", "mx_encoder_create", "mx_encoder_destroy", "mx_encoder_encode",
     "mx_encoder_encode_device", "mx_encoder_set_profiling", "mx_encoder_get_stats",
     "mx_encoder_reset_stats",
+    "mx_tokenizer_create", "mx_tokenizer_create_from_memory", "mx_tokenizer_destroy", "mx_tokenizer_vocab_size",
+    "mx_tokenizer_encode", "mx_tokenizer_decode", "mx_tokenizer_segment", "mx_tokenizer_encode_batch",
 ]
 
 
@@ -111,6 +113,13 @@ def _declare(L: ctypes.CDLL) -> None:
         "mx_encoder_set_profiling": [vp, i32],
         "mx_encoder_get_stats": [vp, P(EncoderStats)],
         "mx_encoder_reset_stats": [vp],
+        "mx_tokenizer_create": [cp, i32, P(vp)],
+        "mx_tokenizer_create_from_memory": [cp, ctypes.c_size_t, i32, P(vp)],
+        "mx_tokenizer_vocab_size": [vp, P(i32)],
+        "mx_tokenizer_encode": [vp, cp, i32, vp, i32, P(i32)],
+        "mx_tokenizer_decode": [vp, vp, i32, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)],
+        "mx_tokenizer_segment": [vp, cp, i32, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t), P(i32)],
+        "mx_tokenizer_encode_batch": [vp, P(cp), i32, i32, vp, i32, vp, P(i32)],
     }
     for name, argtypes in sig.items():
         fn = getattr(L, name)
@@ -120,6 +129,8 @@ def _declare(L: ctypes.CDLL) -> None:
     L.mx_index_close.argtypes = [vp]
     L.mx_encoder_destroy.restype = None
     L.mx_encoder_destroy.argtypes = [vp]
+    L.mx_tokenizer_destroy.restype = None
+    L.mx_tokenizer_destroy.argtypes = [vp]
     L.mx_encoder_weight_bytes.restype = ctypes.c_size_t
     L.mx_encoder_weight_bytes.argtypes = [P(EncoderCfg)]
 

@@ -15,10 +15,11 @@ reference                  here
 =========================  ==================================================================
 
 Tokenisation stays on the host.  The reference downloads the pretrained ``tokenizer.json`` from the
-HF hub (embedding.rs:163); that is impossible offline, so a ``tokenizers.Tokenizer`` (or a path to a
-``tokenizer.json``) can be passed in, and otherwise :class:`WhitespaceHashTokenizer` -- a clearly
-labelled STAND-IN with the same windowing arithmetic -- keeps the plumbing runnable.  A native
-WordPiece segmenter is SURVEY.md section 8 row f-1 (next).
+HF hub (embedding.rs:163); that is impossible offline, so the tokenizer is passed in: a path to a BERT
+``vocab.txt`` selects the NATIVE WordPiece tokenizer / segmenter (``mx_tokenizer_*``,
+``csrc/tokenizer.cpp``, parity-tested against the ``tokenizers`` package), a ``tokenizer.json`` path or
+``tokenizers.Tokenizer`` object is adapted, and with nothing given :class:`WhitespaceHashTokenizer` --
+a clearly labelled STAND-IN with the same windowing arithmetic -- keeps the plumbing runnable.
 """
 from __future__ import annotations
 
@@ -145,6 +146,12 @@ class HFTokenizerAdapter:
 def _as_tokenizer(tokenizer, vocab: int):
     if tokenizer is None:
         return WhitespaceHashTokenizer(vocab)
+    if isinstance(tokenizer, str) and tokenizer.endswith(".txt"):
+        from .tokenizer import WordPieceTokenizer           # native WordPiece over a BERT vocab.txt
+        try:
+            return WordPieceTokenizer(tokenizer, lowercase=True)
+        except Exception as e:
+            raise SetupError(f"Unable to load model <{tokenizer}>") from e
     if isinstance(tokenizer, str):
         try:
             from tokenizers import Tokenizer

@@ -1,0 +1,74 @@
+"""Native WordPiece tokenizer + sliding-window segmenter (``mx_tokenizer_*``, host code in
+``csrc/tokenizer.cpp``): what memex does with the ``tokenizers`` crate in ``segment_text``
+(reference lib/libmemex/src/llm/embedding.rs:155-198) and what rust-bert does before the forward."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+class WordPieceTokenizer:
+    def __init__(self, vocab, lowercase: bool = True):
+        """``vocab``: path to a BERT ``vocab.txt`` or a list of tokens (index = id)."""
+        h = ctypes.c_void_p()
+        if isinstance(vocab, str):
+            check(lib().mx_tokenizer_create(vocab.encode(), 1 if lowercase else 0, ctypes.byref(h)))
+        else:
+            blob = "\n".join(vocab).encode("utf-8")
+            check(lib().mx_tokenizer_create_from_memory(blob, len(blob), 1 if lowercase else 0, ctypes.byref(h)))
+        self._h = h
+        n = ctypes.c_int(0)
+        check(lib().mx_tokenizer_vocab_size(self._h, ctypes.byref(n)))
+        self.vocab = n.value
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().mx_tokenizer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, text: str, add_special_tokens: bool = False) -> List[int]:
+        raw = text.encode("utf-8").replace(b"\0", b"")
+        cap = max(16, len(raw) + 2)
+        ids = (ctypes.c_int32 * cap)()
+        n = ctypes.c_int(0)
+        check(lib().mx_tokenizer_encode(self._h, raw, 1 if add_special_tokens else 0, ids, cap, ctypes.byref(n)))
+        return list(ids[: n.value])
+
+    def decode(self, ids: Sequence[int], skip_special_tokens: bool = True) -> str:
+        arr = (ctypes.c_int32 * max(1, len(ids)))(*ids)
+        nb = ctypes.c_size_t(0)
+        check(lib().mx_tokenizer_decode(self._h, arr, len(ids), 1 if skip_special_tokens else 0, None, 0, ctypes.byref(nb)))
+        buf = ctypes.create_string_buffer(nb.value)
+        check(lib().mx_tokenizer_decode(self._h, arr, len(ids), 1 if skip_special_tokens else 0, buf, nb.value, ctypes.byref(nb)))
+        return buf.value.decode("utf-8")
+
+    def windows(self, text: str, max_length: int, stride: int) -> List[str]:
+        """segment_text: detokenised windows of ``max_length`` tokens overlapping by ``stride``."""
+        raw = text.encode("utf-8").replace(b"\0", b"")
+        nb, ns = ctypes.c_size_t(0), ctypes.c_int(0)
+        check(lib().mx_tokenizer_segment(self._h, raw, max_length, stride, None, 0, ctypes.byref(nb), ctypes.byref(ns)))
+        buf = ctypes.create_string_buffer(nb.value)
+        check(lib().mx_tokenizer_segment(self._h, raw, max_length, stride, buf, nb.value, ctypes.byref(nb), ctypes.byref(ns)))
+        parts = buf.raw[: nb.value].split(b"\0")[: ns.value]
+        return [p.decode("utf-8") for p in parts]
+
+    def encode_batch(self, texts: Sequence[str], max_seq_length: int) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (ids int32 [B,S], lens int32 [B]) with [CLS]/[SEP], truncated, [PAD]-padded to the batch max."""
+        B = len(texts)
+        arr = (ctypes.c_char_p * B)(*[t.encode("utf-8").replace(b"\0", b"") for t in texts])
+        ids = np.zeros((B, max_seq_length), dtype=np.int32)
+        lens = np.zeros(B, dtype=np.int32)
+        S = ctypes.c_int(0)
+        check(lib().mx_tokenizer_encode_batch(self._h, arr, B, max_seq_length, ids.ctypes.data_as(ctypes.c_void_p),
+                                              max_seq_length, lens.ctypes.data_as(ctypes.c_void_p), ctypes.byref(S)))
+        return np.ascontiguousarray(ids[:, : S.value]), lens

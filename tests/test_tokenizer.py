@@ -1,0 +1,125 @@
+"""Native WordPiece tokenizer / segmenter vs the `tokenizers` Python package (same Rust core the
+reference links, lib/libmemex/Cargo.toml:31) on a synthetic vocabulary -- no GPU needed.
+
+The reference's own tokenizer test (embedding.rs:204-217) needs the HF hub; what it pins -- that a
+short string encodes without error under truncation 256 / stride 128 -- is restated at the end."""
+import numpy as np
+import pytest
+
+SPECIALS = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+STEMS = ["the", "of", "and", "tax", "taxes", "bid", "en", "biden", "say", "s", "about", "what", "do", "does", "not",
+         "work", "ing", "ed", "er", "est", "un", "believ", "able", "cafe", "resume", "naive", "zurich", "state",
+         "union", "2023", "20", "23", "a", "b", "c", "d", "e", "i", "o", "u", "x", "y", "z", "n", "t", "m", "re", "ve",
+         "ll", "hello", "world", "token", "ize", "long", "word", "embed", "vector", "search", "gpu", "über", "uber"]
+PUNCT = list("!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~")
+
+
+def make_vocab():
+    toks = list(SPECIALS)
+    for s in STEMS:
+        toks.append(s)
+    for s in STEMS:
+        toks.append("##" + s)
+    toks += PUNCT
+    toks += ["中", "文", "##s"]
+    seen, out = set(), []
+    for t in toks:
+        if t not in seen:
+            seen.add(t)
+            out.append(t)
+    return out
+
+
+@pytest.fixture(scope="module")
+def toks(lib_built, tmp_path_factory):
+    from tokenizers import BertWordPieceTokenizer
+    from memex_amd.tokenizer import WordPieceTokenizer
+    vocab = make_vocab()
+    p = tmp_path_factory.mktemp("vocab") / "vocab.txt"
+    p.write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    hf = BertWordPieceTokenizer(str(p), lowercase=True)
+    return hf, WordPieceTokenizer(str(p), lowercase=True), vocab
+
+
+TEXTS = [
+    "What does Biden say about taxes?",
+    "The STATE of the Union 2023 -- unbelievable, isn't it?!",
+    "Café résumé naïve Zürich ÜBER",
+    "tokenizing   long\twords\nand don't re-embed; they've said: \"we'll do it\".",
+    "unknownword zzzqqq the",
+    "a" * 120 + " the",
+    "中文 and the",
+    "",
+    "   ",
+    "it 's the tax . do not say ' no ' !",
+]
+
+
+def test_ids_match_hf_tokenizers(toks):
+    hf, mine, _ = toks
+    for t in TEXTS:
+        for special in (False, True):
+            assert mine.encode(t, special) == hf.encode(t, add_special_tokens=special).ids, (t, special)
+
+
+def test_random_text_ids_and_decode(toks):
+    hf, mine, _ = toks
+    rng = np.random.default_rng(0)
+    pieces = STEMS + PUNCT + ["Biden's", "WORKING", "unbelievable", "worked,", "x-y", "Ünion"]
+    for _ in range(200):
+        n = int(rng.integers(1, 40))
+        t = " ".join(rng.choice(pieces, size=n))
+        e = hf.encode(t, add_special_tokens=False)
+        ids = mine.encode(t)
+        assert ids == e.ids, t
+        assert mine.decode(ids, True) == hf.decode(e.ids, skip_special_tokens=True), t
+
+
+def test_segment_text_windows_match_reference_calls(toks):
+    """The exact call sequence of embedding.rs:173-195 on the HF side vs mx_tokenizer_segment."""
+    hf, mine, _ = toks
+    rng = np.random.default_rng(1)
+    text = " ".join(rng.choice(STEMS + ["don't", "it's", "' quoted '", "end."], size=900))
+    for max_length, stride in ((256, 86), (256, 128), (64, 10), (1000, 86)):
+        hf.enable_truncation(max_length=max_length, stride=stride)
+        enc = hf.encode(text, add_special_tokens=False)
+        want = [hf.decode(enc.ids, skip_special_tokens=True).replace(" ' ", "'")]
+        want += [hf.decode(o.ids, skip_special_tokens=True) for o in enc.overflowing]
+        hf.no_truncation()
+        got = mine.windows(text, max_length, stride)
+        assert got == want, (max_length, stride, len(got), len(want))
+    assert mine.windows("", 256, 86) == [""]
+
+
+def test_encode_batch_for_the_encoder(toks):
+    hf, mine, vocab = toks
+    texts = ["what does biden say about taxes?", "the", " ".join(["tax"] * 300)]
+    ids, lens = mine.encode_batch(texts, 128)
+    assert ids.shape == (3, 128) and lens.tolist() == [len(hf.encode(texts[0]).ids), 3, 128]
+    cls, sep, pad = vocab.index("[CLS]"), vocab.index("[SEP]"), vocab.index("[PAD]")
+    for b in range(3):
+        assert ids[b, 0] == cls and ids[b, lens[b] - 1] == sep and (ids[b, lens[b]:] == pad).all()
+    assert ids[0, : lens[0]].tolist() == hf.encode(texts[0]).ids
+    short, slens = mine.encode_batch(texts[:2], 128)
+    assert short.shape[1] == slens.max()                      # padded to the batch maximum only
+
+
+def test_reference_tokenizer_test_shape(toks):
+    """embedding.rs:204-217: a 5-word string encodes under truncation(256, stride 128) (the reference
+    then sees 128 ids only because the downloaded tokenizer.json pads to a fixed 128)."""
+    hf, mine, _ = toks
+    ids = mine.encode("this is a test string")
+    assert 0 < len(ids) <= 256 and mine.windows("this is a test string", 256, 128) == [mine.decode(ids, True)]
+
+
+def test_errors(lib_built):
+    from memex_amd import _lib
+    from memex_amd.tokenizer import WordPieceTokenizer
+    with pytest.raises(_lib.MemexHipError) as ei:
+        WordPieceTokenizer("/nonexistent/vocab.txt")
+    assert ei.value.code == _lib.MX_EIO
+    with pytest.raises(_lib.MemexHipError):
+        WordPieceTokenizer(["a", "b"])                       # no special tokens
+    t = WordPieceTokenizer(make_vocab())
+    with pytest.raises(_lib.MemexHipError):
+        t.windows("x", 10, 10)                               # stride must be < max_length
