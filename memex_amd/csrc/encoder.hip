@@ -74,12 +74,15 @@ int upload_f32(mx_encoder *e, const float *src, size_t n, float **dst) {
     return MX_OK;
 }
 
-int upload_bf16(mx_encoder *e, const float *src, size_t n, bf16_t **dst) {
-    std::vector<uint16_t> tmp(n);
-    for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16(src[i]);
-    MX_HIP(hipMalloc(dst, n * sizeof(uint16_t)));
+// Linear weight [rows, k] (nn.Linear layout) -> bf16, K-blocked [k/32][rows][32]: every 16-row x 64-byte
+// staging piece of the GEMM is then one contiguous KiB
+int upload_weight(mx_encoder *e, const float *src, size_t rows, size_t k, bf16_t **dst) {
+    std::vector<uint16_t> tmp(rows * k);
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < k; ++c) tmp[((c >> 5) * rows + r) * 32 + (c & 31)] = f32_to_bf16(src[r * k + c]);
+    MX_HIP(hipMalloc(dst, tmp.size() * sizeof(uint16_t)));
     e->allocs.push_back(*dst);
-    MX_HIP(hipMemcpy(*dst, tmp.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    MX_HIP(hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return MX_OK;
 }
 
@@ -161,20 +164,24 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
     const float qscale = (float)(1.4426950408889634 / std::sqrt((double)dh));
     for (const Layer &L : e->layers) {
         GemmParams g{};
-        g.a = e->x; g.lda = H; g.w = L.wqkv; g.bias = L.bqkv; g.m = t_pad; g.n = 3 * H; g.k = H;
-        g.out = e->q; g.out_k = e->k; g.out_vt = e->vt; g.ldo = H; g.ldvt = t_pad; g.hidden = H; g.qscale = qscale;
+        g.a = e->x; g.lda = H; g.w = L.wqkv; g.w_rows = 3 * H; g.w_row0 = 0; g.bias = L.bqkv; g.m = t_pad; g.n = 2 * H; g.k = H;
+        g.out = e->q; g.out_k = e->k; g.ldo = H; g.hidden = H; g.qscale = qscale;
         MX_HIP(launch_gemm(st, EPI_QKV, g));
+        GemmParams gv{};  // V third of the concatenated projection, written feature-major
+        gv.a = e->x; gv.lda = H; gv.w = L.wqkv; gv.w_rows = 3 * H; gv.w_row0 = 2 * H; gv.bias = L.bqkv + 2 * H; gv.m = t_pad; gv.n = H;
+        gv.k = H; gv.out_vt = e->vt; gv.ldvt = t_pad; gv.hidden = H;
+        MX_HIP(launch_gemm(st, EPI_VT, gv));
         MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->cu, d_lens, B, max_len, heads, dh, H, e->ctx));
         GemmParams o{};
-        o.a = e->ctx; o.lda = H; o.w = L.wo; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = H;
+        o.a = e->ctx; o.lda = H; o.w = L.wo; o.w_rows = H; o.w_row0 = 0; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = H;
         o.out = e->x1; o.ldo = H; o.res = e->x; o.ldres = H; o.gamma = L.ln1g; o.beta = L.ln1b; o.eps = c.ln_eps;
         MX_HIP(launch_gemm(st, EPI_BIAS_RES_LN, o));
         GemmParams f1{};
-        f1.a = e->x1; f1.lda = H; f1.w = L.wi; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = H;
+        f1.a = e->x1; f1.lda = H; f1.w = L.wi; f1.w_rows = F; f1.w_row0 = 0; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = H;
         f1.out = e->hbuf; f1.ldo = F;
         MX_HIP(launch_gemm(st, EPI_BIAS_GELU, f1));
         GemmParams f2{};
-        f2.a = e->hbuf; f2.lda = F; f2.w = L.wo2; f2.bias = L.bo2; f2.m = t_pad; f2.n = H; f2.k = F;
+        f2.a = e->hbuf; f2.lda = F; f2.w = L.wo2; f2.w_rows = H; f2.w_row0 = 0; f2.bias = L.bo2; f2.m = t_pad; f2.n = H; f2.k = F;
         f2.out = e->x; f2.ldo = H; f2.res = e->x1; f2.ldres = H; f2.gamma = L.ln2g; f2.beta = L.ln2b; f2.eps = c.ln_eps;
         MX_HIP(launch_gemm(st, EPI_BIAS_RES_LN, f2));
     }
@@ -302,15 +309,15 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
             memcpy(wqkv.data() + part * H * H, take(H * H), H * H * sizeof(float));
             memcpy(bqkv.data() + part * H, take(H), H * sizeof(float));
         }
-        MX_TRY(upload_bf16(e, wqkv.data(), 3 * H * H, &L.wqkv));
+        MX_TRY(upload_weight(e, wqkv.data(), 3 * H, H, &L.wqkv));
         MX_TRY(upload_f32(e, bqkv.data(), 3 * H, &L.bqkv));
-        MX_TRY(upload_bf16(e, take(H * H), H * H, &L.wo));
+        MX_TRY(upload_weight(e, take(H * H), H, H, &L.wo));
         MX_TRY(upload_f32(e, take(H), H, &L.bo));
         MX_TRY(upload_f32(e, take(H), H, &L.ln1g));
         MX_TRY(upload_f32(e, take(H), H, &L.ln1b));
-        MX_TRY(upload_bf16(e, take(F * H), F * H, &L.wi));
+        MX_TRY(upload_weight(e, take(F * H), F, H, &L.wi));
         MX_TRY(upload_f32(e, take(F), F, &L.bi));
-        MX_TRY(upload_bf16(e, take(H * F), H * F, &L.wo2));
+        MX_TRY(upload_weight(e, take(H * F), H, F, &L.wo2));
         MX_TRY(upload_f32(e, take(H), H, &L.bo2));
         MX_TRY(upload_f32(e, take(H), H, &L.ln2g));
         MX_TRY(upload_f32(e, take(H), H, &L.ln2b));

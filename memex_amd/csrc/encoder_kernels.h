@@ -15,19 +15,22 @@ namespace mx {
 typedef __bf16 bf16_t;
 
 constexpr int kSeqAlign = 8;     // sequence start alignment (tokens)
-constexpr int kRowPad = 128;     // packed token count is padded to this (GEMM BM)
+constexpr int kRowPad = 256;     // packed token count is padded to this (GEMM BM)
 
 enum GemmEpilogue {
     EPI_BIAS = 0,         // out = bf16(acc + bias)
     EPI_BIAS_GELU = 1,    // out = bf16(gelu_erf(acc + bias))
-    EPI_QKV = 2,          // N = 3H: q (scaled) and k token-major, v feature-major (transposed)
+    EPI_QKV = 2,          // N = 2H: q (pre-scaled) and k, token-major into out / out_k
+    EPI_VT = 4,           // N = H: v, feature-major (transposed) into out_vt
     EPI_BIAS_RES_LN = 3,  // out = bf16(LayerNorm(acc + bias + residual))   (BN == N == hidden)
 };
 
 struct GemmParams {
     const bf16_t *a;      // [M, K] activations, row pitch lda (elements)
     int lda;
-    const bf16_t *w;      // [N, K] weights (nn.Linear layout), row pitch K
+    const bf16_t *w;      // weights, K-blocked: [K/32][w_rows][32] (element (n,k) at ((k>>5)*w_rows + n)*32 + (k&31))
+    int w_rows;           // rows of the blocked weight matrix (e.g. 3H for the concatenated QKV)
+    int w_row0;           // first weight row this GEMM uses (V third: 2H)
     const float *bias;    // [N]
     int m, n, k;          // m multiple of 128 (or 64 for the 768-wide LN variant), n multiple of 384, k of 64
     bf16_t *out;          // EPI_BIAS/GELU/LN: [M, N] pitch ldo;  EPI_QKV: q [M, H]
@@ -35,7 +38,7 @@ struct GemmParams {
     bf16_t *out_k;        // EPI_QKV: k [M, H]
     bf16_t *out_vt;       // EPI_QKV: v^T [H, ldvt]
     int ldvt;
-    int hidden;           // EPI_QKV: H
+    int hidden;           // EPI_QKV / EPI_VT: H
     float qscale;         // EPI_QKV: multiplies q (1/sqrt(d_head) * log2(e))
     const bf16_t *res;    // EPI_BIAS_RES_LN: residual [M, N] pitch ldres
     int ldres;

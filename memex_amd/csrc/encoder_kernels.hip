@@ -37,22 +37,24 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vecto
 //   transposed (feature-major) output and uses the opposite roles for the same reason.
 //   Epilogue: registers -> bf16 tile in LDS -> 16-byte coalesced copy-out (+ residual + LayerNorm).
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int BK, int S>
+template <int WM, int WN, int MI, int BK, int S>
 struct GemmGeom {
     static_assert(BK == 32, "staging layout below is written for 64-byte (BK = 32) rows");
     static constexpr int NT = 64 * WM * WN;               // threads
     static constexpr int NWAVE = WM * WN;
-    static constexpr int BM = 64 * WM;
+    static constexpr int BM = 32 * MI * WM;               // wave tile = (32*MI) x 96
+    static constexpr int GR = BM < 128 ? BM : 128;        // rows per epilogue group (LDS output tile)
+    static constexpr int NGROUP = BM / GR;
     static constexpr int BN = 96 * WN;
     static constexpr int ROWS = BM + BN;                  // staged rows per k-tile: A rows then W rows
     static constexpr int STAGE = ROWS * BK * 2;           // bytes per stage (unpadded, lane-linear DMA image)
     static constexpr int PIECES = ROWS / 16;              // 1 KiB DMA pieces (16 rows x 64 B) per stage
     static constexpr int PPW = (PIECES + NWAVE - 1) / NWAVE;  // pieces each wave issues per k-tile
     static constexpr int PO = BN * 2 + 16;                // output tile pitch, row-major [m][n]
-    static constexpr int POT = BM * 2 + 16;               // output tile pitch, feature-major [n][m]
-    static constexpr int OUT_BYTES = (BM * PO > BN * POT) ? BM * PO : BN * POT;
+    static constexpr int POT = GR * 2 + 16;               // output tile pitch, feature-major [n][m]
+    static constexpr int OUT_BYTES = (GR * PO > BN * POT) ? GR * PO : BN * POT;
     static constexpr int LDS = (S * STAGE > OUT_BYTES) ? S * STAGE : OUT_BYTES;
-    static_assert(ROWS % 16 == 0, "piece split");
+    static_assert(ROWS % 16 == 0 && (32 * MI) % GR == 0 || GR % (32 * MI) == 0, "piece / group split");
 };
 
 // erf to ~1.5e-7 absolute (Abramowitz-Stegun 7.1.26): the result is rounded to bf16 (2^-9) anyway
@@ -68,9 +70,9 @@ __device__ __forceinline__ float gelu_erf(float x) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <int EPI, int WM, int WN, int BK, int S>
+template <int EPI, int WM, int WN, int MI, int BK, int S>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) {
-    using G = GemmGeom<WM, WN, BK, S>;
+    using G = GemmGeom<WM, WN, MI, BK, S>;
     constexpr int NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
     // conflicts of the fragment reads are removed by permuting the SOURCE chunk:
     // physical chunk pc holds logical chunk pc ^ ((row>>2)&3).
     const char *src[G::PPW];   // per-lane source address of each of this wave's pieces at k = 0
+    size_t kstep[G::PPW];      // bytes between consecutive k-tiles of that piece's source
     uint32_t dst[G::PPW];      // wave-uniform LDS offset of the piece inside a stage
 #pragma unroll
     for (int i = 0; i < G::PPW; ++i) {
@@ -112,25 +115,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
         piece = piece < G::PIECES ? piece : G::PIECES - 1;  // surplus issues re-load the last piece
         const int row = piece * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
-        const bf16_t *base = row < G::BM ? p.a + (size_t)(m0 + row) * p.lda : p.w + (size_t)(n0 + row - G::BM) * kdim;
+        // activations: row-major [M][K]; weights: K-blocked [K/32][w_rows][32] so that a weight piece
+        // (16 rows x 64 B) is one contiguous KiB of full cache lines
+        const bf16_t *base = row < G::BM ? p.a + (size_t)(m0 + row) * p.lda
+                                         : p.w + (size_t)(p.w_row0 + n0 + row - G::BM) * 32;
         src[i] = reinterpret_cast<const char *>(base + c * 8);
+        kstep[i] = row < G::BM ? (size_t)(BK * 2) : (size_t)p.w_rows * (BK * 2);
         dst[i] = (uint32_t)piece * 1024u;
     }
     auto issue_tile = [&](int kt) __attribute__((always_inline)) {
         const uint32_t sbase = (uint32_t)(kt % S) * G::STAGE;
 #pragma unroll
         for (int i = 0; i < G::PPW; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src[i] + (size_t)kt * (BK * 2)),
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src[i] + (size_t)kt * kstep[i]),
                                              (lds_void_t *)(smem + __builtin_amdgcn_readfirstlane(sbase + dst[i])), 16, 0, 0);
     };
 
     int part = 0;
-    if (EPI == EPI_QKV) part = n0 / p.hidden;  // block-uniform: BN divides hidden
-    const bool feature_major = (EPI == EPI_QKV) && part == 2;
+    if (EPI == EPI_QKV) part = n0 / p.hidden;  // 0 = q, 1 = k (block-uniform: BN divides hidden)
+    constexpr bool feature_major = (EPI == EPI_VT);  // V projection: transposed output, opposite MFMA roles
 
-    f32x16 acc[2][3];  // [i: 32-row m block][j: 32-col n block]
+    f32x16 acc[MI][3];  // [i: 32-row m block][j: 32-col n block]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
 
     // fragment read offsets: row (.. + l31), logical chunk (2*ks + h) -> physical ^ ((l31>>2)&3)
     const uint32_t sw0 = (uint32_t)((h ^ ((l31 >> 2) & 3)) << 4), sw1 = sw0 ^ 32u;
-    const uint32_t a_row = (uint32_t)(wm * 64 + l31) * (BK * 2);
+    const uint32_t a_row = (uint32_t)(wm * 32 * MI + l31) * (BK * 2);
     const uint32_t w_row = (uint32_t)(G::BM + wn * 96 + l31) * (BK * 2);
 
 #pragma unroll 1
@@ -163,20 +170,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const uint32_t sw = ks == 0 ? sw0 : sw1;
-            bf16x8 af[2], bf[3];
+            bf16x8 af[MI], bf[3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(st + a_row + i * 32 * (BK * 2) + sw);
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(st + a_row + i * 32 * (BK * 2) + sw);
 #pragma unroll
             for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const bf16x8 *>(st + w_row + j * 32 * (BK * 2) + sw);
             if (feature_major) {  // D[m][n]: lane owns column n, 4 consecutive rows m per group
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             } else {              // D^T[n][m]: lane owns row m, 4 consecutive columns n per group
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
@@ -186,147 +193,159 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // all waves are done with the ring: its space becomes the output tile
 
-    // ---- epilogue pass 1: registers -> bf16 tile in LDS (staging buffers are free now).
+    // ---- epilogue, one 128-row group at a time (the bf16 output tile of a group fits the ring's
+    // LDS): pass 1 registers -> LDS tile, pass 2 coalesced 16-byte copy-out (+ residual + LayerNorm).
     // 32x32 D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    if (feature_major) {
-        // col = n (one bias per lane), rows = m: write [n][m .. m+3] as one 8-byte store
+    const float oscale = (EPI == EPI_QKV && part == 0) ? p.qscale : 1.0f;
+#pragma unroll 1
+    for (int grp = 0; grp < G::NGROUP; ++grp) {
+        const int g0 = grp * G::GR;                 // first tile row of this group
+        const int wrow0 = wm * 32 * MI;             // first tile row of this wave
+        const bool mine = wrow0 >= g0 && wrow0 < g0 + G::GR;  // wave-uniform
+        if (mine) {
+            if (feature_major) {
+                // col = n (one bias per lane), rows = m: write [n][m .. m+3] as one 8-byte store
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int col = wn * 96 + j * 32 + l31;
-            const float b = p.bias[n0 + col];
+                for (int j = 0; j < 3; ++j) {
+                    const int col = wn * 96 + j * 32 + l31;
+                    const float b = p.bias[n0 + col];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int row0 = wm * 64 + i * 32 + 8 * rg + 4 * h;
-                    bf16x4 pk;
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int row0 = wrow0 - g0 + i * 32 + 8 * rg + 4 * h;
+                            bf16x4 pk;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(acc[i][j][rg * 4 + e] + b);
-                    *reinterpret_cast<bf16x4 *>(smem + col * G::POT + row0 * 2) = pk;
+                            for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(acc[i][j][rg * 4 + e] + b);
+                            *reinterpret_cast<bf16x4 *>(smem + col * G::POT + row0 * 2) = pk;
+                        }
                 }
-        }
-    } else {
-        // col = m (this lane's output row), rows = n: write [m][n .. n+3] as one 8-byte store
-        const float oscale = (EPI == EPI_QKV && part == 0) ? p.qscale : 1.0f;
+            } else {
+                // col = m (this lane's output row), rows = n: write [m][n .. n+3] as one 8-byte store
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int nloc = wn * 96 + j * 32 + 8 * rg + 4 * h;
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + nloc);
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int nloc = wn * 96 + j * 32 + 8 * rg + 4 * h;
+                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + nloc);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int mrow = wm * 64 + i * 32 + l31;
-                    bf16x4 pk;
+                        for (int i = 0; i < MI; ++i) {
+                            const int mrow = wrow0 - g0 + i * 32 + l31;
+                            bf16x4 pk;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = acc[i][j][rg * 4 + e] + b4[e];
-                        if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
-                        pk[e] = (__bf16)(t * oscale);
+                            for (int e = 0; e < 4; ++e) {
+                                float t = acc[i][j][rg * 4 + e] + b4[e];
+                                if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
+                                pk[e] = (__bf16)(t * oscale);
+                            }
+                            *reinterpret_cast<bf16x4 *>(smem + mrow * G::PO + nloc * 2) = pk;
+                        }
                     }
-                    *reinterpret_cast<bf16x4 *>(smem + mrow * G::PO + nloc * 2) = pk;
+            }
+        }
+        __syncthreads();
+        const int mg = m0 + g0;  // first global row of the group
+        if (EPI == EPI_BIAS_RES_LN) {
+            constexpr int TPR = NT / G::GR;            // threads per row
+            constexpr int CPT = G::BN / TPR / 8;       // 16-B chunks per thread
+            static_assert(G::BN % (TPR * 8) == 0 && NT % G::GR == 0, "row split");
+            const int row = tid / TPR, prt = tid % TPR;
+            float y[CPT * 8];
+            float sum = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                // interleave the threads of a row chunk-wise: consecutive threads read consecutive 16 B
+                const int col = (c * TPR + prt) * 8;
+                const bf16x8 o = *reinterpret_cast<const bf16x8 *>(smem + row * G::PO + col * 2);
+                const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res + (size_t)(mg + row) * p.ldres + n0 + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    y[c * 8 + e] = (float)o[e] + (float)rs[e];
+                    sum += y[c * 8 + e];
                 }
             }
-    }
-    __syncthreads();
-
-    // ---- epilogue pass 2: coalesced 16-byte copy-out (+ residual + LayerNorm)
-    if (EPI == EPI_BIAS_RES_LN) {
-        constexpr int TPR = NT / G::BM;            // threads per row
-        constexpr int CPT = G::BN / TPR / 8;       // 16-B chunks per thread
-        static_assert(G::BN % (TPR * 8) == 0 && NT % G::BM == 0, "row split");
-        const int row = tid / TPR, prt = tid % TPR;
-        float y[CPT * 8];
-        float sum = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            // interleave the threads of a row chunk-wise: consecutive threads read consecutive 16 B
-            const int col = (c * TPR + prt) * 8;
-            const bf16x8 o = *reinterpret_cast<const bf16x8 *>(smem + row * G::PO + col * 2);
-            const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res + (size_t)(m0 + row) * p.ldres + n0 + col);
+            for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum / (float)G::BN;
+            float sq = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                y[c * 8 + e] = (float)o[e] + (float)rs[e];
-                sum += y[c * 8 + e];
+            for (int e = 0; e < CPT * 8; ++e) {
+                const float dlt = y[e] - mean;
+                sq += dlt * dlt;
+            }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) sq += __shfl_xor(sq, o);
+            const float rstd = 1.0f / sqrtf(sq / (float)G::BN + p.eps);
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const int col = (c * TPR + prt) * 8;
+                const f32x4 g0v = *reinterpret_cast<const f32x4 *>(p.gamma + n0 + col);
+                const f32x4 g1v = *reinterpret_cast<const f32x4 *>(p.gamma + n0 + col + 4);
+                const f32x4 b0v = *reinterpret_cast<const f32x4 *>(p.beta + n0 + col);
+                const f32x4 b1v = *reinterpret_cast<const f32x4 *>(p.beta + n0 + col + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (__bf16)((y[c * 8 + e] - mean) * rstd * g0v[e] + b0v[e]);
+                    o[4 + e] = (__bf16)((y[c * 8 + 4 + e] - mean) * rstd * g1v[e] + b1v[e]);
+                }
+                *reinterpret_cast<bf16x8 *>(p.out + (size_t)(mg + row) * p.ldo + n0 + col) = o;
+            }
+        } else if (feature_major) {
+            constexpr int CPF = G::GR / 8;  // chunks per feature row
+            const int nloc = n0;
+            for (int c = tid; c < G::BN * CPF; c += NT) {
+                const int f = c / CPF, tc = c % CPF;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + f * G::POT + tc * 16);
+                *reinterpret_cast<u32x4 *>(p.out_vt + (size_t)(nloc + f) * p.ldvt + mg + tc * 8) = v;
+            }
+        } else {
+            constexpr int CPO = G::BN / 8;  // chunks per output row
+            bf16_t *dst = p.out;
+            int nloc = n0;
+            if (EPI == EPI_QKV) {
+                dst = part == 0 ? p.out : p.out_k;
+                nloc = n0 - part * p.hidden;
+            }
+            for (int c = tid; c < G::GR * CPO; c += NT) {
+                const int row = c / CPO, cc = c % CPO;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + row * G::PO + cc * 16);
+                *reinterpret_cast<u32x4 *>(dst + (size_t)(mg + row) * p.ldo + nloc + cc * 8) = v;
             }
         }
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
-        const float mean = sum / (float)G::BN;
-        float sq = 0.0f;
-#pragma unroll
-        for (int e = 0; e < CPT * 8; ++e) {
-            const float dlt = y[e] - mean;
-            sq += dlt * dlt;
-        }
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) sq += __shfl_xor(sq, o);
-        const float rstd = 1.0f / sqrtf(sq / (float)G::BN + p.eps);
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            const int col = (c * TPR + prt) * 8;
-            const f32x4 g0 = *reinterpret_cast<const f32x4 *>(p.gamma + n0 + col);
-            const f32x4 g1 = *reinterpret_cast<const f32x4 *>(p.gamma + n0 + col + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p.beta + n0 + col);
-            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(p.beta + n0 + col + 4);
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (__bf16)((y[c * 8 + e] - mean) * rstd * g0[e] + b0[e]);
-                o[4 + e] = (__bf16)((y[c * 8 + 4 + e] - mean) * rstd * g1[e] + b1[e]);
-            }
-            *reinterpret_cast<bf16x8 *>(p.out + (size_t)(m0 + row) * p.ldo + n0 + col) = o;
-        }
-    } else if (feature_major) {
-        constexpr int CPF = G::BM / 8;  // chunks per feature row
-        const int nloc = n0 - 2 * p.hidden;
-        for (int c = tid; c < G::BN * CPF; c += NT) {
-            const int f = c / CPF, tc = c % CPF;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + f * G::POT + tc * 16);
-            *reinterpret_cast<u32x4 *>(p.out_vt + (size_t)(nloc + f) * p.ldvt + m0 + tc * 8) = v;
-        }
-    } else {
-        constexpr int CPO = G::BN / 8;  // chunks per output row
-        bf16_t *dst = p.out;
-        int nloc = n0;
-        if (EPI == EPI_QKV) {
-            dst = part == 0 ? p.out : p.out_k;
-            nloc = n0 - part * p.hidden;
-        }
-        for (int c = tid; c < G::BM * CPO; c += NT) {
-            const int row = c / CPO, cc = c % CPO;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + row * G::PO + cc * 16);
-            *reinterpret_cast<u32x4 *>(dst + (size_t)(m0 + row) * p.ldo + nloc + cc * 8) = v;
-        }
+        if (grp + 1 < G::NGROUP) __syncthreads();  // the next group reuses the LDS tile
     }
 }
 
-template <int EPI, int WM, int WN, int BK, int S>
+template <int EPI, int WM, int WN, int MI, int BK, int S>
 static hipError_t gemm_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<EPI, WM, WN, BK, S>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, GemmGeom<WM, WN, BK, S>::LDS);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<EPI, WM, WN, MI, BK, S>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GemmGeom<WM, WN, MI, BK, S>::LDS);
 }
 
-template <int EPI, int WM, int WN, int BK, int S>
+template <int EPI, int WM, int WN, int MI, int BK, int S>
 static hipError_t gemm_go(hipStream_t s, const GemmParams &p) {
-    using G = GemmGeom<WM, WN, BK, S>;
+    using G = GemmGeom<WM, WN, MI, BK, S>;
     if (p.m % G::BM || p.n % G::BN || p.k % BK) return hipErrorInvalidValue;
-    if (EPI == EPI_QKV && p.hidden % G::BN) return hipErrorInvalidValue;
+    if (EPI == EPI_QKV && (p.hidden % G::BN || p.n != 2 * p.hidden)) return hipErrorInvalidValue;
     dim3 grid((p.m / G::BM) * (p.n / G::BN));
-    hipLaunchKernelGGL((gemm_kernel<EPI, WM, WN, BK, S>), grid, dim3(G::NT), G::LDS, s, p);
+    hipLaunchKernelGGL((gemm_kernel<EPI, WM, WN, MI, BK, S>), grid, dim3(G::NT), G::LDS, s, p);
     return hipGetLastError();
 }
 
-// tile configurations: 128 x 384 (8 waves, 4-stage 32 KiB ring) everywhere the row is 384-wide or the
-// epilogue is row-independent; 64 x 768 (8 waves, 3-stage 52 KiB ring) for the 768-wide LayerNorm
+// tile configurations.  The main loop is operand-delivery-bound (LDS caps the DMA bytes in flight,
+// so CU ingest sits near 11 B/clk): the lever is flops per staged byte.  256 x 384 (8 waves, wave
+// tile 128 x 96, 4-stage 40 KiB ring = all 160 KiB of LDS) does 154 flop/B; the LayerNorm
+// GEMMs keep a full row per tile: 128 x 384 (4-stage 32 KiB ring) and 64 x 768 (3-stage 52 KiB ring).
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
     switch (epi) {
-        case EPI_BIAS: return gemm_go<EPI_BIAS, 2, 4, 32, 4>(s, p);
-        case EPI_BIAS_GELU: return gemm_go<EPI_BIAS_GELU, 2, 4, 32, 4>(s, p);
-        case EPI_QKV: return gemm_go<EPI_QKV, 2, 4, 32, 4>(s, p);
+        case EPI_BIAS: return gemm_go<EPI_BIAS, 2, 4, 4, 32, 4>(s, p);
+        case EPI_BIAS_GELU: return gemm_go<EPI_BIAS_GELU, 2, 4, 4, 32, 4>(s, p);
+        case EPI_QKV: return gemm_go<EPI_QKV, 2, 4, 4, 32, 4>(s, p);
+        case EPI_VT: return gemm_go<EPI_VT, 2, 4, 4, 32, 4>(s, p);
         case EPI_BIAS_RES_LN:
-            if (p.n == 384) return gemm_go<EPI_BIAS_RES_LN, 2, 4, 32, 4>(s, p);
-            if (p.n == 768) return gemm_go<EPI_BIAS_RES_LN, 1, 8, 32, 3>(s, p);
+            if (p.n == 384) return gemm_go<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>(s, p);
+            if (p.n == 768) return gemm_go<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>(s, p);
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
@@ -658,11 +677,12 @@ hipError_t launch_pool(hipStream_t s, const bf16_t *x, const int32_t *cu, const 
 
 hipError_t encoder_kernels_setup() {
     hipError_t e;
-    if ((e = gemm_attr<EPI_BIAS, 2, 4, 32, 4>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_BIAS_GELU, 2, 4, 32, 4>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_QKV, 2, 4, 32, 4>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_BIAS_RES_LN, 2, 4, 32, 4>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_BIAS_RES_LN, 1, 8, 32, 3>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS, 2, 4, 4, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS_GELU, 2, 4, 4, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_QKV, 2, 4, 4, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_VT, 2, 4, 4, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>()) != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<32>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(512, 32));
     if (e != hipSuccess) return e;
