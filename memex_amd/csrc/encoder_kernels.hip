@@ -54,7 +54,7 @@ struct GemmGeom {
     static constexpr int POT = GR * 2 + 16;               // output tile pitch, feature-major [n][m]
     static constexpr int OUT_BYTES = (GR * PO > BN * POT) ? GR * PO : BN * POT;
     static constexpr int LDS = (S * STAGE > OUT_BYTES) ? S * STAGE : OUT_BYTES;
-    static_assert(ROWS % 16 == 0 && (32 * MI) % GR == 0 || GR % (32 * MI) == 0, "piece / group split");
+    static_assert(ROWS % 16 == 0 && ((32 * MI) % GR == 0 || GR % (32 * MI) == 0), "piece / group split");
 };
 
 // erf to ~1.5e-7 absolute (Abramowitz-Stegun 7.1.26): the result is rounded to bf16 (2^-9) anyway
@@ -333,16 +333,17 @@ static hipError_t gemm_go(hipStream_t s, const GemmParams &p) {
     return hipGetLastError();
 }
 
-// tile configurations.  The main loop is operand-delivery-bound (LDS caps the DMA bytes in flight,
-// so CU ingest sits near 11 B/clk): the lever is flops per staged byte.  256 x 384 (8 waves, wave
-// tile 128 x 96, 4-stage 40 KiB ring = all 160 KiB of LDS) does 154 flop/B; the LayerNorm
-// GEMMs keep a full row per tile: 128 x 384 (4-stage 32 KiB ring) and 64 x 768 (3-stage 52 KiB ring).
+// tile configurations (measured): the epilogues (GELU, LDS staging, HBM writes)
+// take as long as the K = 384 MFMA loops, so the plain GEMMs use 128 x 192 tiles with 4 waves and an
+// 80 KiB 4-stage ring -> TWO workgroups per CU, one's epilogue overlapping the other's MFMAs.  The
+// LayerNorm GEMMs need a full row per tile: 128 x 384 (8 waves, 128 KiB ring) and 64 x 768
+// (3-stage 52 KiB ring); 64 x 384 at 2 workgroups/CU was measured slower (weight re-reads double).
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
     switch (epi) {
-        case EPI_BIAS: return gemm_go<EPI_BIAS, 2, 4, 4, 32, 4>(s, p);
-        case EPI_BIAS_GELU: return gemm_go<EPI_BIAS_GELU, 2, 4, 4, 32, 4>(s, p);
-        case EPI_QKV: return gemm_go<EPI_QKV, 2, 4, 4, 32, 4>(s, p);
-        case EPI_VT: return gemm_go<EPI_VT, 2, 4, 4, 32, 4>(s, p);
+        case EPI_BIAS: return gemm_go<EPI_BIAS, 2, 2, 2, 32, 4>(s, p);
+        case EPI_BIAS_GELU: return gemm_go<EPI_BIAS_GELU, 2, 2, 2, 32, 4>(s, p);
+        case EPI_QKV: return gemm_go<EPI_QKV, 2, 2, 2, 32, 4>(s, p);
+        case EPI_VT: return gemm_go<EPI_VT, 2, 2, 2, 32, 4>(s, p);
         case EPI_BIAS_RES_LN:
             if (p.n == 384) return gemm_go<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>(s, p);
             if (p.n == 768) return gemm_go<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>(s, p);
@@ -677,10 +678,10 @@ hipError_t launch_pool(hipStream_t s, const bf16_t *x, const int32_t *cu, const 
 
 hipError_t encoder_kernels_setup() {
     hipError_t e;
-    if ((e = gemm_attr<EPI_BIAS, 2, 4, 4, 32, 4>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_BIAS_GELU, 2, 4, 4, 32, 4>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_QKV, 2, 4, 4, 32, 4>()) != hipSuccess) return e;
-    if ((e = gemm_attr<EPI_VT, 2, 4, 4, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS_GELU, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_QKV, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_VT, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>()) != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<32>),
