@@ -200,13 +200,18 @@ def main():
     idx.set_id_offset(lo)
     gen = torch.Generator(device="cuda")
     block = 1_000_000
-    for b0 in range(lo, hi, block):
-        nb = min(block, hi - b0)
-        gen.manual_seed(1234 + b0 // block)  # block-indexed seeds: same corpus for every N
+    # the corpus is defined by GLOBAL 1M-row blocks (seed = 1234 + block index): every N sees the
+    # same 10M rows, a rank generates the blocks that overlap its range and keeps its slice
+    for gb in range(lo // block, (hi + block - 1) // block):
+        g0 = gb * block
+        nb = min(block, rows_total - g0)
+        gen.manual_seed(1234 + gb)
         xb = torch.randn((nb, a.dim), device="cuda", dtype=torch.float32, generator=gen)
+        s0, s1 = max(lo, g0) - g0, min(hi, g0 + nb) - g0
+        part = xb[s0:s1].contiguous()
         torch.cuda.synchronize()
-        idx.add_device(xb)
-        del xb
+        idx.add_device(part)
+        del xb, part
     torch.cuda.empty_cache()
     gq = torch.Generator(device="cuda")
     gq.manual_seed(4321)
