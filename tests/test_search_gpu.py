@@ -264,3 +264,75 @@ def test_multi_shard_merge_equals_unsharded(oracle, lib_built):
     np.testing.assert_array_equal(m_ids.cpu().numpy().astype(np.uint64), oi)
     np.testing.assert_array_equal(bits(m_d.cpu().numpy()), bits(od))
     np.testing.assert_array_equal(bits(m_s.cpu().numpy()), bits(os_))
+
+
+def test_large_k_uses_exact_path_transparently(oracle, lib_built):
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(28)
+    X = rng.standard_normal((5000, 96), dtype=np.float32)
+    Q = rng.standard_normal((3, 96), dtype=np.float32)
+    with FlatIndex(96) as idx:
+        idx.add(X)
+        _check(idx, X, Q, 300, oracle)          # k > 256: AUTO routes to the f64 path
+        _check(idx, X, Q, 4096, oracle)         # the documented maximum
+        from memex_amd._lib import MemexHipError
+        with pytest.raises(MemexHipError) as ei:
+            idx.search(Q, 4097)
+        assert ei.value.code == -6            # MX_EUNSUPPORTED, nothing computed
+    with FlatIndex(96) as idx:
+        idx.add(X[:200])
+        _check(idx, X[:200], Q, 300, oracle)    # k > n: n_found = n
+
+
+def test_concurrent_handles_and_threads(oracle, lib_built):
+    """The reference's callers open a store per request on a multi-threaded runtime
+    (handlers.rs:61-63, worker/lib.rs:188-190): concurrent searches and inserts on one shared
+    resident index must stay consistent."""
+    import threading
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(29)
+    X = rng.standard_normal((40000, 128), dtype=np.float32)
+    Q = rng.standard_normal((8, 128), dtype=np.float32)
+    base = FlatIndex(128, key="shared-collection")
+    base.add(X[:20000])
+    want_half = oracle.search(X[:20000], Q, 10)
+    want_full = oracle.search(X, Q, 10)
+    errors = []
+
+    def searcher():
+        try:
+            h = FlatIndex(128, key="shared-collection")          # second handle, same HBM index
+            for _ in range(20):
+                n0 = len(h)
+                ids, _, di, _ = h.search(Q, 10)
+                n1 = len(h)
+                if n0 != n1:
+                    continue                                      # an insert landed in between: any prefix is valid
+                if n0 == 20000 and not np.array_equal(ids, want_half[0]):
+                    errors.append("inconsistent result at 20000")
+                if n0 == 40000 and not np.array_equal(ids, want_full[0]):
+                    errors.append("inconsistent result at 40000")
+            h.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def inserter():
+        try:
+            h = FlatIndex(128, key="shared-collection")
+            for c in range(20000, 40000, 5000):
+                h.add(X[c:c + 5000])
+            h.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=searcher) for _ in range(3)] + [threading.Thread(target=inserter)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert len(base) == 40000
+    ids, _, di, _ = base.search(Q, 10)
+    np.testing.assert_array_equal(ids, want_full[0])
+    np.testing.assert_array_equal(bits(di), bits(want_full[1]))
+    base.close()
