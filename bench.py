@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--scan", choices=["bf16", "f32"], default="bf16",
+                    help="what the scan kernel streams: the bf16 filter copy (default) or the f32 rows")
+    ap.add_argument("--alt-steps", type=int, default=20,
+                    help="N=1 only: extra untimed-for-the-metric steps on the OTHER scan kernel, reported beside the main one (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--recall-queries", type=int, default=4, help="queries re-answered on the EXACT path")
@@ -153,11 +157,11 @@ def ingest_leg(chunks: int, dev: int, world: int, cpu_too: bool = True):
     }
 
 
-def traffic_from_profile(rows_total: int, dim: int, world: int):
+def traffic_from_profile(rows_total: int, dim: int, world: int, scan: str):
     """HBM bytes per launch of the scan kernel from the committed PMC pass (profiles/, FETCH_SIZE x2
     gfx950 correction + WRITE_SIZE, separate --pmc runs).  bench.py cannot collect PMCs itself, so
     this is only reported when the committed profile matches the workload being run."""
-    path = os.path.join(ROOT, "profiles", "r1_scan_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_scan16_traffic.json" if scan == "bf16" else "r1_scan_traffic.json")
     if world != 1 or rows_total != 10_000_000 or dim != 384 or not os.path.exists(path):
         return None
     try:
@@ -196,6 +200,8 @@ def main():
     hi = rows_total * (rank + 1) // world
     n_local = hi - lo
     idx = FlatIndex(a.dim, key=None, device=dev)
+    if a.scan == "f32":
+        idx.set_filter_copy(False)
     idx.reserve(n_local)
     idx.set_id_offset(lo)
     gen = torch.Generator(device="cuda")
@@ -242,22 +248,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    idx.reset_stats()
-    idx.set_profiling(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    st = idx.stats()
-    idx.set_profiling(False)
+    def timed(warmup, steps):
+        for _ in range(warmup):
+            step()
+        idx.reset_stats()
+        idx.set_profiling(True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        st_ = idx.stats()
+        idx.set_profiling(False)
+        return dt_, st_
+
+    def roofline(st_, scan):
+        scan_s = st_.scan_ms / 1e3
+        achieved = (st_.scan_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
+        launches = max(1, st_.scan_launches)
+        elem = 2 if scan == "bf16" else 4
+        tflops = (2.0 * a.batch * (st_.scan_bytes / elem) / scan_s / 1e12) if scan_s > 0 else 0.0
+        kc = (a.dim + 127) // 128
+        return {
+            "bound": "hbm",
+            "kernel": f"mx::scan16_kernel<{kc},1> (bf16 filter copy, main stage)" if scan == "bf16"
+                      else f"mx::scan_kernel<{kc},1> (f32 rows, main stage)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "bytes_per_launch": st_.scan_bytes / launches,
+            "ms_per_launch": st_.scan_ms / launches,
+            "traffic": traffic_from_profile(rows_total, a.dim, world, scan),
+            "mfma_tflops": tflops,
+            "mfma_frac": tflops / MFMA_PEAK_TFLOPS,
+        }
+
+    dt, st = timed(a.warmup, a.steps)
+    ids_main = ids.clone()
+    alt = None
+    if world == 1 and a.alt_steps > 0:
+        # the same job on the other scan kernel (results must be identical: same filter arithmetic)
+        other = "f32" if a.scan == "bf16" else "bf16"
+        idx.set_filter_copy(other == "bf16")
+        dt2, st2 = timed(3, a.alt_steps)
+        alt = {"scan": other, "value": a.batch * a.alt_steps / dt2, "unit": "queries/s", "steps": a.alt_steps,
+               "ms_per_step": dt2 / a.alt_steps * 1e3, "ids_equal_main_run": bool(torch.equal(ids, ids_main)),
+               "roofline": roofline(st2, other)}
+        idx.set_filter_copy(a.scan == "bf16")
 
     # ---- recall@10 against the all-f64 EXACT path on a few queries (oracle-level parity at
     # smaller sizes lives in tests/; the EXACT path is itself oracle-checked there)
@@ -285,8 +328,6 @@ def main():
     ingest = ingest_leg(a.ingest_chunks, dev, world, not a.no_cpu_baseline) if a.ingest_chunks > 0 else None
 
     if rank == 0:
-        scan_s = st.scan_ms / 1e3
-        achieved = (st.scan_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
         out = {
             "metric": "queries/sec, exact cosine top-10 (recall@10 = 1.0) on 10M x 384-d f32",
             "value": a.batch * a.steps / dt,
@@ -299,6 +340,8 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32 corpus, bf16 MFMA filter + f64 rescoring",
+            "scan": a.scan,
+            "filter_copy_bytes": int(st.filter_copy_bytes),
             "data": "synthetic",
             "config": {"workload": f"{rows_total}x{a.dim} f32 corpus in HBM, query batch {a.batch}, top-{k}",
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
@@ -306,18 +349,10 @@ def main():
             "ids_equal_exact_path": recall_exact_order if rank == 0 and a.recall_queries > 0 else None,
             "fallback_queries": int(st.fallback_queries),
             "candidates_per_query": st.candidates / max(1, st.queries),
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "mx::scan_kernel<3,1> (main stage)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "bytes_per_launch": st.scan_bytes / max(1, st.scan_launches),
-                "ms_per_launch": st.scan_ms / max(1, st.scan_launches),
-                "traffic": traffic_from_profile(rows_total, a.dim, world),
-            },
+            "roofline": roofline(st, a.scan),
         }
+        if alt is not None:
+            out["other_scan"] = alt
         if ingest is not None:
             out["ingest"] = ingest
         if world == 1 and not a.no_cpu_baseline:

@@ -105,6 +105,14 @@ int mx_index_search_device(mx_index *idx, const float *d_queries, int B, int k, 
 enum { MX_SEARCH_AUTO = 0, MX_SEARCH_EXACT = 1 };
 int mx_index_set_search_mode(mx_index *idx, int mode);
 
+/* Filter copy.  By default the index keeps, next to the f32 rows, a bf16 copy of them laid out for
+ * the MFMA scan (+50 % HBM: rows*dim_pad*2 bytes).  The AUTO scan then streams 2 bytes per element
+ * instead of 4; candidates are rescored from the f32 rows exactly as before, so results are
+ * bit-identical with and without it.  on = 0 frees the copy (the scan reads the f32 rows), on = 1
+ * (re)builds it.  If HBM for the copy cannot be allocated while the index grows, it is dropped
+ * silently and the index continues on the f32 scan. */
+int mx_index_set_filter_copy(mx_index *idx, int on);
+
 /*
  * Persistence.  Replaces HnswStore::save / load / has_store (storage/local.rs:110-165).  Files in
  * `dir`: `vectors.mxflat` (header + raw f32 rows).  The string-id map `vectors.meta.json`
@@ -122,10 +130,11 @@ typedef struct mx_index_stats {
     uint64_t queries;           /* queries served                                          */
     uint64_t fallback_queries;  /* queries answered by the EXACT path after an overflow    */
     uint64_t scan_launches;     /* launches of the main streaming-scan kernel              */
-    uint64_t scan_bytes;        /* algorithmic bytes those launches covered: rows*dim_pad*4 */
+    uint64_t scan_bytes;        /* bytes those launches streamed: rows*dim_pad*(2 with a filter copy, else 4) */
     double scan_ms;             /* HIP-event time of those launches (profiling on)         */
     uint64_t candidates;        /* candidates exactly rescored                             */
     double max_abs_err;         /* profiling only: max |approx - exact| cosine on candidates */
+    uint64_t filter_copy_bytes; /* HBM held by the bf16 filter copy (0 = scanning the f32 rows) */
 } mx_index_stats;
 int mx_index_set_profiling(mx_index *idx, int on); /* record HIP events around the scan kernel */
 int mx_index_get_stats(mx_index *idx, mx_index_stats *out);

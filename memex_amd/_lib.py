@@ -24,7 +24,7 @@ EXPORTS = [
     "mx_last_error", "mx_version", "mx_device_count",
     "mx_index_open", "mx_index_close", "mx_index_dim", "mx_index_size", "mx_index_reserve",
     "mx_index_set_id_offset", "mx_index_add", "mx_index_add_device", "mx_index_clear",
-    "mx_index_search", "mx_index_search_device", "mx_index_set_search_mode",
+    "mx_index_search", "mx_index_search_device", "mx_index_set_search_mode", "mx_index_set_filter_copy",
     "mx_index_save", "mx_index_load", "mx_index_has_store", "mx_index_store_info", "mx_index_remove_files",
     "mx_index_set_profiling", "mx_index_get_stats", "mx_index_reset_stats", "mx_topk_merge_device",
     "mx_encoder_weight_bytes", "mx_encoder_create", "mx_encoder_destroy", "mx_encoder_encode",
@@ -48,7 +48,8 @@ class IndexStats(ctypes.Structure):
     _fields_ = [("searches", ctypes.c_uint64), ("queries", ctypes.c_uint64),
                 ("fallback_queries", ctypes.c_uint64), ("scan_launches", ctypes.c_uint64),
                 ("scan_bytes", ctypes.c_uint64), ("scan_ms", ctypes.c_double),
-                ("candidates", ctypes.c_uint64), ("max_abs_err", ctypes.c_double)]
+                ("candidates", ctypes.c_uint64), ("max_abs_err", ctypes.c_double),
+                ("filter_copy_bytes", ctypes.c_uint64)]
 
 
 class EncoderCfg(ctypes.Structure):
@@ -98,6 +99,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "mx_index_search": [vp, vp, i32, i32, vp, vp, vp, vp],
         "mx_index_search_device": [vp, vp, i32, i32, vp, vp, vp, vp],
         "mx_index_set_search_mode": [vp, i32],
+        "mx_index_set_filter_copy": [vp, i32],
         "mx_index_save": [vp, cp],
         "mx_index_load": [vp, cp],
         "mx_index_has_store": [cp, P(i32)],

@@ -76,6 +76,8 @@ struct mx_index {
     hipStream_t stream = nullptr;
     float *x = nullptr;
     float *scale = nullptr;
+    void *xh = nullptr;          // bf16 filter copy (fragment order), cap/32 tiles; null = not kept
+    bool want_filter = true;     // keep a filter copy when HBM allows (mx_index_set_filter_copy)
     uint64_t n = 0, cap = 0;
     uint64_t id_offset = 0;
     uint32_t *flags = nullptr;  // device: [0] non-finite rows, [1] out-of-range-norm rows (last add)
@@ -101,7 +103,7 @@ int free_index(mx_index *idx) {
     auto F = [](void *p) {
         if (p) (void)hipFree(p);
     };
-    F(idx->x); F(idx->scale); F(idx->flags);
+    F(idx->x); F(idx->scale); F(idx->xh); F(idx->flags);
     Scratch &s = idx->s;
     F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.dev_flags); F(s.pool[0]); F(s.pool[1]);
     if (s.host_flags) (void)hipHostFree(s.host_flags);
@@ -193,11 +195,29 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
     }
     MX_HIP(hipMemsetAsync(nx + idx->n * (size_t)idx->ds, 0, (want - idx->n) * rowb, idx->stream));
     MX_HIP(hipMemsetAsync(nsc + idx->n, 0, (want - idx->n) * sizeof(float), idx->stream));
+    void *nh = nullptr;
+    if (idx->want_filter && idx->kc <= kMaxKC) {
+        // the filter copy is an accelerator, not a requirement: without HBM for it the index
+        // keeps working on the f32 scan
+        const size_t hb = (size_t)want * idx->ds * 2;
+        if (hipMalloc(&nh, hb) != hipSuccess) {
+            (void)hipGetLastError();
+            nh = nullptr;
+        } else {
+            const size_t used = idx->xh ? (size_t)round_up(idx->n, kTileRows) * idx->ds * 2 : 0;
+            if (used) MX_HIP(hipMemcpyAsync(nh, idx->xh, used, hipMemcpyDeviceToDevice, idx->stream));
+            MX_HIP(hipMemsetAsync(static_cast<char *>(nh) + used, 0, hb - used, idx->stream));
+            if (!idx->xh && idx->n)  // (re)enabled on a populated index
+                MX_HIP(launch_shadow(idx->stream, nx, nsc, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh));
+        }
+    }
     MX_HIP(hipStreamSynchronize(idx->stream));
     if (idx->x) (void)hipFree(idx->x);
     if (idx->scale) (void)hipFree(idx->scale);
+    if (idx->xh) (void)hipFree(idx->xh);
     idx->x = nx;
     idx->scale = nsc;
+    idx->xh = nh;
     idx->cap = want;
     return MX_OK;
 }
@@ -213,6 +233,9 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
     if (rc != MX_OK) return rc;
     MX_HIP(hipMemsetAsync(idx->flags, 0, 2 * sizeof(uint32_t), idx->stream));
     MX_HIP(launch_ingest(idx->stream, d_rows, n, idx->dim, idx->x, idx->scale, idx->n, idx->ds, idx->flags));
+    if (idx->xh)  // tiles touched by this append (the first one may already be partly filled)
+        MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, (uint32_t)(idx->n / kTileRows),
+                             (uint32_t)((idx->n + n + kTileRows - 1) / kTileRows), idx->xh));
     uint32_t fl[2] = {0, 0};
     MX_HIP(hipMemcpyAsync(fl, idx->flags, sizeof(fl), hipMemcpyDeviceToHost, idx->stream));
     MX_HIP(hipStreamSynchronize(idx->stream));
@@ -271,6 +294,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
             for (const Stage &sg : plan_stages(idx->n, idx->nwg, k)) {
                 ScanParams p;
                 p.x = idx->x;
+                p.xh = idx->xh;
                 p.scale = idx->scale;
                 p.qfrag = s.qfrag;
                 p.theta = s.theta;
@@ -282,14 +306,17 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                 p.lane_cnt = s.lane_cnt;
                 p.overflow = s.overflow;
                 if (sg.main && idx->profiling) MX_HIP(hipEventRecord(idx->ev0, st));
-                MX_HIP(launch_scan(st, idx->kc, sg.main, idx->nwg, p));
+                if (idx->xh)
+                    MX_HIP(launch_scan16(st, idx->kc, sg.main, idx->nwg, p));
+                else
+                    MX_HIP(launch_scan(st, idx->kc, sg.main, idx->nwg, p));
                 if (sg.main) {
                     if (idx->profiling) {
                         MX_HIP(hipEventRecord(idx->ev1, st));
                         timed = true;
                     }
                     idx->stats.scan_launches += 1;
-                    idx->stats.scan_bytes += (uint64_t)(sg.t1 - sg.t0) * kTileRows * idx->ds * 4ull;
+                    idx->stats.scan_bytes += (uint64_t)(sg.t1 - sg.t0) * kTileRows * idx->ds * (idx->xh ? 2ull : 4ull);
                 }
                 MX_HIP(launch_update(st, B, k, idx->nwg, s.lane_buf, s.lane_cnt, s.pool[cur], s.pool[cur ^ 1],
                                      s.pool_cnt, s.theta, s.overflow));
@@ -383,7 +410,10 @@ int mx_index_open(const char *key, int dim, int device, mx_index **out) {
     if (device < 0 || device >= ndev) return fail(MX_EDEVICE, "device %d out of range (have %d)", device, ndev);
     DeviceGuard g(device);
     if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
-    std::call_once(g_scan_once, [] { g_scan_setup_err = scan_setup(); });
+    std::call_once(g_scan_once, [] {
+        g_scan_setup_err = scan_setup();
+        if (g_scan_setup_err == hipSuccess) g_scan_setup_err = scan16_setup();
+    });
     if (g_scan_setup_err != hipSuccess)
         return fail(MX_EDEVICE, "scan kernel setup failed: %s (is this a gfx950 device?)", hipGetErrorString(g_scan_setup_err));
     std::unique_ptr<mx_index> idx(new mx_index());
@@ -549,6 +579,31 @@ int mx_index_search(mx_index *idx, const float *q, int B, int k, uint64_t *ids, 
     return MX_OK;
 }
 
+int mx_index_set_filter_copy(mx_index *idx, int on) {
+    if (!idx) return fail(MX_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->device);
+    idx->want_filter = on != 0;
+    if (!on) {
+        if (idx->xh) {
+            MX_HIP(hipStreamSynchronize(idx->stream));
+            (void)hipFree(idx->xh);
+            idx->xh = nullptr;
+        }
+        return MX_OK;
+    }
+    if (idx->xh || idx->cap == 0 || idx->kc > kMaxKC) return MX_OK;  // present, or built with the first rows
+    void *nh = nullptr;
+    const size_t hb = (size_t)idx->cap * idx->ds * 2;
+    hipError_t e = hipMalloc(&nh, hb);
+    if (e != hipSuccess) return fail(MX_ENOMEM, "hipMalloc(filter copy, %zu bytes): %s", hb, hipGetErrorString(e));
+    MX_HIP(hipMemsetAsync(nh, 0, hb, idx->stream));
+    MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh));
+    MX_HIP(hipStreamSynchronize(idx->stream));
+    idx->xh = nh;
+    return MX_OK;
+}
+
 int mx_index_set_profiling(mx_index *idx, int on) {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -565,6 +620,7 @@ int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
         MX_HIP(hipMemcpy(&e, idx->s.max_err, sizeof(float), hipMemcpyDeviceToHost));
         idx->stats.max_abs_err = std::max(idx->stats.max_abs_err, (double)e);
     }
+    idx->stats.filter_copy_bytes = idx->xh ? (uint64_t)idx->cap * idx->ds * 2ull : 0;
     *out = idx->stats;
     return MX_OK;
 }

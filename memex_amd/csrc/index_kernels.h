@@ -21,6 +21,12 @@ constexpr int kScaleRing = 16;     // per-tile 1/|c| vectors (128 B each)
 constexpr int kScanLdsBytes = kNumSlots * kSlotBytes + 2 * kTileRows * (kChunkFloats * 2 + 16) + kScaleRing * kTileRows * 4;
 constexpr int kMaxKC = 6;          // k-chunks per row the MFMA scan supports (dim_pad <= 768)
 
+// ---- scan over the bf16 filter copy (scan16_kernel): a slot is 32 rows x 128 bf16 = 8 KiB, already
+// in MFMA A-fragment order in HBM, so the LDS image is a linear copy and needs no conversion pass
+constexpr int kSlot16Bytes = kTileRows * kChunkFloats * 2;
+constexpr int kRing16 = 16;        // 16 x 8 KiB = 128 KiB ring, 15 slots in flight
+constexpr int kScan16LdsBytes = kRing16 * kSlot16Bytes;
+
 constexpr int kMaxBatch = 256;     // queries per scan pass (8 waves x 32 MFMA columns)
 constexpr int kLaneCap = 32;       // lane-private candidate slots per scan launch
 constexpr int kMaxScanWGs = 256;   // persistent workgroups (<= CUs); pool sizing depends on it
@@ -39,6 +45,7 @@ struct Cand {
 
 struct ScanParams {
     const float *x;          // [cap_rows, ds] f32 corpus (ds = padded dim, multiple of 128)
+    const void *xh;          // bf16 filter copy in fragment order (see launch_shadow); scan16 only
     const float *scale;      // [cap_rows] 1/|c| (f32; +inf for zero rows)
     const void *qfrag;       // bf16 query fragments [8 waves][ds/16][64 lanes][8]
     const float *theta;      // [256] pass threshold per query (cosine units)
@@ -53,7 +60,16 @@ struct ScanParams {
 
 // launches ---------------------------------------------------------------------------------
 hipError_t scan_setup();  // one-time function attributes (dynamic LDS size)
+hipError_t scan16_setup();
 hipError_t launch_scan(hipStream_t s, int kc, bool main_stage, int nwg, const ScanParams &p);
+hipError_t launch_scan16(hipStream_t s, int kc, bool main_stage, int nwg, const ScanParams &p);
+
+// (re)build tiles [tile0, tile1) of the bf16 filter copy from the padded f32 store.  Layout: tile t
+// (32 rows), k-step s (16 dims), MFMA lane l -> 8 bf16 at ((t*(ds/16) + s)*64 + l)*8, holding row
+// 32t + (l&31), dims 16s + 8(l>>5) .. +7: exactly the A operand of v_mfma_f32_32x32x16_bf16.
+// Values are bf16(c_i * 1/|c|) (NaN for a zero-norm row: it must pass every filter).
+hipError_t launch_shadow(hipStream_t s, const float *x, const float *scale, int ds, uint32_t tile0, uint32_t tile1,
+                         void *xh);
 
 // rows [n, d] (device) -> x[first.., ds] zero-padded + scale; flags[0] += non-finite rows,
 // flags[1] += rows whose norm is outside the range the bf16 scan is certified for

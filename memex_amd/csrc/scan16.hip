@@ -1,0 +1,293 @@
+// scan16.hip -- the streaming cosine scan over the bf16 filter copy of the corpus.
+//
+// Same role as scan.hip (exhaustive replacement of `self.hnsw.search(vec, limit, 32)`, reference
+// lib/libmemex/src/storage/local.rs:76) at half the HBM bytes: next to the f32 rows that the exact
+// rescoring reads, the index keeps bf16(c_i / |c|) for every row, stored in MFMA A-fragment order
+// (index_kernels.h, launch_shadow).  The accumulator of a row IS its approximate cosine:
+//   approx = sum_f32 bf16(q_i/|q|) * bf16(c_i/|c|)
+//   |approx - cos| <= (2^-7 + 2^-16) * |q^||c^|   two bf16 roundings (unit roundoff 2^-8) + Cauchy-Schwarz
+//                     + ~1e-4                      f32 normalisation and accumulation over <= 768 terms
+//                  <  kApproxErr = 0.0081          (the same certificate as scan.hip; index.hip relies on it)
+// A zero-norm row is stored as NaN, so it passes every threshold (its exact dist is 0: DistCosine's
+// else-branch), exactly like scan.hip's 0 * inf.
+//
+// One persistent 512-thread workgroup per CU.  Per 8 KiB slot (32 rows x 128 dims):
+//   1. each wave issues ONE 1 KiB LDS-DMA (16 B per lane, nt policy): wave w moves k-step w of the
+//      slot.  HBM address and LDS address are both lane-linear -> perfectly coalesced, no staging, no
+//      conversion pass.  15 slots (120 KiB per CU) are in flight; the stream never branches: past the
+//      last tile the descriptor's num_records is 0 and the DMA touches no memory.
+//   2. s_waitcnt vmcnt(13) + one s_barrier make the next slot visible to all waves.
+//   3. every wave multiplies the slot against its own 32 queries (register-resident B fragments):
+//      8 v_mfma_f32_32x32x16_bf16 on two alternating accumulator chains, each preceded by ONE
+//      conflict-free ds_read_b128 of the NEXT slot's fragment (register double buffer), so LDS reads,
+//      DMA issue and scalar bookkeeping all issue in the shadow of the MFMA pipe.
+// Epilogue per 32-row tile: compare with the query's pass threshold, append survivors to a
+// lane-private buffer.
+//
+// Measured (10M x 384, B = 256; scripts/scan16_ubench.hip): 726 shader cycles per slot against 512 of
+// pure MFMA issue per SIMD; DMA alone 1.13 ms (6.8 TB/s), compute alone 1.15 ms at 2.14 GHz, together
+// 1.9 ms at an effective 1.35 GHz: the launch is bound by the 1400 W package power cap (1.97 TFLOP of
+// bf16 MFMA per launch is ~2 J on its own), not by a pipe.  Earlier forms of the kernel -- fragment
+// reads and DMA issue bunched after the barrier, one accumulator, per-tile scale multiply -- took
+// 1050-1150 cycles per slot and 2.25 ms.
+#include <type_traits>
+
+#include "index_kernels.h"
+
+namespace mx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+#define MX_LDS_DMA16(rsrc, ldsptr, voff, soff, aux) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lds_void *)(ldsptr), 16, (voff), (soff), 0, (aux))
+
+static_assert(kRing16 == 16, "waits below assume a 16-slot ring with 15 slots in flight");
+
+// Ablation switch for scripts/scan16_ubench.hip only (0 = production kernel):
+//   1 = DMA + waits + barriers, 2 = + fragment reads (no MFMA), 4 = everything except the DMA
+//   (compute on whatever LDS holds).  MX_SCAN16_CLOCK: lane_cnt receives the workgroup's s_memtime
+//   cycle count instead of the candidate count (effective-clock probe).
+#ifndef MX_SCAN16_ABLATE
+#define MX_SCAN16_ABLATE 0
+#endif
+
+template <int KC, int TAG>
+__global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParams p) {
+    // KC <= 4: the slot's 8 fragment reads are issued one slot ahead, one per MFMA of the current
+    // slot (register double buffer, two accumulator chains).  KC >= 5 has no registers left for
+    // that (B fragments alone are 160-192 VGPRs): read, then multiply.
+    constexpr bool PIPE = KC <= 4;
+    constexpr bool DUAL = KC <= 5;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+#ifdef MX_SCAN16_CLOCK
+    const uint64_t clk0 = __builtin_amdgcn_s_memtime();
+#endif
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31;  // query column of B and D
+    const int h = lane >> 5;
+
+    // ---- register-resident query fragments (B operand), loaded once per launch
+    bf16x8 qf[KC * 8];
+    {
+        const bf16x8 *src = reinterpret_cast<const bf16x8 *>(p.qfrag) + (size_t)wave * (KC * 8) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KC * 8; ++i) qf[i] = src[(size_t)i * 64];
+    }
+    const float theta = p.theta[wave * 32 + m];
+
+    // ---- tiles of this workgroup: t0, t0 + grid, ...
+    const uint32_t grid = gridDim.x;
+    const uint32_t t0 = p.tile_begin + blockIdx.x;
+    const uint32_t nT = (t0 < p.tile_end) ? (p.tile_end - t0 + grid - 1) / grid : 0;
+    const uint32_t tilebytes = p.ds * (kTileRows * 2);
+
+    const uint32_t voff = (uint32_t)wave * 1024u + (uint32_t)lane * 16u;  // this lane's 16 B of a slot
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+
+    // ---- DMA stream.  Slots are issued strictly in order, 15 ahead of the slot being multiplied,
+    // and ALWAYS: past the last tile the buffer descriptor has num_records = 0, so the load is
+    // out of range and touches no memory.  That keeps the loop free of "is there more?" branches and
+    // the vmcnt arithmetic uniform (exactly one DMA op per slot per wave, dead or alive).
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t is_ti = 0;  // tiles opened so far
+    auto open_tile = [&]() {
+        const char *base = reinterpret_cast<const char *>(p.xh) + (size_t)(t0 + is_ti * grid) * tilebytes;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, is_ti < nT ? tilebytes : 0u, 0x00020000);
+        ++is_ti;
+    };
+    auto issue = [&](int kci, uint32_t ring_pos) {  // kci is a compile-time constant at every call site
+#if MX_SCAN16_ABLATE != 4
+        if (kci == 0) open_tile();
+        char *dst = smem + __builtin_amdgcn_readfirstlane(ring_pos * kSlot16Bytes + wave * 1024);
+        MX_LDS_DMA16(rsrc, dst, voff, kci * kSlot16Bytes, 2 /*nt*/);
+#endif
+    };
+
+    Cand *mybuf = p.lane_buf + ((size_t)tid * gridDim.x + blockIdx.x) * kLaneCap;
+    uint32_t cnt = 0;
+    uint32_t ovf = 0;
+
+    // ---- prologue: slots 0 .. 14 in flight
+#pragma unroll
+    for (int i = 0; i < kRing16 - 1; ++i) issue(i % KC, (uint32_t)i);
+
+    bf16x8 a[PIPE ? 2 : 1][8];  // A fragments: slot being multiplied (+ the next one when PIPE)
+    if (PIPE) {
+        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // slot 0 landed (14 newer may be in flight)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) a[0][ks] = *reinterpret_cast<const bf16x8 *>(smem + lane16 + ks * 1024);
+    }
+
+    uint32_t rp = 0;  // ring position of the slot being multiplied
+    auto tile = [&](uint32_t ti, auto par0) {
+        constexpr int P0 = decltype(par0)::value;  // fragment-buffer parity of the tile's first slot
+        f32x16 acc, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f, acc1[r] = 0.0f;
+
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int cur = PIPE ? ((P0 + kc) & 1) : 0;
+            const uint32_t rp1 = (rp + 1) & (kRing16 - 1);
+            const uint32_t rpi = (rp + kRing16 - 1) & (kRing16 - 1);  // ring position of slot j+15 = of slot j-1
+            // PIPE: slot j+1 must have landed; slots 0 .. j+14 are issued -> 13 newer may be in flight.
+            // else: slot j itself; 14 newer.
+            if (PIPE) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            // One barrier per slot: every wave's piece of the awaited slot is in LDS, and every wave has
+            // finished the fragment reads of slot j-1, whose ring position is refilled below.
+            __builtin_amdgcn_s_barrier();
+            const uint32_t fb = (PIPE ? rp1 : rp) * kSlot16Bytes + lane16;
+            if (!PIPE) {
+#if MX_SCAN16_ABLATE != 1
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) a[0][ks] = *reinterpret_cast<const bf16x8 *>(smem + fb + ks * 1024);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                issue((kc + kRing16 - 1) % KC, rpi);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if constexpr (PIPE) {
+                    // one LDS read of the next slot and (once) the DMA issue in front of each MFMA: they
+                    // issue while the MFMA pipe works on the previous instruction
+#if MX_SCAN16_ABLATE != 1
+                    a[cur ^ 1][ks] = *reinterpret_cast<const bf16x8 *>(smem + fb + ks * 1024);
+#endif
+                    if (ks == 1) issue((kc + kRing16 - 1) % KC, rpi);
+                }
+#if MX_SCAN16_ABLATE == 1 || MX_SCAN16_ABLATE == 2
+                asm volatile("" ::"v"(a[cur][ks]));
+#else
+                if (DUAL && (ks & 1))
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ks], qf[kc * 8 + ks], acc1, 0, 0, 0);
+                else
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ks], qf[kc * 8 + ks], acc, 0, 0, 0);
+#endif
+                if (PIPE) __builtin_amdgcn_sched_barrier(0);
+            }
+            rp = rp1;
+        }
+
+        // ---- tile epilogue: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*h.  The copy
+        // holds c/|c|, so the accumulator already is the approximate cosine (NaN for a zero-norm row).
+        float v[16];
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[r] = DUAL ? acc[r] + acc1[r] : acc[r];
+            any |= !(v[r] < theta);  // NaN passes on purpose
+        }
+        if (__builtin_amdgcn_ballot_w64(any) != 0) {
+            const uint32_t rowb = (t0 + ti * grid) * kTileRows + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
+                if (!(v[r] < theta) && (uint64_t)row < p.n_rows) {
+                    if (cnt < (uint32_t)kLaneCap) {
+                        Cand c;
+                        c.score = v[r];
+                        c.row = row;
+                        mybuf[cnt] = c;
+                        ++cnt;
+                    } else {
+                        ovf = 1;
+                    }
+                }
+            }
+        }
+    };
+
+    // fragment-buffer parity alternates per slot: with odd KC, tiles alternate their starting parity
+#pragma unroll 1
+    for (uint32_t ti = 0; ti < nT; ti += 2) {
+        tile(ti, std::integral_constant<int, 0>{});
+        if (ti + 1 < nT) tile(ti + 1, std::integral_constant<int, KC & 1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // dead DMA ops must not outlive the workgroup's LDS
+
+#ifdef MX_SCAN16_CLOCK
+    cnt = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);
+#endif
+    p.lane_cnt[(size_t)tid * gridDim.x + blockIdx.x] = cnt;
+    if (ovf) p.overflow[wave * 32 + m] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter-copy construction: one workgroup per 32-row tile, one 16-B fragment per thread and step
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shadow_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                     int ds, uint32_t tile0, uint32_t tile1,
+                                                     bf16x8 *__restrict__ xh) {
+    const uint32_t frags = (uint32_t)(ds / 16) * 64u;  // fragments per tile
+    for (uint32_t t = tile0 + blockIdx.x; t < tile1; t += gridDim.x) {
+        const float *xt = x + (size_t)t * kTileRows * ds;
+        bf16x8 *ot = xh + (size_t)t * frags;
+        for (uint32_t f = threadIdx.x; f < frags; f += 256) {
+            const uint32_t ks = f >> 6, l = f & 63, mm = l & 31, hh = l >> 5;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(xt + (size_t)mm * ds + ks * 16 + hh * 8);
+            const float sc = scale[(size_t)t * kTileRows + mm];  // 1/|c|; +inf for a zero row -> 0*inf = NaN
+            const f32x4 lo = src[0] * sc, hi = src[1] * sc;
+            bf16x8 o;
+            o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
+            o[4] = (__bf16)hi[0]; o[5] = (__bf16)hi[1]; o[6] = (__bf16)hi[2]; o[7] = (__bf16)hi[3];
+            ot[f] = o;
+        }
+    }
+}
+
+hipError_t launch_shadow(hipStream_t s, const float *x, const float *scale, int ds, uint32_t tile0, uint32_t tile1,
+                         void *xh) {
+    if (tile1 <= tile0) return hipSuccess;
+    const uint32_t blocks = tile1 - tile0 < 16384u ? tile1 - tile0 : 16384u;
+    hipLaunchKernelGGL(shadow_kernel, dim3(blocks), dim3(256), 0, s, x, scale, ds, tile0, tile1,
+                       reinterpret_cast<bf16x8 *>(xh));
+    return hipGetLastError();
+}
+
+template <int KC, int TAG>
+static hipError_t setup16_one() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16_kernel<KC, TAG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kScan16LdsBytes);
+}
+
+hipError_t scan16_setup() {
+    hipError_t e;
+#define MX_SETUP(KC)                                           \
+    if ((e = setup16_one<KC, 0>()) != hipSuccess) return e;    \
+    if ((e = setup16_one<KC, 1>()) != hipSuccess) return e;
+    MX_SETUP(1) MX_SETUP(2) MX_SETUP(3) MX_SETUP(4) MX_SETUP(5) MX_SETUP(6)
+#undef MX_SETUP
+    return hipSuccess;
+}
+
+template <int KC>
+static hipError_t launch16_kc(hipStream_t s, bool main_stage, int nwg, const ScanParams &p) {
+    if (main_stage)
+        hipLaunchKernelGGL((scan16_kernel<KC, 1>), dim3(nwg), dim3(kScanThreads), kScan16LdsBytes, s, p);
+    else
+        hipLaunchKernelGGL((scan16_kernel<KC, 0>), dim3(nwg), dim3(kScanThreads), kScan16LdsBytes, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan16(hipStream_t s, int kc, bool main_stage, int nwg, const ScanParams &p) {
+    switch (kc) {
+        case 1: return launch16_kc<1>(s, main_stage, nwg, p);
+        case 2: return launch16_kc<2>(s, main_stage, nwg, p);
+        case 3: return launch16_kc<3>(s, main_stage, nwg, p);
+        case 4: return launch16_kc<4>(s, main_stage, nwg, p);
+        case 5: return launch16_kc<5>(s, main_stage, nwg, p);
+        case 6: return launch16_kc<6>(s, main_stage, nwg, p);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mx

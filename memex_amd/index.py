@@ -60,6 +60,10 @@ class FlatIndex:
     def set_search_mode(self, mode: int) -> None:
         check(lib().mx_index_set_search_mode(self._h, int(mode)))
 
+    def set_filter_copy(self, on: bool) -> None:
+        """Keep (default) or drop the bf16 filter copy the scan streams; results do not change."""
+        check(lib().mx_index_set_filter_copy(self._h, 1 if on else 0))
+
     def set_profiling(self, on: bool) -> None:
         check(lib().mx_index_set_profiling(self._h, 1 if on else 0))
 

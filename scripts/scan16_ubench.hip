@@ -1,0 +1,43 @@
+// scripts/scan16_ubench.hip -- standalone microbenchmark of the bf16 filter-copy scan (scan16.hip).
+// Build (one binary per ablation level):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMX_SCAN16_ABLATE=N -I memex_amd/csrc \
+//         scripts/scan16_ubench.hip memex_amd/csrc/scan16.hip -o build_ub/scan16_ub_N
+// Not product code: prints GB/s of the main-stage launch on random data with theta = +inf.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "index_kernels.h"
+using namespace mx;
+#ifndef MX_SCAN16_ABLATE
+#define MX_SCAN16_ABLATE 0
+#endif
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+__global__ void fill16(unsigned short* p, size_t n, unsigned seed) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) { unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; p[i] = (unsigned short)(0x3c00u + (h & 0x3ff) + ((h >> 16) & 0x8000u)); }
+}
+__global__ void fillf(float* p, size_t n) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; for (; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.05f; }
+int main(int argc, char** argv) {
+  size_t rows = argc > 1 ? atoll(argv[1]) : 10000000; int ds = argc > 2 ? atoi(argv[2]) : 384; int reps = argc > 3 ? atoi(argv[3]) : 10; int nwg = argc > 4 ? atoi(argv[4]) : 256;
+  int kc = ds / 128; rows = rows / 32 * 32;
+  float *scale, *theta; void *qf, *xh; Cand* lb; uint32_t *lc, *ovf;
+  CK(hipMalloc(&xh, rows * ds * 2)); CK(hipMalloc(&scale, rows * 4)); CK(hipMalloc(&theta, 1024)); CK(hipMalloc(&qf, 256 * ds * 2));
+  CK(hipMalloc(&lb, (size_t)256 * 512 * kLaneCap * 8)); CK(hipMalloc(&lc, 256 * 512 * 4)); CK(hipMalloc(&ovf, 1024));
+  fill16<<<4096, 256>>>((unsigned short*)xh, rows * ds, 1); fillf<<<1024, 256>>>(scale, rows); fill16<<<64, 256>>>((unsigned short*)qf, 256 * ds, 3);
+  std::vector<float> th(256, INFINITY); CK(hipMemcpy(theta, th.data(), 1024, hipMemcpyHostToDevice));
+  CK(scan16_setup());
+  ScanParams p; p.x = nullptr; p.xh = xh; p.scale = scale; p.qfrag = qf; p.theta = theta; p.n_rows = rows; p.tile_begin = 0; p.tile_end = rows / 32; p.ds = ds; p.lane_buf = lb; p.lane_cnt = lc; p.overflow = ovf;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) CK(launch_scan16(0, kc, true, nwg, p));
+  CK(hipDeviceSynchronize());
+  float best = 1e9, tot = 0;
+  for (int i = 0; i < reps; ++i) { CK(hipEventRecord(e0)); CK(launch_scan16(0, kc, true, nwg, p)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best; tot += ms; }
+  double gb = (double)rows * ds * 2 / 1e9;
+#ifdef MX_SCAN16_CLOCK
+  { std::vector<uint32_t> cyc(nwg); CK(hipMemcpy(cyc.data(), lc, nwg * 4, hipMemcpyDeviceToHost)); double a = 0; for (int i = 0; i < nwg; ++i) a += cyc[i];
+    printf("  s_memtime: %.0f ticks per workgroup (last launch) -> %.3f GHz-equivalent over %.3f ms\n", a / nwg, a / nwg / (tot / reps * 1e-3) / 1e9, tot / reps); }
+#endif
+  printf("scan16 ablate=%d nwg=%d rows=%zu ds=%d: avg %.3f ms (%.0f GB/s)  best %.3f ms (%.0f GB/s)\n", MX_SCAN16_ABLATE, nwg, rows, ds, tot / reps, gb / (tot / reps) * 1e3, best, gb / best * 1e3);
+  return 0;
+}

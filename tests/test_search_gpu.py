@@ -72,12 +72,17 @@ def test_get_vector_storage_roundtrip(tmp_path, lib_built):
 
 
 def _check(idx, X, Q, k, oracle, id_offset=0):
-    ids, sc, di, nf = idx.search(Q, k)
+    """Bit-exact against the oracle on both scan kernels: over the bf16 filter copy (default), over
+    the f32 rows (copy dropped), and over a copy rebuilt from the resident rows."""
     oi, od, os_, onf = oracle.search(X, Q, k, id_offset=id_offset)
-    np.testing.assert_array_equal(ids, oi)
-    np.testing.assert_array_equal(bits(di), bits(od))
-    np.testing.assert_array_equal(bits(sc), bits(os_))
-    np.testing.assert_array_equal(nf, onf)
+    for keep_copy in (None, False, True):
+        if keep_copy is not None:
+            idx.set_filter_copy(keep_copy)
+        ids, sc, di, nf = idx.search(Q, k)
+        np.testing.assert_array_equal(ids, oi)
+        np.testing.assert_array_equal(bits(di), bits(od))
+        np.testing.assert_array_equal(bits(sc), bits(os_))
+        np.testing.assert_array_equal(nf, onf)
 
 
 @pytest.mark.parametrize("n,d,B,k,seed", [
@@ -336,3 +341,34 @@ def test_concurrent_handles_and_threads(oracle, lib_built):
     np.testing.assert_array_equal(ids, want_full[0])
     np.testing.assert_array_equal(bits(di), bits(want_full[1]))
     base.close()
+
+
+def test_filter_copy_follows_incremental_inserts(oracle, lib_built):
+    """Appends that start and end in the middle of a 32-row tile, capacity growth in between, and
+    clear(): the bf16 copy the scan streams must always mirror the resident rows."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(31)
+    X = rng.standard_normal((30000, 200), dtype=np.float32)
+    Q = rng.standard_normal((9, 200), dtype=np.float32)
+    with FlatIndex(200) as idx:
+        done = 0
+        for step in (1, 30, 33, 1000, 4097, 7, 20000, 4832):
+            idx.add(X[done:done + step])
+            done += step
+            ids, _, di, _ = idx.search(Q, 10)
+            want = oracle.search(X[:done], Q, 10)
+            np.testing.assert_array_equal(ids, want[0])
+            np.testing.assert_array_equal(bits(di), bits(want[1]))
+        st = idx.stats()
+        assert st.filter_copy_bytes >= 30000 * 256 * 2 and st.fallback_queries == 0
+        idx.clear()
+        idx.add(X[5000:5100])
+        np.testing.assert_array_equal(idx.search(Q, 10)[0], oracle.search(X[5000:5100], Q, 10)[0])
+        idx.set_filter_copy(False)
+        assert idx.stats().filter_copy_bytes == 0
+        idx.add(X[:777])                                  # grows on the f32 scan only
+        Y = np.concatenate([X[5000:5100], X[:777]])
+        np.testing.assert_array_equal(idx.search(Q, 10)[0], oracle.search(Y, Q, 10)[0])
+        idx.set_filter_copy(True)                         # rebuilt from the resident rows
+        assert idx.stats().filter_copy_bytes > 0
+        np.testing.assert_array_equal(idx.search(Q, 10)[0], oracle.search(Y, Q, 10)[0])
