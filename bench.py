@@ -188,11 +188,17 @@ def main():
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    dev = local_rank if world > 1 else 0
+    # MEMEX_BENCH_ONE_DEVICE=1 is a wiring check for boxes with a single GPU: all ranks share device 0
+    # and the collectives go through gloo (RCCL refuses two ranks on one device).  Never a benchmark.
+    one_device = os.environ.get("MEMEX_BENCH_ONE_DEVICE") == "1"
+    dev = local_rank if (world > 1 and not one_device) else 0
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     # ---- corpus shard in HBM (generated on device in blocks; ids are global)
     rows_total = a.rows
@@ -238,8 +244,14 @@ def main():
     def step():
         idx.search_device(q, k, ids, scores, dists, nf)  # blocks until results are in HBM
         if world > 1:
-            dist.all_gather_into_tensor(g_ids, ids)
-            dist.all_gather_into_tensor(g_dists, dists)
+            if one_device:  # gloo: gather through host memory
+                for dst, src in ((g_ids, ids), (g_dists, dists)):
+                    parts = [torch.empty_like(src, device="cpu") for _ in range(world)]
+                    dist.all_gather(parts, src.cpu())
+                    dst.copy_(torch.stack(parts).to(dst.device))
+            else:
+                dist.all_gather_into_tensor(g_ids, ids)
+                dist.all_gather_into_tensor(g_dists, dists)
             torch.cuda.synchronize()
             merge_topk_device(dev, g_ids, g_dists, m_ids, m_dists, m_scores)
 

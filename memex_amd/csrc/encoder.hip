@@ -11,6 +11,7 @@
 //                     -> FFN2 GEMM(+res+LN) } -> pool (+L2 normalise)
 // with bf16 activations/weights, f32 accumulation and f32 LayerNorm/softmax/GELU.
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -61,6 +62,7 @@ struct mx_encoder {
     int32_t *cu = nullptr, *tok_seq = nullptr, *tok_pos = nullptr, *lens_dev = nullptr, *ids_dev = nullptr;
     float *out_dev = nullptr;
     bool profiling = false;
+    bool fused_mlp = false;  // MLP block as one kernel (hidden 384); MEMEX_HIP_UNFUSED_MLP=1 keeps the two GEMMs
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     mx_encoder_stats stats{};
 };
@@ -176,6 +178,13 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         o.a = e->ctx; o.lda = H; o.w = L.wo; o.w_rows = H; o.w_row0 = 0; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = H;
         o.out = e->x1; o.ldo = H; o.res = e->x; o.ldres = H; o.gamma = L.ln1g; o.beta = L.ln1b; o.eps = c.ln_eps;
         MX_HIP(launch_gemm(st, EPI_BIAS_RES_LN, o));
+        if (e->fused_mlp) {
+            MlpParams mp{};
+            mp.x = e->x1; mp.ldx = H; mp.w1 = L.wi; mp.b1 = L.bi; mp.w2 = L.wo2; mp.b2 = L.bo2; mp.f = F; mp.m = t_pad;
+            mp.out = e->x; mp.ldo = H; mp.gamma = L.ln2g; mp.beta = L.ln2b; mp.eps = c.ln_eps;
+            MX_HIP(launch_mlp(st, mp));
+            continue;
+        }
         GemmParams f1{};
         f1.a = e->x1; f1.lda = H; f1.w = L.wi; f1.w_rows = F; f1.w_row0 = 0; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = H;
         f1.out = e->hbuf; f1.ldo = F;
@@ -267,13 +276,20 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     if (device < 0 || device >= ndev) return fail(MX_EDEVICE, "device %d out of range (have %d)", device, ndev);
     DeviceGuard g(device);
     if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
-    std::call_once(g_enc_once, [] { g_enc_setup = encoder_kernels_setup(); });
+    std::call_once(g_enc_once, [] {
+        g_enc_setup = encoder_kernels_setup();
+        if (g_enc_setup == hipSuccess) g_enc_setup = mlp_setup();
+    });
     if (g_enc_setup != hipSuccess)
         return fail(MX_EDEVICE, "encoder kernel setup failed: %s", hipGetErrorString(g_enc_setup));
 
     mx_encoder *e = new mx_encoder();
     e->cfg = *cfg;
     e->device = device;
+    {
+        const char *ev = getenv("MEMEX_HIP_UNFUSED_MLP");
+        e->fused_mlp = mlp_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
+    }
     auto bail = [&](int code) {
         mx_encoder_destroy(e);
         return code;

@@ -47,6 +47,25 @@ struct GemmParams {
     float eps;
 };
 
+// fused MLP block (encoder_mlp.hip): out = LayerNorm(x + W2 gelu(W1 x + b1) + b2), hidden = 384
+struct MlpParams {
+    const bf16_t *x;      // [M, 384] input and residual, row pitch ldx
+    int ldx;
+    const bf16_t *w1;     // intermediate weights, K-blocked [384/32][f][32]
+    const float *b1;      // [f]
+    const bf16_t *w2;     // output weights, K-blocked [f/32][384][32]
+    const float *b2;      // [384]
+    int f;                // ffn width, multiple of 128
+    int m;                // rows, multiple of 128
+    bf16_t *out;          // [M, 384] pitch ldo
+    int ldo;
+    const float *gamma, *beta;
+    float eps;
+};
+hipError_t mlp_setup();
+bool mlp_supported(int hidden, int ffn);
+hipError_t launch_mlp(hipStream_t s, const MlpParams &p);
+
 hipError_t encoder_kernels_setup();
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p);
 
