@@ -20,6 +20,7 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -331,17 +332,31 @@ int mx_tokenizer_encode_batch(mx_tokenizer *t, const char *const *texts, int B, 
                               int s_cap, int32_t *lens, int *S) {
     if (!t || (B > 0 && (!texts || !ids || !lens)) || !S) return fail(MX_EINVAL, "null argument");
     if (max_seq_length < 2) return fail(MX_EINVAL, "max_seq_length must be >= 2");
-    std::vector<std::vector<int32_t>> rows((size_t)B);
-    int smax = 0;
-    for (int b = 0; b < B; ++b) {
+    for (int b = 0; b < B; ++b)
         if (!texts[b]) return fail(MX_EINVAL, "texts[%d] is null", b);
-        std::vector<int32_t> v = encode_plain(t, texts[b]);
-        if ((int)v.size() > max_seq_length - 2) v.resize((size_t)max_seq_length - 2);  // truncate, keep room for specials
-        v.insert(v.begin(), t->cls);
-        v.push_back(t->sep);
-        smax = std::max(smax, (int)v.size());
-        rows[b] = std::move(v);
+    std::vector<std::vector<int32_t>> rows((size_t)B);
+    // rows are independent and the tokenizer state is read-only: split the batch over host threads
+    // (the GPU consumes ~20M tokens/s; one thread produces 1-2M)
+    auto work = [&](int b0, int b1) {
+        for (int b = b0; b < b1; ++b) {
+            std::vector<int32_t> v = encode_plain(t, texts[b]);
+            if ((int)v.size() > max_seq_length - 2) v.resize((size_t)max_seq_length - 2);  // truncate, keep room for specials
+            v.insert(v.begin(), t->cls);
+            v.push_back(t->sep);
+            rows[(size_t)b] = std::move(v);
+        }
+    };
+    int nthr = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    nthr = std::min(nthr, B / 16);  // below ~16 texts per thread the spawn cost dominates
+    if (nthr <= 1) {
+        work(0, B);
+    } else {
+        std::vector<std::thread> pool;
+        for (int i = 0; i < nthr; ++i) pool.emplace_back(work, (int)((long)B * i / nthr), (int)((long)B * (i + 1) / nthr));
+        for (auto &th : pool) th.join();
     }
+    int smax = 0;
+    for (int b = 0; b < B; ++b) smax = std::max(smax, (int)rows[(size_t)b].size());
     *S = smax;
     if (smax > s_cap) return fail(MX_EINVAL, "row capacity %d < batch maximum %d", s_cap, smax);
     for (int b = 0; b < B; ++b) {

@@ -104,6 +104,23 @@ def test_encode_batch_for_the_encoder(toks):
     assert short.shape[1] == slens.max()                      # padded to the batch maximum only
 
 
+def test_encode_batch_threads_match_single_texts(toks):
+    """Large batches are split over host threads: every row must equal the one-text encoding."""
+    import time
+    hf, mine, _ = toks
+    rng = np.random.default_rng(5)
+    pieces = STEMS + PUNCT + ["Biden's", "WORKING", "unbelievable", "Ünion", "中文"]
+    texts = [" ".join(pieces[int(i)] for i in rng.integers(0, len(pieces), int(rng.integers(1, 400)))) for _ in range(700)]
+    t0 = time.perf_counter()
+    ids, lens = mine.encode_batch(texts, 256)
+    dt = time.perf_counter() - t0
+    assert ids.shape[0] == 700 and lens.max() <= 256
+    for b in range(0, 700, 7):
+        want = mine.encode(texts[b], False)[:254]
+        assert ids[b, 1: lens[b] - 1].tolist() == want
+    assert int(lens.sum()) / dt > 1e5          # sanity only (tokens/s); a hang or serial fallback shows up in CI time
+
+
 def test_reference_tokenizer_test_shape(toks):
     """embedding.rs:204-217: a 5-word string encodes under truncation(256, stride 128) (the reference
     then sees 128 ids only because the downloaded tokenizer.json pads to a fixed 128)."""
