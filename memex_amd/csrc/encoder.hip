@@ -107,8 +107,10 @@ int ensure_ws(mx_encoder *e, int rows, int seqs, int n_ids) {
             MX_HIP(hipMalloc(b, r * H * sizeof(uint16_t)));
             MX_HIP(hipMemsetAsync(*b, 0, r * H * sizeof(uint16_t), e->stream));
         }
-        MX_HIP(hipMalloc(&e->hbuf, r * F * sizeof(uint16_t)));
-        MX_HIP(hipMemsetAsync(e->hbuf, 0, r * F * sizeof(uint16_t), e->stream));
+        if (!e->fused_mlp) {  // the fused MLP keeps the [rows, ffn] intermediate on chip
+            MX_HIP(hipMalloc(&e->hbuf, r * F * sizeof(uint16_t)));
+            MX_HIP(hipMemsetAsync(e->hbuf, 0, r * F * sizeof(uint16_t), e->stream));
+        }
         MX_HIP(hipMalloc(&e->tok_seq, r * sizeof(int32_t)));
         MX_HIP(hipMalloc(&e->tok_pos, r * sizeof(int32_t)));
         e->ws_rows = rows;
