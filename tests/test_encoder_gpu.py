@@ -128,3 +128,24 @@ def test_embed_then_search_pipeline_matches_cpu_path(oracle, lib_built, tmp_path
     qref = bert_oracle.encode(w, cfg.as_dict(), qi, ql).astype(np.float32)[0]
     _, _, cpu_scores, _ = oracle.search(ref, qref, 3)              # all-CPU embed + search
     assert np.abs(np.float32([g[1] for g in got]) - cpu_scores[0]).max() <= TOL
+
+
+def test_fused_mlp_equals_two_gemm_path(lib_built, monkeypatch):
+    """The fused MLP kernel rounds at the same points and accumulates in the same k order as the
+    FFN1(+GELU) / FFN2(+LayerNorm) pair it replaces: outputs must be bit-identical, ragged lengths and
+    a non-default ffn width included."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    for kw, B, S, seed in ((dict(layers=3, hidden=384, heads=12, ffn=1536, vocab=3000), 7, 200, 11),
+                           (dict(layers=2, hidden=384, heads=12, ffn=768, vocab=3000), 4, 64, 12)):
+        cfg = EncoderConfig(**kw)
+        w = synthetic_weights(cfg, seed)
+        rng = np.random.default_rng(seed)
+        ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
+        lens = rng.integers(1, S + 1, B).astype(np.int32)
+        outs = []
+        for unfused in ("1", "0"):
+            monkeypatch.setenv("MEMEX_HIP_UNFUSED_MLP", unfused)
+            with Encoder(cfg, w) as enc:
+                outs.append(enc.encode(ids, lens))
+        np.testing.assert_array_equal(outs[0], outs[1])
