@@ -18,7 +18,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -58,6 +60,11 @@ struct Scratch {
     uint64_t *sel_state = nullptr;  // [4 + ksel]
     int ksel = 0;
     float *max_err = nullptr;
+    // pinned staging of the host API: queries in, results out (one H2D / D2H per combined batch)
+    float *h_q = nullptr;
+    uint64_t *h_ids = nullptr;
+    float *h_scores = nullptr, *h_dists = nullptr;
+    int32_t *h_nf = nullptr;
     uint32_t *host_flags = nullptr;  // pinned: [overflow 256 | pool_cnt 256], one async D2H per batch
     uint32_t *dev_flags = nullptr;   // device: same layout (overflow and pool_cnt live back to back)
     bool ready = false;
@@ -68,11 +75,28 @@ struct Scratch {
 
 using namespace mx;
 
+// one host-API search call waiting to be served (see mx_index_search)
+struct SearchReq {
+    const float *q;
+    int B, k;
+    uint64_t *ids;
+    float *scores, *dists;
+    int32_t *n_found;
+    int rc = MX_OK;
+    std::string err;
+    bool done = false;
+};
+
 struct mx_index {
     std::string key;
     int dim = 0, ds = 0, kc = 0, device = 0;
     int refs = 1;
     std::mutex mu;
+    // request combining (mx_index_search): callers queue here; one of them, the leader, serves batches
+    std::mutex cmu;
+    std::condition_variable ccv;
+    std::deque<SearchReq *> pending;
+    bool leader = false;
     hipStream_t stream = nullptr;
     float *x = nullptr;
     float *scale = nullptr;
@@ -107,6 +131,8 @@ int free_index(mx_index *idx) {
     Scratch &s = idx->s;
     F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.dev_flags); F(s.pool[0]); F(s.pool[1]);
     if (s.host_flags) (void)hipHostFree(s.host_flags);
+    for (void *hp : {(void *)s.h_q, (void *)s.h_ids, (void *)s.h_scores, (void *)s.h_dists, (void *)s.h_nf})
+        if (hp) (void)hipHostFree(hp);
     F(s.lane_buf); F(s.lane_cnt); F(s.qstage); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
     F(s.exact_keys); F(s.sel_state); F(s.max_err);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
@@ -132,6 +158,8 @@ int ensure_scratch(mx_index *idx) {
     MX_HIP(hipMalloc(&s.lane_buf, (size_t)idx->nwg * kScanThreads * kLaneCap * sizeof(Cand)));
     MX_HIP(hipMalloc(&s.lane_cnt, (size_t)idx->nwg * kScanThreads * sizeof(uint32_t)));
     MX_HIP(hipMalloc(&s.qstage, (size_t)kMaxBatch * idx->dim * sizeof(float)));
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_q), (size_t)kMaxBatch * idx->dim * sizeof(float), hipHostMallocDefault));
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_nf), kMaxBatch * sizeof(int32_t), hipHostMallocDefault));
     MX_HIP(hipMalloc(&s.max_err, sizeof(float)));
     MX_HIP(hipMemsetAsync(s.max_err, 0, sizeof(float), idx->stream));
     s.ready = true;
@@ -146,12 +174,18 @@ int ensure_out(mx_index *idx, int k) {
     };
     F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
     s.out_ids = nullptr; s.out_scores = nullptr; s.out_dists = nullptr; s.out_nfound = nullptr;
+    for (void *hp : {(void *)s.h_ids, (void *)s.h_scores, (void *)s.h_dists})
+        if (hp) (void)hipHostFree(hp);
+    s.h_ids = nullptr; s.h_scores = nullptr; s.h_dists = nullptr;
     s.kcap = 0;
     const int kc = std::max(k, 16);
     MX_HIP(hipMalloc(&s.out_ids, (size_t)kMaxBatch * kc * sizeof(uint64_t)));
     MX_HIP(hipMalloc(&s.out_scores, (size_t)kMaxBatch * kc * sizeof(float)));
     MX_HIP(hipMalloc(&s.out_dists, (size_t)kMaxBatch * kc * sizeof(float)));
     MX_HIP(hipMalloc(&s.out_nfound, kMaxBatch * sizeof(int32_t)));
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_ids), (size_t)kMaxBatch * kc * sizeof(uint64_t), hipHostMallocDefault));
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_scores), (size_t)kMaxBatch * kc * sizeof(float), hipHostMallocDefault));
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_dists), (size_t)kMaxBatch * kc * sizeof(float), hipHostMallocDefault));
     s.kcap = kc;
     return MX_OK;
 }
@@ -543,6 +577,56 @@ int mx_index_search_device(mx_index *idx, const float *d_q, int B, int k, uint64
     return MX_OK;
 }
 
+namespace {
+
+// one GPU batch (sum of B <= 256, same k) for a group of host requests: queries are packed into
+// pinned memory, one H2D, search_batch, one D2H per output array, results scattered to the callers
+int run_combined(mx_index *idx, const std::vector<SearchReq *> &batch) {
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->device);
+    const int k = batch[0]->k;
+    int rc = ensure_scratch(idx);
+    if (rc != MX_OK) return rc;
+    rc = ensure_out(idx, k);
+    if (rc != MX_OK) return rc;
+    Scratch &s = idx->s;
+    const size_t dim = (size_t)idx->dim;
+    int nb = 0;
+    for (const SearchReq *r : batch) {
+        memcpy(s.h_q + (size_t)nb * dim, r->q, (size_t)r->B * dim * sizeof(float));
+        nb += r->B;
+    }
+    MX_HIP(hipMemcpyAsync(s.qstage, s.h_q, (size_t)nb * dim * sizeof(float), hipMemcpyHostToDevice, idx->stream));
+    rc = search_batch(idx, s.qstage, nb, k, s.out_ids, s.out_scores, s.out_dists, s.out_nfound);
+    if (rc != MX_OK) return rc;
+    if (k > 0) {
+        MX_HIP(hipMemcpyAsync(s.h_ids, s.out_ids, (size_t)nb * k * sizeof(uint64_t), hipMemcpyDeviceToHost, idx->stream));
+        MX_HIP(hipMemcpyAsync(s.h_scores, s.out_scores, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, idx->stream));
+        MX_HIP(hipMemcpyAsync(s.h_dists, s.out_dists, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, idx->stream));
+    }
+    MX_HIP(hipMemcpyAsync(s.h_nf, s.out_nfound, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, idx->stream));
+    MX_HIP(hipStreamSynchronize(idx->stream));
+    int b0 = 0;
+    for (SearchReq *r : batch) {
+        if (k > 0) {
+            memcpy(r->ids, s.h_ids + (size_t)b0 * k, (size_t)r->B * k * sizeof(uint64_t));
+            memcpy(r->scores, s.h_scores + (size_t)b0 * k, (size_t)r->B * k * sizeof(float));
+            if (r->dists) memcpy(r->dists, s.h_dists + (size_t)b0 * k, (size_t)r->B * k * sizeof(float));
+        }
+        memcpy(r->n_found, s.h_nf + b0, (size_t)r->B * sizeof(int32_t));
+        b0 += r->B;
+    }
+    return MX_OK;
+}
+
+}  // namespace
+
+// The reference serves one query per HTTP request on a multi-threaded runtime (handlers.rs:55-109):
+// calls arrive concurrently, each with B = 1.  A GPU pass over the corpus costs the same for 1 and for
+// 256 queries, so concurrent callers are COMBINED: every call queues its request; whoever finds no
+// leader becomes the leader and serves batches (up to 256 queries with the same k, FIFO) until its
+// own request is done, then hands over.  A lone caller runs immediately (no timer, no added
+// latency); under load the batch is whatever queued up while the previous pass was on the GPU.
 int mx_index_search(mx_index *idx, const float *q, int B, int k, uint64_t *ids, float *scores, float *dists,
                     int32_t *n_found) {
     if (!idx) return fail(MX_ESEARCH, "null index");
@@ -550,33 +634,54 @@ int mx_index_search(mx_index *idx, const float *q, int B, int k, uint64_t *ids, 
     if (B == 0) return MX_OK;
     if (!q || !n_found || (k > 0 && (!ids || !scores))) return fail(MX_EINVAL, "null argument");
     if (k > 4096) return fail(MX_EUNSUPPORTED, "k = %d > 4096", k);
-    std::lock_guard<std::mutex> lk(idx->mu);
-    DeviceGuard g(idx->device);
-    int rc = ensure_scratch(idx);
-    if (rc != MX_OK) return rc;
-    rc = ensure_out(idx, k);
-    if (rc != MX_OK) return rc;
-    Scratch &s = idx->s;
-    for (int b0 = 0; b0 < B; b0 += kMaxBatch) {
-        const int nb = std::min(kMaxBatch, B - b0);
-        MX_HIP(hipMemcpyAsync(s.qstage, q + (size_t)b0 * idx->dim, (size_t)nb * idx->dim * sizeof(float),
-                              hipMemcpyHostToDevice, idx->stream));
-        rc = search_batch(idx, s.qstage, nb, k, s.out_ids, s.out_scores, s.out_dists, s.out_nfound);
-        if (rc != MX_OK) return rc;
-        if (k > 0) {
-            MX_HIP(hipMemcpyAsync(ids + (size_t)b0 * k, s.out_ids, (size_t)nb * k * sizeof(uint64_t),
-                                  hipMemcpyDeviceToHost, idx->stream));
-            MX_HIP(hipMemcpyAsync(scores + (size_t)b0 * k, s.out_scores, (size_t)nb * k * sizeof(float),
-                                  hipMemcpyDeviceToHost, idx->stream));
-            if (dists)
-                MX_HIP(hipMemcpyAsync(dists + (size_t)b0 * k, s.out_dists, (size_t)nb * k * sizeof(float),
-                                      hipMemcpyDeviceToHost, idx->stream));
+    if (B > kMaxBatch) {  // large requests are their own batches: split and recurse
+        for (int b0 = 0; b0 < B; b0 += kMaxBatch) {
+            const int nb = std::min(kMaxBatch, B - b0);
+            int rc = mx_index_search(idx, q + (size_t)b0 * idx->dim, nb, k, ids ? ids + (size_t)b0 * k : nullptr,
+                                     scores ? scores + (size_t)b0 * k : nullptr,
+                                     dists ? dists + (size_t)b0 * k : nullptr, n_found + b0);
+            if (rc != MX_OK) return rc;
         }
-        MX_HIP(hipMemcpyAsync(n_found + b0, s.out_nfound, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost,
-                              idx->stream));
-        MX_HIP(hipStreamSynchronize(idx->stream));
+        return MX_OK;
     }
-    return MX_OK;
+    SearchReq req{q, B, k, ids, scores, dists, n_found};
+    std::unique_lock<std::mutex> ql(idx->cmu);
+    idx->pending.push_back(&req);
+    idx->ccv.wait(ql, [&] { return req.done || !idx->leader; });
+    if (!req.done) {
+        idx->leader = true;
+        while (!req.done) {
+            // FIFO batch: the oldest request decides k; later requests with the same k join while they fit
+            std::vector<SearchReq *> batch;
+            int total = 0;
+            const int bk = idx->pending.front()->k;
+            for (auto it = idx->pending.begin(); it != idx->pending.end();) {
+                SearchReq *r = *it;
+                if (r->k == bk && total + r->B <= kMaxBatch) {
+                    batch.push_back(r);
+                    total += r->B;
+                    it = idx->pending.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            ql.unlock();
+            const int rc = run_combined(idx, batch);
+            const std::string err = rc == MX_OK ? std::string() : last_error_slot();
+            ql.lock();
+            for (SearchReq *r : batch) {
+                r->rc = rc;
+                r->err = err;
+                r->done = true;
+            }
+            idx->ccv.notify_all();
+        }
+        idx->leader = false;
+        idx->ccv.notify_all();  // a waiter (if any) takes over
+    }
+    ql.unlock();
+    if (req.rc != MX_OK) last_error_slot() = req.err;  // the leader's message, in the caller's thread
+    return req.rc;
 }
 
 int mx_index_set_filter_copy(mx_index *idx, int on) {

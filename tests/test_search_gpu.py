@@ -372,3 +372,43 @@ def test_filter_copy_follows_incremental_inserts(oracle, lib_built):
         idx.set_filter_copy(True)                         # rebuilt from the resident rows
         assert idx.stats().filter_copy_bytes > 0
         np.testing.assert_array_equal(idx.search(Q, 10)[0], oracle.search(Y, Q, 10)[0])
+
+
+def test_concurrent_single_queries_are_combined(oracle, lib_built):
+    """One query per call from many threads (the reference's request pattern, handlers.rs:55-109):
+    every caller gets exactly its own answer, and the calls were served in shared GPU batches."""
+    import threading
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(41)
+    X = rng.standard_normal((60000, 384), dtype=np.float32)
+    Q = rng.standard_normal((480, 384), dtype=np.float32)
+    want10 = oracle.search(X, Q, 10)
+    want3 = oracle.search(X, Q, 3)
+    nthreads, per = 48, 10
+    errors = []
+    with FlatIndex(384) as idx:
+        idx.add(X)
+        idx.reset_stats()
+
+        def worker(t):
+            try:
+                for j in range(per):
+                    i = t * per + j
+                    k = 3 if (i % 7 == 0) else 10                 # mixed k: batches are formed per k
+                    want = want3 if k == 3 else want10
+                    ids, sc, di, nf = idx.search(Q[i], k)
+                    if not (np.array_equal(ids[0], want[0][i]) and np.array_equal(bits(di[0]), bits(want[1][i]))
+                            and np.array_equal(bits(sc[0]), bits(want[2][i])) and nf[0] == want[3][i]):
+                        errors.append(f"query {i} (k={k}) got someone else's or a wrong answer")
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        st = idx.stats()
+    assert not errors, errors[:3]
+    assert st.queries == nthreads * per
+    assert st.searches < st.queries, (st.searches, st.queries)     # at least some calls shared a batch
