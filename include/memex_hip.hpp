@@ -446,30 +446,57 @@ class SentenceEmbedder {
         }
         ready.set_value("");
         WhitespaceHashTokenizer tok{cfg.vocab};
-        for (;;) {
-            Msg m;
+        bool stop = false;
+        while (!stop) {
+            // requests that queued up while the previous batch was on the GPU are embedded together
+            // (the reference's runner takes one message per model.encode, :101-109; a row's embedding
+            // does not depend on its batch)
+            std::vector<Msg> msgs;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return !q_.empty(); });
-                m = std::move(q_.front());
-                q_.pop_front();
+                while (!q_.empty() && msgs.size() < 64) {
+                    msgs.push_back(std::move(q_.front()));
+                    q_.pop_front();
+                }
                 cv_.notify_all();
             }
-            if (m.stop) break;
+            std::vector<std::pair<Msg *, std::vector<std::string>>> work;
+            for (Msg &m : msgs) {
+                if (m.stop) {
+                    stop = true;
+                    continue;
+                }
+                try {
+                    work.emplace_back(&m, m.segment ? segment_text(mc, m.text) : std::vector<std::string>{m.text});  // :103-107
+                } catch (...) {
+                    m.reply->set_exception(std::current_exception());
+                }
+            }
+            if (work.empty()) continue;
             try {
-                const auto segments = m.segment ? segment_text(mc, m.text) : std::vector<std::string>{m.text};  // :103-107
+                std::vector<std::string> flat;
+                for (auto &wk : work) flat.insert(flat.end(), wk.second.begin(), wk.second.end());
                 std::vector<int32_t> ids, lens;
                 int S = 0;
-                tok.encode_batch(segments, max_seq_length, ids, lens, S);
-                std::vector<float> out(segments.size() * (size_t)cfg.hidden);
-                rc = mx_encoder_encode(enc, ids.data(), lens.data(), (int)segments.size(), S, out.data());  // model.encode, :109
+                tok.encode_batch(flat, max_seq_length, ids, lens, S);
+                std::vector<float> out(flat.size() * (size_t)cfg.hidden);
+                rc = mx_encoder_encode(enc, ids.data(), lens.data(), (int)flat.size(), S, out.data());  // model.encode, :109
                 if (rc != MX_OK) throw EmbeddingError(EmbeddingError::EncodingFailure, mx_last_error());
-                std::vector<EmbeddingResult> res;
-                for (size_t i = 0; i < segments.size(); ++i)
-                    res.push_back({segments[i], std::vector<float>(out.begin() + i * cfg.hidden, out.begin() + (i + 1) * cfg.hidden)});
-                m.reply->set_value(std::move(res));
+                size_t o = 0;
+                for (auto &wk : work) {
+                    std::vector<EmbeddingResult> res;
+                    for (size_t i = 0; i < wk.second.size(); ++i, ++o)
+                        res.push_back({wk.second[i], std::vector<float>(out.begin() + o * cfg.hidden, out.begin() + (o + 1) * cfg.hidden)});
+                    wk.first->reply->set_value(std::move(res));
+                }
             } catch (...) {
-                m.reply->set_exception(std::current_exception());
+                for (auto &wk : work) {
+                    try {
+                        wk.first->reply->set_exception(std::current_exception());
+                    } catch (const std::future_error &) {  // already answered before the failure
+                    }
+                }
             }
         }
         mx_encoder_destroy(enc);

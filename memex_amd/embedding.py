@@ -211,20 +211,44 @@ class SentenceEmbedder:
             ready.put(e if isinstance(e, EmbeddingError) else SetupError(str(e)))
             return
         ready.put(None)
-        while True:
-            msg = q.get()
-            if msg is None:
-                break
-            text, segment, reply = msg
+        stop = False
+        while not stop:
+            msgs = [q.get()]
+            # Requests that queued up while the previous batch was on the GPU are embedded together
+            # (SURVEY section 8 f-2): one tokenizer call, one encoder call.  The reference's runner takes
+            # one message per model.encode (:101-109); a row's embedding does not depend on its batch.
+            while len(msgs) < 64:
+                try:
+                    msgs.append(q.get_nowait())
+                except queue.Empty:
+                    break
+            work = []                                                            # (reply, segments)
+            for msg in msgs:
+                if msg is None:
+                    stop = True
+                    continue
+                text, segment, reply = msg
+                try:
+                    segs = segment_text(model_config, text, tok) if segment else [text]   # :103-107
+                    work.append((reply, segs))
+                except Exception as e:
+                    reply.put(e)
+            if not work:
+                continue
             try:
-                segments = segment_text(model_config, text, tok) if segment else [text]   # :103-107
-                ids, lens = tok.encode_batch(segments, cfg.max_seq_length)
+                flat = [s_ for _, segs in work for s_ in segs]
+                ids, lens = tok.encode_batch(flat, cfg.max_seq_length)
                 vecs = enc.encode(ids, lens)                                     # model.encode(&segments), :109
-                if len(vecs) != len(segments):
+                if len(vecs) != len(flat):
                     raise EncodingFailure("# of embeddings doesn't match # of segments")
-                reply.put([EmbeddingResult(content=s, vector=v.tolist()) for s, v in zip(segments, vecs)])
+                o = 0
+                for reply, segs in work:
+                    reply.put([EmbeddingResult(content=s_, vector=v.tolist())
+                               for s_, v in zip(segs, vecs[o:o + len(segs)])])
+                    o += len(segs)
             except Exception as e:
-                reply.put(e)
+                for reply, _ in work:
+                    reply.put(e)
         enc.close()
 
     def _call(self, text: str, segment: bool):

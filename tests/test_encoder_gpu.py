@@ -149,3 +149,39 @@ def test_fused_mlp_equals_two_gemm_path(lib_built, monkeypatch):
             with Encoder(cfg, w) as enc:
                 outs.append(enc.encode(ids, lens))
         np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_embedder_batches_concurrent_requests(lib_built):
+    """Concurrent encode / encode_single calls on one embedder are embedded together; every caller
+    still receives exactly what a lone call returns (a row's embedding is batch-independent)."""
+    import threading
+    from memex_amd import embedding as E
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    cfg = EncoderConfig(layers=2, hidden=384, heads=12, ffn=1536, vocab=30522, max_seq_length=128)
+    w = synthetic_weights(cfg, 13)
+    rng = np.random.default_rng(13)
+    words = [f"tok{i}" for i in range(300)]
+    texts = [" ".join(rng.choice(words, size=int(n))) for n in rng.integers(3, 700, 40)]
+    th, emb = E.SentenceEmbedder.spawn(E.ModelConfig(), weights=w, encoder_config=cfg)
+    alone = [emb.encode(t) for t in texts]                          # one at a time
+    got = [None] * len(texts)
+    errs = []
+
+    def worker(i):
+        try:
+            got[i] = emb.encode(texts[i]) if i % 3 else [emb.encode_single(texts[i])]
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(texts))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    single = [emb.encode_single(t) for t in texts]
+    emb.shutdown()
+    assert not errs, errs[:2]
+    for i in range(len(texts)):
+        want = alone[i] if i % 3 else [single[i]]
+        assert [r.content for r in got[i]] == [r.content for r in want]
+        np.testing.assert_array_equal(np.float32([r.vector for r in got[i]]), np.float32([r.vector for r in want]))
