@@ -177,7 +177,7 @@ def main():
     import torch.distributed as dist
 
     from memex_amd import _lib
-    from memex_amd.index import FlatIndex, merge_topk_device
+    from memex_amd.index import FlatIndex, merge_topk_packed_device, packed_result_block
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -229,13 +229,12 @@ def main():
     gq.manual_seed(4321)
     q = torch.randn((a.batch, a.dim), device="cuda", dtype=torch.float32, generator=gq)
     k = a.k
-    ids = torch.zeros((a.batch, k), device="cuda", dtype=torch.int64)
+    # ids and dists live in one block so that the N>1 exchange is ONE all-gather (B*k*12 bytes per rank)
+    block, ids, dists = packed_result_block(a.batch, k, "cuda")
     scores = torch.zeros((a.batch, k), device="cuda", dtype=torch.float32)
-    dists = torch.zeros((a.batch, k), device="cuda", dtype=torch.float32)
     nf = torch.zeros((a.batch,), device="cuda", dtype=torch.int32)
     if world > 1:
-        g_ids = torch.zeros((world, a.batch, k), device="cuda", dtype=torch.int64)
-        g_dists = torch.zeros((world, a.batch, k), device="cuda", dtype=torch.float32)
+        g_block = torch.zeros((world, block.numel()), device="cuda", dtype=torch.uint8)
         m_ids = torch.zeros((a.batch, k), device="cuda", dtype=torch.int64)
         m_dists = torch.zeros((a.batch, k), device="cuda", dtype=torch.float32)
         m_scores = torch.zeros((a.batch, k), device="cuda", dtype=torch.float32)
@@ -245,15 +244,13 @@ def main():
         idx.search_device(q, k, ids, scores, dists, nf)  # blocks until results are in HBM
         if world > 1:
             if one_device:  # gloo: gather through host memory
-                for dst, src in ((g_ids, ids), (g_dists, dists)):
-                    parts = [torch.empty_like(src, device="cpu") for _ in range(world)]
-                    dist.all_gather(parts, src.cpu())
-                    dst.copy_(torch.stack(parts).to(dst.device))
+                parts = [torch.empty_like(block, device="cpu") for _ in range(world)]
+                dist.all_gather(parts, block.cpu())
+                g_block.copy_(torch.stack(parts).to(g_block.device))
             else:
-                dist.all_gather_into_tensor(g_ids, ids)
-                dist.all_gather_into_tensor(g_dists, dists)
+                dist.all_gather_into_tensor(g_block, block)
             torch.cuda.synchronize()
-            merge_topk_device(dev, g_ids, g_dists, m_ids, m_dists, m_scores)
+            merge_topk_packed_device(dev, g_block, world, a.batch, k, m_ids, m_dists, m_scores)
 
     def fence():
         if world > 1:
@@ -335,6 +332,11 @@ def main():
             recall_exact_order = bool(torch.equal(final_ids, e_ids))
         else:
             recall_exact_order = None
+            # N > 1: no rank holds the whole corpus; check the merge's invariants instead (lists ordered by
+            # (dist, id), ids unique and inside the corpus, every list full)
+            md, mi = m_dists.cpu(), m_ids.cpu()
+            merged_ok = bool((md[:, 1:] >= md[:, :-1]).all()) and bool(((mi >= 1) & (mi <= rows_total)).all()) and \
+                all(len(set(r.tolist())) == k for r in mi)
     if world > 1:
         dist.barrier()
     ingest = ingest_leg(a.ingest_chunks, dev, world, not a.no_cpu_baseline) if a.ingest_chunks > 0 else None
@@ -359,6 +361,7 @@ def main():
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
             "recall_at_10": recall,
             "ids_equal_exact_path": recall_exact_order if rank == 0 and a.recall_queries > 0 else None,
+            "merged_lists_ok": merged_ok if world > 1 and a.recall_queries > 0 else None,
             "fallback_queries": int(st.fallback_queries),
             "candidates_per_query": st.candidates / max(1, st.queries),
             "roofline": roofline(st, a.scan),

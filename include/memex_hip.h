@@ -150,6 +150,11 @@ int mx_index_reset_stats(mx_index *idx);
  */
 int mx_topk_merge_device(int device, const uint64_t *d_ids, const float *d_dists, int G, int B, int k,
                          uint64_t *d_out_ids, float *d_out_dists, float *d_out_scores);
+/* Same merge for ONE all-gather: every shard writes its results into one block
+ * [ids: B*k u64][dists: B*k f32] (pass `block` and `block + B*k*8` to mx_index_search_device), the
+ * collective gathers the G blocks back to back into d_packed. */
+int mx_topk_merge_packed_device(int device, const void *d_packed, int G, int B, int k, uint64_t *d_out_ids,
+                                float *d_out_dists, float *d_out_scores);
 
 /* =====================================================================================
  * Sentence encoder  (replaces the rust-bert model owned by SentenceEmbedder::runner,

@@ -861,7 +861,22 @@ int mx_topk_merge_device(int device, const uint64_t *d_ids, const float *d_dists
     if (!d_ids || !d_dists || !d_out_ids || !d_out_dists) return fail(MX_EINVAL, "null argument");
     DeviceGuard g(device);
     if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
-    MX_HIP(launch_merge(hipStreamPerThread, d_ids, d_dists, G, B, k, d_out_ids, d_out_dists, d_out_scores));
+    MX_HIP(launch_merge(hipStreamPerThread, d_ids, (size_t)B * k * sizeof(uint64_t), d_dists, (size_t)B * k * sizeof(float),
+                        G, B, k, d_out_ids, d_out_dists, d_out_scores));
+    MX_HIP(hipStreamSynchronize(hipStreamPerThread));
+    return MX_OK;
+}
+
+int mx_topk_merge_packed_device(int device, const void *d_packed, int G, int B, int k, uint64_t *d_out_ids,
+                                float *d_out_dists, float *d_out_scores) {
+    if (G < 1 || B < 0 || k < 0) return fail(MX_EINVAL, "bad merge shape");
+    if (B == 0 || k == 0) return MX_OK;
+    if (!d_packed || !d_out_ids || !d_out_dists) return fail(MX_EINVAL, "null argument");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
+    const size_t ids_bytes = (size_t)B * k * sizeof(uint64_t), blk = ids_bytes + (size_t)B * k * sizeof(float);
+    MX_HIP(launch_merge(hipStreamPerThread, d_packed, blk, static_cast<const char *>(d_packed) + ids_bytes, blk, G, B, k,
+                        d_out_ids, d_out_dists, d_out_scores));
     MX_HIP(hipStreamSynchronize(hipStreamPerThread));
     return MX_OK;
 }

@@ -100,7 +100,7 @@ hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *
                               uint64_t *sel_state, uint64_t *ids, float *scores, float *dists,
                               int32_t *n_found);
 
-hipError_t launch_merge(hipStream_t s, const uint64_t *ids, const float *dists, int G, int B, int k,
-                        uint64_t *out_ids, float *out_dists, float *out_scores);
+hipError_t launch_merge(hipStream_t s, const void *ids, size_t ids_stride, const void *dists, size_t dists_stride,
+                        int G, int B, int k, uint64_t *out_ids, float *out_dists, float *out_scores);
 
 }  // namespace mx

@@ -510,7 +510,9 @@ hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *
 // ---------------------------------------------------------------------------------------------
 // multi-GPU merge of per-shard top-k lists (after the RCCL all-gather)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void merge_kernel(const uint64_t *__restrict__ ids, const float *__restrict__ dists,
+// shard g's lists: ids at ids_base + g*ids_stride, dists at dists_base + g*dists_stride (bytes), each [B, k]
+__global__ __launch_bounds__(256) void merge_kernel(const char *__restrict__ ids_base, size_t ids_stride,
+                                                    const char *__restrict__ dists_base, size_t dists_stride,
                                                     int G, int B, int k, uint64_t *out_ids, float *out_dists,
                                                     float *out_scores) {
     const int b = blockIdx.x;
@@ -524,16 +526,17 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t *__restrict__
     __syncthreads();
     for (int c = tid; c < total; c += 256) {
         const int g = c / k, j = c % k;
-        const size_t o = ((size_t)g * B + b) * k + j;
-        const uint64_t id = ids[o];
+        const size_t o = (size_t)b * k + j;
+        const uint64_t id = reinterpret_cast<const uint64_t *>(ids_base + (size_t)g * ids_stride)[o];
         if (id == 0) continue;
-        const float d = dists[o];
+        const float d = reinterpret_cast<const float *>(dists_base + (size_t)g * dists_stride)[o];
         int rank = 0;
         for (int c2 = 0; c2 < total; ++c2) {
-            const size_t o2 = ((size_t)(c2 / k) * B + b) * k + (c2 % k);
-            const uint64_t id2 = ids[o2];
+            const int g2 = c2 / k;
+            const size_t o2 = (size_t)b * k + (c2 % k);
+            const uint64_t id2 = reinterpret_cast<const uint64_t *>(ids_base + (size_t)g2 * ids_stride)[o2];
             if (id2 == 0) continue;
-            const float d2 = dists[o2];
+            const float d2 = reinterpret_cast<const float *>(dists_base + (size_t)g2 * dists_stride)[o2];
             rank += (d2 < d || (d2 == d && id2 < id)) ? 1 : 0;
         }
         if (rank < k) {
@@ -544,10 +547,11 @@ __global__ __launch_bounds__(256) void merge_kernel(const uint64_t *__restrict__
     }
 }
 
-hipError_t launch_merge(hipStream_t s, const uint64_t *ids, const float *dists, int G, int B, int k,
-                        uint64_t *out_ids, float *out_dists, float *out_scores) {
+hipError_t launch_merge(hipStream_t s, const void *ids, size_t ids_stride, const void *dists, size_t dists_stride,
+                        int G, int B, int k, uint64_t *out_ids, float *out_dists, float *out_scores) {
     if (B <= 0 || k <= 0) return hipSuccess;
-    hipLaunchKernelGGL(merge_kernel, dim3(B), dim3(256), 0, s, ids, dists, G, B, k, out_ids, out_dists, out_scores);
+    hipLaunchKernelGGL(merge_kernel, dim3(B), dim3(256), 0, s, static_cast<const char *>(ids), ids_stride,
+                       static_cast<const char *>(dists), dists_stride, G, B, k, out_ids, out_dists, out_scores);
     return hipGetLastError();
 }
 

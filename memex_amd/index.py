@@ -155,3 +155,20 @@ def merge_topk_device(device: int, ids, dists, out_ids, out_dists, out_scores) -
                                      G, B, k, ctypes.c_void_p(out_ids.data_ptr()),
                                      ctypes.c_void_p(out_dists.data_ptr()),
                                      ctypes.c_void_p(out_scores.data_ptr()) if out_scores is not None else None))
+
+
+def packed_result_block(B: int, k: int, device):
+    """One contiguous device block [ids: B*k i64][dists: B*k f32] plus its two views: search results
+    written through the views travel in ONE all-gather."""
+    import torch
+    block = torch.zeros((B * k * 12,), dtype=torch.uint8, device=device)
+    ids = block[: B * k * 8].view(torch.int64).view(B, k)
+    dists = block[B * k * 8:].view(torch.float32).view(B, k)
+    return block, ids, dists
+
+
+def merge_topk_packed_device(device: int, packed, G: int, B: int, k: int, out_ids, out_dists, out_scores) -> None:
+    """packed: uint8 device tensor [G, B*k*12], shard blocks as laid out by packed_result_block."""
+    check(lib().mx_topk_merge_packed_device(int(device), ctypes.c_void_p(packed.data_ptr()), int(G), int(B), int(k),
+                                            ctypes.c_void_p(out_ids.data_ptr()), ctypes.c_void_p(out_dists.data_ptr()),
+                                            ctypes.c_void_p(out_scores.data_ptr()) if out_scores is not None else None))

@@ -21,7 +21,7 @@ from typing import Callable, List, Tuple
 import torch
 import torch.distributed as dist
 
-from .index import FlatIndex, merge_topk_device
+from .index import FlatIndex, merge_topk_packed_device, packed_result_block
 
 
 def partition(n_total: int, world: int) -> List[Tuple[int, int]]:
@@ -43,7 +43,7 @@ class ShardedFlatIndex:
         self.index = (index_factory or (lambda: FlatIndex(dim, key=None, device=device)))()
         self.index.reserve(self.hi - self.lo)
         self.index.set_id_offset(self.lo)
-        self._merge = merge_fn or (lambda ids, dists, oi, od, os_: merge_topk_device(device, ids, dists, oi, od, os_))
+        self._merge = merge_fn  # None: native merge of the gathered blocks
 
     def owns(self, global_row: int) -> bool:
         return self.lo <= global_row < self.hi
@@ -59,24 +59,27 @@ class ShardedFlatIndex:
         (ids int64 [B,k], dists f32 [B,k], scores f32 [B,k]) identical on every rank."""
         B = q.shape[0]
         dev = q.device
-        ids = torch.zeros((B, k), dtype=torch.int64, device=dev)
+        # results land in one block [ids | dists] so that ONE all-gather moves them (B*k*12 bytes per rank)
+        block, ids, dists = packed_result_block(B, k, dev)
         scores = torch.zeros((B, k), dtype=torch.float32, device=dev)
-        dists = torch.zeros((B, k), dtype=torch.float32, device=dev)
         nf = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.index.search_device(q, k, ids, scores, dists, nf)
         if self.world == 1:
             return ids, dists, scores
-        g_ids = torch.zeros((self.world, B, k), dtype=torch.int64, device=dev)
-        g_dists = torch.zeros((self.world, B, k), dtype=torch.float32, device=dev)
+        g_block = torch.zeros((self.world, block.numel()), dtype=torch.uint8, device=dev)
         # list-of-views form: accepted by both RCCL ("nccl") and gloo (CPU tests)
-        dist.all_gather(list(g_ids.unbind(0)), ids, group=self.group)
-        dist.all_gather(list(g_dists.unbind(0)), dists, group=self.group)
+        dist.all_gather(list(g_block.unbind(0)), block, group=self.group)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         m_ids = torch.zeros((B, k), dtype=torch.int64, device=dev)
         m_dists = torch.zeros((B, k), dtype=torch.float32, device=dev)
         m_scores = torch.zeros((B, k), dtype=torch.float32, device=dev)
-        self._merge(g_ids, g_dists, m_ids, m_dists, m_scores)
+        if self._merge is None:
+            merge_topk_packed_device(self.device, g_block, self.world, B, k, m_ids, m_dists, m_scores)
+        else:  # injected merge (tests): takes the unpacked [G, B, k] arrays
+            g_ids = g_block[:, : B * k * 8].contiguous().view(torch.int64).view(self.world, B, k)
+            g_dists = g_block[:, B * k * 8:].contiguous().view(torch.float32).view(self.world, B, k)
+            self._merge(g_ids, g_dists, m_ids, m_dists, m_scores)
         return m_ids, m_dists, m_scores
 
     def close(self) -> None:
