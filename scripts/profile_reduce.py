@@ -51,7 +51,11 @@ def main():
     if stats:
         with open(stats) as f, open(os.path.join(prof, f"{tag}_bench_kernel_stats.csv"), "w") as g:
             g.write(f.read())
-    for name in ("bench.json", "bench_under_rocprof.json"):
+    enc = find(os.path.join(out_dir, "enc_stats"), "_kernel_stats.csv")
+    if enc:
+        with open(enc) as f, open(os.path.join(prof, f"{tag}_encoder_kernel_stats.csv"), "w") as g:
+            g.write(f.read())
+    for name in ("bench.json", "bench_under_rocprof.json", "bench_default.json"):
         src = os.path.join(out_dir, name)
         if os.path.exists(src):
             lines = [ln for ln in open(src).read().splitlines() if ln.startswith("{")]

@@ -15,4 +15,7 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WA
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$D" -- $BENCH --steps 6 --warmup 2 --alt-steps 6 > "$D.json" 2> "$D.log"
 done
 $BENCH > "$OUT/bench.json" 2> "$OUT/bench.log"
+# encoder kernels (MiniLM-L6 shape, 2048 x 512-token chunks) and the default bench line (all legs)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/enc_stats" -- python $ROOT/scripts/gpu_encoder_prof.py l6 > /dev/null 2> "$OUT/enc_stats.log"
+python $ROOT/bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.log"
 python "$ROOT/scripts/profile_reduce.py" "$OUT" "$TAG"
