@@ -30,6 +30,21 @@
 
 namespace mx {
 
+#ifdef MX_MLP_TRACE
+// scripts/mlp_ubench.hip only: per-segment s_memtime totals of workgroup 0 / wave 0, kept in scalar
+// registers during the kernel (a segment = the code between two MX_TRACE points, named by its END tag)
+__device__ unsigned long long g_mlp_trace[32];
+#define MX_TRACE(tag)                                                    \
+    do {                                                                 \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        tr_seg[tag] += now_ - tr_last;                                   \
+        tr_cnt[tag] += 1;                                                \
+        tr_last = now_;                                                  \
+    } while (0)
+#else
+#define MX_TRACE(tag) do { } while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -86,6 +101,10 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpParams p) {
     const int F = p.f;
     const int nch = F / kFC;
     const int total = nch * kSPC;  // stages
+#ifdef MX_MLP_TRACE
+    unsigned long long tr_seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
+    unsigned int tr_cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     // ---- LDS-DMA sources.  A piece is 16 stage rows x 64 B; lane l -> row 16P + (l>>2), physical 16-B
     // chunk l&3, which holds logical chunk (l&3) ^ ((row>>2)&3).  All piece bases are multiples of 16
@@ -137,51 +156,57 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpParams p) {
             for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
     }
 
-    // ---- software pipeline over k-steps (2 per stage).  While the MFMAs of k-step t execute, the
-    // wave issues the fragment reads of k-step t+1 into the other register buffer; when t+1 opens a
-    // new stage, the counted wait + barrier that publish that stage (and the DMA issue that refills the
-    // slot freed two stages ago) also sit in front of k-step t's MFMAs, i.e. under the MFMAs of t-1
-    // that are still in the pipe.  The only drain is the G1 -> G2 hand-over (E1 needs the finished
-    // accumulators and G2's first fragments come from the tile E1 writes).
-    bf16x8 fa[2][2];  // activation fragments (x rows / h rows) of k-step parity 0 / 1
-    bf16x8 fw[2][3];  // weight fragments (G1 uses [.][0])
+    // ---- software pipeline.  Fragment registers are double-buffered (fb[2][6]):
+    //   G1 (wave tile 64 x 32: only 2 MFMAs per k-step, less than one LDS latency) is pipelined a whole
+    //   STAGE ahead: at the start of stage i the wave publishes stage i+1 (counted wait, barrier, DMA
+    //   refill) and reads all 6 of its fragments between the 4 MFMAs of stage i;
+    //   G2 (6 MFMAs per k-step) is pipelined one k-step ahead, the publish of the next stage sits in
+    //   front of its second k-step.
+    // The only drain is the G1 -> G2 hand-over (E1 needs the finished accumulators and G2's first
+    // fragments come from the tile E1 writes).
+    bf16x8 fb[2][6];  // G1: [3*ks + {W1, x rows 0-31, x rows 32-63}]; G2: [W2 x3, h rows x2] of one k-step
     uint32_t slot = 0;  // byte offset of the ring slot of the stage being multiplied
     auto next_slot = [](uint32_t sl) { return sl + kSlot == (uint32_t)(kS * kSlot) ? 0u : sl + kSlot; };
     auto prev_slot = [](uint32_t sl) { return sl == 0u ? (uint32_t)((kS - 1) * kSlot) : sl - kSlot; };
-    // fragment reads of k-step (i, ks) from the slot at byte offset sl; `which` selects one read so
-    // that the caller can place them between MFMAs
-    auto read_frag = [&](int i, int ks, uint32_t sl, int buf, int which) __attribute__((always_inline)) {
-        const uint32_t sw = ks == 0 ? sw0 : sw1;
+    auto read_g1 = [&](uint32_t sl, int buf, int which) __attribute__((always_inline)) {  // which: 0..5
 #if MX_MLP_ABLATE & 8
         return;
 #endif
-        if (i < kG1) {
-            if (which == 0) fw[buf][0] = *reinterpret_cast<const bf16x8 *>(smem + sl + g1_w + sw);
-            else if (which <= 2) fa[buf][which - 1] = *reinterpret_cast<const bf16x8 *>(smem + sl + g1_a + (which - 1) * (32 * 64) + sw);
-        } else {
-            const int kt2 = i - kG1;
-            if (which < 3) fw[buf][which] = *reinterpret_cast<const bf16x8 *>(smem + sl + g2_w + which * (32 * 64) + sw);
-            else fa[buf][which - 3] = *reinterpret_cast<const bf16x8 *>(smem + g2_a + (which - 3) * (32 * kHtPitch) + (kt2 * 32 + ks * 16) * 2);
-        }
+        const uint32_t sw = which < 3 ? sw0 : sw1;
+        const int part = which % 3;
+        fb[buf][which] = *reinterpret_cast<const bf16x8 *>(smem + sl + (part == 0 ? g1_w : g1_a + (part - 1) * (32 * 64)) + sw);
     };
-    // publish stage g+1 (stage-in-chunk i1 = (i+1) % 16): counted wait, barrier, refill the slot of stage g-1
+    auto read_g2 = [&](int i, int ks, uint32_t sl, int buf, int which) __attribute__((always_inline)) {  // which: 0..4
+#if MX_MLP_ABLATE & 8
+        return;
+#endif
+        const uint32_t sw = ks == 0 ? sw0 : sw1;
+        const int kt2 = i - kG1;
+        if (which < 3) fb[buf][which] = *reinterpret_cast<const bf16x8 *>(smem + sl + g2_w + which * (32 * 64) + sw);
+        else fb[buf][which] = *reinterpret_cast<const bf16x8 *>(smem + g2_a + (which - 3) * (32 * kHtPitch) + (kt2 * 32 + ks * 16) * 2);
+    };
+    // publish stage g+1: counted wait, barrier, refill the slot of stage g-1 with stage g+4
     auto publish_next = [&](int chunk, int i, int g) __attribute__((always_inline)) {
         if (g + 1 >= total) return;
+        MX_TRACE(1);
         // issued so far: stages <= g+3; stage g+1 has landed once at most stages g+2, g+3 are outstanding
         if (g + 3 < total) wait_vm(stage_ops(i + 2) + stage_ops(i + 3));
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MX_TRACE(2);
         __builtin_amdgcn_s_barrier();
+        MX_TRACE(3);
         if (g + 4 < total) {
             const int i4 = (i + 4) % kSPC, c4 = chunk + (i + 4) / kSPC;
             issue(c4, i4, prev_slot(slot));
         }
+        MX_TRACE(4);
     };
 
     // b1 -> LDS: loads first (older than the DMA prologue, so their wait does not drain it), stores after
     float b1v[kMaxF / 512];
 #pragma unroll
     for (int c = 0; c < kMaxF / 512; ++c) b1v[c] = (c * 512 + tid < F) ? p.b1[c * 512 + tid] : 0.0f;
-    // ---- prologue: stages 0 .. 3 in flight, first fragments in registers
+    // ---- prologue: stages 0 .. 3 in flight, stage 0's fragments in registers
 #pragma unroll
     for (int i = 0; i < kS - 1; ++i) issue(0, i, (uint32_t)i * kSlot);
 #pragma unroll
@@ -189,56 +214,41 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpParams p) {
     wait_vm(stage_ops(1) + stage_ops(2) + stage_ops(3));
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int w = 0; w < 3; ++w) read_frag(0, 0, 0u, 0, w);
+    for (int w = 0; w < 6; ++w) read_g1(0u, 0, w);
 
 #pragma unroll 1
     for (int chunk = 0; chunk < nch; ++chunk) {
         const int g0 = chunk * kSPC;
 #pragma unroll
         for (int i = 0; i < kSPC; ++i) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int cur = ks, nxt = ks ^ 1;
-                const bool drain = (i == kG1 - 1 && ks == 1);   // next k-step is G2's first: no prefetch
-                const int ni = ks == 0 ? i : (i + 1) % kSPC;    // stage-in-chunk and k-step of t+1
-                const int nks = ks ^ 1;
+            if (i < kG1) {
+                // ---------------- G1 stage i: fragments in fb[i & 1] ----------------
+                const int cur = i & 1, nxt = cur ^ 1;
+                const bool last = i == kG1 - 1;  // next stage is G2's first: no prefetch (drain)
                 uint32_t nslot = slot;
-                if (ks == 1 && !drain) {
+                if (!last) {
                     publish_next(chunk, i, g0 + i);
                     nslot = next_slot(slot);
                 }
-                const int nreads = drain ? 0 : (ni < kG1 ? 3 : 5);
-                if (i < kG1) {
 #pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        // reads first: they issue while the MFMA pipe is still busy with older work
-#pragma unroll
-                        for (int w = 0; w < 5; ++w)
-                            if (w < nreads && (w < (nreads + 1) / 2) == (ii == 0)) read_frag(ni, nks, nslot, nxt, w);
-#if MX_MLP_ABLATE & 4
-                        asm volatile("" ::"v"(fw[cur][0]), "v"(fa[cur][ii]));
-#else
-                        acc1[ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cur][0], fa[cur][ii], acc1[ii], 0, 0, 0);
-#endif
-                        __builtin_amdgcn_sched_barrier(0);
+                for (int mm = 0; mm < 4; ++mm) {
+                    const int ks = mm >> 1, ii = mm & 1;
+                    if (!last) {  // the 6 fragment reads of stage i+1, spread 2-2-1-1 in front of the 4 MFMAs
+                        if (mm == 0) { read_g1(nslot, nxt, 0); read_g1(nslot, nxt, 1); }
+                        if (mm == 1) { read_g1(nslot, nxt, 2); read_g1(nslot, nxt, 3); }
+                        if (mm == 2) read_g1(nslot, nxt, 4);
+                        if (mm == 3) read_g1(nslot, nxt, 5);
                     }
-                } else {
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const int q = ii * 3 + j;
-                            if (q < nreads) read_frag(ni, nks, nslot, nxt, q);
 #if MX_MLP_ABLATE & 4
-                            asm volatile("" ::"v"(fw[cur][j]), "v"(fa[cur][ii]));
+                    asm volatile("" ::"v"(fb[cur][3 * ks]), "v"(fb[cur][3 * ks + 1 + ii]));
 #else
-                            acc2[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cur][j], fa[cur][ii], acc2[ii][j], 0, 0, 0);
+                    acc1[ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][3 * ks], fb[cur][3 * ks + 1 + ii], acc1[ii], 0, 0, 0);
 #endif
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (ks == 1) slot = next_slot(slot);
-                if (drain) {
+                slot = next_slot(slot);
+                MX_TRACE(5);
+                if (last) {
 #if !(MX_MLP_ABLATE & 32)
                     // ---- E1: h = gelu(acc1 + b1) -> bf16 -> h tile.  Lane owns token row (l31) of each
                     // 32-row block and features 8*rg + 4*h + (0..3) of the wave's 32.
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpParams p) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc1[ii][r] = 0.0f;
 #endif
+                    MX_TRACE(6);
                     // publish stage kG1 (G2's first) and the h tile: all h-tile writes done (lgkmcnt),
                     // then the same wait/barrier/refill as everywhere else; `slot` already points at it
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -274,11 +285,47 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpParams p) {
                         if (g + 4 < total) issue(chunk + (i + 4) / kSPC, (i + 4) % kSPC, prev_slot(prev_slot(slot)));
                     }
 #pragma unroll
-                    for (int w = 0; w < 5; ++w) read_frag(kG1, 0, slot, 0, w);
+                    for (int w = 0; w < 5; ++w) read_g2(kG1, 0, slot, 0, w);
+                    MX_TRACE(7);
+                }
+            } else {
+                // ---------------- G2 stage i: k-step ks in fb[ks] ----------------
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int cur = ks, nxt = ks ^ 1;
+                    uint32_t nslot = slot;
+                    if (ks == 1) {
+                        publish_next(chunk, i, g0 + i);
+                        nslot = next_slot(slot);
+                    }
+                    const bool to_g1 = ks == 1 && i == kSPC - 1;  // next: stage 0 of the next chunk (6 fragments)
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const int q = ii * 3 + j;
+                            if (to_g1) read_g1(nslot, nxt, q);
+                            else if (q < 5) read_g2(ks == 0 ? i : i + 1, ks ^ 1, nslot, nxt, q);
+#if MX_MLP_ABLATE & 4
+                            asm volatile("" ::"v"(fb[cur][j]), "v"(fb[cur][3 + ii]));
+#else
+                            acc2[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fb[cur][3 + ii], acc2[ii][j], 0, 0, 0);
+#endif
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    if (ks == 1) slot = next_slot(slot);
+                    MX_TRACE(8 + ks);
                 }
             }
         }
     }
+#ifdef MX_MLP_TRACE
+    if (blockIdx.x == 0 && tid == 0)
+        for (int t = 0; t < 10; ++t) {
+            g_mlp_trace[t] = tr_seg[t];
+            g_mlp_trace[16 + t] = tr_cnt[t];
+        }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // ring and h tile are dead: their space becomes the 128 x 384 output tile
 

@@ -16,6 +16,9 @@ __global__ void fill16(unsigned short* p, size_t n, unsigned seed) {
   for (; i < n; i += (size_t)gridDim.x * blockDim.x) { unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; p[i] = (unsigned short)(0x3a00u + (h & 0x3ff) + ((h >> 16) & 0x8000u)); }
 }
 __global__ void fillf(float* p, size_t n, float v) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; for (; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v; }
+#ifdef MX_MLP_TRACE
+namespace mx { extern __device__ unsigned long long g_mlp_trace[32]; }
+#endif
 int main(int argc, char** argv) {
   int m = argc > 1 ? atoi(argv[1]) : 131072; int f = argc > 2 ? atoi(argv[2]) : 1536; int reps = argc > 3 ? atoi(argv[3]) : 20; int zero = argc > 4 ? atoi(argv[4]) : 0;
   bf16_t *x, *w1, *w2, *out; float *b1, *b2, *g, *b;
@@ -31,6 +34,13 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) CK(launch_mlp(0, p)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+#ifdef MX_MLP_TRACE
+  { unsigned long long tr[32]; CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(mx::g_mlp_trace), sizeof(tr)));
+    double tot = 0; for (int t = 1; t < 10; ++t) tot += (double)tr[t];
+    printf("trace (workgroup 0, wave 0; last launch): %.0f ticks in the main loop\n", tot);
+    const char* nm[16] = {"", "MFMA block before a publish", "vmcnt wait", "barrier", "DMA issue", "G1 stage MFMAs+reads", "E1", "drain publish + exposed reads", "G2 k-step 0", "G2 k-step 1 (after its publish)"};
+    for (int t = 1; t < 10; ++t) if (tr[16 + t]) printf("  tag %d %-34s n=%5llu  %9.0f ticks  %5.1f%%  avg %.0f\n", t, nm[t], tr[16 + t], (double)tr[t], 100.0 * tr[t] / tot, (double)tr[t] / tr[16 + t]); }
+#endif
   double fl = 4.0 * (double)m * 384 * f;
   printf("mlp ablate=%d zero=%d m=%d f=%d: %.1f us  %.0f TFLOP/s (%.1f%% of 2.5 PF)\n", MX_MLP_ABLATE, zero, m, f, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
   return 0;
