@@ -355,34 +355,48 @@ hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
 // ---------------------------------------------------------------------------------------------
 // token map
 // ---------------------------------------------------------------------------------------------
-__global__ void token_map_kernel(const int32_t *__restrict__ lens, int B, int S, int32_t *cu, int32_t *tok_seq,
-                                 int32_t *tok_pos, int t_pad) {
-    // single block: exclusive scan of aligned lengths (B is small), then fill the maps
+__global__ __launch_bounds__(1024) void token_map_kernel(const int32_t *__restrict__ lens, int B, int S, int32_t *cu,
+                                                         int32_t *tok_seq, int32_t *tok_pos, int t_pad) {
+    // single block of 1024 threads (B <= 1024): parallel exclusive scan of the aligned lengths, then every
+    // packed row finds its sequence by binary search in the scanned starts
     __shared__ int s_cu[1025];
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int b = 0; b < B; ++b) {
-            s_cu[b] = acc;
-            int l = lens[b];
-            l = l < 1 ? 1 : (l > S ? S : l);
-            acc += (l + kSeqAlign - 1) / kSeqAlign * kSeqAlign;
-        }
-        s_cu[B] = acc;
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b <= B; b += blockDim.x) cu[b] = s_cu[b];
-    for (int t = threadIdx.x; t < t_pad; t += blockDim.x) {
-        tok_seq[t] = -1;
-        tok_pos[t] = 0;
-    }
-    __syncthreads();
-    for (int b = 0; b < B; ++b) {
-        int l = lens[b];
+    __shared__ int s_len[1024];
+    const int tid = threadIdx.x;
+    int l = 0, al = 0;
+    if (tid < B) {
+        l = lens[tid];
         l = l < 1 ? 1 : (l > S ? S : l);
-        for (int i = threadIdx.x; i < l; i += blockDim.x) {
-            tok_seq[s_cu[b] + i] = b;
-            tok_pos[s_cu[b] + i] = i;
+        al = (l + kSeqAlign - 1) / kSeqAlign * kSeqAlign;
+    }
+    s_len[tid] = l;
+    s_cu[tid + 1] = al;
+    if (tid == 0) s_cu[0] = 0;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan of s_cu[1..1024]
+        const int v = tid + 1 > off ? s_cu[tid + 1 - off] : 0;
+        __syncthreads();
+        s_cu[tid + 1] += v;
+        __syncthreads();
+    }
+    if (tid <= B) cu[tid] = s_cu[tid];
+    const int total = s_cu[B];
+    for (int t = tid; t < t_pad; t += 1024) {
+        int seq = -1, pos = 0;
+        if (t < total) {
+            int lo = 0, hi = B - 1;  // last b with s_cu[b] <= t
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_cu[mid] <= t) lo = mid;
+                else hi = mid - 1;
+            }
+            const int p_ = t - s_cu[lo];
+            if (p_ < s_len[lo]) {  // rows between a sequence's end and the next aligned start stay unmapped
+                seq = lo;
+                pos = p_;
+            }
         }
+        tok_seq[t] = seq;
+        tok_pos[t] = pos;
     }
 }
 
