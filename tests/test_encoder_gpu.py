@@ -136,13 +136,16 @@ def test_fused_mlp_equals_two_gemm_path(lib_built, monkeypatch):
     a non-default ffn width included."""
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, synthetic_weights
-    for kw, B, S, seed in ((dict(layers=3, hidden=384, heads=12, ffn=1536, vocab=3000), 7, 200, 11),
-                           (dict(layers=2, hidden=384, heads=12, ffn=768, vocab=3000), 4, 64, 12)):
+    # passes below 32768 packed rows always take the two-GEMM path (a 128-row-per-workgroup kernel cannot
+    # fill 256 CUs with them), so the shapes here are large enough to run the fused kernel
+    for kw, B, S, seed in ((dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000), 96, 512, 11),
+                           (dict(layers=2, hidden=384, heads=12, ffn=768, vocab=3000), 300, 160, 12)):
         cfg = EncoderConfig(**kw)
         w = synthetic_weights(cfg, seed)
         rng = np.random.default_rng(seed)
         ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
-        lens = rng.integers(1, S + 1, B).astype(np.int32)
+        lens = rng.integers(S // 2 + S // 4, S + 1, B).astype(np.int32)
+        assert int(((lens + 7) // 8 * 8).sum()) >= 32768
         outs = []
         for unfused in ("1", "0"):
             monkeypatch.setenv("MEMEX_HIP_UNFUSED_MLP", unfused)
