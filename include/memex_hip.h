@@ -59,6 +59,36 @@ typedef struct mx_index mx_index;
 int mx_index_open(const char *key, int dim, int device, mx_index **out);
 void mx_index_close(mx_index *idx); /* drops one reference; frees HBM when the last one goes */
 
+/*
+ * Multi-GPU index inside ONE process (SURVEY.md section 8b `n_dev`, 8e): the Rust host is a single
+ * process (bin/memex/src/main.rs spawns api + worker as tasks), so the 8-way shard of BASELINE
+ * configs[3] has to live behind this handle.  Rows are dealt to the n_dev shards in blocks of
+ * block_rows consecutive rows (0 = 65536; rounded up to 32): global row r lives on shard
+ * (r / block_rows) % n_dev, so an append-only collection stays balanced without knowing its final
+ * size.  devices[g] = HIP ordinal of shard g (NULL = 0 .. n_dev-1); ordinals may repeat (logical
+ * shards on one GPU: how the sharded path is tested on a 1-GPU box).
+ * A search runs the local scan of every shard concurrently (one host thread + one stream per
+ * device), exchanges the per-shard top-k blocks ([ids | dists], B*k*12 bytes each) with ONE RCCL
+ * all-gather over xGMI (librccl is dlopen'ed on first use; peer copies into a slot per shard when the
+ * shards share a device or MEMEX_HIP_EXCHANGE=p2p) and merges by (dist, id) on devices[0].
+ * Results are bit-identical to the unsharded index for every n_dev.
+ * Every mx_index_* function accepts the returned handle; *_device pointers refer to devices[0];
+ * vectors.mxflat written by mx_index_save does not depend on n_dev.
+ */
+int mx_index_open_sharded(const char *key, int dim, int n_dev, const int *devices, uint64_t block_rows,
+                          mx_index **out);
+int mx_index_n_shards(mx_index *idx, int *n_shards); /* 1 for a plain index */
+
+/*
+ * Stream contract of the *_device entry points.  The index works on its own HIP stream and every
+ * call returns only after its results are complete in HBM (host-synchronous), so the caller may read
+ * outputs from any stream afterwards.  INPUTS (and zero-fills of output buffers) enqueued on a
+ * caller stream are NOT ordered against the index's stream by themselves: either synchronise that
+ * stream first, or call mx_index_wait_stream(idx, stream) -- the next operation on the index then
+ * starts after everything enqueued on `stream` (a hipStream_t; NULL = the default stream) so far.
+ */
+int mx_index_wait_stream(mx_index *idx, void *hip_stream);
+
 int mx_index_dim(mx_index *idx, int *dim);
 int mx_index_size(mx_index *idx, uint64_t *n_rows); /* = _id_map.len(), storage/local.rs:63 */
 int mx_index_reserve(mx_index *idx, uint64_t n_rows); /* pre-size HBM (optional)             */
@@ -131,13 +161,15 @@ int mx_index_remove_files(const char *dir);        /* the file half of delete_al
 typedef struct mx_index_stats {
     uint64_t searches;          /* query batches served                                   */
     uint64_t queries;           /* queries served                                          */
-    uint64_t fallback_queries;  /* queries answered by the EXACT path after an overflow    */
+    uint64_t fallback_queries;  /* queries answered by the EXACT path (rescan overflowed too) */
     uint64_t scan_launches;     /* launches of the main streaming-scan kernel              */
     uint64_t scan_bytes;        /* bytes those launches streamed: rows*dim_pad*(2 with a filter copy, else 4) */
     double scan_ms;             /* HIP-event time of those launches (profiling on)         */
-    uint64_t candidates;        /* candidates exactly rescored                             */
+    uint64_t candidates;        /* candidates that passed the bf16 filter and were rescored in f32 */
     double max_abs_err;         /* profiling only: max |approx - exact| cosine on candidates */
     uint64_t filter_copy_bytes; /* HBM held by the bf16 filter copy (0 = scanning the f32 rows) */
+    uint64_t retry_queries;     /* queries rescanned once with a tightened threshold (lane buffer overflow) */
+    double approx_err_bound;    /* per-query bound e1 on |bf16 score - cosine| in force for the last batch */
 } mx_index_stats;
 int mx_index_set_profiling(mx_index *idx, int on); /* record HIP events around the scan kernel */
 int mx_index_get_stats(mx_index *idx, mx_index_stats *out);

@@ -3,28 +3,34 @@
 // lib/libmemex/src/storage/local.rs:21-166) reached through the VectorStore trait
 // (lib/libmemex/src/storage/mod.rs:55-66).
 //
-// Search pipeline per batch of <= 256 queries (kernels: scan.hip, index_kernels.hip):
-//   prep      normalise queries -> bf16 MFMA fragments; f64 query norms (DistCosine order)
-//   stage 0   scan the first 32*nwg rows with theta = -inf: every score lands in a lane buffer
-//   update    gather -> k-th best approximate cosine -> theta = kth - margin, prune pool
-//   stage i   scan geometrically growing row ranges, appending only rows with score >= theta
-//   final     exact f64 DistCosine on the surviving pool, order by (dist_f32, id), emit
-// The pool provably contains the exact top-k: |approx - exact| <= kApproxErr for every row, and a
-// row is only ever discarded when its approximate score is more than 2*kApproxErr below the k-th
-// best approximate score seen so far.  Buffer overflows (pathological duplicates / orderings) are
-// detected per query and re-answered on the EXACT path (f64 on every row).
+// Search pipeline per batch of <= 256 queries (kernels: scan16.hip / scan.hip, index_kernels.hip):
+//   prep      normalise queries -> bf16 MFMA fragments; f64 query norms (DistCosine order);
+//             per-query error bound e1 of the bf16 scan from measured rounding residuals
+//   sample    scan an evenly spread ~1/32 of the tiles keeping only each lane's maximum
+//   theta     k-th largest lane maximum - 2*e1 = pass threshold (certified: keeps the exact top-k)
+//   collect   scan every tile, appending rows with score >= theta to lane-private buffers
+//   finish    gather -> k-th best approximate score, keep [kth - 2*e1, inf) -> f32 rescoring (error
+//             e2 ~ 5e-5) -> keep [kth - 2*e2, inf) -> exact f64 DistCosine -> order by (dist, id)
+// Five launches; corpora of <= 2 tiles per workgroup skip sample/theta (theta = -inf).
+// A query whose lane buffers overflowed (dense neighbourhoods, weak sample threshold) is rescanned
+// ONCE with the tight threshold finish derived from what it did collect (all such queries of the
+// batch share that one extra pass); only if that overflows too -- more than ~16k rows within e1 of
+// the k-th neighbour -- is it answered on the EXACT path (f64 on every row).
+#include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "index_kernels.h"
@@ -39,16 +45,22 @@ std::string &last_error_slot() {
 
 namespace {
 
+// device block copied to the host once per batch: [overflow 256 | cand_cnt 256 | e1 256 | qflags 4]
+constexpr int kFlagWords = 3 * kMaxBatch + 4;
+
 struct Scratch {
     void *qfrag = nullptr;
     float *qpad = nullptr;
     double *qnorm2 = nullptr;
-    float *theta = nullptr;
-    uint32_t *overflow = nullptr;
-    uint32_t *pool_cnt = nullptr;
-    Cand *pool[2] = {nullptr, nullptr};
+    float *theta = nullptr, *theta_retry = nullptr;
+    uint32_t *todo = nullptr;
+    uint32_t *dev_flags = nullptr;   // [kFlagWords]
+    uint32_t *host_flags = nullptr;  // pinned mirror, one async D2H per batch
+    uint32_t *overflow = nullptr, *cand_cnt = nullptr, *qflags = nullptr;  // views into dev_flags
+    float *e1 = nullptr;
     Cand *lane_buf = nullptr;
     uint32_t *lane_cnt = nullptr;
+    float *lane_max = nullptr;
     float *qstage = nullptr;       // [256, dim] host->device query staging
     uint64_t *out_ids = nullptr;   // [256, kcap] device outputs for the host API
     float *out_scores = nullptr;
@@ -65,9 +77,20 @@ struct Scratch {
     uint64_t *h_ids = nullptr;
     float *h_scores = nullptr, *h_dists = nullptr;
     int32_t *h_nf = nullptr;
-    uint32_t *host_flags = nullptr;  // pinned: [overflow 256 | pool_cnt 256], one async D2H per batch
-    uint32_t *dev_flags = nullptr;   // device: same layout (overflow and pool_cnt live back to back)
     bool ready = false;
+};
+
+// RCCL entry points, resolved with dlopen the first time a sharded index spans more than one device
+// (libmemex_hip.so itself links only the HIP runtime; a single-GPU host never loads RCCL)
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
 };
 
 }  // namespace
@@ -103,15 +126,32 @@ struct mx_index {
     void *xh = nullptr;          // bf16 filter copy (fragment order), cap/32 tiles; null = not kept
     bool want_filter = true;     // keep a filter copy when HBM allows (mx_index_set_filter_copy)
     uint64_t n = 0, cap = 0;
-    uint64_t id_offset = 0;
-    uint32_t *flags = nullptr;  // device: [0] non-finite rows, [1] out-of-range-norm rows (last add)
+    IdMap idmap{0, 0, 1, 0};
+    uint32_t *flags = nullptr;  // device: [0] non-finite rows, [1] out-of-range-norm rows (last add), [2] ec_max (float bits)
     uint64_t wild_rows = 0;
     int mode = MX_SEARCH_AUTO;
     bool profiling = false;
     int n_cu = 0, nwg = 0;
     Scratch s;
     mx_index_stats stats{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
+    // persistence bookkeeping: what vectors.mxflat in `disk_dir` holds, as far as this handle knows
+    std::string disk_dir;
+    uint64_t disk_rows = 0;
+    off_t disk_size = 0;
+    struct timespec disk_mtime {};
+    // ---- composite (mx_index_open_sharded): rows are dealt to `shards` in blocks of block_rows
+    std::vector<mx_index *> shards;
+    uint64_t block_rows = 0;
+    uint64_t total = 0;
+    bool use_rccl = false;
+    std::vector<void *> comms;       // ncclComm_t per shard (RCCL exchange)
+    std::vector<void *> sh_block;    // per shard, on its device: packed result block [ids | dists]
+    std::vector<void *> sh_gather;   // per shard, on its device: [G] packed blocks (RCCL recv); [0] is the merge input
+    std::vector<float *> sh_q, sh_scores;
+    std::vector<int32_t *> sh_nf;
+    int sh_kcap = 0;
+    bool composite() const { return !shards.empty(); }
 };
 
 namespace {
@@ -120,8 +160,55 @@ std::mutex g_reg_mu;
 std::map<std::string, mx_index *> g_registry;
 std::once_flag g_scan_once;
 hipError_t g_scan_setup_err = hipSuccess;
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+
+bool load_rccl() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return g_rccl.ok;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return false;
+    auto sym = [&](const char *n) { return dlsym(g_rccl.lib, n); };
+    g_rccl.CommInitAll = reinterpret_cast<int (*)(void **, int, const int *)>(sym("ncclCommInitAll"));
+    g_rccl.CommDestroy = reinterpret_cast<int (*)(void *)>(sym("ncclCommDestroy"));
+    g_rccl.AllGather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(sym("ncclAllGather"));
+    g_rccl.GroupStart = reinterpret_cast<int (*)()>(sym("ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<int (*)()>(sym("ncclGroupEnd"));
+    g_rccl.GetErrorString = reinterpret_cast<const char *(*)(int)>(sym("ncclGetErrorString"));
+    g_rccl.ok = g_rccl.CommInitAll && g_rccl.CommDestroy && g_rccl.AllGather && g_rccl.GroupStart && g_rccl.GroupEnd;
+    return g_rccl.ok;
+}
+
+void free_composite_buffers(mx_index *idx) {
+    for (size_t g = 0; g < idx->shards.size(); ++g) {
+        DeviceGuard dg(idx->shards[g]->device);
+        auto F = [](void *p) {
+            if (p) (void)hipFree(p);
+        };
+        if (g < idx->sh_block.size()) F(idx->sh_block[g]);
+        if (g < idx->sh_gather.size()) F(idx->sh_gather[g]);
+        if (g < idx->sh_q.size()) F(idx->sh_q[g]);
+        if (g < idx->sh_scores.size()) F(idx->sh_scores[g]);
+        if (g < idx->sh_nf.size()) F(idx->sh_nf[g]);
+    }
+    idx->sh_block.clear(); idx->sh_gather.clear(); idx->sh_q.clear(); idx->sh_scores.clear(); idx->sh_nf.clear();
+    idx->sh_kcap = 0;
+}
 
 int free_index(mx_index *idx) {
+    {   // nobody may still be inside a call on this handle (a combined search holds idx->mu)
+        std::lock_guard<std::mutex> lk(idx->mu);
+    }
+    if (idx->composite()) {
+        free_composite_buffers(idx);
+        for (void *c : idx->comms)
+            if (c && g_rccl.ok) (void)g_rccl.CommDestroy(c);
+        for (mx_index *sh : idx->shards) free_index(sh);
+        idx->shards.clear();
+    }
     DeviceGuard g(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     auto F = [](void *p) {
@@ -129,14 +216,15 @@ int free_index(mx_index *idx) {
     };
     F(idx->x); F(idx->scale); F(idx->xh); F(idx->flags);
     Scratch &s = idx->s;
-    F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.dev_flags); F(s.pool[0]); F(s.pool[1]);
+    F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.theta_retry); F(s.todo); F(s.dev_flags);
     if (s.host_flags) (void)hipHostFree(s.host_flags);
     for (void *hp : {(void *)s.h_q, (void *)s.h_ids, (void *)s.h_scores, (void *)s.h_dists, (void *)s.h_nf})
         if (hp) (void)hipHostFree(hp);
-    F(s.lane_buf); F(s.lane_cnt); F(s.qstage); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
+    F(s.lane_buf); F(s.lane_cnt); F(s.lane_max); F(s.qstage); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
     F(s.exact_keys); F(s.sel_state); F(s.max_err);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
+    if (idx->ev_wait) (void)hipEventDestroy(idx->ev_wait);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
     return MX_OK;
@@ -150,13 +238,18 @@ int ensure_scratch(mx_index *idx) {
     MX_HIP(hipMalloc(&s.qpad, (size_t)kMaxBatch * ds * 4));
     MX_HIP(hipMalloc(&s.qnorm2, kMaxBatch * sizeof(double)));
     MX_HIP(hipMalloc(&s.theta, kMaxBatch * sizeof(float)));
-    MX_HIP(hipMalloc(&s.dev_flags, 2 * kMaxBatch * sizeof(uint32_t)));
+    MX_HIP(hipMalloc(&s.theta_retry, kMaxBatch * sizeof(float)));
+    MX_HIP(hipMalloc(&s.todo, kMaxBatch * sizeof(uint32_t)));
+    MX_HIP(hipMalloc(&s.dev_flags, kFlagWords * sizeof(uint32_t)));
+    MX_HIP(hipMemsetAsync(s.dev_flags, 0, kFlagWords * sizeof(uint32_t), idx->stream));
     s.overflow = s.dev_flags;
-    s.pool_cnt = s.dev_flags + kMaxBatch;
-    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.host_flags), 2 * kMaxBatch * sizeof(uint32_t), hipHostMallocDefault));
-    for (int i = 0; i < 2; ++i) MX_HIP(hipMalloc(&s.pool[i], (size_t)kMaxBatch * kPoolCap * sizeof(Cand)));
+    s.cand_cnt = s.dev_flags + kMaxBatch;
+    s.e1 = reinterpret_cast<float *>(s.dev_flags + 2 * kMaxBatch);
+    s.qflags = s.dev_flags + 3 * kMaxBatch;
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.host_flags), kFlagWords * sizeof(uint32_t), hipHostMallocDefault));
     MX_HIP(hipMalloc(&s.lane_buf, (size_t)idx->nwg * kScanThreads * kLaneCap * sizeof(Cand)));
     MX_HIP(hipMalloc(&s.lane_cnt, (size_t)idx->nwg * kScanThreads * sizeof(uint32_t)));
+    MX_HIP(hipMalloc(&s.lane_max, (size_t)idx->nwg * kScanThreads * sizeof(float)));
     MX_HIP(hipMalloc(&s.qstage, (size_t)kMaxBatch * idx->dim * sizeof(float)));
     MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_q), (size_t)kMaxBatch * idx->dim * sizeof(float), hipHostMallocDefault));
     MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_nf), kMaxBatch * sizeof(int32_t), hipHostMallocDefault));
@@ -211,47 +304,57 @@ int ensure_exact(mx_index *idx, int k) {
     return MX_OK;
 }
 
+// device buffers being built by ensure_capacity: freed unless handed over
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    void *release() {
+        void *r = p;
+        p = nullptr;
+        return r;
+    }
+};
+
 int ensure_capacity(mx_index *idx, uint64_t rows) {
     if (rows <= idx->cap) return MX_OK;
     uint64_t want = std::max<uint64_t>(rows, idx->cap + idx->cap / 2);
     want = round_up(std::max<uint64_t>(want, 1024), kTileRows);
-    float *nx = nullptr, *nsc = nullptr;
+    DevBuf nx, nsc, nh;
     const size_t rowb = (size_t)idx->ds * sizeof(float);
-    MX_HIP(hipMalloc(&nx, want * rowb));
-    hipError_t e = hipMalloc(&nsc, want * sizeof(float));
-    if (e != hipSuccess) {
-        (void)hipFree(nx);
-        return fail(MX_ENOMEM, "hipMalloc(scale): %s", hipGetErrorString(e));
-    }
+    MX_HIP(hipMalloc(&nx.p, want * rowb));
+    MX_HIP(hipMalloc(&nsc.p, want * sizeof(float)));
+    float *fx = static_cast<float *>(nx.p), *fsc = static_cast<float *>(nsc.p);
     if (idx->n) {
-        MX_HIP(hipMemcpyAsync(nx, idx->x, idx->n * rowb, hipMemcpyDeviceToDevice, idx->stream));
-        MX_HIP(hipMemcpyAsync(nsc, idx->scale, idx->n * sizeof(float), hipMemcpyDeviceToDevice, idx->stream));
+        MX_HIP(hipMemcpyAsync(fx, idx->x, idx->n * rowb, hipMemcpyDeviceToDevice, idx->stream));
+        MX_HIP(hipMemcpyAsync(fsc, idx->scale, idx->n * sizeof(float), hipMemcpyDeviceToDevice, idx->stream));
     }
-    MX_HIP(hipMemsetAsync(nx + idx->n * (size_t)idx->ds, 0, (want - idx->n) * rowb, idx->stream));
-    MX_HIP(hipMemsetAsync(nsc + idx->n, 0, (want - idx->n) * sizeof(float), idx->stream));
-    void *nh = nullptr;
+    MX_HIP(hipMemsetAsync(fx + idx->n * (size_t)idx->ds, 0, (want - idx->n) * rowb, idx->stream));
+    MX_HIP(hipMemsetAsync(fsc + idx->n, 0, (want - idx->n) * sizeof(float), idx->stream));
     if (idx->want_filter && idx->kc <= kMaxKC) {
         // the filter copy is an accelerator, not a requirement: without HBM for it the index
         // keeps working on the f32 scan
         const size_t hb = (size_t)want * idx->ds * 2;
-        if (hipMalloc(&nh, hb) != hipSuccess) {
+        if (hipMalloc(&nh.p, hb) != hipSuccess) {
             (void)hipGetLastError();
-            nh = nullptr;
+            nh.p = nullptr;
         } else {
             const size_t used = idx->xh ? (size_t)round_up(idx->n, kTileRows) * idx->ds * 2 : 0;
-            if (used) MX_HIP(hipMemcpyAsync(nh, idx->xh, used, hipMemcpyDeviceToDevice, idx->stream));
-            MX_HIP(hipMemsetAsync(static_cast<char *>(nh) + used, 0, hb - used, idx->stream));
+            if (used) MX_HIP(hipMemcpyAsync(nh.p, idx->xh, used, hipMemcpyDeviceToDevice, idx->stream));
+            MX_HIP(hipMemsetAsync(static_cast<char *>(nh.p) + used, 0, hb - used, idx->stream));
             if (!idx->xh && idx->n)  // (re)enabled on a populated index
-                MX_HIP(launch_shadow(idx->stream, nx, nsc, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh));
+                MX_HIP(launch_shadow(idx->stream, fx, fsc, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh.p,
+                                     idx->flags + 2));
         }
     }
     MX_HIP(hipStreamSynchronize(idx->stream));
     if (idx->x) (void)hipFree(idx->x);
     if (idx->scale) (void)hipFree(idx->scale);
     if (idx->xh) (void)hipFree(idx->xh);
-    idx->x = nx;
-    idx->scale = nsc;
-    idx->xh = nh;
+    idx->x = static_cast<float *>(nx.release());
+    idx->scale = static_cast<float *>(nsc.release());
+    idx->xh = nh.release();
     idx->cap = want;
     return MX_OK;
 }
@@ -259,7 +362,7 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
 // rows already on the device ([n, dim]); appends and validates
 int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *first_id) {
     if (n == 0) {
-        if (first_id) *first_id = idx->id_offset + idx->n + 1;
+        if (first_id) *first_id = idx->idmap.id_of((uint32_t)idx->n);
         return MX_OK;
     }
     if (idx->n + n > 0xfffffff0ull) return fail(MX_EINSERT, "index shard limited to 2^32 rows");
@@ -269,45 +372,43 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
     MX_HIP(launch_ingest(idx->stream, d_rows, n, idx->dim, idx->x, idx->scale, idx->n, idx->ds, idx->flags));
     if (idx->xh)  // tiles touched by this append (the first one may already be partly filled)
         MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, (uint32_t)(idx->n / kTileRows),
-                             (uint32_t)((idx->n + n + kTileRows - 1) / kTileRows), idx->xh));
+                             (uint32_t)((idx->n + n + kTileRows - 1) / kTileRows), idx->xh, idx->flags + 2));
     uint32_t fl[2] = {0, 0};
     MX_HIP(hipMemcpyAsync(fl, idx->flags, sizeof(fl), hipMemcpyDeviceToHost, idx->stream));
     MX_HIP(hipStreamSynchronize(idx->stream));
-    if (fl[0] != 0) return fail(MX_EINVAL, "%u row(s) contain non-finite values; nothing inserted", fl[0]);
+    if (fl[0] != 0) {
+        // rows past idx->n are never read, but the filter copy's tile of row n may now hold garbage: rebuild it
+        if (idx->xh)
+            MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, (uint32_t)(idx->n / kTileRows),
+                                 (uint32_t)(idx->n / kTileRows + 1), idx->xh, idx->flags + 2));
+        return fail(MX_EINVAL, "%u row(s) contain non-finite values; nothing inserted", fl[0]);
+    }
     idx->wild_rows += fl[1];
-    if (first_id) *first_id = idx->id_offset + idx->n + 1;  // local.rs:63: next_id = len + 1
+    if (first_id) *first_id = idx->idmap.id_of((uint32_t)idx->n);  // local.rs:63: next_id = len + 1
     idx->n += n;
     return MX_OK;
 }
 
-struct Stage {
-    uint32_t t0, t1;
-    bool main;
-};
+// how many tiles the sample launch visits: enough that the k-th largest of 2*nwg lane maxima is a
+// useful threshold (expected survivors of the collect launch ~ k * N / sample, times the margin's
+// share) and small enough to stay a few percent of the pass
+uint32_t sample_stride(uint64_t full_tiles, int nwg, int k) {
+    const double f = std::min(0.5, std::max(1.0 / 32.0, (double)k / 320.0));
+    const uint64_t target = std::max<uint64_t>((uint64_t)nwg, (uint64_t)((double)full_tiles * f));
+    return (uint32_t)std::max<uint64_t>(1, full_tiles / std::max<uint64_t>(target, 1));
+}
 
-std::vector<Stage> plan_stages(uint64_t n, int nwg, int k) {
-    std::vector<Stage> st;
-    const uint64_t tiles = (n + kTileRows - 1) / kTileRows;
-    if (tiles == 0) return st;
-    const uint64_t head = std::min<uint64_t>(tiles, (uint64_t)nwg);
-    st.push_back({0u, (uint32_t)head, false});
-    if (tiles > head) {
-        // rows passing a stage ~ k * (growth-1) * tail(margin); keep that a few per lane buffer
-        const double R = (double)tiles / (double)head;
-        const double G = std::min(48.0, std::max(2.0, 1.0 + 400.0 / (double)std::max(k, 1)));
-        const int s = std::max(1, (int)std::ceil(std::log(R) / std::log(G) - 1e-9));
-        uint64_t prev = head;
-        for (int i = 1; i <= s; ++i) {
-            uint64_t b = i == s ? tiles : (uint64_t)std::llround((double)head * std::pow(R, (double)i / s));
-            b = std::min<uint64_t>(std::max<uint64_t>(b, prev + 1), tiles);
-            st.push_back({(uint32_t)prev, (uint32_t)b, false});
-            prev = b;
-            if (b == tiles) break;
-        }
-    }
-    Stage &last = st.back();
-    if ((uint64_t)(last.t1 - last.t0) * 2 >= tiles) last.main = true;
-    return st;
+int run_exact(mx_index *idx, const std::vector<int> &qs, int k, uint64_t *d_ids, float *d_scores, float *d_dists,
+              int32_t *d_nfound) {
+    if (qs.empty()) return MX_OK;
+    int rc = ensure_exact(idx, k);
+    if (rc != MX_OK) return rc;
+    Scratch &s = idx->s;
+    for (int b : qs)
+        MX_HIP(launch_exact_query(idx->stream, k, idx->dim, idx->ds, idx->x, idx->n, idx->idmap,
+                                  s.qpad + (size_t)b * idx->ds, s.exact_keys, s.sel_state, d_ids + (size_t)b * k,
+                                  d_scores + (size_t)b * k, d_dists ? d_dists + (size_t)b * k : nullptr, d_nfound + b));
+    return MX_OK;
 }
 
 // one batch (B <= 256) with queries and outputs on the device
@@ -317,204 +418,364 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     if (rc != MX_OK) return rc;
     Scratch &s = idx->s;
     hipStream_t st = idx->stream;
-    MX_HIP(launch_prep_queries(st, d_q, B, idx->dim, idx->ds, s.qfrag, s.qpad, s.qnorm2, s.theta, s.overflow,
-                               s.pool_cnt));
-    const bool fast = idx->mode == MX_SEARCH_AUTO && idx->kc <= kMaxKC && idx->wild_rows == 0 && k <= 256 && k > 0;
-    std::vector<int> redo;
+    MX_HIP(hipMemsetAsync(s.qflags, 0, 4 * sizeof(uint32_t), st));
+    MX_HIP(launch_prep_queries(st, d_q, B, idx->dim, idx->ds, s.qfrag, s.qpad, s.qnorm2, s.theta, s.e1,
+                               idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags));
+    const bool trivial = idx->n == 0 || k == 0;
+    const bool fast = !trivial && idx->mode == MX_SEARCH_AUTO && idx->kc <= kMaxKC && idx->wild_rows == 0 && k <= 256;
+    const uint32_t *h_ovf = s.host_flags, *h_cnt = s.host_flags + kMaxBatch, *h_qfl = s.host_flags + 3 * kMaxBatch;
     bool timed = false;
-    if (fast || idx->n == 0 || k == 0) {
-        int cur = 0;
-        if (fast) {
-            for (const Stage &sg : plan_stages(idx->n, idx->nwg, k)) {
-                ScanParams p;
-                p.x = idx->x;
-                p.xh = idx->xh;
-                p.scale = idx->scale;
-                p.qfrag = s.qfrag;
-                p.theta = s.theta;
-                p.n_rows = idx->n;
-                p.tile_begin = sg.t0;
-                p.tile_end = sg.t1;
-                p.ds = (uint32_t)idx->ds;
-                p.lane_buf = s.lane_buf;
-                p.lane_cnt = s.lane_cnt;
-                p.overflow = s.overflow;
-                if (sg.main && idx->profiling) MX_HIP(hipEventRecord(idx->ev0, st));
-                if (idx->xh)
-                    MX_HIP(launch_scan16(st, idx->kc, sg.main, idx->nwg, p));
-                else
-                    MX_HIP(launch_scan(st, idx->kc, sg.main, idx->nwg, p));
-                if (sg.main) {
-                    if (idx->profiling) {
-                        MX_HIP(hipEventRecord(idx->ev1, st));
-                        timed = true;
-                    }
-                    idx->stats.scan_launches += 1;
-                    idx->stats.scan_bytes += (uint64_t)(sg.t1 - sg.t0) * kTileRows * idx->ds * (idx->xh ? 2ull : 4ull);
-                }
-                MX_HIP(launch_update(st, B, k, idx->nwg, s.lane_buf, s.lane_cnt, s.pool[cur], s.pool[cur ^ 1],
-                                     s.pool_cnt, s.theta, s.overflow));
-                cur ^= 1;
+
+    FinishParams fp;
+    fp.k = k;
+    fp.ds = idx->ds;
+    fp.nwg = idx->nwg;
+    fp.x = idx->x;
+    fp.scale = idx->scale;
+    fp.n_rows = trivial ? 0 : idx->n;
+    fp.idmap = idx->idmap;
+    fp.qpad = s.qpad;
+    fp.qnorm2 = s.qnorm2;
+    fp.e1 = s.e1;
+    fp.e2 = (float)(idx->ds + 8) * 5.9604645e-8f + 1e-6f;  // f32 fma dot of <= ds terms of unit vectors, any order
+    fp.lane_buf = s.lane_buf;
+    fp.lane_cnt = s.lane_cnt;
+    fp.overflow = s.overflow;
+    fp.todo = nullptr;
+    fp.theta_retry = s.theta_retry;
+    fp.cand_cnt = s.cand_cnt;
+    fp.ids = d_ids;
+    fp.scores = d_scores;
+    fp.dists = d_dists;
+    fp.n_found = d_nfound;
+    fp.max_err = idx->profiling ? s.max_err : nullptr;
+
+    std::vector<int> exact;
+    if (trivial) {
+        MX_HIP(launch_finish(st, B, fp));  // n_found = 0, empty slots
+    } else if (fast) {
+        const uint64_t tiles = (idx->n + kTileRows - 1) / kTileRows, full = idx->n / kTileRows;
+        ScanParams p;
+        p.x = idx->x;
+        p.xh = idx->xh;
+        p.scale = idx->scale;
+        p.qfrag = s.qfrag;
+        p.theta = s.theta;
+        p.n_rows = idx->n;
+        p.ds = (uint32_t)idx->ds;
+        p.lane_buf = s.lane_buf;
+        p.lane_cnt = s.lane_cnt;
+        p.lane_max = s.lane_max;
+        p.overflow = s.overflow;
+        auto scan = [&](bool collect) {
+            return idx->xh ? launch_scan16(st, idx->kc, collect, idx->nwg, p) : launch_scan(st, idx->kc, collect, idx->nwg, p);
+        };
+        auto collect = [&](bool first) -> int {
+            p.tile_begin = 0;
+            p.tile_end = (uint32_t)tiles;
+            p.tile_stride = 1;
+            // the first collect launch of a batch is the one the roofline is quoted on
+            if (first && idx->profiling) MX_HIP(hipEventRecord(idx->ev0, st));
+            MX_HIP(scan(true));
+            if (first && idx->profiling) {
+                MX_HIP(hipEventRecord(idx->ev1, st));
+                timed = true;
             }
+            if (first) {
+                idx->stats.scan_launches += 1;
+                idx->stats.scan_bytes += tiles * kTileRows * idx->ds * (idx->xh ? 2ull : 4ull);
+            }
+            return MX_OK;
+        };
+        // a lane holds 16 scores per tile of its workgroup: up to 2 tiles per workgroup everything fits
+        // in the lane buffers and no threshold is needed
+        if (tiles > 2ull * idx->nwg) {
+            p.tile_begin = 0;
+            p.tile_end = (uint32_t)full;
+            p.tile_stride = sample_stride(full, idx->nwg, k);
+            MX_HIP(scan(false));
+            MX_HIP(launch_theta(st, B, k, idx->nwg, s.lane_max, s.e1, s.theta));
         }
-        MX_HIP(launch_final(st, B, k, idx->dim, idx->ds, idx->x, idx->n, idx->id_offset, s.qpad, s.qnorm2,
-                            s.pool[cur], s.pool_cnt, s.overflow, d_ids, d_scores, d_dists, d_nfound,
-                            idx->profiling ? s.max_err : nullptr));
-        if (fast) {
-            const uint32_t *ovf = s.host_flags, *cnt = s.host_flags + kMaxBatch;
-            MX_HIP(hipMemcpyAsync(s.host_flags, s.dev_flags, 2 * kMaxBatch * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if ((rc = collect(true)) != MX_OK) return rc;
+        MX_HIP(launch_finish(st, B, fp));
+        MX_HIP(hipMemcpyAsync(s.host_flags, s.dev_flags, kFlagWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        MX_HIP(hipStreamSynchronize(st));
+        if (timed) {
+            float ms = 0.f;
+            MX_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
+            idx->stats.scan_ms += ms;
+            timed = false;
+        }
+        if (h_qfl[0]) return fail(MX_EINVAL, "a query contains non-finite values");
+        int retry = 0;
+        for (int b = 0; b < B; ++b) {
+            idx->stats.candidates += h_cnt[b];
+            if (h_ovf[b] == 1) ++retry;
+            else if (h_ovf[b] >= 2) exact.push_back(b);
+        }
+        if (retry) {
+            // ONE more pass for all overflowed queries of the batch, with the threshold finish derived
+            // from what they did collect (everyone else is parked at theta = +inf)
+            idx->stats.retry_queries += (uint64_t)retry;
+            MX_HIP(launch_retry_setup(st, s.theta, s.theta_retry, s.overflow, s.todo));
+            if ((rc = collect(false)) != MX_OK) return rc;
+            fp.todo = s.todo;
+            MX_HIP(launch_finish(st, B, fp));
+            MX_HIP(hipMemcpyAsync(s.host_flags, s.dev_flags, kFlagWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             MX_HIP(hipStreamSynchronize(st));
-            for (int b = 0; b < B; ++b) {
-                if (ovf[b]) redo.push_back(b);
-                else idx->stats.candidates += cnt[b];
-            }
+            exact.clear();
+            for (int b = 0; b < B; ++b)
+                if (h_ovf[b] != 0) exact.push_back(b);
         }
+        idx->stats.fallback_queries += exact.size();
     } else {
-        for (int b = 0; b < B; ++b) redo.push_back(b);
+        MX_HIP(hipMemcpyAsync(s.host_flags, s.dev_flags, kFlagWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        MX_HIP(hipStreamSynchronize(st));
+        if (h_qfl[0]) return fail(MX_EINVAL, "a query contains non-finite values");
+        for (int b = 0; b < B; ++b) exact.push_back(b);
     }
-    if (!redo.empty()) {
-        rc = ensure_exact(idx, k);
-        if (rc != MX_OK) return rc;
-        for (int b : redo) {
-            MX_HIP(launch_exact_query(st, k, idx->dim, idx->ds, idx->x, idx->n, idx->id_offset,
-                                      s.qpad + (size_t)b * idx->ds, s.exact_keys, s.sel_state,
-                                      d_ids + (size_t)b * k, d_scores + (size_t)b * k,
-                                      d_dists ? d_dists + (size_t)b * k : nullptr, d_nfound + b));
-        }
-        if (idx->mode == MX_SEARCH_AUTO) idx->stats.fallback_queries += redo.size();
-    }
+    rc = run_exact(idx, exact, k, d_ids, d_scores, d_dists, d_nfound);
+    if (rc != MX_OK) return rc;
     MX_HIP(hipStreamSynchronize(st));
-    if (timed) {
-        float ms = 0.f;
-        MX_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
-        idx->stats.scan_ms += ms;
-    }
     idx->stats.searches += 1;
     idx->stats.queries += (uint64_t)B;
     return MX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// composite: rows dealt block-cyclically to shard indexes (one per device), local top-k per shard,
+// exchange of the packed [ids | dists] blocks (RCCL all-gather over xGMI, or peer copies), merge
+// ---------------------------------------------------------------------------------------------
+int ensure_composite_buffers(mx_index *idx, int k) {
+    if (k <= idx->sh_kcap) return MX_OK;
+    free_composite_buffers(idx);
+    const int kc = std::max(k, 16);
+    const size_t G = idx->shards.size();
+    const size_t blk = (size_t)kMaxBatch * kc * 12;
+    idx->sh_block.assign(G, nullptr); idx->sh_gather.assign(G, nullptr); idx->sh_q.assign(G, nullptr);
+    idx->sh_scores.assign(G, nullptr); idx->sh_nf.assign(G, nullptr);
+    for (size_t g = 0; g < G; ++g) {
+        DeviceGuard dg(idx->shards[g]->device);
+        MX_HIP(hipMalloc(&idx->sh_block[g], blk));
+        if (g == 0 || idx->use_rccl) MX_HIP(hipMalloc(&idx->sh_gather[g], blk * G));
+        MX_HIP(hipMalloc(reinterpret_cast<void **>(&idx->sh_q[g]), (size_t)kMaxBatch * idx->dim * sizeof(float)));
+        MX_HIP(hipMalloc(reinterpret_cast<void **>(&idx->sh_scores[g]), (size_t)kMaxBatch * kc * sizeof(float)));
+        MX_HIP(hipMalloc(reinterpret_cast<void **>(&idx->sh_nf[g]), kMaxBatch * sizeof(int32_t)));
+    }
+    idx->sh_kcap = kc;
+    return MX_OK;
+}
+
+// local row count of shard g when the composite holds `total` rows
+uint64_t shard_rows(uint64_t total, uint64_t R, uint64_t G, uint64_t g) {
+    const uint64_t full_blocks = total / R, tail = total % R;
+    uint64_t rows = (full_blocks / G) * R + (g < full_blocks % G ? R : 0);
+    if (full_blocks % G == g) rows += tail;
+    return rows;
+}
+
+// one batch on a composite: d_q and the outputs live on shards[0]'s device
+int composite_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids, float *d_scores, float *d_dists,
+                    int32_t *d_nfound) {
+    const int G = (int)idx->shards.size();
+    int rc = ensure_composite_buffers(idx, std::max(k, 1));
+    if (rc != MX_OK) return rc;
+    const size_t ids_bytes = (size_t)B * k * sizeof(uint64_t), blk = ids_bytes + (size_t)B * k * sizeof(float);
+    std::vector<int> rcs(G, MX_OK);
+    std::vector<std::string> errs(G);
+    auto local = [&](int g) {
+        mx_index *sh = idx->shards[g];
+        std::lock_guard<std::mutex> lk(sh->mu);
+        DeviceGuard dg(sh->device);
+        auto run = [&]() -> int {
+            MX_HIP(hipMemcpyAsync(idx->sh_q[g], d_q, (size_t)B * idx->dim * sizeof(float), hipMemcpyDefault, sh->stream));
+            char *blkp = static_cast<char *>(idx->sh_block[g]);
+            int r = search_batch(sh, idx->sh_q[g], B, k, reinterpret_cast<uint64_t *>(blkp), idx->sh_scores[g],
+                                 reinterpret_cast<float *>(blkp + ids_bytes), idx->sh_nf[g]);
+            if (r != MX_OK) return r;
+            if (!idx->use_rccl && k > 0) {  // peer copy into slot g of the gather area on shards[0]'s device
+                MX_HIP(hipMemcpyAsync(static_cast<char *>(idx->sh_gather[0]) + (size_t)g * blk, blkp, blk, hipMemcpyDefault, sh->stream));
+                MX_HIP(hipStreamSynchronize(sh->stream));
+            }
+            return MX_OK;
+        };
+        rcs[g] = run();
+        if (rcs[g] != MX_OK) errs[g] = last_error_slot();
+    };
+    // the query batch must be complete on shards[0]'s stream before other devices read it
+    {
+        DeviceGuard dg(idx->shards[0]->device);
+        MX_HIP(hipStreamSynchronize(idx->shards[0]->stream));
+    }
+    bool distinct = true;
+    for (int g = 1; g < G; ++g) distinct = distinct && idx->shards[g]->device != idx->shards[0]->device;
+    if (G > 1 && distinct) {
+        std::vector<std::thread> th;
+        for (int g = 1; g < G; ++g) th.emplace_back(local, g);
+        local(0);
+        for (auto &t : th) t.join();
+    } else {
+        for (int g = 0; g < G; ++g) local(g);
+    }
+    for (int g = 0; g < G; ++g)
+        if (rcs[g] != MX_OK) {
+            last_error_slot() = errs[g];
+            return rcs[g];
+        }
+    mx_index *s0 = idx->shards[0];
+    DeviceGuard dg(s0->device);
+    if (k > 0) {
+        if (idx->use_rccl) {
+            // ONE all-gather of B*k*12 bytes per shard over xGMI; every device receives all
+            // blocks, device 0 merges
+            int e = g_rccl.GroupStart();
+            for (int g = 0; g < G && e == 0; ++g)
+                e = g_rccl.AllGather(idx->sh_block[g], idx->sh_gather[g], blk, 1 /*ncclUint8*/, idx->comms[g], idx->shards[g]->stream);
+            const int e2 = g_rccl.GroupEnd();
+            if (e != 0 || e2 != 0)
+                return fail(MX_EDEVICE, "RCCL all-gather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e ? e : e2) : "?");
+            for (int g = 1; g < G; ++g) {
+                DeviceGuard d2(idx->shards[g]->device);
+                MX_HIP(hipStreamSynchronize(idx->shards[g]->stream));
+            }
+        }
+        MX_HIP(launch_merge(s0->stream, idx->sh_gather[0], blk, static_cast<const char *>(idx->sh_gather[0]) + ids_bytes, blk, G, B,
+                            k, d_ids, d_dists ? d_dists : reinterpret_cast<float *>(static_cast<char *>(idx->sh_block[0]) + ids_bytes),
+                            d_scores));
+    }
+    MX_HIP(launch_fill_nfound(s0->stream, d_nfound, B, (int32_t)std::min<uint64_t>((uint64_t)k, idx->total)));
+    MX_HIP(hipStreamSynchronize(s0->stream));
+    idx->stats.searches += 1;
+    idx->stats.queries += (uint64_t)B;
+    return MX_OK;
+}
+
+int any_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids, float *d_scores, float *d_dists,
+              int32_t *d_nfound) {
+    return idx->composite() ? composite_batch(idx, d_q, B, k, d_ids, d_scores, d_dists, d_nfound)
+                            : search_batch(idx, d_q, B, k, d_ids, d_scores, d_dists, d_nfound);
+}
+
+// append host rows to a composite: global row r -> block b = r / R, shard b % G
+int composite_add(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_id, bool on_device) {
+    const uint64_t R = idx->block_rows, G = idx->shards.size();
+    if (first_id) *first_id = idx->total + 1;
+    if (n == 0) return MX_OK;
+    const size_t rowf = (size_t)idx->dim;
+    // per shard: the (contiguous in the source) segments it receives, in order
+    std::vector<std::vector<std::pair<uint64_t, uint64_t>>> seg(G);  // (source row, count)
+    for (uint64_t r = idx->total, done = 0; done < n;) {
+        const uint64_t b = r / R, take = std::min(n - done, R - r % R);
+        seg[b % G].push_back({done, take});
+        r += take;
+        done += take;
+    }
+    // all-or-nothing: validate host rows up front (device rows are validated per shard by the ingest kernel)
+    if (!on_device) {
+        const size_t totalf = (size_t)n * rowf;
+        for (size_t i = 0; i < totalf; ++i)
+            if (!std::isfinite(rows[i])) return fail(MX_EINVAL, "row %zu contains a non-finite value; nothing inserted", i / rowf);
+    }
+    for (uint64_t g = 0; g < G; ++g) {
+        if (seg[g].empty()) continue;
+        mx_index *sh = idx->shards[g];
+        std::lock_guard<std::mutex> lk(sh->mu);
+        DeviceGuard dg(sh->device);
+        uint64_t cnt = 0;
+        for (auto &sgm : seg[g]) cnt += sgm.second;
+        float *stage = nullptr;
+        MX_HIP(hipMalloc(reinterpret_cast<void **>(&stage), (size_t)cnt * rowf * sizeof(float)));
+        DevBuf hold;
+        hold.p = stage;
+        uint64_t at = 0;
+        for (auto &sgm : seg[g]) {
+            MX_HIP(hipMemcpyAsync(stage + (size_t)at * rowf, rows + (size_t)sgm.first * rowf, (size_t)sgm.second * rowf * sizeof(float),
+                                  on_device ? hipMemcpyDefault : hipMemcpyHostToDevice, sh->stream));
+            at += sgm.second;
+        }
+        int rc = add_device_locked(sh, stage, cnt, nullptr);
+        if (rc != MX_OK) return rc;  // device rows only: a partial append leaves the composite unusable -> caller clears
+    }
+    idx->total += n;
+    return MX_OK;
+}
+
 const char kMagic[8] = {'M', 'X', 'F', 'L', 'A', 'T', '0', '1'};
+constexpr long kHeaderBytes = 24;
 std::string store_file(const char *dir) { return std::string(dir) + "/vectors.mxflat"; }
 
-}  // namespace
+int mkdir_p(const std::string &dir) {  // create_dir_all (local.rs:144)
+    struct stat sb;
+    if (stat(dir.c_str(), &sb) == 0) return S_ISDIR(sb.st_mode) ? 0 : -1;
+    const size_t slash = dir.find_last_of('/');
+    if (slash != std::string::npos && slash > 0 && mkdir_p(dir.substr(0, slash)) != 0) return -1;
+    return (mkdir(dir.c_str(), 0755) == 0 || errno == EEXIST) ? 0 : -1;
+}
 
-// =============================================================================================
-// C ABI
-// =============================================================================================
-extern "C" {
+void remember_disk(mx_index *idx, const char *dir, uint64_t rows) {
+    struct stat sb;
+    idx->disk_dir.clear();
+    if (stat(store_file(dir).c_str(), &sb) != 0) return;
+    idx->disk_dir = dir;
+    idx->disk_rows = rows;
+    idx->disk_size = sb.st_size;
+    idx->disk_mtime = sb.st_mtim;
+}
 
-const char *mx_last_error(void) { return last_error_slot().c_str(); }
-const char *mx_version(void) { return "memex-hip 0.1.0 (gfx950)"; }
+bool disk_in_sync(mx_index *idx, const char *dir) {  // vectors.mxflat in dir is what this handle last wrote / read
+    if (idx->disk_dir.empty() || idx->disk_dir != dir) return false;
+    struct stat sb;
+    if (stat(store_file(dir).c_str(), &sb) != 0) return false;
+    return sb.st_size == idx->disk_size && sb.st_mtim.tv_sec == idx->disk_mtime.tv_sec &&
+           sb.st_mtim.tv_nsec == idx->disk_mtime.tv_nsec;
+}
 
-int mx_device_count(int *n) {
-    if (!n) return fail(MX_EINVAL, "null argument");
-    int c = 0;
-    hipError_t e = hipGetDeviceCount(&c);
-    if (e != hipSuccess) {
-        *n = 0;
-        return fail(MX_EDEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+// rows [r0, r0 + m) of the index in global order -> host buffer [m, dim]
+int fetch_rows(mx_index *idx, uint64_t r0, uint64_t m, float *out, std::vector<float> &tmp) {
+    if (!idx->composite()) {
+        DeviceGuard dg(idx->device);
+        MX_HIP(hipMemcpy2D(out, (size_t)idx->dim * 4, idx->x + (size_t)r0 * idx->ds, (size_t)idx->ds * 4, (size_t)idx->dim * 4, m,
+                           hipMemcpyDeviceToHost));
+        return MX_OK;
     }
-    *n = c;
+    (void)tmp;
+    const uint64_t R = idx->block_rows, G = idx->shards.size();
+    for (uint64_t r = r0, done = 0; done < m;) {
+        const uint64_t b = r / R, take = std::min(m - done, R - r % R);
+        mx_index *sh = idx->shards[b % G];
+        const uint64_t lrow = (b / G) * R + r % R;
+        DeviceGuard dg(sh->device);
+        MX_HIP(hipMemcpy2D(out + (size_t)done * idx->dim, (size_t)idx->dim * 4, sh->x + (size_t)lrow * sh->ds, (size_t)sh->ds * 4,
+                           (size_t)idx->dim * 4, take, hipMemcpyDeviceToHost));
+        r += take;
+        done += take;
+    }
     return MX_OK;
 }
 
-int mx_index_open(const char *key, int dim, int device, mx_index **out) {
-    if (!out) return fail(MX_EINVAL, "out is null");
-    *out = nullptr;
-    if (dim < 1 || dim > (1 << 16)) return fail(MX_EINVAL, "dim %d out of range", dim);
-    const std::string k = key ? key : "";
-    std::lock_guard<std::mutex> lk(g_reg_mu);
-    if (!k.empty()) {
-        auto it = g_registry.find(k);
-        if (it != g_registry.end()) {
-            mx_index *idx = it->second;
-            if (idx->dim != dim) return fail(MX_EINVAL, "index '%s' is open with dim %d, not %d", k.c_str(), idx->dim, dim);
-            if (idx->device != device)
-                return fail(MX_EINVAL, "index '%s' lives on device %d, not %d", k.c_str(), idx->device, device);
-            idx->refs += 1;
-            *out = idx;
-            return MX_OK;
+uint64_t rows_of(mx_index *idx) { return idx->composite() ? idx->total : idx->n; }
+
+int clear_locked(mx_index *idx) {
+    if (idx->composite()) {
+        for (mx_index *sh : idx->shards) {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            clear_locked(sh);
+        }
+        idx->total = 0;
+    } else {
+        idx->n = 0;  // ids restart at 1 (local.rs:50,63); HBM is kept for reuse
+        idx->wild_rows = 0;
+        if (idx->flags) {
+            DeviceGuard dg(idx->device);
+            (void)hipMemsetAsync(idx->flags + 2, 0, sizeof(uint32_t), idx->stream);  // ec_max
         }
     }
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0)
-        return fail(MX_EDEVICE, "no HIP device available (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
-    if (device < 0 || device >= ndev) return fail(MX_EDEVICE, "device %d out of range (have %d)", device, ndev);
-    DeviceGuard g(device);
-    if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
-    std::call_once(g_scan_once, [] {
-        g_scan_setup_err = scan_setup();
-        if (g_scan_setup_err == hipSuccess) g_scan_setup_err = scan16_setup();
-    });
-    if (g_scan_setup_err != hipSuccess)
-        return fail(MX_EDEVICE, "scan kernel setup failed: %s (is this a gfx950 device?)", hipGetErrorString(g_scan_setup_err));
-    std::unique_ptr<mx_index> idx(new mx_index());
-    idx->key = k;
-    idx->dim = dim;
-    idx->ds = (int)round_up((uint64_t)dim, kChunkFloats);
-    idx->kc = idx->ds / kChunkFloats;
-    idx->device = device;
-    hipDeviceProp_t prop;
-    MX_HIP(hipGetDeviceProperties(&prop, device));
-    idx->n_cu = prop.multiProcessorCount;
-    idx->nwg = std::max(1, std::min(idx->n_cu, kMaxScanWGs));
-    MX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
-    MX_HIP(hipEventCreate(&idx->ev0));
-    MX_HIP(hipEventCreate(&idx->ev1));
-    MX_HIP(hipMalloc(&idx->flags, 2 * sizeof(uint32_t)));
-    mx_index *raw = idx.release();
-    if (!k.empty()) g_registry[k] = raw;
-    *out = raw;
+    idx->disk_dir.clear();
     return MX_OK;
 }
 
-void mx_index_close(mx_index *idx) {
-    if (!idx) return;
-    std::lock_guard<std::mutex> lk(g_reg_mu);
-    if (--idx->refs > 0) return;
-    if (!idx->key.empty()) g_registry.erase(idx->key);
-    free_index(idx);
-}
-
-int mx_index_dim(mx_index *idx, int *dim) {
-    if (!idx || !dim) return fail(MX_EINVAL, "null argument");
-    *dim = idx->dim;
-    return MX_OK;
-}
-
-int mx_index_size(mx_index *idx, uint64_t *n) {
-    if (!idx || !n) return fail(MX_EINVAL, "null argument");
-    std::lock_guard<std::mutex> lk(idx->mu);
-    *n = idx->n;
-    return MX_OK;
-}
-
-int mx_index_reserve(mx_index *idx, uint64_t rows) {
-    if (!idx) return fail(MX_EINVAL, "null index");
-    std::lock_guard<std::mutex> lk(idx->mu);
-    DeviceGuard g(idx->device);
-    return ensure_capacity(idx, rows);
-}
-
-int mx_index_set_id_offset(mx_index *idx, uint64_t off) {
-    if (!idx) return fail(MX_EINVAL, "null index");
-    std::lock_guard<std::mutex> lk(idx->mu);
-    idx->id_offset = off;
-    return MX_OK;
-}
-
-int mx_index_add_device(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *first_id) {
-    if (!idx || (!d_rows && n)) return fail(MX_EINVAL, "null argument");
-    std::lock_guard<std::mutex> lk(idx->mu);
-    DeviceGuard g(idx->device);
-    return add_device_locked(idx, d_rows, n, first_id);
-}
-
-int mx_index_add(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_id) {
-    if (!idx || (!rows && n)) return fail(MX_EINVAL, "null argument");
-    std::lock_guard<std::mutex> lk(idx->mu);
+int add_host_locked(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_id) {
+    if (idx->composite()) return composite_add(idx, rows, n, first_id, false);
     DeviceGuard g(idx->device);
     if (n == 0) return add_device_locked(idx, nullptr, 0, first_id);
     // validate on the host first so that a rejected call leaves the index untouched
@@ -543,12 +804,260 @@ int mx_index_add(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_i
     return rc;
 }
 
+int open_plain(const std::string &k, int dim, int device, mx_index **out) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(MX_EDEVICE, "no HIP device available (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(MX_EDEVICE, "device %d out of range (have %d)", device, ndev);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
+    std::call_once(g_scan_once, [] {
+        g_scan_setup_err = scan_setup();
+        if (g_scan_setup_err == hipSuccess) g_scan_setup_err = scan16_setup();
+        if (g_scan_setup_err == hipSuccess) g_scan_setup_err = finish_setup();
+    });
+    if (g_scan_setup_err != hipSuccess)
+        return fail(MX_EDEVICE, "scan kernel setup failed: %s (is this a gfx950 device?)", hipGetErrorString(g_scan_setup_err));
+    std::unique_ptr<mx_index> idx(new mx_index());
+    idx->key = k;
+    idx->dim = dim;
+    idx->ds = (int)round_up((uint64_t)dim, kChunkFloats);
+    idx->kc = idx->ds / kChunkFloats;
+    idx->device = device;
+    hipDeviceProp_t prop;
+    MX_HIP(hipGetDeviceProperties(&prop, device));
+    idx->n_cu = prop.multiProcessorCount;
+    idx->nwg = std::max(1, std::min(idx->n_cu, kMaxScanWGs));
+    MX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+    MX_HIP(hipEventCreate(&idx->ev0));
+    MX_HIP(hipEventCreate(&idx->ev1));
+    MX_HIP(hipEventCreateWithFlags(&idx->ev_wait, hipEventDisableTiming));
+    MX_HIP(hipMalloc(&idx->flags, 4 * sizeof(uint32_t)));
+    MX_HIP(hipMemset(idx->flags, 0, 4 * sizeof(uint32_t)));
+    *out = idx.release();
+    return MX_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char *mx_last_error(void) { return last_error_slot().c_str(); }
+const char *mx_version(void) { return "memex-hip 0.2.0 (gfx950)"; }
+
+int mx_device_count(int *n) {
+    if (!n) return fail(MX_EINVAL, "null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return fail(MX_EDEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *n = c;
+    return MX_OK;
+}
+
+int mx_index_open(const char *key, int dim, int device, mx_index **out) {
+    if (!out) return fail(MX_EINVAL, "out is null");
+    *out = nullptr;
+    if (dim < 1 || dim > (1 << 16)) return fail(MX_EINVAL, "dim %d out of range", dim);
+    const std::string k = key ? key : "";
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (!k.empty()) {
+        auto it = g_registry.find(k);
+        if (it != g_registry.end()) {
+            mx_index *idx = it->second;
+            if (idx->dim != dim) return fail(MX_EINVAL, "index '%s' is open with dim %d, not %d", k.c_str(), idx->dim, dim);
+            if (!idx->composite() && idx->device != device)
+                return fail(MX_EINVAL, "index '%s' lives on device %d, not %d", k.c_str(), idx->device, device);
+            idx->refs += 1;
+            *out = idx;
+            return MX_OK;
+        }
+    }
+    mx_index *raw = nullptr;
+    int rc = open_plain(k, dim, device, &raw);
+    if (rc != MX_OK) return rc;
+    if (!k.empty()) g_registry[k] = raw;
+    *out = raw;
+    return MX_OK;
+}
+
+int mx_index_open_sharded(const char *key, int dim, int n_dev, const int *devices, uint64_t block_rows, mx_index **out) {
+    if (!out) return fail(MX_EINVAL, "out is null");
+    *out = nullptr;
+    if (dim < 1 || dim > (1 << 16)) return fail(MX_EINVAL, "dim %d out of range", dim);
+    if (n_dev < 1 || n_dev > 64) return fail(MX_EINVAL, "n_dev %d out of range", n_dev);
+    const std::string k = key ? key : "";
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (!k.empty()) {
+        auto it = g_registry.find(k);
+        if (it != g_registry.end()) {
+            mx_index *idx = it->second;
+            if (idx->dim != dim) return fail(MX_EINVAL, "index '%s' is open with dim %d, not %d", k.c_str(), idx->dim, dim);
+            if ((int)idx->shards.size() != n_dev) return fail(MX_EINVAL, "index '%s' is open with %zu shards, not %d", k.c_str(), idx->shards.size(), n_dev);
+            idx->refs += 1;
+            *out = idx;
+            return MX_OK;
+        }
+    }
+    std::unique_ptr<mx_index> idx(new mx_index());
+    idx->key = k;
+    idx->dim = dim;
+    idx->block_rows = round_up(block_rows ? block_rows : 65536, kTileRows);
+    bool distinct = n_dev > 1;
+    for (int g = 0; g < n_dev; ++g) {
+        const int dev = devices ? devices[g] : g;
+        mx_index *sh = nullptr;
+        int rc = open_plain("", dim, dev, &sh);
+        if (rc != MX_OK) {
+            for (mx_index *s2 : idx->shards) free_index(s2);
+            return rc;
+        }
+        sh->idmap = IdMap{0, (uint32_t)idx->block_rows, (uint32_t)n_dev, (uint32_t)g};
+        idx->shards.push_back(sh);
+        for (int h = 0; h < g; ++h) distinct = distinct && idx->shards[h]->device != dev;
+    }
+    idx->device = idx->shards[0]->device;
+    // exchange: RCCL all-gather when every shard has its own device (MEMEX_HIP_EXCHANGE=p2p forces
+    // peer copies, =rccl insists on RCCL and fails without it); logical shards on one device use copies
+    const char *ex = getenv("MEMEX_HIP_EXCHANGE");
+    const bool want_rccl = ex ? strcmp(ex, "rccl") == 0 : distinct;
+    const bool forbid_rccl = ex && strcmp(ex, "p2p") == 0;
+    if (want_rccl && !forbid_rccl && (distinct || n_dev == 1)) {
+        if (load_rccl()) {
+            std::vector<int> devs;
+            for (mx_index *sh : idx->shards) devs.push_back(sh->device);
+            idx->comms.assign(n_dev, nullptr);
+            const int e = g_rccl.CommInitAll(idx->comms.data(), n_dev, devs.data());
+            if (e == 0) {
+                idx->use_rccl = true;
+            } else {
+                idx->comms.clear();
+                if (ex) {
+                    for (mx_index *s2 : idx->shards) free_index(s2);
+                    return fail(MX_EDEVICE, "ncclCommInitAll failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+                }
+            }
+        } else if (ex) {
+            for (mx_index *s2 : idx->shards) free_index(s2);
+            return fail(MX_EDEVICE, "MEMEX_HIP_EXCHANGE=rccl but librccl.so.1 cannot be loaded");
+        }
+    }
+    if (!idx->use_rccl && distinct) {
+        // peer copies between the shards' devices and shards[0]'s
+        for (int g = 1; g < n_dev; ++g) {
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, idx->shards[0]->device, idx->shards[g]->device);
+            if (can) {
+                DeviceGuard dg(idx->shards[0]->device);
+                (void)hipDeviceEnablePeerAccess(idx->shards[g]->device, 0);
+                (void)hipGetLastError();
+                DeviceGuard d2(idx->shards[g]->device);
+                (void)hipDeviceEnablePeerAccess(idx->shards[0]->device, 0);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    mx_index *raw = idx.release();
+    if (!k.empty()) g_registry[k] = raw;
+    *out = raw;
+    return MX_OK;
+}
+
+void mx_index_close(mx_index *idx) {
+    if (!idx) return;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (--idx->refs > 0) return;
+        if (!idx->key.empty()) g_registry.erase(idx->key);
+    }
+    free_index(idx);
+}
+
+int mx_index_dim(mx_index *idx, int *dim) {
+    if (!idx || !dim) return fail(MX_EINVAL, "null argument");
+    *dim = idx->dim;
+    return MX_OK;
+}
+
+int mx_index_n_shards(mx_index *idx, int *n) {
+    if (!idx || !n) return fail(MX_EINVAL, "null argument");
+    *n = idx->composite() ? (int)idx->shards.size() : 1;
+    return MX_OK;
+}
+
+int mx_index_size(mx_index *idx, uint64_t *n) {
+    if (!idx || !n) return fail(MX_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    *n = rows_of(idx);
+    return MX_OK;
+}
+
+int mx_index_reserve(mx_index *idx, uint64_t rows) {
+    if (!idx) return fail(MX_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->composite()) {
+        const uint64_t G = idx->shards.size();
+        for (uint64_t g = 0; g < G; ++g) {
+            mx_index *sh = idx->shards[g];
+            std::lock_guard<std::mutex> l2(sh->mu);
+            DeviceGuard dg(sh->device);
+            int rc = ensure_capacity(sh, shard_rows(rows, idx->block_rows, G, g));
+            if (rc != MX_OK) return rc;
+        }
+        return MX_OK;
+    }
+    DeviceGuard g(idx->device);
+    return ensure_capacity(idx, rows);
+}
+
+int mx_index_set_id_offset(mx_index *idx, uint64_t off) {
+    if (!idx) return fail(MX_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->idmap.id_offset = off;
+    for (mx_index *sh : idx->shards) sh->idmap.id_offset = off;
+    return MX_OK;
+}
+
+int mx_index_wait_stream(mx_index *idx, void *stream) {
+    if (!idx) return fail(MX_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    mx_index *t = idx->composite() ? idx->shards[0] : idx;
+    DeviceGuard g(t->device);
+    MX_HIP(hipEventRecord(t->ev_wait, static_cast<hipStream_t>(stream)));
+    MX_HIP(hipStreamWaitEvent(t->stream, t->ev_wait, 0));
+    return MX_OK;
+}
+
+int mx_index_add_device(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *first_id) {
+    if (!idx || (!d_rows && n)) return fail(MX_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->composite()) {
+        {   // rows must be complete on shards[0]'s stream before other devices copy them
+            DeviceGuard dg(idx->shards[0]->device);
+            MX_HIP(hipStreamSynchronize(idx->shards[0]->stream));
+        }
+        return composite_add(idx, d_rows, n, first_id, true);
+    }
+    DeviceGuard g(idx->device);
+    return add_device_locked(idx, d_rows, n, first_id);
+}
+
+int mx_index_add(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_id) {
+    if (!idx || (!rows && n)) return fail(MX_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    return add_host_locked(idx, rows, n, first_id);
+}
+
 int mx_index_clear(mx_index *idx) {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
-    idx->n = 0;  // ids restart at 1 (local.rs:50,63); HBM is kept for reuse
-    idx->wild_rows = 0;
-    return MX_OK;
+    return clear_locked(idx);
 }
 
 int mx_index_set_search_mode(mx_index *idx, int mode) {
@@ -556,6 +1065,7 @@ int mx_index_set_search_mode(mx_index *idx, int mode) {
     if (mode != MX_SEARCH_AUTO && mode != MX_SEARCH_EXACT) return fail(MX_EINVAL, "unknown search mode %d", mode);
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->mode = mode;
+    for (mx_index *sh : idx->shards) sh->mode = mode;
     return MX_OK;
 }
 
@@ -570,8 +1080,8 @@ int mx_index_search_device(mx_index *idx, const float *d_q, int B, int k, uint64
     DeviceGuard g(idx->device);
     for (int b0 = 0; b0 < B; b0 += kMaxBatch) {
         const int nb = std::min(kMaxBatch, B - b0);
-        int rc = search_batch(idx, d_q + (size_t)b0 * idx->dim, nb, k, d_ids + (size_t)b0 * k,
-                              d_scores + (size_t)b0 * k, d_dists ? d_dists + (size_t)b0 * k : nullptr, d_nfound + b0);
+        int rc = any_batch(idx, d_q + (size_t)b0 * idx->dim, nb, k, d_ids + (size_t)b0 * k,
+                           d_scores + (size_t)b0 * k, d_dists ? d_dists + (size_t)b0 * k : nullptr, d_nfound + b0);
         if (rc != MX_OK) return rc;
     }
     return MX_OK;
@@ -580,32 +1090,33 @@ int mx_index_search_device(mx_index *idx, const float *d_q, int B, int k, uint64
 namespace {
 
 // one GPU batch (sum of B <= 256, same k) for a group of host requests: queries are packed into
-// pinned memory, one H2D, search_batch, one D2H per output array, results scattered to the callers
+// pinned memory, one H2D, the search pipeline, one D2H per output array, results scattered to the callers
 int run_combined(mx_index *idx, const std::vector<SearchReq *> &batch) {
     std::lock_guard<std::mutex> lk(idx->mu);
-    DeviceGuard g(idx->device);
+    mx_index *t = idx->composite() ? idx->shards[0] : idx;  // owner of the staging buffers and the stream
+    DeviceGuard g(t->device);
     const int k = batch[0]->k;
-    int rc = ensure_scratch(idx);
+    int rc = ensure_scratch(t);
     if (rc != MX_OK) return rc;
-    rc = ensure_out(idx, k);
+    rc = ensure_out(t, k);
     if (rc != MX_OK) return rc;
-    Scratch &s = idx->s;
+    Scratch &s = t->s;
     const size_t dim = (size_t)idx->dim;
     int nb = 0;
     for (const SearchReq *r : batch) {
         memcpy(s.h_q + (size_t)nb * dim, r->q, (size_t)r->B * dim * sizeof(float));
         nb += r->B;
     }
-    MX_HIP(hipMemcpyAsync(s.qstage, s.h_q, (size_t)nb * dim * sizeof(float), hipMemcpyHostToDevice, idx->stream));
-    rc = search_batch(idx, s.qstage, nb, k, s.out_ids, s.out_scores, s.out_dists, s.out_nfound);
+    MX_HIP(hipMemcpyAsync(s.qstage, s.h_q, (size_t)nb * dim * sizeof(float), hipMemcpyHostToDevice, t->stream));
+    rc = any_batch(idx, s.qstage, nb, k, s.out_ids, s.out_scores, s.out_dists, s.out_nfound);
     if (rc != MX_OK) return rc;
     if (k > 0) {
-        MX_HIP(hipMemcpyAsync(s.h_ids, s.out_ids, (size_t)nb * k * sizeof(uint64_t), hipMemcpyDeviceToHost, idx->stream));
-        MX_HIP(hipMemcpyAsync(s.h_scores, s.out_scores, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, idx->stream));
-        MX_HIP(hipMemcpyAsync(s.h_dists, s.out_dists, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, idx->stream));
+        MX_HIP(hipMemcpyAsync(s.h_ids, s.out_ids, (size_t)nb * k * sizeof(uint64_t), hipMemcpyDeviceToHost, t->stream));
+        MX_HIP(hipMemcpyAsync(s.h_scores, s.out_scores, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+        MX_HIP(hipMemcpyAsync(s.h_dists, s.out_dists, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, t->stream));
     }
-    MX_HIP(hipMemcpyAsync(s.h_nf, s.out_nfound, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, idx->stream));
-    MX_HIP(hipStreamSynchronize(idx->stream));
+    MX_HIP(hipMemcpyAsync(s.h_nf, s.out_nfound, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    MX_HIP(hipStreamSynchronize(t->stream));
     int b0 = 0;
     for (SearchReq *r : batch) {
         if (k > 0) {
@@ -634,6 +1145,11 @@ int mx_index_search(mx_index *idx, const float *q, int B, int k, uint64_t *ids, 
     if (B == 0) return MX_OK;
     if (!q || !n_found || (k > 0 && (!ids || !scores))) return fail(MX_EINVAL, "null argument");
     if (k > 4096) return fail(MX_EUNSUPPORTED, "k = %d > 4096", k);
+    {   // reject non-finite queries here, per caller: inside a combined batch they would fail everyone
+        const size_t total = (size_t)B * idx->dim;
+        for (size_t i = 0; i < total; ++i)
+            if (!std::isfinite(q[i])) return fail(MX_EINVAL, "query %zu contains a non-finite value", i / idx->dim);
+    }
     if (B > kMaxBatch) {  // large requests are their own batches: split and recurse
         for (int b0 = 0; b0 < B; b0 += kMaxBatch) {
             const int nb = std::min(kMaxBatch, B - b0);
@@ -687,6 +1203,13 @@ int mx_index_search(mx_index *idx, const float *q, int B, int k, uint64_t *ids, 
 int mx_index_set_filter_copy(mx_index *idx, int on) {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->composite()) {
+        for (mx_index *sh : idx->shards) {
+            int rc = mx_index_set_filter_copy(sh, on);
+            if (rc != MX_OK) return rc;
+        }
+        return MX_OK;
+    }
     DeviceGuard g(idx->device);
     idx->want_filter = on != 0;
     if (!on) {
@@ -703,7 +1226,9 @@ int mx_index_set_filter_copy(mx_index *idx, int on) {
     hipError_t e = hipMalloc(&nh, hb);
     if (e != hipSuccess) return fail(MX_ENOMEM, "hipMalloc(filter copy, %zu bytes): %s", hb, hipGetErrorString(e));
     MX_HIP(hipMemsetAsync(nh, 0, hb, idx->stream));
-    MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh));
+    MX_HIP(hipMemsetAsync(idx->flags + 2, 0, sizeof(uint32_t), idx->stream));
+    MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh,
+                         idx->flags + 2));
     MX_HIP(hipStreamSynchronize(idx->stream));
     idx->xh = nh;
     return MX_OK;
@@ -713,17 +1238,42 @@ int mx_index_set_profiling(mx_index *idx, int on) {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->profiling = on != 0;
+    for (mx_index *sh : idx->shards) sh->profiling = on != 0;
     return MX_OK;
 }
 
 int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
     if (!idx || !out) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->composite()) {
+        mx_index_stats acc = idx->stats;  // searches / queries are counted on the composite
+        for (mx_index *sh : idx->shards) {
+            mx_index_stats s1;
+            int rc = mx_index_get_stats(sh, &s1);
+            if (rc != MX_OK) return rc;
+            acc.fallback_queries += s1.fallback_queries;
+            acc.retry_queries += s1.retry_queries;
+            acc.scan_launches += s1.scan_launches;
+            acc.scan_bytes += s1.scan_bytes;
+            acc.scan_ms += s1.scan_ms;
+            acc.candidates += s1.candidates;
+            acc.max_abs_err = std::max(acc.max_abs_err, s1.max_abs_err);
+            acc.approx_err_bound = std::max(acc.approx_err_bound, s1.approx_err_bound);
+            acc.filter_copy_bytes += s1.filter_copy_bytes;
+        }
+        *out = acc;
+        return MX_OK;
+    }
     if (idx->s.max_err) {  // device-side running maximum (profiling mode); fetched on demand
         DeviceGuard g(idx->device);
         float e = 0.f;
         MX_HIP(hipMemcpy(&e, idx->s.max_err, sizeof(float), hipMemcpyDeviceToHost));
         idx->stats.max_abs_err = std::max(idx->stats.max_abs_err, (double)e);
+    }
+    if (idx->s.host_flags) {  // e1 of the last batch's first query (all queries share Ec; Eq varies little)
+        float e1 = 0.f;
+        memcpy(&e1, idx->s.host_flags + 2 * kMaxBatch, sizeof(float));
+        idx->stats.approx_err_bound = e1;
     }
     idx->stats.filter_copy_bytes = idx->xh ? (uint64_t)idx->cap * idx->ds * 2ull : 0;
     *out = idx->stats;
@@ -734,6 +1284,7 @@ int mx_index_reset_stats(mx_index *idx) {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->stats = mx_index_stats{};
+    for (mx_index *sh : idx->shards) (void)mx_index_reset_stats(sh);
     if (idx->s.max_err) {
         DeviceGuard g(idx->device);
         (void)hipMemset(idx->s.max_err, 0, sizeof(float));
@@ -742,85 +1293,110 @@ int mx_index_reset_stats(mx_index *idx) {
 }
 
 // ---- persistence (replaces hnsw file_dump / load_hnsw, local.rs:115-165) ----------------------
+// vectors.mxflat: magic[8] | u32 dim | u32 0 | u64 n_rows | n_rows * dim f32 (row-major, global id
+// order: the file does not depend on how many devices hold the index).  The reference saves after
+// EVERY insert (local.rs:67); to make that affordable a save into the directory this handle last
+// saved to / loaded from APPENDS the new rows and patches the header instead of rewriting the file.
 int mx_index_save(mx_index *idx, const char *dir) {
     if (!idx || !dir) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
-    DeviceGuard g(idx->device);
-    struct stat sb;
-    if (stat(dir, &sb) != 0 && mkdir(dir, 0755) != 0) return fail(MX_EIO, "cannot create directory %s", dir);
-    const std::string tmp = store_file(dir) + ".tmp";
+    if (mkdir_p(dir) != 0) return fail(MX_EIO, "cannot create directory %s", dir);
+    const uint64_t n = rows_of(idx);
+    const std::string path = store_file(dir);
+    const uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / ((uint64_t)idx->dim * 4));
+    std::vector<float> host((size_t)std::min<uint64_t>(chunk, std::max<uint64_t>(n, 1)) * idx->dim), tmpv;
+    auto write_rows = [&](FILE *f, uint64_t r0) -> int {
+        for (uint64_t r = r0; r < n; r += chunk) {
+            const uint64_t m = std::min(chunk, n - r);
+            int rc = fetch_rows(idx, r, m, host.data(), tmpv);
+            if (rc != MX_OK) return rc;
+            if (fwrite(host.data(), sizeof(float), (size_t)m * idx->dim, f) != (size_t)m * idx->dim)
+                return fail(MX_EIO, "write to %s failed", path.c_str());
+        }
+        return MX_OK;
+    };
+    if (disk_in_sync(idx, dir) && idx->disk_rows <= n) {
+        if (idx->disk_rows == n) return MX_OK;  // nothing new
+        FILE *f = fopen(path.c_str(), "r+b");
+        if (!f) return fail(MX_EIO, "cannot open %s for appending", path.c_str());
+        int rc = fseek(f, kHeaderBytes + (long)(idx->disk_rows * (uint64_t)idx->dim * 4), SEEK_SET) == 0 ? MX_OK : fail(MX_EIO, "seek in %s failed", path.c_str());
+        if (rc == MX_OK) rc = write_rows(f, idx->disk_rows);
+        // the header is patched last: a crash before this point leaves the old, consistent store
+        if (rc == MX_OK && (fflush(f) != 0 || fseek(f, 16, SEEK_SET) != 0 || fwrite(&n, sizeof(n), 1, f) != 1))
+            rc = fail(MX_EIO, "write to %s failed", path.c_str());
+        if (fclose(f) != 0 && rc == MX_OK) rc = fail(MX_EIO, "write to %s failed", path.c_str());
+        if (rc == MX_OK) remember_disk(idx, dir, n);
+        else idx->disk_dir.clear();
+        return rc;
+    }
+    const std::string tmp = path + ".tmp";
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return fail(MX_EIO, "cannot open %s for writing", tmp.c_str());
     uint32_t hdr[2] = {(uint32_t)idx->dim, 0};
-    uint64_t n = idx->n;
-    bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, sizeof(hdr), 1, f) == 1 && fwrite(&n, sizeof(n), 1, f) == 1;
-    const uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / ((uint64_t)idx->ds * 4));
-    std::vector<float> host((size_t)std::min<uint64_t>(chunk, std::max<uint64_t>(n, 1)) * idx->ds);
-    for (uint64_t r = 0; ok && r < n; r += chunk) {
-        const uint64_t m = std::min(chunk, n - r);
-        hipError_t e = hipMemcpy(host.data(), idx->x + (size_t)r * idx->ds, (size_t)m * idx->ds * 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            fclose(f);
-            unlink(tmp.c_str());
-            return fail(MX_EDEVICE, "hipMemcpy D2H: %s", hipGetErrorString(e));
-        }
-        for (uint64_t i = 0; ok && i < m; ++i)
-            ok = fwrite(host.data() + (size_t)i * idx->ds, sizeof(float), (size_t)idx->dim, f) == (size_t)idx->dim;
-    }
-    ok = (fclose(f) == 0) && ok;
-    if (!ok || rename(tmp.c_str(), store_file(dir).c_str()) != 0) {
+    int rc = (fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, sizeof(hdr), 1, f) == 1 && fwrite(&n, sizeof(n), 1, f) == 1)
+                 ? MX_OK : fail(MX_EIO, "write to %s failed", tmp.c_str());
+    if (rc == MX_OK) rc = write_rows(f, 0);
+    if (fclose(f) != 0 && rc == MX_OK) rc = fail(MX_EIO, "write to %s failed", tmp.c_str());
+    if (rc == MX_OK && rename(tmp.c_str(), path.c_str()) != 0) rc = fail(MX_EIO, "cannot rename %s", tmp.c_str());
+    if (rc != MX_OK) {
         unlink(tmp.c_str());
-        return fail(MX_EIO, "write to %s failed", store_file(dir).c_str());
+        return rc;
     }
+    remember_disk(idx, dir, n);
     return MX_OK;
 }
 
 int mx_index_load(mx_index *idx, const char *dir) {
     if (!idx || !dir) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
-    DeviceGuard g(idx->device);
-    FILE *f = fopen(store_file(dir).c_str(), "rb");
-    if (!f) return fail(MX_EIO, "cannot open %s", store_file(dir).c_str());
+    const std::string path = store_file(dir);
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return fail(MX_EIO, "cannot open %s", path.c_str());
     char magic[8];
     uint32_t hdr[2];
     uint64_t n = 0;
+    struct stat sb;
     if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kMagic, 8) != 0 || fread(hdr, sizeof(hdr), 1, f) != 1 ||
-        fread(&n, sizeof(n), 1, f) != 1) {
+        fread(&n, sizeof(n), 1, f) != 1 || fstat(fileno(f), &sb) != 0) {
         fclose(f);
-        return fail(MX_EIO, "%s: bad header", store_file(dir).c_str());
+        return fail(MX_EIO, "%s: bad header", path.c_str());
     }
     if ((int)hdr[0] != idx->dim) {
         fclose(f);
-        return fail(MX_EIO, "%s holds dim %u, index has dim %d", store_file(dir).c_str(), hdr[0], idx->dim);
+        return fail(MX_EIO, "%s holds dim %u, index has dim %d", path.c_str(), hdr[0], idx->dim);
     }
-    idx->n = 0;
-    idx->wild_rows = 0;
+    // validate BEFORE touching the live contents: a truncated file must not destroy them
+    if ((uint64_t)sb.st_size < (uint64_t)kHeaderBytes + n * (uint64_t)idx->dim * 4) {
+        fclose(f);
+        return fail(MX_EIO, "%s: truncated (%lld bytes for %llu rows)", path.c_str(), (long long)sb.st_size, (unsigned long long)n);
+    }
+    // get_vector_storage loads the store on every request (storage/mod.rs:115-116): when the resident
+    // rows are exactly what this file holds, attaching is O(1)
+    if (disk_in_sync(idx, dir) && idx->disk_rows == n && rows_of(idx) == n) {
+        fclose(f);
+        return MX_OK;
+    }
+    clear_locked(idx);
     const uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / ((uint64_t)idx->dim * 4));
     std::vector<float> host((size_t)std::min<uint64_t>(chunk, std::max<uint64_t>(n, 1)) * idx->dim);
-    float *stage = nullptr;
-    hipError_t e = hipMalloc(&stage, host.size() * sizeof(float));
-    if (e != hipSuccess) {
-        fclose(f);
-        return fail(MX_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
-    }
     int rc = MX_OK;
     for (uint64_t r = 0; r < n && rc == MX_OK; r += chunk) {
         const uint64_t m = std::min(chunk, n - r);
         if (fread(host.data(), sizeof(float), (size_t)m * idx->dim, f) != (size_t)m * idx->dim) {
-            rc = fail(MX_EIO, "%s: truncated", store_file(dir).c_str());
+            rc = fail(MX_EIO, "%s: read failed", path.c_str());
             break;
         }
-        e = hipMemcpy(stage, host.data(), (size_t)m * idx->dim * 4, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            rc = fail(MX_EDEVICE, "hipMemcpy H2D: %s", hipGetErrorString(e));
-            break;
-        }
-        rc = add_device_locked(idx, stage, m, nullptr);
+        rc = add_host_locked(idx, host.data(), m, nullptr);
     }
-    (void)hipFree(stage);
     fclose(f);
-    if (rc != MX_OK) idx->n = 0;
-    return rc;
+    if (rc != MX_OK) {
+        const std::string keep = last_error_slot();
+        clear_locked(idx);
+        last_error_slot() = keep;
+        return rc;
+    }
+    remember_disk(idx, dir, n);
+    return MX_OK;
 }
 
 int mx_index_has_store(const char *dir, int *exists) {

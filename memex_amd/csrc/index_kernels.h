@@ -29,18 +29,34 @@ constexpr int kScan16LdsBytes = kRing16 * kSlot16Bytes;
 
 constexpr int kMaxBatch = 256;     // queries per scan pass (8 waves x 32 MFMA columns)
 constexpr int kLaneCap = 32;       // lane-private candidate slots per scan launch
-constexpr int kMaxScanWGs = 256;   // persistent workgroups (<= CUs); pool sizing depends on it
-constexpr int kPoolCap = kLaneCap * kMaxScanWGs;  // per-query candidate pool (entries)
-constexpr int kFinalCap = 1024;    // candidates exactly rescored per query before falling back
+constexpr int kMaxScanWGs = 256;   // persistent workgroups (<= CUs)
+constexpr int kCandCap = 2 * kLaneCap * kMaxScanWGs;  // everything one query can collect in a launch (2 lanes per workgroup)
 
-// cosine-unit bound on |approx - exact| of the bf16 scan: two bf16 roundings (2^-8 each) on
-// |q||c|-normalised products (<= 2^-7 + 2^-16 by Cauchy-Schwarz) + f32 accumulation/normalisation.
+// cosine-unit bounds on |approx - exact| of the bf16 scan.
+//   a priori:  two bf16 roundings (unit roundoff 2^-8 each) of unit vectors, Cauchy-Schwarz:
+//              2^-7 + 2^-16, + kAccSlack for f32 accumulation/normalisation  ->  kApproxErr
+//   per query: e1 = min(kApproxErr, Ec + Eq + Ec*Eq + kAccSlack) with the MEASURED residual norms
+//              Ec = max_rows |bf16(c/|c|) - c/|c|| (tracked while the filter copy is built) and
+//              Eq = |bf16(q/|q|) - q/|q|| (prep_queries_kernel): typically 0.0045.
 constexpr float kApproxErr = 0.0081f;
-constexpr float kMargin = 2.0f * kApproxErr + 1e-4f;
+constexpr float kAccSlack = 2.7e-4f;
 
 struct Cand {
     float score;   // approximate cosine (NaN / +2 = "zero-norm row": exact dist is 0)
     uint32_t row;  // local row
+};
+
+// local row -> id reported to the caller.  Default (block_rows = 0): id_offset + row + 1, the
+// reference's dense 1-based insertion ids (local.rs:63).  A shard of a block-cyclic sharded index
+// (shard g of G, blocks of block_rows rows) owns global rows ((row / R) * G + g) * R + row % R.
+struct IdMap {
+    uint64_t id_offset;
+    uint32_t block_rows, n_shards, shard;
+    __host__ __device__ uint64_t id_of(uint32_t row) const {
+        const uint64_t r = block_rows ? ((uint64_t)(row / block_rows) * n_shards + shard) * block_rows + row % block_rows
+                                      : (uint64_t)row;
+        return id_offset + r + 1;
+    }
 };
 
 struct ScanParams {
@@ -50,26 +66,30 @@ struct ScanParams {
     const void *qfrag;       // bf16 query fragments [8 waves][ds/16][64 lanes][8]
     const float *theta;      // [256] pass threshold per query (cosine units)
     uint64_t n_rows;         // valid rows
-    uint32_t tile_begin;     // tile range of this stage
+    uint32_t tile_begin;     // workgroup b handles tiles tile_begin + (b + i*grid)*tile_stride < tile_end
     uint32_t tile_end;
+    uint32_t tile_stride;    // 1 = every tile; > 1 = the evenly spread sample
     uint32_t ds;             // floats per stored row
     Cand *lane_buf;          // [512][nwg][kLaneCap]  (thread-in-workgroup major)
     uint32_t *lane_cnt;      // [512][nwg]
+    float *lane_max;         // [512][nwg] sample mode: running maximum of each lane
     uint32_t *overflow;      // [256]
 };
 
 // launches ---------------------------------------------------------------------------------
 hipError_t scan_setup();  // one-time function attributes (dynamic LDS size)
 hipError_t scan16_setup();
-hipError_t launch_scan(hipStream_t s, int kc, bool main_stage, int nwg, const ScanParams &p);
-hipError_t launch_scan16(hipStream_t s, int kc, bool main_stage, int nwg, const ScanParams &p);
+// collect = false: sample launch (lane maxima only); collect = true: survivors of theta are appended
+hipError_t launch_scan(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
+hipError_t launch_scan16(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
 
 // (re)build tiles [tile0, tile1) of the bf16 filter copy from the padded f32 store.  Layout: tile t
 // (32 rows), k-step s (16 dims), MFMA lane l -> 8 bf16 at ((t*(ds/16) + s)*64 + l)*8, holding row
 // 32t + (l&31), dims 16s + 8(l>>5) .. +7: exactly the A operand of v_mfma_f32_32x32x16_bf16.
 // Values are bf16(c_i * 1/|c|) (NaN for a zero-norm row: it must pass every filter).
+// ec_max: device word, atomicMax'ed with the float bits of the largest |bf16(c/|c|) - c/|c|| built.
 hipError_t launch_shadow(hipStream_t s, const float *x, const float *scale, int ds, uint32_t tile0, uint32_t tile1,
-                         void *xh);
+                         void *xh, uint32_t *ec_max);
 
 // rows [n, d] (device) -> x[first.., ds] zero-padded + scale; flags[0] += non-finite rows,
 // flags[1] += rows whose norm is outside the range the bf16 scan is certified for
@@ -77,29 +97,52 @@ hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, flo
                          uint64_t first, int ds, uint32_t *flags);
 
 // queries [B, d] (device) -> qfrag (normalised bf16 fragments), qpad [256, ds] f32 original
-// values zero padded, qnorm2 [256] f64 (sequential DistCosine accumulation), theta init
+// values zero padded, qnorm2 [256] f64 (sequential DistCosine accumulation), theta init, e1 [256]
+// per-query error bound of the scan (ec_max: device word holding the filter copy's largest row
+// residual as float bits, or null = a-priori bound); flags[0] |= 1 when a query is not finite
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag,
-                               float *qpad, double *qnorm2, float *theta, uint32_t *overflow,
-                               uint32_t *pool_cnt);
+                               float *qpad, double *qnorm2, float *theta, float *e1, const uint32_t *ec_max,
+                               uint32_t *overflow, uint32_t *flags);
 
-// gather lane buffers of one scan stage into the per-query pool, select the k-th best approximate
-// score, prune the pool to [kth - margin, +inf) and publish theta = kth - margin
-hipError_t launch_update(hipStream_t s, int B, int k, int nwg, const Cand *lane_buf,
-                         const uint32_t *lane_cnt, Cand *pool_in, Cand *pool_out, uint32_t *pool_cnt,
-                         float *theta, uint32_t *overflow);
+// theta[q] = (k-th largest of query q's lane maxima) - 2*e1[q]
+hipError_t launch_theta(hipStream_t s, int B, int k, int nwg, const float *lane_max, const float *e1, float *theta);
 
-// exact DistCosine rescoring of the pool + ordering by (dist, id) + outputs
-hipError_t launch_final(hipStream_t s, int B, int k, int d, int ds, const float *x, uint64_t n_rows,
-                        uint64_t id_offset, const float *qpad, const double *qnorm2, const Cand *pool,
-                        const uint32_t *pool_cnt, uint32_t *overflow, uint64_t *ids, float *scores,
-                        float *dists, int32_t *n_found, float *max_err);
+// per query: gather the collect launch's lane buffers -> keep [kth approx - 2*e1, inf) -> f32
+// rescoring (error e2) -> keep [kth - 2*e2, inf) -> exact DistCosine -> order by (dist, id) -> emit.
+// overflow[q] (in: 1 = a lane buffer overflowed) out: 0 = answered, 1 = rescan with theta_retry[q],
+// >= 2 = answer on the EXACT path.
+struct FinishParams {
+    int k, ds, nwg;
+    const float *x;             // [cap_rows, ds]
+    const float *scale;         // [cap_rows] 1/|c|
+    uint64_t n_rows;
+    IdMap idmap;
+    const float *qpad;          // [256, ds]
+    const double *qnorm2;       // [256]
+    const float *e1;            // [256]
+    float e2;                   // bound on |f32 rescoring - cosine|
+    const Cand *lane_buf;
+    const uint32_t *lane_cnt;
+    uint32_t *overflow;         // [256]
+    const uint32_t *todo;       // null = every query; else only queries with todo[q] != 0
+    float *theta_retry;         // [256]
+    uint32_t *cand_cnt;         // [256] candidates rescored in f32 (statistics)
+    uint64_t *ids;
+    float *scores, *dists;
+    int32_t *n_found;
+    float *max_err;             // null unless profiling
+};
+hipError_t finish_setup();
+hipError_t launch_finish(hipStream_t s, int B, const FinishParams &p);
+hipError_t launch_retry_setup(hipStream_t s, float *theta, const float *theta_retry, uint32_t *overflow, uint32_t *todo);
 
 // EXACT path: one query against every row in f64, then a 64-step radix select on (dist,row) keys
 hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *x, uint64_t n_rows,
-                              uint64_t id_offset, const float *qpad_row, uint64_t *keys,
+                              const IdMap &idmap, const float *qpad_row, uint64_t *keys,
                               uint64_t *sel_state, uint64_t *ids, float *scores, float *dists,
                               int32_t *n_found);
 
+hipError_t launch_fill_nfound(hipStream_t s, int32_t *nf, int B, int32_t v);
 hipError_t launch_merge(hipStream_t s, const void *ids, size_t ids_stride, const void *dists, size_t dists_stride,
                         int G, int B, int k, uint64_t *out_ids, float *out_dists, float *out_scores);
 

@@ -100,15 +100,21 @@ hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, flo
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restrict__ q, int B, int d, int ds,
                                                            __bf16 *__restrict__ qfrag, float *__restrict__ qpad,
                                                            double *__restrict__ qnorm2, float *__restrict__ theta,
-                                                           uint32_t *__restrict__ overflow,
-                                                           uint32_t *__restrict__ pool_cnt) {
+                                                           float *__restrict__ e1, const uint32_t *__restrict__ ec_max,
+                                                           uint32_t *__restrict__ overflow, uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
     float *s_row = reinterpret_cast<float *>(psm);  // [d] this query (coalesced load; the chain reads LDS)
     __shared__ float s_inv;
+    __shared__ uint32_t s_red[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const bool live = b < B;
-    for (int i = tid; i < d; i += 256) s_row[i] = live ? q[(size_t)b * d + i] : 0.0f;
+    bool bad = false;
+    for (int i = tid; i < d; i += 256) {
+        const float v = live ? q[(size_t)b * d + i] : 0.0f;
+        s_row[i] = v;
+        bad |= !isfinite(v);
+    }
     __syncthreads();
     if (tid == 0) {
         double na = 0.0;
@@ -121,196 +127,111 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
         s_inv = usable ? (float)(1.0 / sqrt(na)) : 0.0f;
         theta[b] = usable ? -INFINITY : INFINITY;  // zero / padded queries never pass the scan filter
         overflow[b] = 0;
-        pool_cnt[b] = 0;
     }
     __syncthreads();
     const float inv = s_inv;
     const int ksteps = ds / 16;
     const int w = b >> 5, col = b & 31;
+    float r2 = 0.0f;  // |bf16(q/|q|) - q/|q||^2: this query's share of the scan's error bound
     for (int dim = tid; dim < ds; dim += 256) {
         const float v = dim < d ? s_row[dim] : 0.0f;
         qpad[(size_t)b * ds + dim] = v;
         // MFMA 32x32x16 B-operand: lane l holds B[k = 8*(l>>5)+i][n = l&31]
         const int ks = dim >> 4, hh = (dim >> 3) & 1, i = dim & 7;
         const int lane = hh * 32 + col;
-        qfrag[(((size_t)w * ksteps + ks) * 64 + lane) * 8 + i] = (__bf16)(v * inv);
+        const float vn = v * inv;
+        const __bf16 vb = (__bf16)vn;
+        qfrag[(((size_t)w * ksteps + ks) * 64 + lane) * 8 + i] = vb;
+        const float r = (float)vb - vn;
+        r2 += r * r;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
+    const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0;
+    if ((tid & 63) == 0) s_red[tid >> 6] = __float_as_uint(r2);
+    __syncthreads();
+    if (tid == 0) {
+        // |approx - cos| <= |c^ - c| + |q^ - q| + |c^ - c||q^ - q| + f32 accumulation (unit vectors,
+        // Cauchy-Schwarz).  ec_max is the largest row residual the filter copy holds (shadow_kernel);
+        // without a filter copy (f32 scan: rows are rounded unnormalised) the a-priori bound is used.
+        const float eq = sqrtf(__uint_as_float(s_red[0]) + __uint_as_float(s_red[1]) + __uint_as_float(s_red[2]) +
+                               __uint_as_float(s_red[3])) * 1.01f + 1e-6f;
+        float e = kApproxErr;
+        if (ec_max) {
+            const float ec = __uint_as_float(*ec_max) * 1.01f + 1e-6f;
+            e = fminf(kApproxErr, ec + eq + ec * eq + kAccSlack);
+        }
+        e1[b] = e;
+    }
+    if (live && anybad && (tid & 63) == 0) atomicOr(&flags[0], 1u);  // non-finite query: the call fails with MX_EINVAL
 }
 
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag, float *qpad,
-                               double *qnorm2, float *theta, uint32_t *overflow, uint32_t *pool_cnt) {
-    hipLaunchKernelGGL(prep_queries_kernel, dim3(kMaxBatch), dim3(256), sizeof(float) * (size_t)d, s, q, B, d, ds, (__bf16 *)qfrag, qpad,
-                       qnorm2, theta, overflow, pool_cnt);
+                               double *qnorm2, float *theta, float *e1, const uint32_t *ec_max, uint32_t *overflow,
+                               uint32_t *flags) {
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(kMaxBatch), dim3(256), sizeof(float) * (size_t)d, s, q, B, d, ds,
+                       (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
-// pool update: gather a stage's lane buffers, select the k-th best approximate score, prune
+// theta: pass threshold of the collect launch from the sample launch's lane maxima
 // ---------------------------------------------------------------------------------------------
-constexpr int kPer = kPoolCap / 256;  // pool entries held per thread
-
-__global__ __launch_bounds__(256) void update_kernel(int k, int nwg, const Cand *__restrict__ lane_buf,
-                                                     const uint32_t *__restrict__ lane_cnt, Cand *pool_in,
-                                                     Cand *pool_out, uint32_t *pool_cnt, float *theta,
-                                                     uint32_t *overflow) {
-    __shared__ uint32_t s_cnt;
-    __shared__ uint32_t s_sel[2][4];
+// A query's 2*nwg lane maxima are approximate scores of 2*nwg DISTINCT rows, so the k-th largest of
+// them, a_k, is a lower bound of the k-th best approximate score, the exact k-th best cosine is
+// >= a_k - e1, and every row of the exact top-k has an approximate score >= a_k - 2*e1.
+__global__ __launch_bounds__(256) void theta_kernel(int k, int nwg, const float *__restrict__ lane_max,
+                                                    const float *__restrict__ e1, float *__restrict__ theta) {
+    __shared__ float s_v[2 * kMaxScanWGs];
+    __shared__ float s_kth;
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
-    Cand *pin = pool_in + (size_t)q * kPoolCap;
-    Cand *pout = pool_out + (size_t)q * kPoolCap;
-    const uint32_t m_old = pool_cnt[q];
-    if (tid == 0) s_cnt = m_old;
+    const int n = 2 * nwg;
+    const uint32_t t0 = (uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31);
+    for (int i = tid; i < n; i += 256) {
+        const int hh = i / nwg, w = i - hh * nwg;
+        s_v[i] = lane_max[(size_t)(t0 + 32 * hh) * nwg + w];
+    }
+    if (tid == 0) s_kth = -INFINITY;
     __syncthreads();
-
-    // ---- gather: scan workgroup w kept this query's candidates in lanes L0 and L0+32 of wave q/32.
-    // All loads of a lane buffer are issued before the first store (16-byte vectors, 2 entries each):
-    // a load-store-load chain through HBM latency is what made this kernel slow.
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    for (int w = tid; w < nwg; w += 256) {
-        // [thread-in-workgroup][workgroup] layout (scan.hip): consecutive threads read consecutive words
-        const uint32_t t0 = (uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31);
-        const uint32_t l0 = t0 * (uint32_t)nwg + (uint32_t)w, l1 = (t0 + 32) * (uint32_t)nwg + (uint32_t)w;
-        const uint32_t c0 = lane_cnt[l0], c1 = lane_cnt[l1];
-        for (int half = 0; half < 2; ++half) {
-            const uint32_t c = half ? c1 : c0;
-            if (c == 0) continue;
-            const uint32_t pos = atomicAdd(&s_cnt, c);
-            const u32x4 *src = reinterpret_cast<const u32x4 *>(lane_buf + (size_t)(half ? l1 : l0) * kLaneCap);
-            u32x4 v[kLaneCap / 2];
-#pragma unroll
-            for (int e = 0; e < kLaneCap / 2; ++e)
-                if ((uint32_t)(2 * e) < c) v[e] = src[e];
-#pragma unroll
-            for (int e = 0; e < kLaneCap / 2; ++e) {
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const uint32_t i = 2 * e + hh;
-                    if (i < c && pos + i < (uint32_t)kPoolCap) {
-                        Cand cd;
-                        cd.score = __uint_as_float(v[e][2 * hh]);
-                        cd.row = v[e][2 * hh + 1];
-                        if (!(cd.score == cd.score)) cd.score = 2.0f;  // NaN = zero-norm row: rank first
-                        pin[pos + i] = cd;
-                    }
-                }
-            }
+    for (int i = tid; i < n; i += 256) {
+        const float me = s_v[i];
+        int gt = 0, ge = 0;
+        for (int j = 0; j < n; ++j) {
+            const float o = s_v[j];
+            gt += o > me ? 1 : 0;
+            ge += o >= me ? 1 : 0;
         }
+        if (gt < k && k <= ge) s_kth = me;  // ties write the same value
     }
     __syncthreads();
-    uint32_t m = s_cnt;
-    if (m > (uint32_t)kPoolCap) {
-        if (tid == 0) overflow[q] = 1;
-        m = kPoolCap;
-    }
-    __syncthreads();
-
-    // ---- load my entries (entry e*256 + tid)
-    uint32_t key[kPer];
-    uint32_t row[kPer];
-    const int per = (int)((m + 255) / 256);
-#pragma unroll
-    for (int e = 0; e < kPer; ++e) {
-        const uint32_t i = (uint32_t)e * 256 + tid;
-        if (e < per && i < m) {
-            const Cand cd = pin[i];
-            key[e] = f32_key(cd.score);
-            row[e] = cd.row;
-        } else {
-            key[e] = 0;  // below every real key
-            row[e] = 0xffffffffu;
-        }
-    }
-
-    const float th_old = theta[q];
-    float th_new = th_old;
-    uint32_t keep_key = 0;  // keep everything
-    if (m >= (uint32_t)k && k > 0 && th_old != INFINITY) {
-        // k-th largest key.  Only the bits below the highest bit in which the keys differ need a
-        // decision; counts are wave ballots + popcounts (scalar), one LDS exchange and one barrier
-        // per bit.
-        uint32_t kmax = 0, kmin = 0xffffffffu;
-#pragma unroll
-        for (int e = 0; e < kPer; ++e)
-            if (e < per && row[e] != 0xffffffffu) {
-                kmax = key[e] > kmax ? key[e] : kmax;
-                kmin = key[e] < kmin ? key[e] : kmin;
-            }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t a = __shfl_xor(kmax, o), b = __shfl_xor(kmin, o);
-            kmax = a > kmax ? a : kmax;
-            kmin = b < kmin ? b : kmin;
-        }
-        if ((tid & 63) == 0) {
-            s_sel[0][tid >> 6] = kmax;
-            s_sel[1][tid >> 6] = kmin;
-        }
-        __syncthreads();
-        kmax = max(max(s_sel[0][0], s_sel[0][1]), max(s_sel[0][2], s_sel[0][3]));
-        kmin = min(min(s_sel[1][0], s_sel[1][1]), min(s_sel[1][2], s_sel[1][3]));
-        __syncthreads();
-        const uint32_t diff = kmax ^ kmin;
-        uint32_t prefix = kmax;
-        if (diff != 0) {
-            const int top = 31 - __clz((int)diff);
-            prefix = top == 31 ? 0u : (kmax & ~((2u << top) - 1u));  // bits above `top` are common
-            for (int bit = top; bit >= 0; --bit) {
-                const uint32_t trial = prefix | (1u << bit);
-                uint32_t c = 0;
-#pragma unroll
-                for (int e = 0; e < kPer; ++e)
-                    if (e < per) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(key[e] >= trial));
-                uint32_t *slot = s_sel[bit & 1];
-                if ((tid & 63) == 0) slot[tid >> 6] = c;
-                __syncthreads();  // slots alternate per bit, so one barrier per bit suffices
-                c = slot[0] + slot[1] + slot[2] + slot[3];
-                if (c >= (uint32_t)k) prefix = trial;
-            }
-        }
-        const float kth = key_f32(prefix);
-        th_new = kth - kMargin;
-        if (th_new > th_old || th_old == -INFINITY) {
-            keep_key = f32_key(th_new);
-        } else {
-            th_new = th_old;
-        }
-    }
-
-    // ---- prune into pool_out
-    __syncthreads();
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-#pragma unroll
-    for (int e = 0; e < kPer; ++e) mine += (e < per && row[e] != 0xffffffffu && key[e] >= keep_key) ? 1u : 0u;
-    uint32_t pos = mine ? atomicAdd(&s_cnt, mine) : 0;
-#pragma unroll
-    for (int e = 0; e < kPer; ++e) {
-        if (e < per && row[e] != 0xffffffffu && key[e] >= keep_key) {
-            Cand cd;
-            cd.score = key_f32(key[e]);
-            cd.row = row[e];
-            pout[pos++] = cd;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        pool_cnt[q] = s_cnt;
-        theta[q] = th_new;
-    }
+    if (tid == 0 && theta[q] != INFINITY) theta[q] = s_kth - 2.0f * e1[q];  // -inf when fewer than k lanes saw a row
 }
 
-hipError_t launch_update(hipStream_t s, int B, int k, int nwg, const Cand *lane_buf, const uint32_t *lane_cnt,
-                         Cand *pool_in, Cand *pool_out, uint32_t *pool_cnt, float *theta, uint32_t *overflow) {
+hipError_t launch_theta(hipStream_t s, int B, int k, int nwg, const float *lane_max, const float *e1, float *theta) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(update_kernel, dim3(B), dim3(256), 0, s, k, nwg, lane_buf, lane_cnt, pool_in, pool_out,
-                       pool_cnt, theta, overflow);
+    hipLaunchKernelGGL(theta_kernel, dim3(B), dim3(256), 0, s, k, nwg, lane_max, e1, theta);
+    return hipGetLastError();
+}
+
+// retry launch: queries whose lane buffers overflowed are scanned again with the tight threshold
+// finish_kernel derived from what was collected; every other query is parked at +inf
+__global__ void retry_setup_kernel(float *theta, const float *theta_retry, uint32_t *overflow, uint32_t *todo) {
+    const int q = threadIdx.x;
+    const bool again = overflow[q] == 1;
+    todo[q] = again ? 1u : 0u;
+    theta[q] = again ? theta_retry[q] : INFINITY;
+    if (again) overflow[q] = 0;
+}
+
+hipError_t launch_retry_setup(hipStream_t s, float *theta, const float *theta_retry, uint32_t *overflow, uint32_t *todo) {
+    hipLaunchKernelGGL(retry_setup_kernel, dim3(1), dim3(kMaxBatch), 0, s, theta, theta_retry, overflow, todo);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
-// exact rescoring + ordering of the candidate pool (K7)
+// finish: gather a query's candidates, prune by approximate score, rescore in f32, prune again,
+// exact DistCosine on the survivors, order by (dist, id), emit            (K7)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float exact_dist_row(const float *__restrict__ qv, const float *__restrict__ row, int ds,
                                                 double na, double *cos_out) {
@@ -330,82 +251,357 @@ __device__ __forceinline__ float exact_dist_row(const float *__restrict__ qv, co
     return dist_from_sums(dot, na, nb);
 }
 
-__global__ __launch_bounds__(256) void final_kernel(int k, int ds, const float *__restrict__ x, uint64_t n_rows,
-                                                    uint64_t id_offset, const float *__restrict__ qpad,
-                                                    const double *__restrict__ qnorm2, const Cand *__restrict__ pool,
-                                                    const uint32_t *__restrict__ pool_cnt, uint32_t *overflow,
-                                                    uint64_t *ids, float *scores, float *dists, int32_t *n_found,
-                                                    float *max_err) {
+constexpr int kFinThreads = 1024;
+constexpr int kFinWaves = kFinThreads / 64;
+constexpr int kFinPer = kCandCap / kFinThreads;  // candidates held per thread
+static_assert(kCandCap % kFinThreads == 0, "candidate capacity must divide over the block");
+
+// block-wide exclusive scan of a small unsigned value over 1024 threads; total in *total
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *lds_w, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) lds_w[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kFinWaves; ++w) {
+        const uint32_t c = lds_w[w];
+        base += w < wave ? c : 0u;
+        tot += c;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// k-th largest of the u32 keys the block holds in registers (key[e] valid for e < per and
+// row[e] != ~0).  MSB-first: only the bits below the highest bit in which the keys differ need a
+// decision; counts are wave ballots + popcounts, one LDS exchange and one barrier per bit.
+__device__ __forceinline__ uint32_t block_kth_largest(const uint32_t (&key)[kFinPer], const uint32_t (&row)[kFinPer],
+                                                      int per, uint32_t k, uint32_t (*s_sel)[kFinWaves]) {
+    const int tid = threadIdx.x;
+    uint32_t kmax = 0, kmin = 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < kFinPer; ++e)
+        if (e < per && row[e] != 0xffffffffu) {
+            kmax = key[e] > kmax ? key[e] : kmax;
+            kmin = key[e] < kmin ? key[e] : kmin;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmax, o), b = __shfl_xor(kmin, o);
+        kmax = a > kmax ? a : kmax;
+        kmin = b < kmin ? b : kmin;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        s_sel[0][tid >> 6] = kmax;
+        s_sel[1][tid >> 6] = kmin;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kFinWaves; ++w) {
+        kmax = s_sel[0][w] > kmax ? s_sel[0][w] : kmax;
+        kmin = s_sel[1][w] < kmin ? s_sel[1][w] : kmin;
+    }
+    __syncthreads();
+    const uint32_t diff = kmax ^ kmin;
+    uint32_t prefix = kmax;
+    if (diff != 0) {
+        const int top = 31 - __clz((int)diff);
+        prefix = top == 31 ? 0u : (kmax & ~((2u << top) - 1u));  // bits above `top` are common
+        for (int bit = top; bit >= 0; --bit) {
+            const uint32_t trial = prefix | (1u << bit);
+            uint32_t c = 0;
+#pragma unroll
+            for (int e = 0; e < kFinPer; ++e)
+                if (e < per) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(row[e] != 0xffffffffu && key[e] >= trial));
+            uint32_t *slot = s_sel[bit & 1];
+            if ((tid & 63) == 0) slot[tid >> 6] = c;
+            __syncthreads();  // slots alternate per bit, so one barrier per bit suffices
+            c = 0;
+#pragma unroll
+            for (int w = 0; w < kFinWaves; ++w) c += slot[w];
+            if (c >= k) prefix = trial;
+        }
+    }
+    return prefix;
+}
+
+__global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams p) {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
-    uint64_t *keys = reinterpret_cast<uint64_t *>(fsm);                        // [kFinalCap]
-    float *qv = reinterpret_cast<float *>(fsm + sizeof(uint64_t) * kFinalCap);  // [ds]
+    Cand *ent = reinterpret_cast<Cand *>(fsm);                                        // [kCandCap]
+    uint64_t *keys = reinterpret_cast<uint64_t *>(fsm);                               // same storage, later
+    float *qv = reinterpret_cast<float *>(fsm + sizeof(Cand) * (size_t)kCandCap);     // [ds] raw query
+    __shared__ uint32_t s_w[kFinWaves];
+    __shared__ uint32_t s_sel[2][kFinWaves];
+    __shared__ uint32_t s_cnt;
+
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
-    const uint64_t want64 = n_rows < (uint64_t)k ? n_rows : (uint64_t)k;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (p.todo && !p.todo[q]) return;
+    const int k = p.k, ds = p.ds;
+    const uint64_t want64 = p.n_rows < (uint64_t)k ? p.n_rows : (uint64_t)k;
     const int want = (int)want64;
-    uint64_t *oid = ids + (size_t)q * k;
-    float *osc = scores + (size_t)q * k;
-    float *odi = dists ? dists + (size_t)q * k : nullptr;
-    if (tid == 0) n_found[q] = want;
-    for (int j = tid; j < k; j += 256) {  // defaults for unused slots
+    uint64_t *oid = p.ids + (size_t)q * k;
+    float *osc = p.scores + (size_t)q * k;
+    float *odi = p.dists ? p.dists + (size_t)q * k : nullptr;
+    if (tid == 0) {
+        p.n_found[q] = want;
+        p.cand_cnt[q] = 0;
+    }
+    for (int j = tid; j < k; j += kFinThreads) {  // defaults for unused slots
         oid[j] = 0;
         osc[j] = 0.0f;
         if (odi) odi[j] = INFINITY;
     }
-    const double na = qnorm2[q];
+    if (want == 0) return;
+    const double na = p.qnorm2[q];
     if (!(na > 0.0)) {
         // zero-norm query: DistCosine returns 0 for every row -> ties broken by id (local.rs:63 ids)
-        for (int j = tid; j < want; j += 256) {
-            oid[j] = id_offset + (uint64_t)j + 1;
+        for (int j = tid; j < want; j += kFinThreads) {
+            oid[j] = p.idmap.id_of((uint32_t)j);
             osc[j] = 1.0f;
             if (odi) odi[j] = 0.0f;
         }
         return;
     }
-    const uint32_t m = pool_cnt[q];
-    if (m > (uint32_t)kFinalCap || m < (uint32_t)want) {
-        if (tid == 0) overflow[q] = 1;  // host re-answers this query on the EXACT path
+    const uint32_t lane_ovf = p.overflow[q];
+    const float e1 = p.e1[q];
+    for (int i = tid; i < ds; i += kFinThreads) qv[i] = p.qpad[(size_t)q * ds + i];
+
+    // ---- gather: scan workgroup w kept this query's candidates in lanes L0 and L0+32 of wave q/32
+    // ([thread-in-workgroup][workgroup] layout, scan16.hip).  All loads of a lane buffer are issued
+    // before the first store (16-byte vectors, 2 entries each).
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const int nwg = p.nwg;
+    uint32_t c = 0;
+    size_t l = 0;
+    if (tid < 2 * nwg) {
+        const int hh = tid / nwg, w = tid - hh * nwg;
+        l = (size_t)((uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31) + 32u * hh) * nwg + w;
+        c = p.lane_cnt[l];
+        c = c > (uint32_t)kLaneCap ? (uint32_t)kLaneCap : c;
+    }
+    uint32_t M;
+    const uint32_t pos = block_scan_1024(c, s_w, &M);
+    if (c) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(p.lane_buf + l * kLaneCap);
+        u32x4 v[kLaneCap / 2];
+#pragma unroll
+        for (int e = 0; e < kLaneCap / 2; ++e)
+            if ((uint32_t)(2 * e) < c) v[e] = src[e];
+#pragma unroll
+        for (int e = 0; e < kLaneCap / 2; ++e) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const uint32_t i = 2 * e + hh;
+                if (i < c) {
+                    Cand cd;
+                    cd.score = __uint_as_float(v[e][2 * hh]);
+                    cd.row = v[e][2 * hh + 1];
+                    // NaN = zero-norm row: its exact dist is 0, i.e. cosine 1 with no error
+                    if (!(cd.score == cd.score)) cd.score = 1.0f;
+                    ent[pos + i] = cd;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (M < (uint32_t)want) {  // cannot happen unless candidates were lost: leave it to the host
+        if (tid == 0) p.overflow[q] = lane_ovf ? 3u : 2u;
         return;
     }
-    for (int i = tid; i < ds; i += 256) qv[i] = qpad[(size_t)q * ds + i];
-    __syncthreads();
-    const Cand *pl = pool + (size_t)q * kPoolCap;
-    float err = 0.0f;
-    for (uint32_t c = tid; c < m; c += 256) {
-        const Cand cd = pl[c];
-        double cosv;
-        const float d = exact_dist_row(qv, x + (size_t)cd.row * ds, ds, na, max_err ? &cosv : nullptr);
-        keys[c] = ((uint64_t)__float_as_uint(d) << 32) | cd.row;
-        if (max_err && cd.score < 1.5f) err = fmaxf(err, fabsf((float)cosv - cd.score));
+
+    // ---- stage 1: k-th best approximate score; keep [kth - 2*e1, +inf)
+    uint32_t key[kFinPer], row[kFinPer];
+    int per = (int)((M + kFinThreads - 1) / kFinThreads);
+#pragma unroll
+    for (int e = 0; e < kFinPer; ++e) {
+        const uint32_t i = (uint32_t)e * kFinThreads + tid;
+        if (e < per && i < M) {
+            const Cand cd = ent[i];
+            key[e] = f32_key(cd.score);
+            row[e] = cd.row;
+        } else {
+            key[e] = 0;
+            row[e] = 0xffffffffu;
+        }
     }
-    if (max_err) {
+    {
+        const uint32_t kth = block_kth_largest(key, row, per, (uint32_t)want, s_sel);
+        const uint32_t keep = f32_key(key_f32(kth) - 2.0f * e1);
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();  // also: every thread has its entries in registers, ent[] may be overwritten
+        uint32_t mine = 0;
+#pragma unroll
+        for (int e = 0; e < kFinPer; ++e) mine += (e < per && row[e] != 0xffffffffu && key[e] >= keep) ? 1u : 0u;
+        uint32_t at = mine ? atomicAdd(&s_cnt, mine) : 0;
+#pragma unroll
+        for (int e = 0; e < kFinPer; ++e)
+            if (e < per && row[e] != 0xffffffffu && key[e] >= keep) {
+                Cand cd;
+                cd.score = key_f32(key[e]);
+                cd.row = row[e];
+                ent[at++] = cd;
+            }
+        __syncthreads();
+    }
+    const uint32_t m1 = s_cnt;
+    if (tid == 0) p.cand_cnt[q] = m1;
+
+    // ---- stage 2: f32 rescoring of the m1 survivors (one wave per row, 4 rows in flight per wave):
+    // s2 = sum fma(q_i/|q|, c_i/|c|), |s2 - cos| <= e2 (any summation order)
+    const float invq = (float)(1.0 / sqrt(na));
+    const int nc4 = ds >> 2;
+    float err = 0.0f;
+    for (uint32_t base = (uint32_t)wave * 4; base < m1; base += kFinWaves * 4) {
+        float dot[4];
+        float sc[4];
+        uint32_t rr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = base + j < m1 ? base + j : base;
+            rr[j] = ent[i].row;
+            sc[j] = p.scale[rr[j]];
+            dot[j] = 0.0f;
+        }
+        for (int c4 = lane; c4 < nc4; c4 += 64) {
+            const float4 a = *reinterpret_cast<const float4 *>(qv + 4 * c4);
+            float4 x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = reinterpret_cast<const float4 *>(p.x + (size_t)rr[j] * ds)[c4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dot[j] = fmaf(a.x * invq, x[j].x * sc[j], dot[j]);
+                dot[j] = fmaf(a.y * invq, x[j].y * sc[j], dot[j]);
+                dot[j] = fmaf(a.z * invq, x[j].z * sc[j], dot[j]);
+                dot[j] = fmaf(a.w * invq, x[j].w * sc[j], dot[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dot[j] += __shfl_xor(dot[j], o);
+        }
+        if (lane < 4 && base + lane < m1) {
+            const float d0 = lane == 0 ? dot[0] : lane == 1 ? dot[1] : lane == 2 ? dot[2] : dot[3];
+            const float s0 = lane == 0 ? sc[0] : lane == 1 ? sc[1] : lane == 2 ? sc[2] : sc[3];
+            const float s2 = isinf(s0) ? 1.0f : d0;  // zero-norm row: dist 0
+            if (p.max_err && !isinf(s0)) err = fmaxf(err, fabsf(s2 - ent[base + lane].score));
+            ent[base + lane].score = s2;
+        }
+    }
+    if (p.max_err) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) err = fmaxf(err, __shfl_xor(err, o));
-        if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(max_err), __float_as_uint(err));
+        if (lane == 0 && err > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(p.max_err), __float_as_uint(err));
     }
     __syncthreads();
-    for (uint32_t c = tid; c < m; c += 256) {
-        const uint64_t me = keys[c];
+
+    // ---- k-th best f32 score L; keep [L - 2*e2, +inf); publish the retry threshold
+    per = (int)((m1 + kFinThreads - 1) / kFinThreads);
+#pragma unroll
+    for (int e = 0; e < kFinPer; ++e) {
+        const uint32_t i = (uint32_t)e * kFinThreads + tid;
+        if (e < per && i < m1) {
+            const Cand cd = ent[i];
+            key[e] = f32_key(cd.score);
+            row[e] = cd.row;
+        } else {
+            key[e] = 0;
+            row[e] = 0xffffffffu;
+        }
+    }
+    {
+        const uint32_t kth = block_kth_largest(key, row, per, (uint32_t)want, s_sel);
+        const float L = key_f32(kth);
+        if (tid == 0) {
+            p.theta_retry[q] = L - p.e2 - e1 - 1e-6f;
+            s_cnt = 0;
+        }
+        if (lane_ovf) {  // incomplete candidate set: the host rescans this query with theta_retry
+            if (tid == 0) p.overflow[q] = 1;
+            return;
+        }
+        const uint32_t keep = f32_key(L - 2.0f * p.e2);
+        __syncthreads();
+        uint32_t mine = 0;
+#pragma unroll
+        for (int e = 0; e < kFinPer; ++e) mine += (e < per && row[e] != 0xffffffffu && key[e] >= keep) ? 1u : 0u;
+        uint32_t at = mine ? atomicAdd(&s_cnt, mine) : 0;
+#pragma unroll
+        for (int e = 0; e < kFinPer; ++e)
+            if (e < per && row[e] != 0xffffffffu && key[e] >= keep) {
+                Cand cd;
+                cd.score = key_f32(key[e]);
+                cd.row = row[e];
+                ent[at++] = cd;
+            }
+        __syncthreads();
+    }
+    const uint32_t m2 = s_cnt;
+
+    // ---- stage 3: exact DistCosine (sequential f64 chain, one thread per row; the rows are L2-warm
+    // from stage 2), key = (dist_bits << 32 | row) written over the entry it came from
+    for (uint32_t cI = tid; cI < m2; cI += kFinThreads) {
+        const uint32_t r = ent[cI].row;
+        const float d = exact_dist_row(qv, p.x + (size_t)r * ds, ds, na, nullptr);
+        keys[cI] = ((uint64_t)__float_as_uint(d) << 32) | r;
+    }
+    __syncthreads();
+
+    // ---- order by (dist, row) and emit the first `want`
+    uint64_t lim = ~0ull;  // keys above the want-th smallest need no rank
+    if (m2 > 2048u) {
+        // many exact ties (duplicated rows): select the want-th smallest key first (64-bit radix,
+        // MSB first), so that the quadratic ranking below runs on `want` keys only
+        uint64_t prefix = 0;
+        for (int bit = 63; bit >= 0; --bit) {
+            const uint64_t trial = prefix | (1ull << bit);
+            uint32_t cc = 0;
+            for (uint32_t cI = tid; cI < m2; cI += kFinThreads) cc += keys[cI] < trial ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cc += __shfl_xor(cc, o);
+            uint32_t *slot = s_sel[bit & 1];
+            if (lane == 0) slot[wave] = cc;
+            __syncthreads();
+            cc = 0;
+#pragma unroll
+            for (int w = 0; w < kFinWaves; ++w) cc += slot[w];
+            if (cc < (uint32_t)want) prefix = trial;  // fewer than `want` keys below trial: the want-th is >= trial
+        }
+        lim = prefix;
+    }
+    for (uint32_t cI = tid; cI < m2; cI += kFinThreads) {
+        const uint64_t me = keys[cI];
+        if (me > lim) continue;
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < m; ++j) rank += keys[j] < me ? 1u : 0u;
+        for (uint32_t j = 0; j < m2; ++j) rank += keys[j] < me ? 1u : 0u;
         if (rank < (uint32_t)want) {
             const float d = __uint_as_float((uint32_t)(me >> 32));
-            oid[rank] = id_offset + (uint64_t)(uint32_t)me + 1;
+            oid[rank] = p.idmap.id_of((uint32_t)me);
             osc[rank] = score_from_dist(d);
             if (odi) odi[rank] = d;
         }
     }
 }
 
-hipError_t launch_final(hipStream_t s, int B, int k, int d, int ds, const float *x, uint64_t n_rows,
-                        uint64_t id_offset, const float *qpad, const double *qnorm2, const Cand *pool,
-                        const uint32_t *pool_cnt, uint32_t *overflow, uint64_t *ids, float *scores, float *dists,
-                        int32_t *n_found, float *max_err) {
-    (void)d;
+hipError_t finish_setup() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)kMaxKC * kChunkFloats));
+}
+
+hipError_t launch_finish(hipStream_t s, int B, const FinishParams &p) {
     if (B <= 0) return hipSuccess;
-    const size_t lds = sizeof(uint64_t) * kFinalCap + sizeof(float) * (size_t)ds;
-    hipLaunchKernelGGL(final_kernel, dim3(B), dim3(256), lds, s, k, ds, x, n_rows, id_offset, qpad, qnorm2, pool,
-                       pool_cnt, overflow, ids, scores, dists, n_found, max_err);
+    const size_t lds = sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)p.ds;
+    hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(kFinThreads), lds, s, p);
     return hipGetLastError();
 }
 
@@ -461,7 +657,7 @@ __global__ __launch_bounds__(256) void exact_collect_kernel(const uint64_t *__re
         }
     }
 }
-__global__ __launch_bounds__(256) void exact_emit_kernel(int k, uint64_t kk, uint64_t id_offset,
+__global__ __launch_bounds__(256) void exact_emit_kernel(int k, uint64_t kk, IdMap idmap,
                                                          const uint64_t *__restrict__ sel, uint64_t *ids,
                                                          float *scores, float *dists, int32_t *n_found) {
     const int tid = threadIdx.x;
@@ -477,14 +673,14 @@ __global__ __launch_bounds__(256) void exact_emit_kernel(int k, uint64_t kk, uin
         uint64_t rank = 0;
         for (uint64_t j = 0; j < kk; ++j) rank += sel[j] < me ? 1u : 0u;
         const float d = __uint_as_float((uint32_t)(me >> 32));
-        ids[rank] = id_offset + (uint64_t)(uint32_t)me + 1;
+        ids[rank] = idmap.id_of((uint32_t)me);
         scores[rank] = score_from_dist(d);
         if (dists) dists[rank] = d;
     }
 }
 
 hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *x, uint64_t n_rows,
-                              uint64_t id_offset, const float *qpad_row, uint64_t *keys, uint64_t *sel_state,
+                              const IdMap &idmap, const float *qpad_row, uint64_t *keys, uint64_t *sel_state,
                               uint64_t *ids, float *scores, float *dists, int32_t *n_found) {
     (void)d;
     const uint64_t kk = n_rows < (uint64_t)k ? n_rows : (uint64_t)k;
@@ -503,7 +699,7 @@ hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *
         }
         hipLaunchKernelGGL(exact_collect_kernel, dim3(cblocks), dim3(256), 0, s, keys, n_rows, kk, sel_state, sel);
     }
-    hipLaunchKernelGGL(exact_emit_kernel, dim3(1), dim3(256), 0, s, k, kk, id_offset, sel, ids, scores, dists, n_found);
+    hipLaunchKernelGGL(exact_emit_kernel, dim3(1), dim3(256), 0, s, k, kk, idmap, sel, ids, scores, dists, n_found);
     return hipGetLastError();
 }
 
@@ -545,6 +741,17 @@ __global__ __launch_bounds__(256) void merge_kernel(const char *__restrict__ ids
             if (out_scores) out_scores[(size_t)b * k + rank] = score_from_dist(d);
         }
     }
+}
+
+__global__ void fill_nfound_kernel(int32_t *nf, int B, int32_t v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) nf[i] = v;
+}
+
+hipError_t launch_fill_nfound(hipStream_t s, int32_t *nf, int B, int32_t v) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_nfound_kernel, dim3((B + 255) / 256), dim3(256), 0, s, nf, B, v);
+    return hipGetLastError();
 }
 
 hipError_t launch_merge(hipStream_t s, const void *ids, size_t ids_stride, const void *dists, size_t dists_stride,

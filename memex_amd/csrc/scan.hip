@@ -48,7 +48,7 @@ constexpr uint32_t kScaleOff = kTileOff + 2 * kTileBytes;  // per-tile 1/|c| rin
 static_assert(kScaleOff + kScaleRing * kTileRows * 4 == kScanLdsBytes, "LDS layout");
 static_assert(kPrefetch == kNumSlots && kNumSlots == 8, "waits below assume an 8-slot ring, all in flight");
 
-template <int KC, int TAG>
+template <int KC, int MODE>
 __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -65,12 +65,13 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
 #pragma unroll
         for (int i = 0; i < KC * 8; ++i) qf[i] = src[(size_t)i * 64];
     }
-    const float theta = p.theta[wave * 32 + m];
+    const float theta = MODE == 1 ? p.theta[wave * 32 + m] : 0.0f;
 
-    // ---- tiles of this workgroup: t0, t0 + grid, ...
+    // ---- tiles of this workgroup: tile_begin + (blockIdx + i*grid) * tile_stride
     const uint32_t grid = gridDim.x;
-    const uint32_t t0 = p.tile_begin + blockIdx.x;
-    const uint32_t nT = (t0 < p.tile_end) ? (p.tile_end - t0 + grid - 1) / grid : 0;
+    const uint32_t t0 = p.tile_begin + blockIdx.x * p.tile_stride;
+    const uint32_t tstep = grid * p.tile_stride;
+    const uint32_t nT = (t0 < p.tile_end) ? (p.tile_end - t0 + tstep - 1) / tstep : 0;
     const uint32_t total = nT * KC;  // slots this workgroup consumes
     const uint32_t rowbytes = p.ds * 4;
 
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     uint32_t nx = 0, nx_ti = 0, nx_kc = 0, nx_rp = 0;  // next slot to issue (all wave-uniform)
     auto issue_next = [&]() {
         if (nx >= total) return;
-        const uint32_t t = t0 + nx_ti * grid;
+        const uint32_t t = t0 + nx_ti * tstep;
         const char *base = reinterpret_cast<const char *>(p.x) + (size_t)t * kTileRows * rowbytes;
         __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, kTileRows * rowbytes, 0x00020000);
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     Cand *mybuf = p.lane_buf + ((size_t)tid * gridDim.x + blockIdx.x) * kLaneCap;
     uint32_t cnt = 0;
     uint32_t ovf = 0;
+    float best = -INFINITY;  // MODE 0 (sample): running maximum of this lane's scores (scan16.hip)
 
     // ---- prologue: fill the ring, convert slot 0
 #pragma unroll 1
@@ -222,10 +224,11 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         for (int r = 0; r < 16; ++r) {
             const f32x4 sv = (r >> 2) == 0 ? s0 : (r >> 2) == 1 ? s1 : (r >> 2) == 2 ? s2 : s3;
             v[r] = acc[r] * sv[r & 3];
+            if (MODE == 0) best = fmaxf(best, v[r]);  // NaN (zero-norm row) is dropped: only weakens the bound
             any |= !(v[r] < theta);  // NaN (zero-norm row: 0 * inf) passes on purpose
         }
-        if (__builtin_amdgcn_ballot_w64(any) != 0) {
-            const uint32_t rowb = (t0 + ti * grid) * kTileRows + 4 * h;
+        if (MODE == 1 && __builtin_amdgcn_ballot_w64(any) != 0) {
+            const uint32_t rowb = (t0 + ti * tstep) * kTileRows + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
@@ -244,13 +247,17 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         }
     }
 
+    if (MODE == 0) {
+        p.lane_max[(size_t)tid * gridDim.x + blockIdx.x] = best;
+        return;
+    }
     p.lane_cnt[(size_t)tid * gridDim.x + blockIdx.x] = cnt;
     if (ovf) p.overflow[wave * 32 + m] = 1;
 }
 
-template <int KC, int TAG>
+template <int KC, int MODE>
 static hipError_t setup_one() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<KC, TAG>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<KC, MODE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kScanLdsBytes);
 }
 
@@ -265,24 +272,24 @@ hipError_t scan_setup() {
 }
 
 template <int KC>
-static hipError_t launch_kc(hipStream_t s, bool main_stage, int nwg, const ScanParams &p) {
-    if (main_stage)
+static hipError_t launch_kc(hipStream_t s, bool collect, int nwg, const ScanParams &p) {
+    if (collect)
         hipLaunchKernelGGL((scan_kernel<KC, 1>), dim3(nwg), dim3(kScanThreads), kScanLdsBytes, s, p);
     else
         hipLaunchKernelGGL((scan_kernel<KC, 0>), dim3(nwg), dim3(kScanThreads), kScanLdsBytes, s, p);
     return hipGetLastError();
 }
 
-// TAG 1 ("main") is the launch that covers the bulk of the corpus; it is a distinct symbol so
-// that rocprofv3 --stats averages it separately from the short warm-up stages (TAG 0).
-hipError_t launch_scan(hipStream_t s, int kc, bool main_stage, int nwg, const ScanParams &p) {
+// MODE 1 (collect) is the launch that covers the corpus; MODE 0 is the short sample launch.  They are
+// distinct symbols, so rocprofv3 --stats averages them separately.
+hipError_t launch_scan(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p) {
     switch (kc) {
-        case 1: return launch_kc<1>(s, main_stage, nwg, p);
-        case 2: return launch_kc<2>(s, main_stage, nwg, p);
-        case 3: return launch_kc<3>(s, main_stage, nwg, p);
-        case 4: return launch_kc<4>(s, main_stage, nwg, p);
-        case 5: return launch_kc<5>(s, main_stage, nwg, p);
-        case 6: return launch_kc<6>(s, main_stage, nwg, p);
+        case 1: return launch_kc<1>(s, collect, nwg, p);
+        case 2: return launch_kc<2>(s, collect, nwg, p);
+        case 3: return launch_kc<3>(s, collect, nwg, p);
+        case 4: return launch_kc<4>(s, collect, nwg, p);
+        case 5: return launch_kc<5>(s, collect, nwg, p);
+        case 6: return launch_kc<6>(s, collect, nwg, p);
         default: return hipErrorInvalidValue;
     }
 }

@@ -18,11 +18,20 @@
 //      last tile the descriptor's num_records is 0 and the DMA touches no memory.
 //   2. s_waitcnt vmcnt(13) + one s_barrier make the next slot visible to all waves.
 //   3. every wave multiplies the slot against its own 32 queries (register-resident B fragments):
-//      8 v_mfma_f32_32x32x16_bf16 on two alternating accumulator chains, each preceded by ONE
-//      conflict-free ds_read_b128 of the NEXT slot's fragment (register double buffer), so LDS reads,
-//      DMA issue and scalar bookkeeping all issue in the shadow of the MFMA pipe.
-// Epilogue per 32-row tile: compare with the query's pass threshold, append survivors to a
-// lane-private buffer.
+//      8 v_mfma_f32_32x32x16_bf16, each followed by ONE conflict-free ds_read_b128 that refills the
+//      fragment register it just consumed with the fragment R k-steps ahead (register ring, R = 8
+//      for dim_pad <= 512, R = 4 above: the B fragments of 768 dims take 192 of the 256 VGPRs), so
+//      LDS reads, DMA issue and scalar bookkeeping all issue in the shadow of the MFMA pipe.
+// Epilogue per 32-row tile, by MODE:
+//   MODE 1 (collect): compare with the query's pass threshold, append survivors to a lane-private
+//                     buffer.
+//   MODE 0 (sample):  keep only the lane's running maximum.  The k-th largest of a query's lane
+//                     maxima (2 lanes per workgroup) is a certified lower bound of its k-th best
+//                     approximate score: index.hip turns it into the pass threshold of the collect
+//                     launch (theta_kernel), so no score of the sample is ever written to HBM.
+// Tiles are dealt round-robin: workgroup b handles tiles tile_begin + (b + i*grid)*tile_stride.
+// tile_stride > 1 spreads the sample evenly over the corpus (a contiguous head of the corpus can be
+// unrepresentative: the first documents ingested).
 //
 // Measured (10M x 384, B = 256; scripts/scan16_ubench.hip): 726 shader cycles per slot against 512 of
 // pure MFMA issue per SIMD; DMA alone 1.13 ms (6.8 TB/s), compute alone 1.15 ms at 2.14 GHz, together
@@ -54,13 +63,17 @@ static_assert(kRing16 == 16, "waits below assume a 16-slot ring with 15 slots in
 #define MX_SCAN16_ABLATE 0
 #endif
 
-template <int KC, int TAG>
+#ifndef MX_SCAN16_AUX
+#define MX_SCAN16_AUX 2 /* nt */
+#endif
+
+template <int KC, int MODE>
 __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParams p) {
-    // KC <= 4: the slot's 8 fragment reads are issued one slot ahead, one per MFMA of the current
-    // slot (register double buffer, two accumulator chains).  KC >= 5 has no registers left for
-    // that (B fragments alone are 160-192 VGPRs): read, then multiply.
-    constexpr bool PIPE = KC <= 4;
-    constexpr bool DUAL = KC <= 5;
+    // Fragment ring: the A fragment of k-step f lives in ring[f % R] and is re-read R k-steps ahead
+    // right after the MFMA that consumed it.  8 % R == 0, so the ring index of a k-step does not
+    // depend on the slot and is a compile-time constant everywhere.
+    constexpr int R = KC <= 4 ? 8 : 4;
+    constexpr bool DUAL = KC <= 4;  // two accumulator chains (16 more VGPRs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
 #ifdef MX_SCAN16_CLOCK
@@ -79,12 +92,14 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
 #pragma unroll
         for (int i = 0; i < KC * 8; ++i) qf[i] = src[(size_t)i * 64];
     }
-    const float theta = p.theta[wave * 32 + m];
+    const float theta = MODE == 1 ? p.theta[wave * 32 + m] : 0.0f;
 
-    // ---- tiles of this workgroup: t0, t0 + grid, ...
+    // ---- tiles of this workgroup: tile_begin + (blockIdx + i*grid) * tile_stride
     const uint32_t grid = gridDim.x;
-    const uint32_t t0 = p.tile_begin + blockIdx.x;
-    const uint32_t nT = (t0 < p.tile_end) ? (p.tile_end - t0 + grid - 1) / grid : 0;
+    const uint32_t stride = p.tile_stride;
+    const uint32_t t0 = p.tile_begin + blockIdx.x * stride;
+    const uint32_t tstep = grid * stride;
+    const uint32_t nT = (t0 < p.tile_end) ? (p.tile_end - t0 + tstep - 1) / tstep : 0;
     const uint32_t tilebytes = p.ds * (kTileRows * 2);
 
     const uint32_t voff = (uint32_t)wave * 1024u + (uint32_t)lane * 16u;  // this lane's 16 B of a slot
@@ -97,7 +112,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t is_ti = 0;  // tiles opened so far
     auto open_tile = [&]() {
-        const char *base = reinterpret_cast<const char *>(p.xh) + (size_t)(t0 + is_ti * grid) * tilebytes;
+        const char *base = reinterpret_cast<const char *>(p.xh) + (size_t)(t0 + is_ti * tstep) * tilebytes;
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, is_ti < nT ? tilebytes : 0u, 0x00020000);
         ++is_ti;
     };
@@ -105,74 +120,62 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
 #if MX_SCAN16_ABLATE != 4
         if (kci == 0) open_tile();
         char *dst = smem + __builtin_amdgcn_readfirstlane(ring_pos * kSlot16Bytes + wave * 1024);
-        MX_LDS_DMA16(rsrc, dst, voff, kci * kSlot16Bytes, 2 /*nt*/);
+        MX_LDS_DMA16(rsrc, dst, voff, kci * kSlot16Bytes, MX_SCAN16_AUX);
 #endif
     };
 
     Cand *mybuf = p.lane_buf + ((size_t)tid * gridDim.x + blockIdx.x) * kLaneCap;
     uint32_t cnt = 0;
     uint32_t ovf = 0;
+    float best = -INFINITY;  // MODE 0: running maximum of this lane's scores
 
-    // ---- prologue: slots 0 .. 14 in flight
+    // ---- prologue: slots 0 .. 14 in flight, fragments of k-steps 0 .. R-1 in the ring
 #pragma unroll
     for (int i = 0; i < kRing16 - 1; ++i) issue(i % KC, (uint32_t)i);
 
-    bf16x8 a[PIPE ? 2 : 1][8];  // A fragments: slot being multiplied (+ the next one when PIPE)
-    if (PIPE) {
-        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // slot 0 landed (14 newer may be in flight)
-        __builtin_amdgcn_s_barrier();
+    bf16x8 a[R];
+    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // slot 0 landed (14 newer may be in flight)
+    __builtin_amdgcn_s_barrier();
+#if MX_SCAN16_ABLATE != 1
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) a[0][ks] = *reinterpret_cast<const bf16x8 *>(smem + lane16 + ks * 1024);
-    }
+    for (int ks = 0; ks < R; ++ks) a[ks] = *reinterpret_cast<const bf16x8 *>(smem + lane16 + ks * 1024);
+#endif
 
     uint32_t rp = 0;  // ring position of the slot being multiplied
-    auto tile = [&](uint32_t ti, auto par0) {
-        constexpr int P0 = decltype(par0)::value;  // fragment-buffer parity of the tile's first slot
+#pragma unroll 1
+    for (uint32_t ti = 0; ti < nT; ++ti) {
         f32x16 acc, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f, acc1[r] = 0.0f;
 
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            const int cur = PIPE ? ((P0 + kc) & 1) : 0;
             const uint32_t rp1 = (rp + 1) & (kRing16 - 1);
             const uint32_t rpi = (rp + kRing16 - 1) & (kRing16 - 1);  // ring position of slot j+15 = of slot j-1
-            // PIPE: slot j+1 must have landed; slots 0 .. j+14 are issued -> 13 newer may be in flight.
-            // else: slot j itself; 14 newer.
-            if (PIPE) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-            // One barrier per slot: every wave's piece of the awaited slot is in LDS, and every wave has
-            // finished the fragment reads of slot j-1, whose ring position is refilled below.
+            // Slot j+1 (the ring reads ahead into it) must have landed; slots 0 .. j+14 are issued ->
+            // 13 newer may be in flight.
+            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            // One barrier per slot: every wave's piece of slot j+1 is in LDS, and every wave has
+            // consumed (MFMA issued) its fragments of slot j-1, whose ring position is refilled below.
             __builtin_amdgcn_s_barrier();
-            const uint32_t fb = (PIPE ? rp1 : rp) * kSlot16Bytes + lane16;
-            if (!PIPE) {
-#if MX_SCAN16_ABLATE != 1
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) a[0][ks] = *reinterpret_cast<const bf16x8 *>(smem + fb + ks * 1024);
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-                issue((kc + kRing16 - 1) % KC, rpi);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            const uint32_t fb0 = rp * kSlot16Bytes + lane16, fb1 = rp1 * kSlot16Bytes + lane16;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                if constexpr (PIPE) {
-                    // one LDS read of the next slot and (once) the DMA issue in front of each MFMA: they
-                    // issue while the MFMA pipe works on the previous instruction
-#if MX_SCAN16_ABLATE != 1
-                    a[cur ^ 1][ks] = *reinterpret_cast<const bf16x8 *>(smem + fb + ks * 1024);
-#endif
-                    if (ks == 1) issue((kc + kRing16 - 1) % KC, rpi);
-                }
 #if MX_SCAN16_ABLATE == 1 || MX_SCAN16_ABLATE == 2
-                asm volatile("" ::"v"(a[cur][ks]));
+                asm volatile("" ::"v"(a[ks % R]));
 #else
                 if (DUAL && (ks & 1))
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ks], qf[kc * 8 + ks], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % R], qf[kc * 8 + ks], acc1, 0, 0, 0);
                 else
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ks], qf[kc * 8 + ks], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % R], qf[kc * 8 + ks], acc, 0, 0, 0);
 #endif
-                if (PIPE) __builtin_amdgcn_sched_barrier(0);
+                // refill the register just consumed with the fragment R k-steps ahead (this slot or
+                // the next one): the read issues while the MFMA pipe works on the instruction above
+#if MX_SCAN16_ABLATE != 1
+                a[ks % R] = *reinterpret_cast<const bf16x8 *>(smem + (ks + R < 8 ? fb0 : fb1) + ((ks + R) & 7) * 1024);
+#endif
+                if (ks == 1) issue((kc + kRing16 - 1) % KC, rpi);
+                __builtin_amdgcn_sched_barrier(0);
             }
             rp = rp1;
         }
@@ -180,45 +183,49 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
         // ---- tile epilogue: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*h.  The copy
         // holds c/|c|, so the accumulator already is the approximate cosine (NaN for a zero-norm row).
         float v[16];
-        bool any = false;
+        if (MODE == 0) {
+            // sample: only full tiles are sampled (index.hip), so every row is a real row.  fmaxf drops
+            // NaN (zero-norm rows): ignoring a row only weakens the bound.
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = DUAL ? acc[r] + acc1[r] : acc[r];
-            any |= !(v[r] < theta);  // NaN passes on purpose
-        }
-        if (__builtin_amdgcn_ballot_w64(any) != 0) {
-            const uint32_t rowb = (t0 + ti * grid) * kTileRows + 4 * h;
+            for (int r = 0; r < 16; ++r) best = fmaxf(best, DUAL ? acc[r] + acc1[r] : acc[r]);
+        } else {
+            bool any = false;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
-                if (!(v[r] < theta) && (uint64_t)row < p.n_rows) {
-                    if (cnt < (uint32_t)kLaneCap) {
-                        Cand c;
-                        c.score = v[r];
-                        c.row = row;
-                        mybuf[cnt] = c;
-                        ++cnt;
-                    } else {
-                        ovf = 1;
+                v[r] = DUAL ? acc[r] + acc1[r] : acc[r];
+                any |= !(v[r] < theta);  // NaN passes on purpose
+            }
+            if (__builtin_amdgcn_ballot_w64(any) != 0) {
+                const uint32_t rowb = (t0 + ti * tstep) * kTileRows + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
+                    if (!(v[r] < theta) && (uint64_t)row < p.n_rows) {
+                        if (cnt < (uint32_t)kLaneCap) {
+                            Cand c;
+                            c.score = v[r];
+                            c.row = row;
+                            mybuf[cnt] = c;
+                            ++cnt;
+                        } else {
+                            ovf = 1;
+                        }
                     }
                 }
             }
         }
-    };
-
-    // fragment-buffer parity alternates per slot: with odd KC, tiles alternate their starting parity
-#pragma unroll 1
-    for (uint32_t ti = 0; ti < nT; ti += 2) {
-        tile(ti, std::integral_constant<int, 0>{});
-        if (ti + 1 < nT) tile(ti + 1, std::integral_constant<int, KC & 1>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // dead DMA ops must not outlive the workgroup's LDS
 
 #ifdef MX_SCAN16_CLOCK
     cnt = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);
 #endif
-    p.lane_cnt[(size_t)tid * gridDim.x + blockIdx.x] = cnt;
-    if (ovf) p.overflow[wave * 32 + m] = 1;
+    if (MODE == 0) {
+        p.lane_max[(size_t)tid * gridDim.x + blockIdx.x] = best;
+    } else {
+        p.lane_cnt[(size_t)tid * gridDim.x + blockIdx.x] = cnt;
+        if (ovf) p.overflow[wave * 32 + m] = 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -226,11 +233,15 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void shadow_kernel(const float *__restrict__ x, const float *__restrict__ scale,
                                                      int ds, uint32_t tile0, uint32_t tile1,
-                                                     bf16x8 *__restrict__ xh) {
+                                                     bf16x8 *__restrict__ xh, uint32_t *__restrict__ ec_max) {
+    __shared__ float s_r2[kTileRows];  // per row: |bf16(c/|c|) - c/|c||^2, the row's share of the scan's error bound
     const uint32_t frags = (uint32_t)(ds / 16) * 64u;  // fragments per tile
+    float worst = 0.0f;
     for (uint32_t t = tile0 + blockIdx.x; t < tile1; t += gridDim.x) {
         const float *xt = x + (size_t)t * kTileRows * ds;
         bf16x8 *ot = xh + (size_t)t * frags;
+        if (threadIdx.x < kTileRows) s_r2[threadIdx.x] = 0.0f;
+        __syncthreads();
         for (uint32_t f = threadIdx.x; f < frags; f += 256) {
             const uint32_t ks = f >> 6, l = f & 63, mm = l & 31, hh = l >> 5;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(xt + (size_t)mm * ds + ks * 16 + hh * 8);
@@ -240,22 +251,37 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float *__restrict__ x
             o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
             o[4] = (__bf16)hi[0]; o[5] = (__bf16)hi[1]; o[6] = (__bf16)hi[2]; o[7] = (__bf16)hi[3];
             ot[f] = o;
+            float r2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = (float)o[i] - lo[i], b = (float)o[4 + i] - hi[i];
+                r2 += a * a + b * b;
+            }
+            if (r2 == r2) atomicAdd(&s_r2[mm], r2);  // NaN: zero-norm row, handled exactly (no error)
         }
+        __syncthreads();
+        if (threadIdx.x < kTileRows) worst = fmaxf(worst, s_r2[threadIdx.x]);
+        __syncthreads();
+    }
+    if (threadIdx.x < kTileRows) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
+        if (threadIdx.x == 0 && worst > 0.0f) atomicMax(ec_max, __float_as_uint(sqrtf(worst)));
     }
 }
 
 hipError_t launch_shadow(hipStream_t s, const float *x, const float *scale, int ds, uint32_t tile0, uint32_t tile1,
-                         void *xh) {
+                         void *xh, uint32_t *ec_max) {
     if (tile1 <= tile0) return hipSuccess;
     const uint32_t blocks = tile1 - tile0 < 16384u ? tile1 - tile0 : 16384u;
     hipLaunchKernelGGL(shadow_kernel, dim3(blocks), dim3(256), 0, s, x, scale, ds, tile0, tile1,
-                       reinterpret_cast<bf16x8 *>(xh));
+                       reinterpret_cast<bf16x8 *>(xh), ec_max);
     return hipGetLastError();
 }
 
-template <int KC, int TAG>
+template <int KC, int MODE>
 static hipError_t setup16_one() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16_kernel<KC, TAG>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16_kernel<KC, MODE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kScan16LdsBytes);
 }
 
@@ -270,22 +296,22 @@ hipError_t scan16_setup() {
 }
 
 template <int KC>
-static hipError_t launch16_kc(hipStream_t s, bool main_stage, int nwg, const ScanParams &p) {
-    if (main_stage)
+static hipError_t launch16_kc(hipStream_t s, bool collect, int nwg, const ScanParams &p) {
+    if (collect)
         hipLaunchKernelGGL((scan16_kernel<KC, 1>), dim3(nwg), dim3(kScanThreads), kScan16LdsBytes, s, p);
     else
         hipLaunchKernelGGL((scan16_kernel<KC, 0>), dim3(nwg), dim3(kScanThreads), kScan16LdsBytes, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_scan16(hipStream_t s, int kc, bool main_stage, int nwg, const ScanParams &p) {
+hipError_t launch_scan16(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p) {
     switch (kc) {
-        case 1: return launch16_kc<1>(s, main_stage, nwg, p);
-        case 2: return launch16_kc<2>(s, main_stage, nwg, p);
-        case 3: return launch16_kc<3>(s, main_stage, nwg, p);
-        case 4: return launch16_kc<4>(s, main_stage, nwg, p);
-        case 5: return launch16_kc<5>(s, main_stage, nwg, p);
-        case 6: return launch16_kc<6>(s, main_stage, nwg, p);
+        case 1: return launch16_kc<1>(s, collect, nwg, p);
+        case 2: return launch16_kc<2>(s, collect, nwg, p);
+        case 3: return launch16_kc<3>(s, collect, nwg, p);
+        case 4: return launch16_kc<4>(s, collect, nwg, p);
+        case 5: return launch16_kc<5>(s, collect, nwg, p);
+        case 6: return launch16_kc<6>(s, collect, nwg, p);
         default: return hipErrorInvalidValue;
     }
 }

@@ -18,14 +18,47 @@ def _ptr(a: np.ndarray):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _caller_stream(t) -> ctypes.c_void_p | None:
+    """The HIP stream torch is enqueueing work for tensor ``t`` on (None when torch is not in use)."""
+    try:
+        import torch
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    except ImportError:
+        pass
+    return None
+
+
 class FlatIndex:
-    def __init__(self, dim: int, key: str | None = None, device: int = 0):
+    """``devices=None``: one index on ``device``.  ``devices=[...]``: the in-library sharded index
+    (``mx_index_open_sharded``): rows dealt to the listed devices in blocks of ``block_rows``, local
+    scans in parallel, one exchange of the per-shard top-k, merge on ``devices[0]``."""
+
+    def __init__(self, dim: int, key: str | None = None, device: int = 0, devices=None, block_rows: int = 0):
         h = ctypes.c_void_p()
-        check(lib().mx_index_open(key.encode() if key else None, int(dim), int(device), ctypes.byref(h)))
+        if devices is None:
+            check(lib().mx_index_open(key.encode() if key else None, int(dim), int(device), ctypes.byref(h)))
+        else:
+            devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            check(lib().mx_index_open_sharded(key.encode() if key else None, int(dim), len(devices), devs,
+                                              int(block_rows), ctypes.byref(h)))
+            device = int(devices[0])
         self._h = h
         self.dim = int(dim)
         self.device = int(device)
         self.key = key
+
+    @property
+    def n_shards(self) -> int:
+        n = ctypes.c_int(0)
+        check(lib().mx_index_n_shards(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def wait_stream(self, stream) -> None:
+        """Order the next operation on this index after everything enqueued on ``stream`` (a raw
+        hipStream_t as int / c_void_p, or None for the default stream).  See the stream contract in
+        include/memex_hip.h; the ``*_device`` methods call this with torch's current stream."""
+        check(lib().mx_index_wait_stream(self._h, stream))
 
     # -- lifetime -------------------------------------------------------------------------
     def close(self) -> None:
@@ -91,6 +124,9 @@ class FlatIndex:
         """Append rows held in HBM (contiguous f32 [n, dim] tensor on this index's device)."""
         n = int(t.shape[0])
         first = ctypes.c_uint64(0)
+        st = _caller_stream(t)
+        if st is not None:
+            self.wait_stream(st)
         check(lib().mx_index_add_device(self._h, ctypes.c_void_p(t.data_ptr()), n, ctypes.byref(first)))
         return int(first.value)
 
@@ -117,6 +153,9 @@ class FlatIndex:
         """All arguments are device tensors: q f32 [B,dim]; ids i64/u64 [B,k]; scores, dists f32 [B,k];
         n_found i32 [B].  Blocks until the results are in HBM."""
         B = int(q.shape[0])
+        st = _caller_stream(q)
+        if st is not None:  # q and the (possibly just zero-filled) outputs were produced on torch's stream
+            self.wait_stream(st)
         check(lib().mx_index_search_device(self._h, ctypes.c_void_p(q.data_ptr()), B, int(k),
                                            ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(scores.data_ptr()),
                                            ctypes.c_void_p(dists.data_ptr()) if dists is not None else None,

@@ -122,28 +122,84 @@ class VectorStore(abc.ABC):
     def search(self, vec: Sequence[float], limit: int) -> List[VectorSearchResult]: ...
 
 
+# Process-wide registry of resident stores, keyed by (real storage path, device).  The reference builds
+# a store per request / per task (handlers.rs:61-63, worker/lib.rs:190) and pays a full reload each
+# time (storage/mod.rs:115-116); here a collection that is already in HBM is attached in O(1): the
+# SAME store object (GPU index + id map) is handed out as long as the files it last wrote / read are
+# unchanged on disk.  (The Rust shim keeps the equivalent `HashMap<PathBuf, Arc<Mutex<HipFlatStore>>>`,
+# INTEGRATION.md.)
+_RESIDENT: Dict[Tuple[str, int], "HipFlatStore"] = {}
+_RESIDENT_MU = threading.Lock()
+
+
+def _file_sig(path: str):
+    try:
+        st = os.stat(path)
+        return (st.st_mtime_ns, st.st_size)
+    except OSError:
+        return None
+
+
+def evict_resident(storage_path: str | None = None) -> None:
+    """Drop resident stores (all, or the one for ``storage_path``): frees their HBM once unused."""
+    with _RESIDENT_MU:
+        for key in [k for k in _RESIDENT if storage_path is None or k[0] == os.path.realpath(str(storage_path))]:
+            st = _RESIDENT.pop(key)
+            if st._index is not None:
+                st._index.close()
+                st._index = None
+
+
 @dataclass
 class HipFlatStore(VectorStore):
     """Drop-in for ``HnswStore``: same id map, same score formula, exact search on the GPU."""
     storage_path: str
     device: int = 0
+    devices: Sequence[int] | None = None   # several GPUs: the in-library sharded index (mx_index_open_sharded)
     _id_map: Dict[int, str] = field(default_factory=dict)
     _index: FlatIndex | None = None
     _dim: int | None = None
+    _lock: threading.RLock = field(default_factory=threading.RLock, repr=False, compare=False)
+    _meta_sig: tuple | None = None          # (mtime_ns, size) of vectors.meta.json as last written / read
+    _meta_ids: int = 0                      # ids that file holds
 
     # -- construction (local.rs:95-141) ----------------------------------------------------
     @classmethod
-    def new(cls, storage_path: str, device: int = 0) -> "HipFlatStore":
-        return cls(storage_path=str(storage_path), device=device)
+    def new(cls, storage_path: str, device: int = 0, devices: Sequence[int] | None = None) -> "HipFlatStore":
+        store = cls(storage_path=str(storage_path), device=device, devices=devices)
+        with _RESIDENT_MU:
+            old = _RESIDENT.pop(store._rkey(), None)
+            if old is not None and old._index is not None:
+                old._index.close()
+                old._index = None
+            _RESIDENT[store._rkey()] = store
+        return store
+
+    def _rkey(self) -> Tuple[str, int]:
+        return (os.path.realpath(self.storage_path), int(self.device))
 
     @staticmethod
     def has_store(store_path: str) -> bool:
         return os.path.exists(os.path.join(str(store_path), META_FILE))  # local.rs:110-113
 
     @classmethod
-    def load(cls, store_path: str, device: int = 0) -> "HipFlatStore":
+    def load(cls, store_path: str, device: int = 0, devices: Sequence[int] | None = None) -> "HipFlatStore":
         store_path = str(store_path)
         meta = os.path.join(store_path, META_FILE)
+        probe = cls(storage_path=store_path, device=device, devices=devices)
+        with _RESIDENT_MU:
+            res = _RESIDENT.get(probe._rkey())
+        if res is not None:
+            with res._lock:
+                if res._meta_sig is not None and res._meta_sig == _file_sig(meta) and len(res._id_map) == res._meta_ids:
+                    if not res._id_map:
+                        return res
+                    try:
+                        res._index.load(store_path)      # O(1) when vectors.mxflat is what this index last wrote / read
+                    except _lib.MemexHipError as e:
+                        _raise_from(e)
+                    if len(res._index) == len(res._id_map):
+                        return res
         try:
             with open(meta, "r", encoding="utf-8") as f:
                 raw = json.load(f)
@@ -151,11 +207,13 @@ class HipFlatStore(VectorStore):
             raise FileIOError(str(e)) from e
         except ValueError as e:
             raise SerdeError(str(e)) from e
-        store = cls(storage_path=store_path, device=device)
+        store = probe
         try:
             store._id_map = {int(k): str(v) for k, v in raw.items()}
         except (AttributeError, ValueError) as e:
             raise SerdeError(str(e)) from e
+        store._meta_sig = _file_sig(meta)
+        store._meta_ids = len(store._id_map)
         if store._id_map:
             try:
                 if not FlatIndex.has_store(store_path):
@@ -167,26 +225,55 @@ class HipFlatStore(VectorStore):
                 _raise_from(e)
             if len(store._index) != len(store._id_map):
                 raise FileIOError(f"{store_path}: {len(store._index)} vectors vs {len(store._id_map)} ids")
+        with _RESIDENT_MU:
+            old = _RESIDENT.get(store._rkey())
+            _RESIDENT[store._rkey()] = store
+        if old is not None and old is not store and old._index is not None and old._index is not store._index:
+            old._index.close()
+            old._index = None
         return store
 
     def save(self, store_path: str | None = None) -> None:
-        """local.rs:143-165: vectors + ``vectors.meta.json`` (``{"<usize>": "<_id>"}``)."""
+        """local.rs:143-165: vectors + ``vectors.meta.json`` (``{"<usize>": "<_id>"}``).  The reference
+        calls this after EVERY insert (local.rs:67) and rewrites both files; here a save into the
+        store's own directory appends: the index adds the new rows to ``vectors.mxflat``
+        (``mx_index_save``) and the JSON object gets the new ``"id": "_id"`` pairs spliced in before
+        its closing brace -- same file format, O(new rows) per insert."""
         store_path = str(store_path or self.storage_path)
-        try:
-            os.makedirs(store_path, exist_ok=True)
-            if self._index is not None:
-                self._index.save(store_path)
-            doc = {str(k): v for k, v in self._id_map.items()}
-            with open(os.path.join(store_path, META_FILE), "w", encoding="utf-8") as f:
-                json.dump(doc, f)
-        except _lib.MemexHipError as e:
-            raise SaveError(e.msg) from e
-        except OSError as e:
-            raise FileIOError(str(e)) from e
+        with self._lock:
+            try:
+                os.makedirs(store_path, exist_ok=True)
+                if self._index is not None:
+                    self._index.save(store_path)
+                meta = os.path.join(store_path, META_FILE)
+                own = os.path.realpath(store_path) == os.path.realpath(self.storage_path)
+                n = len(self._id_map)
+                if own and self._meta_sig is not None and self._meta_sig == _file_sig(meta) and 0 < self._meta_ids <= n:
+                    if self._meta_ids < n:
+                        tail = ",".join(f"{json.dumps(str(i))}: {json.dumps(self._id_map[i])}"
+                                        for i in range(self._meta_ids + 1, n + 1))
+                        with open(meta, "r+b") as f:
+                            f.seek(-1, os.SEEK_END)
+                            if f.read(1) != b"}":
+                                raise OSError(f"{meta}: unexpected tail")
+                            f.seek(-1, os.SEEK_END)
+                            f.write((", " + tail + "}").encode("utf-8"))
+                else:
+                    with open(meta, "w", encoding="utf-8") as f:
+                        json.dump({str(k): v for k, v in self._id_map.items()}, f)
+                if own:
+                    self._meta_sig = _file_sig(meta)
+                    self._meta_ids = n
+            except _lib.MemexHipError as e:
+                raise SaveError(e.msg) from e
+            except OSError as e:
+                raise FileIOError(str(e)) from e
 
     def _open(self, dim: int) -> None:
+        # keyed by the collection's path: every handle on this collection shares ONE resident GPU index
+        key = f"{os.path.realpath(self.storage_path)}@{'+'.join(map(str, self.devices)) if self.devices else self.device}"
         try:
-            self._index = FlatIndex(dim, key=None, device=self.device)
+            self._index = FlatIndex(dim, key=key, device=self.device, devices=self.devices)
         except _lib.MemexHipError as e:
             _raise_from(e)
         self._dim = dim
@@ -197,37 +284,48 @@ class HipFlatStore(VectorStore):
         raise NotImplementedError("single-point delete is not supported (reference: unimplemented!())")
 
     def delete_all(self) -> None:
-        for name in (META_FILE,):
-            p = os.path.join(self.storage_path, name)
-            if os.path.exists(p):
-                os.remove(p)
-        try:
-            FlatIndex.remove_files(self.storage_path)
-            if self._index is not None:
-                self._index.clear()
-        except _lib.MemexHipError as e:
-            raise DeleteError(e.msg) from e
-        self._id_map.clear()
+        with self._lock:
+            for name in (META_FILE,):
+                p = os.path.join(self.storage_path, name)
+                if os.path.exists(p):
+                    os.remove(p)
+            try:
+                FlatIndex.remove_files(self.storage_path)
+                if self._index is not None:
+                    self._index.clear()
+            except _lib.MemexHipError as e:
+                raise DeleteError(e.msg) from e
+            self._id_map.clear()
+            self._meta_sig = None
+            self._meta_ids = 0
 
     def bulk_insert(self, data: Sequence[VectorData]) -> None:
-        """local.rs:55-60 semantics (ids in order), one device transfer instead of a loop."""
+        """local.rs:55-69 semantics (ids in order, store persisted before returning), one device
+        transfer and one incremental save instead of a save per vector."""
         if not data:
             return
         rows = np.asarray([np.asarray(d.vector, dtype=np.float32) for d in data], dtype=np.float32)
         if rows.ndim != 2:
             raise InsertionError("vectors of one bulk_insert must share a dimension")
-        if self._index is None:
-            self._open(rows.shape[1])
-        if rows.shape[1] != self._dim:
-            raise InsertionError(f"vector dimension {rows.shape[1]} != store dimension {self._dim}")
-        try:
-            first = self._index.add(rows)
-        except _lib.MemexHipError as e:
-            _raise_from(e, InsertionError)
-        next_id = len(self._id_map) + 1  # local.rs:63
-        assert first == next_id, (first, next_id)
-        for i, d in enumerate(data):
-            self._id_map[next_id + i] = str(d._id)
+        with self._lock:
+            if self._index is None:
+                self._open(rows.shape[1])
+                if len(self._index) != len(self._id_map):   # a stale resident index under this key
+                    self._index.clear()
+            if rows.shape[1] != self._dim:
+                raise InsertionError(f"vector dimension {rows.shape[1]} != store dimension {self._dim}")
+            try:
+                first = self._index.add(rows)
+            except _lib.MemexHipError as e:
+                _raise_from(e, InsertionError)
+            next_id = len(self._id_map) + 1  # local.rs:63
+            assert first == next_id, (first, next_id)
+            for i, d in enumerate(data):
+                self._id_map[next_id + i] = str(d._id)
+            try:
+                self.save()  # local.rs:67 `let _ = self.save(..)`: errors are ignored there too
+            except VectorStoreError:
+                pass
 
     def insert(self, data: VectorData) -> None:
         self.bulk_insert([data])
@@ -243,11 +341,12 @@ class HipFlatStore(VectorStore):
         except _lib.MemexHipError as e:
             _raise_from(e, SearchError)
         out: List[VectorSearchResult] = []
-        for j in range(int(nf[0])):
-            d_id = int(ids[0, j])
-            if d_id not in self._id_map:  # local.rs:80-83 panics here; we raise
-                raise SearchError("Internal inconsistency. Id from vector store not mapped.")
-            out.append((self._id_map[d_id], float(scores[0, j])))
+        with self._lock:
+            for j in range(int(nf[0])):
+                d_id = int(ids[0, j])
+                if d_id not in self._id_map:  # local.rs:80-83 panics here; we raise
+                    raise SearchError("Internal inconsistency. Id from vector store not mapped.")
+                out.append((self._id_map[d_id], float(scores[0, j])))
         return out
 
 
@@ -271,9 +370,10 @@ class VectorStorage:
             return self.client.search(query, limit)
 
 
-def get_vector_storage(uri: str, collection: str, device: int = 0) -> VectorStorage:
+def get_vector_storage(uri: str, collection: str, device: int = 0, devices: Sequence[int] | None = None) -> VectorStorage:
     """mod.rs:95-139.  ``hnsw://<dir>`` (the reference's file backend, now served from HBM) and
-    ``hip://<dir>`` select the GPU store; collections are folders under ``<dir>``."""
+    ``hip://<dir>`` select the GPU store; collections are folders under ``<dir>``.  Called per
+    request like the reference's; a collection that is already resident is attached, not reloaded."""
     try:
         scheme = urlparse(uri).scheme
     except ValueError:
@@ -286,7 +386,14 @@ def get_vector_storage(uri: str, collection: str, device: int = 0) -> VectorStor
             os.makedirs(storage, exist_ok=True)
         except OSError as e:
             raise FileIOError(str(e)) from e
-        store = HipFlatStore.load(storage, device) if HipFlatStore.has_store(storage) else HipFlatStore.new(storage, device)
+        if HipFlatStore.has_store(storage):
+            store = HipFlatStore.load(storage, device, devices)
+        else:
+            probe = HipFlatStore(storage_path=storage, device=device, devices=devices)
+            with _RESIDENT_MU:
+                res = _RESIDENT.get(probe._rkey())
+            # an empty resident store (created by an earlier request, nothing inserted yet) is reused
+            store = res if res is not None and not res._id_map else HipFlatStore.new(storage, device, devices)
         return VectorStorage(store)
     # opensearch+https:// is a remote-service client in the reference (mod.rs:122-133): out of scope
     raise Unsupported(uri)

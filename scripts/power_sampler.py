@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Samples package power and clocks of GPU 0 while another command runs (profiles/*_power_*.log).
+
+  python scripts/power_sampler.py OUT.log -- <command ...>
+
+Sources, both recorded when present: the amdgpu hwmon sysfs files (power1_average / power1_input in
+microwatts, freq1_input = sclk in Hz, freq2_input = mclk) at ~20 Hz, and one `rocm-smi --showpower
+--showclocks` text dump per second (slow: ~0.3 s per call).  Not product code."""
+import glob
+import os
+import subprocess
+import sys
+import threading
+import time
+
+
+def read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def main():
+    out_path = sys.argv[1]
+    cmd = sys.argv[sys.argv.index("--") + 1:]
+    hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+    stop = threading.Event()
+    lines = []
+    t0 = time.time()
+
+    def fast():
+        while not stop.is_set():
+            row = [f"{time.time() - t0:8.3f}"]
+            for h in hw[:1]:
+                for name in ("power1_average", "power1_input", "freq1_input", "freq2_input", "temp1_input"):
+                    v = read(os.path.join(h, name))
+                    if v is not None:
+                        row.append(f"{name}={v}")
+            pp = read(os.path.join(os.path.dirname(os.path.dirname(hw[0])), "pp_dpm_sclk")) if hw else None
+            if pp:
+                cur = [l for l in pp.splitlines() if l.endswith("*")]
+                row.append("pp_dpm_sclk=" + (cur[0] if cur else "?"))
+            lines.append("S " + " ".join(row))
+            time.sleep(0.05)
+
+    def slow():
+        while not stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "-d", "0"], capture_output=True, text=True, timeout=10)
+                keep = [l for l in r.stdout.splitlines() if ("Power" in l or "sclk" in l or "mclk" in l or "fclk" in l)]
+                lines.append(f"R {time.time() - t0:8.3f} " + " | ".join(k.strip() for k in keep))
+            except Exception as e:  # noqa
+                lines.append(f"R {time.time() - t0:8.3f} rocm-smi failed: {e!r}")
+            time.sleep(0.7)
+
+    th = [threading.Thread(target=fast, daemon=True), threading.Thread(target=slow, daemon=True)]
+    for t in th:
+        t.start()
+    time.sleep(0.5)  # idle baseline
+    lines.append(f"C {time.time() - t0:8.3f} start: {' '.join(cmd)}")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    lines.append(f"C {time.time() - t0:8.3f} end rc={r.returncode}")
+    time.sleep(0.5)
+    stop.set()
+    for t in th:
+        t.join(timeout=12)
+    with open(out_path, "w") as f:
+        f.write("# hwmon dirs: " + ",".join(hw) + "\n")
+        f.write("\n".join(lines) + "\n")
+        f.write("# ---- command stdout ----\n" + r.stdout + "\n# ---- command stderr ----\n" + r.stderr[-2000:] + "\n")
+    sys.stdout.write(r.stdout)
+    return r.returncode
+
+
+if __name__ == "__main__":
+    sys.exit(main())

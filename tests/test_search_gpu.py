@@ -151,9 +151,10 @@ def test_edge_zero_rows_zero_query_duplicates(oracle, lib_built):
         assert idx.stats().fallback_queries == 0
 
 
-def test_overflow_falls_back_to_exact_and_stays_bit_exact(oracle, lib_built):
-    """More near-identical rows than the candidate buffers hold: the AUTO path must detect it and
-    re-answer on the EXACT path, still bit-exact (lowest ids among the ties win)."""
+def test_many_exact_ties_are_ordered_in_the_finish_kernel(oracle, lib_built):
+    """6000 copies of one row, query = that row: every copy ties at dist 0 and the lowest ids win.
+    The candidates fit the lane buffers (consecutive tiles go to different workgroups), so the finish
+    kernel orders all of them by (dist, id) itself -- no rescan, no EXACT fallback."""
     from memex_amd.index import FlatIndex
     rng = np.random.default_rng(23)
     X = rng.standard_normal((60000, 384), dtype=np.float32)
@@ -163,7 +164,92 @@ def test_overflow_falls_back_to_exact_and_stays_bit_exact(oracle, lib_built):
     with FlatIndex(384) as idx:
         idx.add(X)
         _check(idx, X, Q, 10, oracle)
-        assert idx.stats().fallback_queries >= 1
+        st = idx.stats()
+        assert st.fallback_queries == 0 and st.retry_queries == 0
+
+
+def _rows_with_cosine(rng, q, cosines):
+    """Rows c with cos(q, c) = cosines[i] (up to f32 rounding): cos*q^ + sin*u, u random, u _|_ q."""
+    qh = (q / np.linalg.norm(q)).astype(np.float64)
+    U = rng.standard_normal((len(cosines), q.shape[0]))
+    U -= np.outer(U @ qh, qh)
+    U /= np.linalg.norm(U, axis=1, keepdims=True)
+    c = np.asarray(cosines, dtype=np.float64)[:, None]
+    return (c * qh[None, :] + np.sqrt(1.0 - c * c) * U).astype(np.float32)
+
+
+def test_lane_overflow_is_rescanned_with_a_tight_threshold(oracle, lib_built):
+    """A dense neighbourhood the sample cannot see: every tile of ONE scan workgroup is filled with
+    rows close to the query (cosines 0.99 .. 0.79, all distinct).  Only 2 of a query's 512 lanes see
+    them, so the sample threshold stays at background level, those lanes overflow (> 32 survivors),
+    and the query must be rescanned with the threshold derived from what it did collect.  Still
+    bit-exact, and no EXACT fallback."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(123)
+    n, d = 120000, 384
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    Q = rng.standard_normal((6, d), dtype=np.float32)
+    tiles = [t for t in range(n // 32) if t % 256 == 5]          # one workgroup's tiles (256 CUs)
+    rows = np.concatenate([np.arange(32 * t, 32 * t + 32) for t in tiles])
+    X[rows] = _rows_with_cosine(rng, Q[2], np.linspace(0.99, 0.79, len(rows)))
+    with FlatIndex(d) as idx:
+        idx.add(X)
+        _check(idx, X, Q, 10, oracle)
+        st = idx.stats()
+        assert st.retry_queries >= 1 and st.fallback_queries == 0
+
+
+def test_rescan_overflow_falls_back_to_exact_and_stays_bit_exact(oracle, lib_built):
+    """More exact duplicates than a query's lane buffers hold (40000 copies; a lane holds 32): the
+    rescan overflows as well -- no threshold separates exact ties -- and the query is answered on the
+    EXACT path, still bit-exact (lowest ids among the ties win)."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(223)
+    X = rng.standard_normal((60000, 384), dtype=np.float32)
+    X[10000:50000] = X[11]
+    Q = rng.standard_normal((3, 384), dtype=np.float32)
+    Q[1] = X[11]
+    with FlatIndex(384) as idx:
+        idx.add(X)
+        ids, sc, di, nf = idx.search(Q, 10)
+        oi, od, os_, onf = oracle.search(X, Q, 10)
+        np.testing.assert_array_equal(ids, oi)
+        np.testing.assert_array_equal(bits(di), bits(od))
+        np.testing.assert_array_equal(bits(sc), bits(os_))
+        st = idx.stats()
+        assert st.retry_queries >= 1 and st.fallback_queries >= 1
+
+
+def test_rejects_non_finite_queries(lib_built):
+    from memex_amd import _lib
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(5)
+    with FlatIndex(16) as idx:
+        idx.add(rng.standard_normal((100, 16), dtype=np.float32))
+        q = rng.standard_normal((3, 16), dtype=np.float32)
+        q[1, 4] = np.inf
+        with pytest.raises(_lib.MemexHipError) as ei:
+            idx.search(q, 5)
+        assert ei.value.code == _lib.MX_EINVAL
+        ids, _, _, nf = idx.search(q[[0, 2]], 5)                   # the index keeps working
+        assert (nf == 5).all() and ids.min() >= 1
+
+
+def test_zero_rows_do_not_hide_exact_matches(oracle, lib_built):
+    """>= k zero-norm rows (dist 0 to everything) plus rows identical to the query (dist 0 as well,
+    some with LOWER ids): the oracle orders all of them by id; none may be pruned by the filter."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((40000, 384), dtype=np.float32)
+    Q = rng.standard_normal((4, 384), dtype=np.float32)
+    X[100:130] = 0
+    X[7] = Q[0] * 2.0
+    X[20007] = Q[0]
+    X[150] = Q[0] * 0.5
+    with FlatIndex(384) as idx:
+        idx.add(X)
+        _check(idx, X, Q, 10, oracle)
+        _check(idx, X, Q, 40, oracle)
 
 
 def test_incremental_adds_ids_offsets_and_clear(oracle, lib_built):
@@ -228,7 +314,8 @@ def test_registry_shares_one_resident_index(lib_built):
 
 
 def test_approximation_error_bound_holds(lib_built):
-    """The exactness argument needs |bf16 score - exact cosine| <= kApproxErr (0.0081)."""
+    """The exactness argument needs |bf16 score - cosine| <= e1, the per-query bound built from the
+    measured rounding residuals (itself capped by the a-priori kApproxErr = 0.0081)."""
     from memex_amd.index import FlatIndex
     rng = np.random.default_rng(26)
     for d, scale in ((3, 1.0), (16, 1.0), (384, 1.0), (384, 50.0), (768, 1e-3)):
@@ -238,7 +325,8 @@ def test_approximation_error_bound_holds(lib_built):
             idx.set_profiling(True)
             idx.add(X)
             idx.search(Q, 10)
-            assert idx.stats().max_abs_err <= 0.0081
+            st = idx.stats()
+            assert 0.0 < st.max_abs_err <= st.approx_err_bound <= 0.0081
 
 
 def test_multi_shard_merge_equals_unsharded(oracle, lib_built):
