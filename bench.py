@@ -4,17 +4,22 @@
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a 10M x 384-d f32
 synthetic corpus resident in HBM, query batch 256, top-10, exact cosine search through the C ABI
 (`mx_index_search_device`).  One "step" = one 256-query batch answered end to end (query prep,
-streaming scan, candidate select, f64 rescoring, ordering; plus the RCCL all-gather + merge when
-N > 1).  Inputs are resident in HBM before the timed region.
+sample scan, threshold, collect scan, candidate select + f32/f64 rescoring + ordering; plus the RCCL
+all-gather + merge when N > 1).  Inputs are resident in HBM before the timed region.
 
 N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`): STRONG scaling on the same 10M-row
-corpus -- rank r owns rows [r*10M/N, (r+1)*10M/N) with global ids, every rank answers the same
-256 queries on its shard, one all-gather of the per-shard top-10 (ids + dists) and a merge kernel
-give every rank the global answer.
+corpus (north_star: "on a 10M x 384-d corpus ... queries/sec at 1/2/4/8 GPUs") -- rank r owns rows
+[r*10M/N, (r+1)*10M/N) with global ids, every rank answers the same 256 queries on its shard, ONE
+all-gather of the per-shard top-10 blocks (ids + dists) and a merge kernel give every rank the
+global answer.
 
-Printed JSON (one line, rank 0): metric/value/unit per the contract + `roofline` for the scan
+Printed JSON (one line, rank 0): metric/value/unit per the contract + `roofline` for the collect-scan
 kernel (algorithmic bytes / HIP-event time of the kernel on the library's stream) + `cpu_baseline`
-(the C oracle on the host cores, bounded sample, rank 0 at N=1 only).
+(rank 0 at N = 1 only): the C oracle's exact brute force on all host cores AND the reference's real
+algorithm, HNSW with memex's parameters, on one thread with its recall@10.  Reported beside the
+headline at N = 1: the same job on clustered data (dense neighbourhoods, duplicates), the host-pointer
+API the Rust shim binds, BASELINE configs[3]'s per-GPU shard (10M x 768), and the ingest leg
+(configs[4]).
 """
 from __future__ import annotations
 
@@ -29,7 +34,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, same guide
+BLOCK = 1_000_000          # the corpus is defined by GLOBAL 1M-row blocks: every N sees the same rows
 
 
 def parse():
@@ -41,27 +48,96 @@ def parse():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--data", choices=["gaussian", "clustered"], default="gaussian",
+                    help="rows of the headline corpus: i.i.d. N(0,1) (BASELINE's synthetic corpus) or clustered")
     ap.add_argument("--scan", choices=["bf16", "f32"], default="bf16",
                     help="what the scan kernel streams: the bf16 filter copy (default) or the f32 rows")
     ap.add_argument("--alt-steps", type=int, default=20,
-                    help="N=1 only: extra untimed-for-the-metric steps on the OTHER scan kernel, reported beside the main one (0 = skip)")
+                    help="N=1 only: extra steps on the OTHER scan kernel, reported beside the main one (0 = skip)")
+    ap.add_argument("--side-steps", type=int, default=20,
+                    help="N=1 only: steps of each side leg (clustered data, host API, 10M x 768 shard); 0 = skip them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the brute-force baseline sample")
+    ap.add_argument("--hnsw-rows", type=int, default=100_000, help="corpus size of the HNSW CPU baseline (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=4, help="queries re-answered on the EXACT path")
-    ap.add_argument("--ingest-chunks", type=int, default=4096, help="512-token chunks per GPU for the ingest leg (0 = skip)")
+    ap.add_argument("--ingest-chunks", type=int, default=262_144, help="512-token chunks per GPU for the ingest leg (0 = skip)")
     return ap.parse_args()
 
 
-def cpu_baseline(dim: int, batch: int, k: int, rows_total: int, target_s: float):
-    """Time the C oracle (oracle/cosine_oracle.c: DistCosine brute force, OpenMP over queries) on a
-    bounded sample of the same workload and scale to the full corpus."""
+# ------------------------------------------------------------------------------------------------
+# synthetic corpora (generated on the device, block by block, identical for every world size)
+# ------------------------------------------------------------------------------------------------
+N_CENTRES = 20_000
+
+
+def clustered_centres(dim: int, dev="cuda"):
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(777)
+    c = torch.randn((N_CENTRES, dim), device=dev, generator=g)
+    c /= c.norm(dim=1, keepdim=True)
+    sig = 0.23 + 0.27 * torch.rand((N_CENTRES, 1), device=dev, generator=g)  # pairwise cosine inside a cluster 0.95 .. 0.8
+    return c, sig
+
+
+def clustered_rows(n: int, dim: int, seed: int, centres, dev="cuda"):
+    """n rows = unit centre + sigma * unit-variance noise (intra-cluster cosine 0.8 .. 0.95), 1 % of
+    them exact duplicates of another row of the block, random lengths (the path must normalise)."""
+    import torch
+    c, sig = centres
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    which = torch.randint(0, N_CENTRES, (n,), device=dev, generator=g)
+    x = torch.randn((n, dim), device=dev, generator=g) * (sig[which] / dim ** 0.5) + c[which]
+    x *= 0.5 + torch.rand((n, 1), device=dev, generator=g)
+    ndup = n // 100
+    src = torch.randint(0, n, (ndup,), device=dev, generator=g)
+    dst = torch.randint(0, n, (ndup,), device=dev, generator=g)
+    x[dst] = x[src]
+    return x
+
+
+def gaussian_rows(n: int, dim: int, seed: int, dev="cuda"):
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    return torch.randn((n, dim), device=dev, dtype=torch.float32, generator=g)
+
+
+def fill_index(idx, rows_total: int, dim: int, lo: int, hi: int, data: str):
+    """Append global rows [lo, hi) to idx (a rank generates the blocks that overlap its range)."""
+    import torch
+    centres = clustered_centres(dim) if data == "clustered" else None
+    for gb in range(lo // BLOCK, (hi + BLOCK - 1) // BLOCK):
+        g0 = gb * BLOCK
+        nb = min(BLOCK, rows_total - g0)
+        xb = clustered_rows(nb, dim, 5000 + gb, centres) if data == "clustered" else gaussian_rows(nb, dim, 1234 + gb)
+        s0, s1 = max(lo, g0) - g0, min(hi, g0 + nb) - g0
+        part = xb[s0:s1].contiguous()
+        idx.add_device(part)
+        del xb, part
+    torch.cuda.empty_cache()
+
+
+def make_queries(batch: int, dim: int, data: str):
+    import torch
+    if data == "clustered":  # queries live in clusters too: each has a dense neighbourhood
+        return clustered_rows(batch, dim, 4321, clustered_centres(dim))
+    return gaussian_rows(batch, dim, 4321)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1): test/bench infrastructure under oracle/, never the thing shipped
+# ------------------------------------------------------------------------------------------------
+def cpu_bruteforce(dim: int, batch: int, k: int, rows_total: int, target_s: float):
+    """The C oracle (oracle/cosine_oracle.c: DistCosine brute force, OpenMP over queries) on a bounded
+    sample of the same workload, scaled linearly to the full corpus."""
     from oracle.search_oracle import COracle
 
     orc = COracle()
     cores = orc.num_threads()
     rng = np.random.default_rng(99)
     q = rng.standard_normal((batch, dim), dtype=np.float32)
-    # calibrate on a small slab, then size the sample for ~target_s
     cal_rows = 2000
     x = rng.standard_normal((cal_rows, dim), dtype=np.float32)
     t0 = time.perf_counter()
@@ -78,11 +154,41 @@ def cpu_baseline(dim: int, batch: int, k: int, rows_total: int, target_s: float)
         "unit": "queries/s",
         "cores": cores,
         "kind": "port",
+        "algorithm": "exact brute force, DistCosine arithmetic (oracle/cosine_oracle.c), OpenMP over queries",
         "sample": f"{batch} queries x {rows} rows x {dim}-d in {dt:.2f}s, scaled linearly to {rows_total} rows",
     }
 
 
-MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
+def cpu_hnsw(dim: int, batch: int, k: int, rows: int):
+    """The reference's real search algorithm: HNSW M=16, ef_construction=200, search ef=32, DistCosine,
+    one thread per query (local.rs:76,101), restated in oracle/hnsw_baseline.cpp.  QPS at `rows` rows
+    (NOT scaled: HNSW cost grows ~log N) and its recall@k against exact search, on both corpora."""
+    import torch
+    from oracle.hnsw_baseline import HnswBaseline
+    from oracle.search_oracle import COracle
+
+    out = []
+    for data in ("gaussian", "clustered"):
+        if data == "clustered":
+            cen = clustered_centres(dim, "cpu")
+            x = clustered_rows(rows, dim, 5000, cen, "cpu").numpy()
+            q = clustered_rows(batch, dim, 4321, cen, "cpu").numpy()
+        else:
+            x = gaussian_rows(rows, dim, 1234, "cpu").numpy()
+            q = gaussian_rows(batch, dim, 4321, "cpu").numpy()
+        t0 = time.perf_counter()
+        h = HnswBaseline(x, seed=1, threads=0)
+        build_s = time.perf_counter() - t0
+        ids, _, sec = h.search(q, k)
+        h.close()
+        oi = COracle().search(x, q, k)[0]
+        rec = float(np.mean([len(set(a) & set(b)) / float(k) for a, b in zip(ids.tolist(), oi.tolist())]))
+        out.append({"data": data, "rows": rows, "value": batch / sec, "unit": "queries/s", "cores": 1,
+                    "recall_at_10": rec, "build_s": build_s, "build_threads": torch.get_num_threads()})
+    return {"kind": "hnsw-port",
+            "algorithm": "HNSW M=16 ef_construction=200 ef=32 DistCosine (local.rs:76,101), oracle/hnsw_baseline.cpp; "
+                         "search on ONE thread like the reference, parallel build (not timed)",
+            "runs": out}
 
 
 def encoder_cpu_baseline(cfg, chunks: int = 16):
@@ -98,9 +204,8 @@ def encoder_cpu_baseline(cfg, chunks: int = 16):
         ids = torch.randint(1000, cfg.vocab, (chunks, 512))
         with torch.no_grad():
             m(input_ids=ids[:2])
-            # bounded sample of ~10 s: batches of `chunks` until the budget is used
             done, t0 = 0, time.perf_counter()
-            while True:
+            while True:  # bounded sample of ~10 s
                 m(input_ids=ids)
                 done += chunks
                 dt = time.perf_counter() - t0
@@ -112,10 +217,15 @@ def encoder_cpu_baseline(cfg, chunks: int = 16):
         return {"error": repr(e)}
 
 
+# ------------------------------------------------------------------------------------------------
+# ingest leg (BASELINE.json configs[4])
+# ------------------------------------------------------------------------------------------------
 def ingest_leg(chunks: int, dev: int, world: int, cpu_too: bool = True):
-    """BASELINE.json configs[4] shape: 512-token chunks, all-MiniLM-L6-v2 architecture with seeded
-    synthetic weights (no checkpoints offline), bf16 MFMA encoder, data-parallel replicas (no
-    collective).  Reported next to the headline metric; not part of `value`."""
+    """512-token chunks, all-MiniLM-L6-v2 architecture with seeded synthetic weights (no checkpoints
+    offline), bf16 MFMA encoder, data-parallel replicas (no collective).  The timed region starts
+    from token ids in HOST memory and ends with the f32 embeddings back in host memory (H2D of ids,
+    D2H of outputs included: what the worker's embed step sees), in calls of 16384 chunks.
+    Reported next to the headline metric; not part of `value`."""
     import torch
     import torch.distributed as dist
     from memex_amd import weights as W
@@ -123,54 +233,50 @@ def ingest_leg(chunks: int, dev: int, world: int, cpu_too: bool = True):
 
     cfg = W.ALL_MINILM_L6_V2
     enc = Encoder(cfg, W.synthetic_weights(cfg, 0), device=dev)
-    g = torch.Generator(device="cuda")
-    g.manual_seed(77)
-    ids = torch.randint(1000, cfg.vocab, (chunks, 512), device="cuda", dtype=torch.int32, generator=g)
-    lens = torch.full((chunks,), 512, device="cuda", dtype=torch.int32)
-    out = torch.zeros((chunks, cfg.hidden), device="cuda")
-    torch.cuda.synchronize()
-    enc.encode_device(ids[:256], lens[:256], out[:256])  # warm-up
+    call = 16384
+    rng = np.random.default_rng(77)
+    ids = rng.integers(1000, cfg.vocab, size=(call, 512), dtype=np.int32)   # one call's worth, reused (content does not matter)
+    lens = np.full((call,), 512, dtype=np.int32)
+    enc.encode(ids[:256], lens[:256])  # warm-up
     enc.reset_stats()
     enc.set_profiling(True)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    reps = 2
-    for _ in range(reps):
-        enc.encode_device(ids, lens, out)
-    torch.cuda.synchronize()
+    done = 0
+    while done < chunks:
+        n = min(call, chunks - done)
+        enc.encode(ids[:n], lens[:n])
+        done += n
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = enc.stats()
-    # ragged variant of BASELINE configs[4] (lengths U[64, 512]); one pass, reported only
     ragged = None
-    if world == 1:
-        rl = torch.randint(64, 513, (chunks,), device="cuda", dtype=torch.int32, generator=g)
+    if world == 1:  # lengths U[64, 512] (BASELINE configs[4]'s ragged variant); reported only
+        rl = rng.integers(64, 513, size=(call,), dtype=np.int32)
         enc.reset_stats()
-        torch.cuda.synchronize()
         tr = time.perf_counter()
-        enc.encode_device(ids, rl, out)
-        torch.cuda.synchronize()
+        for _ in range(4):
+            enc.encode(ids, rl)
         dr = time.perf_counter() - tr
         sr = enc.stats()
-        ragged = {"value": chunks / dr, "unit": "chunks/s", "tokens_per_s": sr.tokens / dr,
+        ragged = {"value": 4 * call / dr, "unit": "chunks/s", "tokens_per_s": sr.tokens / dr,
                   "tflops": sr.flops / (sr.gpu_ms / 1e3) / 1e12 if sr.gpu_ms > 0 else 0.0,
                   "lengths": "uniform in [64, 512]"}
     enc.close()
     tf = st.flops / (st.gpu_ms / 1e3) / 1e12 if st.gpu_ms > 0 else 0.0
-    cpu = None
-    if world == 1 and cpu_too:
-        cpu = encoder_cpu_baseline(cfg)
+    cpu = encoder_cpu_baseline(cfg) if (world == 1 and cpu_too) else None
     return {
         "cpu_baseline": cpu,
-        "metric": "ingest chunks/sec (512-token chunks, all-MiniLM-L6-v2 shape, bf16 MFMA)",
-        "value": chunks * reps * world / dt,
+        "metric": "ingest chunks/sec (512-token chunks, all-MiniLM-L6-v2 shape, bf16 MFMA; host ids in, host embeddings out)",
+        "value": chunks * world / dt,
         "unit": "chunks/s",
-        "chunks_per_gpu": chunks * reps,
+        "chunks_per_gpu": chunks,
         "gflop_per_chunk": st.flops / max(1, st.sequences) / 1e9,
+        "gpu_only_chunks_per_s": st.sequences / (st.gpu_ms / 1e3) if st.gpu_ms > 0 else 0.0,
         "ragged": ragged,
         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / MFMA_PEAK_TFLOPS, "note": "rank-0 GPU time by HIP events on the encoder stream"},
@@ -178,17 +284,105 @@ def ingest_leg(chunks: int, dev: int, world: int, cpu_too: bool = True):
 
 
 def traffic_from_profile(rows_total: int, dim: int, world: int, scan: str):
-    """HBM bytes per launch of the scan kernel from the committed PMC pass (profiles/, FETCH_SIZE x2
-    gfx950 correction + WRITE_SIZE, separate --pmc runs).  bench.py cannot collect PMCs itself, so
-    this is only reported when the committed profile matches the workload being run."""
-    path = os.path.join(ROOT, "profiles", "r1_scan16_traffic.json" if scan == "bf16" else "r1_scan_traffic.json")
-    if world != 1 or rows_total != 10_000_000 or dim != 384 or not os.path.exists(path):
+    """HBM bytes per launch of the collect-scan kernel from the committed PMC pass (profiles/, FETCH_SIZE
+    x2 gfx950 correction + WRITE_SIZE, separate --pmc runs).  bench.py cannot collect PMCs itself, so
+    this is only reported when a committed profile matches the workload being run."""
+    tag = {(384, "bf16"): "scan16", (384, "f32"): "scan", (768, "bf16"): "scan16_768"}.get((dim, scan))
+    if world != 1 or rows_total != 10_000_000 or tag is None:
         return None
-    try:
-        with open(path) as f:
-            return float(json.load(f)["traffic_bytes_per_launch"])
-    except Exception:
-        return None
+    for rnd in ("r2", "r1"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_traffic.json")
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    return float(json.load(f)["traffic_bytes_per_launch"])
+            except Exception:
+                return None
+    return None
+
+
+class SearchBuffers:
+    def __init__(self, batch: int, k: int):
+        import torch
+        from memex_amd.index import packed_result_block
+        # ids and dists live in one block so that the N>1 exchange is ONE all-gather (B*k*12 bytes per rank)
+        self.block, self.ids, self.dists = packed_result_block(batch, k, "cuda")
+        self.scores = torch.zeros((batch, k), device="cuda", dtype=torch.float32)
+        self.nf = torch.zeros((batch,), device="cuda", dtype=torch.int32)
+
+
+def roofline_of(st, scan: str, dim: int, batch: int, rows_total: int, world: int):
+    scan_s = st.scan_ms / 1e3
+    achieved = (st.scan_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
+    launches = max(1, st.scan_launches)
+    elem = 2 if scan == "bf16" else 4
+    tflops = (2.0 * batch * (st.scan_bytes / elem) / scan_s / 1e12) if scan_s > 0 else 0.0
+    kc = (dim + 127) // 128
+    return {
+        "bound": "hbm",
+        "kernel": f"mx::scan16_kernel<{kc},1> (bf16 filter copy, collect launch)" if scan == "bf16"
+                  else f"mx::scan_kernel<{kc},1> (f32 rows, collect launch)",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "bytes_per_launch": st.scan_bytes / launches,
+        "ms_per_launch": st.scan_ms / launches,
+        "traffic": traffic_from_profile(rows_total, dim, world, scan),
+        "mfma_tflops": tflops,
+        "mfma_frac": tflops / MFMA_PEAK_TFLOPS,
+        "power_note": "package power sits at its 1400 W cap during this kernel (profiles/r2_power_*.log)",
+    }
+
+
+def timed_steps(idx, step, fence, warmup: int, steps: int, world: int):
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    idx.reset_stats()
+    idx.set_profiling(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = idx.stats()
+    idx.set_profiling(False)
+    return dt, st
+
+
+def leg_report(st, dt: float, steps: int, workload: str, dim: int, batch: int, rows: int):
+    return {"workload": workload, "value": batch * steps / dt, "unit": "queries/s", "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "candidates_per_query": st.candidates / max(1, st.queries),
+            "retry_queries": int(st.retry_queries), "fallback_queries": int(st.fallback_queries),
+            "approx_err_bound": st.approx_err_bound, "roofline": roofline_of(st, "bf16", dim, batch, rows, 1)}
+
+
+def side_leg(rows: int, dim: int, batch: int, k: int, steps: int, data: str):
+    """A second workload on a fresh index, N = 1: same measurement as the headline, fewer steps."""
+    import torch
+    from memex_amd.index import FlatIndex
+    idx = FlatIndex(dim, key=None, device=0)
+    idx.reserve(rows)
+    fill_index(idx, rows, dim, 0, rows, data)
+    q = make_queries(batch, dim, data)
+    bufs = SearchBuffers(batch, k)
+    torch.cuda.synchronize()
+
+    def step():
+        idx.search_device(q, k, bufs.ids, bufs.scores, bufs.dists, bufs.nf)
+    dt, st = timed_steps(idx, step, torch.cuda.synchronize, 3, steps, 1)
+    out = leg_report(st, dt, steps, f"{rows}x{dim} f32 corpus ({data}), query batch {batch}, top-{k}", dim, batch, rows)
+    idx.close()
+    del idx, q, bufs
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -197,7 +391,7 @@ def main():
     import torch.distributed as dist
 
     from memex_amd import _lib
-    from memex_amd.index import FlatIndex, merge_topk_packed_device, packed_result_block
+    from memex_amd.index import FlatIndex, merge_topk_packed_device
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -230,128 +424,71 @@ def main():
         idx.set_filter_copy(False)
     idx.reserve(n_local)
     idx.set_id_offset(lo)
-    gen = torch.Generator(device="cuda")
-    block = 1_000_000
-    # the corpus is defined by GLOBAL 1M-row blocks (seed = 1234 + block index): every N sees the
-    # same 10M rows, a rank generates the blocks that overlap its range and keeps its slice
-    for gb in range(lo // block, (hi + block - 1) // block):
-        g0 = gb * block
-        nb = min(block, rows_total - g0)
-        gen.manual_seed(1234 + gb)
-        xb = torch.randn((nb, a.dim), device="cuda", dtype=torch.float32, generator=gen)
-        s0, s1 = max(lo, g0) - g0, min(hi, g0 + nb) - g0
-        part = xb[s0:s1].contiguous()
-        torch.cuda.synchronize()
-        idx.add_device(part)
-        del xb, part
-    torch.cuda.empty_cache()
-    gq = torch.Generator(device="cuda")
-    gq.manual_seed(4321)
-    q = torch.randn((a.batch, a.dim), device="cuda", dtype=torch.float32, generator=gq)
+    fill_index(idx, rows_total, a.dim, lo, hi, a.data)
+    q = make_queries(a.batch, a.dim, a.data)
     k = a.k
-    # ids and dists live in one block so that the N>1 exchange is ONE all-gather (B*k*12 bytes per rank)
-    block, ids, dists = packed_result_block(a.batch, k, "cuda")
-    scores = torch.zeros((a.batch, k), device="cuda", dtype=torch.float32)
-    nf = torch.zeros((a.batch,), device="cuda", dtype=torch.int32)
+    bufs = SearchBuffers(a.batch, k)
     if world > 1:
-        g_block = torch.zeros((world, block.numel()), device="cuda", dtype=torch.uint8)
+        g_block = torch.zeros((world, bufs.block.numel()), device="cuda", dtype=torch.uint8)
         m_ids = torch.zeros((a.batch, k), device="cuda", dtype=torch.int64)
         m_dists = torch.zeros((a.batch, k), device="cuda", dtype=torch.float32)
         m_scores = torch.zeros((a.batch, k), device="cuda", dtype=torch.float32)
     torch.cuda.synchronize()
 
     def step():
-        idx.search_device(q, k, ids, scores, dists, nf)  # blocks until results are in HBM
+        idx.search_device(q, k, bufs.ids, bufs.scores, bufs.dists, bufs.nf)  # blocks until results are in HBM
         if world > 1:
             if one_device:  # gloo: gather through host memory
-                parts = [torch.empty_like(block, device="cpu") for _ in range(world)]
-                dist.all_gather(parts, block.cpu())
+                parts = [torch.empty_like(bufs.block, device="cpu") for _ in range(world)]
+                dist.all_gather(parts, bufs.block.cpu())
                 g_block.copy_(torch.stack(parts).to(g_block.device))
             else:
-                dist.all_gather_into_tensor(g_block, block)
-            torch.cuda.synchronize()
-            merge_topk_packed_device(dev, g_block, world, a.batch, k, m_ids, m_dists, m_scores)
+                dist.all_gather_into_tensor(g_block, bufs.block)
+            # the merge is enqueued on torch's stream, behind the collective: no host round trip here
+            merge_topk_packed_device(dev, g_block, world, a.batch, k, m_ids, m_dists, m_scores,
+                                     stream=torch.cuda.current_stream().cuda_stream)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(warmup, steps):
-        for _ in range(warmup):
-            step()
-        idx.reset_stats()
-        idx.set_profiling(True)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        fence()
-        dt_ = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt_], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_ = float(t.item())
-        st_ = idx.stats()
-        idx.set_profiling(False)
-        return dt_, st_
-
-    def roofline(st_, scan):
-        scan_s = st_.scan_ms / 1e3
-        achieved = (st_.scan_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
-        launches = max(1, st_.scan_launches)
-        elem = 2 if scan == "bf16" else 4
-        tflops = (2.0 * a.batch * (st_.scan_bytes / elem) / scan_s / 1e12) if scan_s > 0 else 0.0
-        kc = (a.dim + 127) // 128
-        return {
-            "bound": "hbm",
-            "kernel": f"mx::scan16_kernel<{kc},1> (bf16 filter copy, main stage)" if scan == "bf16"
-                      else f"mx::scan_kernel<{kc},1> (f32 rows, main stage)",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "bytes_per_launch": st_.scan_bytes / launches,
-            "ms_per_launch": st_.scan_ms / launches,
-            "traffic": traffic_from_profile(rows_total, a.dim, world, scan),
-            "mfma_tflops": tflops,
-            "mfma_frac": tflops / MFMA_PEAK_TFLOPS,
-        }
-
-    dt, st = timed(a.warmup, a.steps)
-    ids_main = ids.clone()
+    dt, st = timed_steps(idx, step, fence, a.warmup, a.steps, world)
+    ids_main = bufs.ids.clone()
     alt = None
     if world == 1 and a.alt_steps > 0:
-        # the same job on the other scan kernel (results must be identical: same filter arithmetic)
+        # the same job on the other scan kernel (results must be identical: same certificate, same rescoring)
         other = "f32" if a.scan == "bf16" else "bf16"
         idx.set_filter_copy(other == "bf16")
-        dt2, st2 = timed(3, a.alt_steps)
+        dt2, st2 = timed_steps(idx, step, fence, 3, a.alt_steps, world)
         alt = {"scan": other, "value": a.batch * a.alt_steps / dt2, "unit": "queries/s", "steps": a.alt_steps,
-               "ms_per_step": dt2 / a.alt_steps * 1e3, "ids_equal_main_run": bool(torch.equal(ids, ids_main)),
-               "roofline": roofline(st2, other)}
+               "ms_per_step": dt2 / a.alt_steps * 1e3, "ids_equal_main_run": bool(torch.equal(bufs.ids, ids_main)),
+               "roofline": roofline_of(st2, other, a.dim, a.batch, rows_total, world)}
         idx.set_filter_copy(a.scan == "bf16")
+        step()
+    host_api = None
+    if world == 1 and a.side_steps > 0:
+        # the entry point the Rust shim binds: host pointers in and out (queries H2D, results D2H inside the step)
+        qh = q.cpu().numpy()
+        dt3, st3 = timed_steps(idx, lambda: idx.search(qh, k), fence, 3, a.side_steps, world)
+        host_api = leg_report(st3, dt3, a.side_steps, f"{rows_total}x{a.dim} f32 corpus ({a.data}), query batch {a.batch}, "
+                              f"top-{k}, mx_index_search (host pointers)", a.dim, a.batch, rows_total)
 
-    # ---- recall@10 against the all-f64 EXACT path on a few queries (oracle-level parity at
-    # smaller sizes lives in tests/; the EXACT path is itself oracle-checked there)
-    recall = None
+    # ---- recall@10 against the all-f64 EXACT path on a few queries (oracle-level parity at smaller
+    # sizes and the oracle-based 10M check live in tests/; the EXACT path is itself oracle-checked there)
+    recall = recall_exact_order = merged_ok = None
     if rank == 0 and a.recall_queries > 0:
         nq = min(a.recall_queries, a.batch)
-        final_ids = (m_ids if world > 1 else ids)[:nq].clone()
+        final_ids = (m_ids if world > 1 else bufs.ids)[:nq].clone()
         if world == 1:
-            e_ids = torch.zeros((nq, k), device="cuda", dtype=torch.int64)
-            e_sc = torch.zeros((nq, k), device="cuda", dtype=torch.float32)
-            e_di = torch.zeros((nq, k), device="cuda", dtype=torch.float32)
-            e_nf = torch.zeros((nq,), device="cuda", dtype=torch.int32)
+            e = SearchBuffers(nq, k)
             idx.set_search_mode(_lib.MX_SEARCH_EXACT)
-            idx.search_device(q[:nq].contiguous(), k, e_ids, e_sc, e_di, e_nf)
+            idx.search_device(q[:nq].contiguous(), k, e.ids, e.scores, e.dists, e.nf)
             idx.set_search_mode(_lib.MX_SEARCH_AUTO)
-            hit = 0
-            for b in range(nq):
-                hit += len(set(final_ids[b].tolist()) & set(e_ids[b].tolist()))
+            hit = sum(len(set(final_ids[b].tolist()) & set(e.ids[b].tolist())) for b in range(nq))
             recall = hit / float(nq * k)
-            recall_exact_order = bool(torch.equal(final_ids, e_ids))
+            recall_exact_order = bool(torch.equal(final_ids, e.ids))
         else:
-            recall_exact_order = None
             # N > 1: no rank holds the whole corpus; check the merge's invariants instead (lists ordered by
             # (dist, id), ids unique and inside the corpus, every list full)
             md, mi = m_dists.cpu(), m_ids.cpu()
@@ -359,9 +496,20 @@ def main():
                 all(len(set(r.tolist())) == k for r in mi)
     if world > 1:
         dist.barrier()
+    idx.close()
+    del idx
+    torch.cuda.empty_cache()
+
+    sides = {}
+    if world == 1 and a.side_steps > 0:
+        sides["host_api"] = host_api
+        other_data = "clustered" if a.data == "gaussian" else "gaussian"
+        sides[other_data] = side_leg(rows_total, a.dim, a.batch, k, a.side_steps, other_data)
+        sides["cfg4_shard_10Mx768"] = side_leg(10_000_000, 768, a.batch, k, a.side_steps, "gaussian")
     ingest = ingest_leg(a.ingest_chunks, dev, world, not a.no_cpu_baseline) if a.ingest_chunks > 0 else None
 
     if rank == 0:
+        roof = roofline_of(st, a.scan, a.dim, a.batch, n_local, world)
         out = {
             "metric": "queries/sec, exact cosine top-10 (recall@10 = 1.0) on 10M x 384-d f32",
             "value": a.batch * a.steps / dt,
@@ -373,27 +521,36 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 corpus, bf16 MFMA filter + f64 rescoring",
+            "dtype": "f32 corpus; bf16 MFMA filter -> f32 rescoring -> f64 DistCosine on the survivors (results bit-identical to all-f64)",
             "scan": a.scan,
             "filter_copy_bytes": int(st.filter_copy_bytes),
-            "data": "synthetic",
-            "config": {"workload": f"{rows_total}x{a.dim} f32 corpus in HBM, query batch {a.batch}, top-{k}",
+            "data": "synthetic" if a.data == "gaussian" else "synthetic (clustered)",
+            "config": {"workload": f"{rows_total}x{a.dim} f32 corpus in HBM ({a.data}), query batch {a.batch}, top-{k}",
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
             "recall_at_10": recall,
-            "ids_equal_exact_path": recall_exact_order if rank == 0 and a.recall_queries > 0 else None,
-            "merged_lists_ok": merged_ok if world > 1 and a.recall_queries > 0 else None,
+            "ids_equal_exact_path": recall_exact_order,
+            "merged_lists_ok": merged_ok,
             "fallback_queries": int(st.fallback_queries),
+            "retry_queries": int(st.retry_queries),
             "candidates_per_query": st.candidates / max(1, st.queries),
-            "roofline": roofline(st, a.scan),
+            "approx_err_bound": st.approx_err_bound,
+            "ms_outside_collect_launch": dt / a.steps * 1e3 - roof["ms_per_launch"],
+            "roofline": roof,
         }
         if alt is not None:
             out["other_scan"] = alt
+        out.update(sides)
         if ingest is not None:
             out["ingest"] = ingest
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.dim, a.batch, k, rows_total, a.cpu_seconds)
+            cb = cpu_bruteforce(a.dim, a.batch, k, rows_total, a.cpu_seconds)
+            if a.hnsw_rows > 0:
+                try:
+                    cb["hnsw"] = cpu_hnsw(a.dim, a.batch, k, a.hnsw_rows)
+                except Exception as e:  # the baseline must never fail the bench
+                    cb["hnsw"] = {"error": repr(e)}
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    idx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -187,6 +187,11 @@ int mx_topk_merge_device(int device, const uint64_t *d_ids, const float *d_dists
  * collective gathers the G blocks back to back into d_packed. */
 int mx_topk_merge_packed_device(int device, const void *d_packed, int G, int B, int k, uint64_t *d_out_ids,
                                 float *d_out_dists, float *d_out_scores);
+/* The same merge ENQUEUED on the caller's stream (a hipStream_t; NULL = default stream), returning
+ * at once: put it on the stream the all-gather was issued on and no host round trip separates the
+ * collective from the merge. */
+int mx_topk_merge_packed_async(int device, void *hip_stream, const void *d_packed, int G, int B, int k,
+                               uint64_t *d_out_ids, float *d_out_dists, float *d_out_scores);
 
 /* =====================================================================================
  * Sentence encoder  (replaces the rust-bert model owned by SentenceEmbedder::runner,

@@ -393,7 +393,16 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
 // useful threshold (expected survivors of the collect launch ~ k * N / sample, times the margin's
 // share) and small enough to stay a few percent of the pass
 uint32_t sample_stride(uint64_t full_tiles, int nwg, int k) {
-    const double f = std::min(0.5, std::max(1.0 / 32.0, (double)k / 320.0));
+    // 1/32 of the tiles for k <= 10.  Measured at 10M x 384 (B = 256): a smaller sample is cheaper (60 us at 1/32,
+    // 35 at 1/64, 22 at 1/128) but its weaker threshold sends more tiles of the collect launch down the
+    // append path (1.92 / 1.99 / 2.06 ms): 1/32 is the fastest end to end.  MEMEX_HIP_SAMPLE_DIV
+    // overrides the 32 (a tuning knob: results do not depend on it).
+    static const double div = [] {
+        const char *e = getenv("MEMEX_HIP_SAMPLE_DIV");
+        const double v = e ? atof(e) : 32.0;
+        return v >= 2.0 && v <= 4096.0 ? v : 32.0;
+    }();
+    const double f = std::min(0.5, std::max(1.0 / div, (double)k / (10.0 * div)));
     const uint64_t target = std::max<uint64_t>((uint64_t)nwg, (uint64_t)((double)full_tiles * f));
     return (uint32_t)std::max<uint64_t>(1, full_tiles / std::max<uint64_t>(target, 1));
 }
@@ -449,6 +458,11 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     fp.dists = d_dists;
     fp.n_found = d_nfound;
     fp.max_err = idx->profiling ? s.max_err : nullptr;
+    static const int dbg_stop = [] {
+        const char *e = getenv("MEMEX_HIP_FINISH_STOP");
+        return e ? atoi(e) : 0;
+    }();
+    fp.debug_stop = dbg_stop;
 
     std::vector<int> exact;
     if (trivial) {
@@ -1454,6 +1468,19 @@ int mx_topk_merge_packed_device(int device, const void *d_packed, int G, int B, 
     MX_HIP(launch_merge(hipStreamPerThread, d_packed, blk, static_cast<const char *>(d_packed) + ids_bytes, blk, G, B, k,
                         d_out_ids, d_out_dists, d_out_scores));
     MX_HIP(hipStreamSynchronize(hipStreamPerThread));
+    return MX_OK;
+}
+
+int mx_topk_merge_packed_async(int device, void *hip_stream, const void *d_packed, int G, int B, int k, uint64_t *d_out_ids,
+                               float *d_out_dists, float *d_out_scores) {
+    if (G < 1 || B < 0 || k < 0) return fail(MX_EINVAL, "bad merge shape");
+    if (B == 0 || k == 0) return MX_OK;
+    if (!d_packed || !d_out_ids || !d_out_dists) return fail(MX_EINVAL, "null argument");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
+    const size_t ids_bytes = (size_t)B * k * sizeof(uint64_t), blk = ids_bytes + (size_t)B * k * sizeof(float);
+    MX_HIP(launch_merge(static_cast<hipStream_t>(hip_stream), d_packed, blk, static_cast<const char *>(d_packed) + ids_bytes, blk, G,
+                        B, k, d_out_ids, d_out_dists, d_out_scores));
     return MX_OK;
 }
 

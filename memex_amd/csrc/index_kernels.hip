@@ -48,6 +48,87 @@ __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t *lds4) {
     return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
+
+// k-th largest of the u32 keys a block holds in registers (PER per thread; valid[e] marks real
+// entries).  MSB-first radix select over the bits in which the keys actually differ (scores of one
+// query share sign, exponent and leading mantissa bits), up to 8 bits per pass: LDS histogram of the
+// digit among the keys that still match the prefix, one wave walks the bins from the top.
+// hist: 256 words of LDS; s_pick: 2 words.  Requires 1 <= k <= number of valid keys, blockDim <= 1024.
+template <int PER>
+__device__ __forceinline__ uint32_t block_kth_largest(const uint32_t (&key)[PER], const bool (&valid)[PER], uint32_t k,
+                                                      uint32_t *hist, uint32_t *s_pick) {
+    const int tid = threadIdx.x;
+    uint32_t kmax = 0, kmin = 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < PER; ++e)
+        if (valid[e]) {
+            kmax = key[e] > kmax ? key[e] : kmax;
+            kmin = key[e] < kmin ? key[e] : kmin;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmax, o), b = __shfl_xor(kmin, o);
+        kmax = a > kmax ? a : kmax;
+        kmin = b < kmin ? b : kmin;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        hist[tid >> 6] = kmax;
+        hist[16 + (tid >> 6)] = kmin;
+    }
+    __syncthreads();
+    const int nw = (int)(blockDim.x >> 6);
+    for (int w = 0; w < nw; ++w) {
+        kmax = hist[w] > kmax ? hist[w] : kmax;
+        kmin = hist[16 + w] < kmin ? hist[16 + w] : kmin;
+    }
+    const uint32_t diff = kmax ^ kmin;
+    if (diff == 0) return kmax;
+    int hi = 31 - __clz((int)diff);  // highest bit in which two keys differ
+    uint32_t mask = hi == 31 ? 0u : ~((2u << hi) - 1u);
+    uint32_t prefix = kmax & mask;
+#pragma unroll 1
+    while (hi >= 0) {
+        const int lo = hi >= 7 ? hi - 7 : 0;
+        const uint32_t dmask = (1u << (hi - lo + 1)) - 1u;
+        __syncthreads();  // the previous pass's picks / the reduction slots are consumed
+        for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+            if (valid[e] && (key[e] & mask) == prefix) atomicAdd(&hist[(key[e] >> lo) & dmask], 1u);
+        __syncthreads();
+        if (tid < 64) {
+            // lane l owns bins 4l .. 4l+3; above(l) = keys in bins owned by higher lanes
+            const uint32_t b0 = hist[4 * tid], b1 = hist[4 * tid + 1], b2 = hist[4 * tid + 2], b3 = hist[4 * tid + 3];
+            const uint32_t mine = b0 + b1 + b2 + b3;
+            uint32_t inc = mine;  // inclusive suffix sum over lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_down(inc, o);
+                if (tid + o < 64) inc += t;
+            }
+            const uint32_t above = inc - mine;
+            if (above < k && k <= inc) {  // the k-th largest key has its digit in one of my bins
+                uint32_t a = above;
+                int dg;
+                if (a + b3 >= k) dg = 3;
+                else if ((a += b3) + b2 >= k) dg = 2;
+                else if ((a += b2) + b1 >= k) dg = 1;
+                else { a += b1; dg = 0; }
+                s_pick[0] = (uint32_t)(4 * tid + dg);
+                s_pick[1] = k - a;  // rank inside that bin
+            }
+        }
+        __syncthreads();
+        prefix |= s_pick[0] << lo;
+        mask |= dmask << lo;
+        k = s_pick[1];
+        hi = lo - 1;
+    }
+    return prefix;
+}
+
 // ---------------------------------------------------------------------------------------------
 // ingest: copy rows into the padded store and compute 1/|c|   (replaces hnsw.insert, local.rs:65)
 // ---------------------------------------------------------------------------------------------
@@ -182,30 +263,33 @@ hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int 
 // >= a_k - e1, and every row of the exact top-k has an approximate score >= a_k - 2*e1.
 __global__ __launch_bounds__(256) void theta_kernel(int k, int nwg, const float *__restrict__ lane_max,
                                                     const float *__restrict__ e1, float *__restrict__ theta) {
-    __shared__ float s_v[2 * kMaxScanWGs];
-    __shared__ float s_kth;
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_pick[2];
+    __shared__ uint32_t s_nvalid[4];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
-    const int n = 2 * nwg;
+    const int n = 2 * nwg;  // <= 512: two values per thread
     const uint32_t t0 = (uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31);
-    for (int i = tid; i < n; i += 256) {
-        const int hh = i / nwg, w = i - hh * nwg;
-        s_v[i] = lane_max[(size_t)(t0 + 32 * hh) * nwg + w];
-    }
-    if (tid == 0) s_kth = -INFINITY;
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const float me = s_v[i];
-        int gt = 0, ge = 0;
-        for (int j = 0; j < n; ++j) {
-            const float o = s_v[j];
-            gt += o > me ? 1 : 0;
-            ge += o >= me ? 1 : 0;
+    uint32_t key[2];
+    bool valid[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int i = e * 256 + tid;
+        float v = -INFINITY;
+        if (i < n) {
+            const int hh = i / nwg, w = i - hh * nwg;
+            v = lane_max[(size_t)(t0 + 32 * hh) * nwg + w];
         }
-        if (gt < k && k <= ge) s_kth = me;  // ties write the same value
+        valid[e] = v > -INFINITY;  // a lane that saw no row keeps -inf
+        key[e] = f32_key(v);
     }
+    uint32_t nv = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(valid[0])) + (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(valid[1]));
+    if ((tid & 63) == 0) s_nvalid[tid >> 6] = nv;
     __syncthreads();
-    if (tid == 0 && theta[q] != INFINITY) theta[q] = s_kth - 2.0f * e1[q];  // -inf when fewer than k lanes saw a row
+    nv = s_nvalid[0] + s_nvalid[1] + s_nvalid[2] + s_nvalid[3];
+    float kth = -INFINITY;  // fewer than k lanes saw a row: no threshold
+    if (nv >= (uint32_t)k && k > 0) kth = key_f32(block_kth_largest<2>(key, valid, (uint32_t)k, s_hist, s_pick));
+    if (tid == 0 && theta[q] != INFINITY) theta[q] = kth - 2.0f * e1[q];
 }
 
 hipError_t launch_theta(hipStream_t s, int B, int k, int nwg, const float *lane_max, const float *e1, float *theta) {
@@ -279,60 +363,6 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *lds_w,
     return base + inc - v;
 }
 
-// k-th largest of the u32 keys the block holds in registers (key[e] valid for e < per and
-// row[e] != ~0).  MSB-first: only the bits below the highest bit in which the keys differ need a
-// decision; counts are wave ballots + popcounts, one LDS exchange and one barrier per bit.
-__device__ __forceinline__ uint32_t block_kth_largest(const uint32_t (&key)[kFinPer], const uint32_t (&row)[kFinPer],
-                                                      int per, uint32_t k, uint32_t (*s_sel)[kFinWaves]) {
-    const int tid = threadIdx.x;
-    uint32_t kmax = 0, kmin = 0xffffffffu;
-#pragma unroll
-    for (int e = 0; e < kFinPer; ++e)
-        if (e < per && row[e] != 0xffffffffu) {
-            kmax = key[e] > kmax ? key[e] : kmax;
-            kmin = key[e] < kmin ? key[e] : kmin;
-        }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t a = __shfl_xor(kmax, o), b = __shfl_xor(kmin, o);
-        kmax = a > kmax ? a : kmax;
-        kmin = b < kmin ? b : kmin;
-    }
-    __syncthreads();
-    if ((tid & 63) == 0) {
-        s_sel[0][tid >> 6] = kmax;
-        s_sel[1][tid >> 6] = kmin;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < kFinWaves; ++w) {
-        kmax = s_sel[0][w] > kmax ? s_sel[0][w] : kmax;
-        kmin = s_sel[1][w] < kmin ? s_sel[1][w] : kmin;
-    }
-    __syncthreads();
-    const uint32_t diff = kmax ^ kmin;
-    uint32_t prefix = kmax;
-    if (diff != 0) {
-        const int top = 31 - __clz((int)diff);
-        prefix = top == 31 ? 0u : (kmax & ~((2u << top) - 1u));  // bits above `top` are common
-        for (int bit = top; bit >= 0; --bit) {
-            const uint32_t trial = prefix | (1u << bit);
-            uint32_t c = 0;
-#pragma unroll
-            for (int e = 0; e < kFinPer; ++e)
-                if (e < per) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(row[e] != 0xffffffffu && key[e] >= trial));
-            uint32_t *slot = s_sel[bit & 1];
-            if ((tid & 63) == 0) slot[tid >> 6] = c;
-            __syncthreads();  // slots alternate per bit, so one barrier per bit suffices
-            c = 0;
-#pragma unroll
-            for (int w = 0; w < kFinWaves; ++w) c += slot[w];
-            if (c >= k) prefix = trial;
-        }
-    }
-    return prefix;
-}
-
 __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams p) {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     Cand *ent = reinterpret_cast<Cand *>(fsm);                                        // [kCandCap]
@@ -340,6 +370,8 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     float *qv = reinterpret_cast<float *>(fsm + sizeof(Cand) * (size_t)kCandCap);     // [ds] raw query
     __shared__ uint32_t s_w[kFinWaves];
     __shared__ uint32_t s_sel[2][kFinWaves];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_pick[2];
     __shared__ uint32_t s_cnt;
 
     const int q = blockIdx.x;
@@ -421,11 +453,12 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
 
     // ---- stage 1: k-th best approximate score; keep [kth - 2*e1, +inf)
     uint32_t key[kFinPer], row[kFinPer];
-    int per = (int)((M + kFinThreads - 1) / kFinThreads);
+    bool valid[kFinPer];
 #pragma unroll
     for (int e = 0; e < kFinPer; ++e) {
         const uint32_t i = (uint32_t)e * kFinThreads + tid;
-        if (e < per && i < M) {
+        valid[e] = i < M;
+        if (valid[e]) {
             const Cand cd = ent[i];
             key[e] = f32_key(cd.score);
             row[e] = cd.row;
@@ -435,17 +468,17 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
         }
     }
     {
-        const uint32_t kth = block_kth_largest(key, row, per, (uint32_t)want, s_sel);
+        const uint32_t kth = block_kth_largest<kFinPer>(key, valid, (uint32_t)want, s_hist, s_pick);
         const uint32_t keep = f32_key(key_f32(kth) - 2.0f * e1);
         if (tid == 0) s_cnt = 0;
         __syncthreads();  // also: every thread has its entries in registers, ent[] may be overwritten
         uint32_t mine = 0;
 #pragma unroll
-        for (int e = 0; e < kFinPer; ++e) mine += (e < per && row[e] != 0xffffffffu && key[e] >= keep) ? 1u : 0u;
+        for (int e = 0; e < kFinPer; ++e) mine += (valid[e] && key[e] >= keep) ? 1u : 0u;
         uint32_t at = mine ? atomicAdd(&s_cnt, mine) : 0;
 #pragma unroll
         for (int e = 0; e < kFinPer; ++e)
-            if (e < per && row[e] != 0xffffffffu && key[e] >= keep) {
+            if (valid[e] && key[e] >= keep) {
                 Cand cd;
                 cd.score = key_f32(key[e]);
                 cd.row = row[e];
@@ -455,6 +488,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     }
     const uint32_t m1 = s_cnt;
     if (tid == 0) p.cand_cnt[q] = m1;
+    if (p.debug_stop == 1) return;
 
     // ---- stage 2: f32 rescoring of the m1 survivors (one wave per row, 4 rows in flight per wave):
     // s2 = sum fma(q_i/|q|, c_i/|c|), |s2 - cos| <= e2 (any summation order)
@@ -472,17 +506,29 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
             sc[j] = p.scale[rr[j]];
             dot[j] = 0.0f;
         }
-        for (int c4 = lane; c4 < nc4; c4 += 64) {
-            const float4 a = *reinterpret_cast<const float4 *>(qv + 4 * c4);
-            float4 x[4];
+        // ds <= 768: at most 3 float4 per lane and row; all 12 row loads are in flight together (the rows
+        // are random 1.5-3 KB reads in a multi-GB array: every one is a TLB miss)
+        float4 x[4][kMaxKC / 2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = reinterpret_cast<const float4 *>(p.x + (size_t)rr[j] * ds)[c4];
+        for (int t = 0; t < kMaxKC / 2; ++t) {
+            const int c4 = lane + 64 * t;
+            if (c4 < nc4) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dot[j] = fmaf(a.x * invq, x[j].x * sc[j], dot[j]);
-                dot[j] = fmaf(a.y * invq, x[j].y * sc[j], dot[j]);
-                dot[j] = fmaf(a.z * invq, x[j].z * sc[j], dot[j]);
-                dot[j] = fmaf(a.w * invq, x[j].w * sc[j], dot[j]);
+                for (int j = 0; j < 4; ++j) x[j][t] = reinterpret_cast<const float4 *>(p.x + (size_t)rr[j] * ds)[c4];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kMaxKC / 2; ++t) {
+            const int c4 = lane + 64 * t;
+            if (c4 < nc4) {
+                const float4 a = *reinterpret_cast<const float4 *>(qv + 4 * c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dot[j] = fmaf(a.x * invq, x[j][t].x * sc[j], dot[j]);
+                    dot[j] = fmaf(a.y * invq, x[j][t].y * sc[j], dot[j]);
+                    dot[j] = fmaf(a.z * invq, x[j][t].z * sc[j], dot[j]);
+                    dot[j] = fmaf(a.w * invq, x[j][t].w * sc[j], dot[j]);
+                }
             }
         }
 #pragma unroll
@@ -504,13 +550,14 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
         if (lane == 0 && err > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(p.max_err), __float_as_uint(err));
     }
     __syncthreads();
+    if (p.debug_stop == 2) return;
 
     // ---- k-th best f32 score L; keep [L - 2*e2, +inf); publish the retry threshold
-    per = (int)((m1 + kFinThreads - 1) / kFinThreads);
 #pragma unroll
     for (int e = 0; e < kFinPer; ++e) {
         const uint32_t i = (uint32_t)e * kFinThreads + tid;
-        if (e < per && i < m1) {
+        valid[e] = i < m1;
+        if (valid[e]) {
             const Cand cd = ent[i];
             key[e] = f32_key(cd.score);
             row[e] = cd.row;
@@ -520,7 +567,25 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
         }
     }
     {
-        const uint32_t kth = block_kth_largest(key, row, per, (uint32_t)want, s_sel);
+        uint32_t kth;
+        if (m1 <= 64u) {
+            // the usual case (a few dozen survivors): wave 0 ranks them with shuffles, no histogram passes
+            if (wave == 0) {
+                const uint32_t mk = key[0];  // entry `lane` (kFinThreads >= 64: entry e = 0 of threads 0..63)
+                uint32_t gt = 0, ge = 0;
+                for (int j = 0; j < 64; ++j) {
+                    const uint32_t o = __shfl(mk, j);
+                    const bool ov = (uint32_t)j < m1;
+                    gt += (ov && o > mk) ? 1u : 0u;
+                    ge += (ov && o >= mk) ? 1u : 0u;
+                }
+                if (valid[0] && gt < (uint32_t)want && (uint32_t)want <= ge) s_pick[0] = mk;  // ties write the same value
+            }
+            __syncthreads();
+            kth = s_pick[0];
+        } else {
+            kth = block_kth_largest<kFinPer>(key, valid, (uint32_t)want, s_hist, s_pick);
+        }
         const float L = key_f32(kth);
         if (tid == 0) {
             p.theta_retry[q] = L - p.e2 - e1 - 1e-6f;
@@ -534,11 +599,11 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
         __syncthreads();
         uint32_t mine = 0;
 #pragma unroll
-        for (int e = 0; e < kFinPer; ++e) mine += (e < per && row[e] != 0xffffffffu && key[e] >= keep) ? 1u : 0u;
+        for (int e = 0; e < kFinPer; ++e) mine += (valid[e] && key[e] >= keep) ? 1u : 0u;
         uint32_t at = mine ? atomicAdd(&s_cnt, mine) : 0;
 #pragma unroll
         for (int e = 0; e < kFinPer; ++e)
-            if (e < per && row[e] != 0xffffffffu && key[e] >= keep) {
+            if (valid[e] && key[e] >= keep) {
                 Cand cd;
                 cd.score = key_f32(key[e]);
                 cd.row = row[e];
@@ -547,15 +612,39 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
         __syncthreads();
     }
     const uint32_t m2 = s_cnt;
+    if (p.debug_stop == 3) return;
 
-    // ---- stage 3: exact DistCosine (sequential f64 chain, one thread per row; the rows are L2-warm
-    // from stage 2), key = (dist_bits << 32 | row) written over the entry it came from
-    for (uint32_t cI = tid; cI < m2; cI += kFinThreads) {
-        const uint32_t r = ent[cI].row;
-        const float d = exact_dist_row(qv, p.x + (size_t)r * ds, ds, na, nullptr);
-        keys[cI] = ((uint64_t)__float_as_uint(d) << 32) | r;
+    // ---- stage 3: exact DistCosine: sequential f64 chain, one thread per row, key = (dist_bits << 32 |
+    // row).  Up to kStageRows survivors (the usual case: k plus a few) are first copied to LDS by the
+    // whole block -- one coalesced fetch instead of a dozen dependent ones per chain; beyond that the
+    // chains read global memory (the rows are L2-warm from stage 2).
+    constexpr int kStageRows = 32;
+    uint32_t *srow = reinterpret_cast<uint32_t *>(qv + ds);                     // [kStageRows] row ids
+    float *stage = reinterpret_cast<float *>(fsm) + 2 * kStageRows;            // behind kStageRows keys
+    const int pitch = ds + 4;                                                   // +16 B: conflict-free ds_read_b128 across rows
+    if (m2 <= (uint32_t)kStageRows) {
+        if (tid < (int)m2) srow[tid] = ent[tid].row;
+        __syncthreads();  // row ids are out of ent[]: its storage becomes keys + staged rows
+        const uint32_t nc4s = (uint32_t)ds >> 2;
+        for (uint32_t i = tid; i < m2 * nc4s; i += kFinThreads) {
+            const uint32_t r = i / nc4s, c4 = i - r * nc4s;
+            *reinterpret_cast<float4 *>(stage + (size_t)r * pitch + 4 * c4) =
+                reinterpret_cast<const float4 *>(p.x + (size_t)srow[r] * ds)[c4];
+        }
+        __syncthreads();
+        if (tid < (int)m2) {
+            const float d = exact_dist_row(qv, stage + (size_t)tid * pitch, ds, na, nullptr);
+            keys[tid] = ((uint64_t)__float_as_uint(d) << 32) | srow[tid];
+        }
+    } else {
+        for (uint32_t cI = tid; cI < m2; cI += kFinThreads) {
+            const uint32_t r = ent[cI].row;
+            const float d = exact_dist_row(qv, p.x + (size_t)r * ds, ds, na, nullptr);
+            keys[cI] = ((uint64_t)__float_as_uint(d) << 32) | r;
+        }
     }
     __syncthreads();
+    if (p.debug_stop == 4) return;
 
     // ---- order by (dist, row) and emit the first `want`
     uint64_t lim = ~0ull;  // keys above the want-th smallest need no rank
@@ -595,12 +684,12 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
 
 hipError_t finish_setup() {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)kMaxKC * kChunkFloats));
+                               (int)(sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)kMaxKC * kChunkFloats + 128));
 }
 
 hipError_t launch_finish(hipStream_t s, int B, const FinishParams &p) {
     if (B <= 0) return hipSuccess;
-    const size_t lds = sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)p.ds;
+    const size_t lds = sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)p.ds + 128;  // candidates | query | staged row ids
     hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(kFinThreads), lds, s, p);
     return hipGetLastError();
 }

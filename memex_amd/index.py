@@ -206,8 +206,14 @@ def packed_result_block(B: int, k: int, device):
     return block, ids, dists
 
 
-def merge_topk_packed_device(device: int, packed, G: int, B: int, k: int, out_ids, out_dists, out_scores) -> None:
-    """packed: uint8 device tensor [G, B*k*12], shard blocks as laid out by packed_result_block."""
-    check(lib().mx_topk_merge_packed_device(int(device), ctypes.c_void_p(packed.data_ptr()), int(G), int(B), int(k),
-                                            ctypes.c_void_p(out_ids.data_ptr()), ctypes.c_void_p(out_dists.data_ptr()),
-                                            ctypes.c_void_p(out_scores.data_ptr()) if out_scores is not None else None))
+def merge_topk_packed_device(device: int, packed, G: int, B: int, k: int, out_ids, out_dists, out_scores,
+                             stream: int | None = None) -> None:
+    """packed: uint8 device tensor [G, B*k*12], shard blocks as laid out by packed_result_block.
+    ``stream`` (raw hipStream_t): enqueue the merge there and return at once -- e.g. torch's current
+    stream, right behind the all-gather; without it the call blocks until the merge is done."""
+    args = (ctypes.c_void_p(packed.data_ptr()), int(G), int(B), int(k), ctypes.c_void_p(out_ids.data_ptr()),
+            ctypes.c_void_p(out_dists.data_ptr()), ctypes.c_void_p(out_scores.data_ptr()) if out_scores is not None else None)
+    if stream is None:
+        check(lib().mx_topk_merge_packed_device(int(device), *args))
+    else:
+        check(lib().mx_topk_merge_packed_async(int(device), ctypes.c_void_p(stream), *args))
