@@ -140,3 +140,78 @@ def test_errors(lib_built):
     t = WordPieceTokenizer(make_vocab())
     with pytest.raises(_lib.MemexHipError):
         t.windows("x", 10, 10)                               # stride must be < max_length
+
+
+# ---- full-Unicode normaliser / pre-tokenizer (generated tables, scripts/gen_unicode_tables.py) ----------
+UNI_STEMS = ["привет", "мир", "при", "##вет", "ελληνικα", "ελλη", "##νικα", "γεια", "σου", "ς", "σ", "istanbul", "i",
+             "strasse", "ß", "ss", "ᄒ", "ᅡ", "ᆫ", "한", "##ᅡ", "##ᆫ", "नमसत", "न", "##म", "##स", "##त", "عربي", "ع", "##ر",
+             "##ب", "##ي", "𝓐", "ａ", "ｂ", "fi", "ﬁ", "dz", "ǆ", "ǳ", "あ", "か", "##か", "カ", "ガ", "é", "e", "œ", "ø", "đ",
+             "ł", "ı", "ŉ", "ʼ", "n", "##n", "x", "##x", "🙂", "🫠", "ก", "ิ", "##ิ"]
+UNI_PUNCT = ["¡", "¿", "«", "»", "–", "—", "‘", "’", "“", "”", "…", "、", "。", "「", "」", "！", "？", "·", "§", "¶", "‰",
+             "₀", "+", "÷", "×", "©", "™", "°", "^", "~", "|", "¦", "¬", "$", "€", "£"]
+
+
+@pytest.fixture(scope="module")
+def uni_toks(lib_built, tmp_path_factory):
+    from tokenizers import BertWordPieceTokenizer
+    from memex_amd.tokenizer import WordPieceTokenizer
+    seen, vocab = set(), []
+    for t in SPECIALS + STEMS + ["##" + s for s in STEMS] + PUNCT + UNI_STEMS + UNI_PUNCT:
+        if t not in seen:
+            seen.add(t)
+            vocab.append(t)
+    p = tmp_path_factory.mktemp("vocab_uni") / "vocab.txt"
+    p.write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    out = {}
+    for lower in (True, False):
+        out[lower] = (BertWordPieceTokenizer(str(p), lowercase=lower, strip_accents=None),
+                      WordPieceTokenizer(str(p), lowercase=lower))
+    return out
+
+
+UNI_TEXTS = [
+    "ПРИВЕТ, Мир!  Привет—мир…", "ΕΛΛΗΝΙΚΑ Γειά σου ΣΟΥ Σ σ ς", "İstanbul I ı İ i̇", "Straße STRASSE ẞ ß",
+    "한국어 한 한", "नमस्ते नमस्ते।", "عَرَبِيّ ﻋﺮﺑﻲ", "ｆｕｌｌ ｗｉｄｔｈ ａｂ Ａ", "ﬁ ﬂ ǅ ǲ Ǆ", "がか ガカ が",
+    "é é É É ñ ñ å å ç ç", "Œuvre Øre Đà Łódź ŉ ʼn", "x­y x​y x‍y x﻿y x y x y x　y",
+    "🙂 🫠 x🙂y", "กิ กิ", "à̖b à̖b", "„Zitat“ «cita» ‹x› 「引用」 a·b a‧b 5‰ 1÷2×3", "tab\there\r\nnew\x0bline\x0cfeed\x1funit\x7fdel",
+    "한".encode("utf-8", "ignore").decode(), "ǅemal Ǉ ǈ ǉ ǋ", "ΐ ΰ ẖ ǰ ﬃ ﬆ ք ﬓ", "K Å Ω", "ſ ẛ ς",
+]
+
+
+def test_unicode_texts_match_hf(uni_toks):
+    for lower, (hf, mine) in uni_toks.items():
+        for t in UNI_TEXTS:
+            assert mine.encode(t, False) == hf.encode(t, add_special_tokens=False).ids, (lower, t)
+
+
+def test_unicode_fuzz_matches_hf(uni_toks):
+    """Random strings drawn from many scripts / categories plus the vocabulary's own characters: the
+    native normaliser + pre-tokenizer + WordPiece must agree with `tokenizers` id for id."""
+    rng = np.random.default_rng(1234)
+    blocks = [(0x20, 0x7f), (0xa0, 0x17f), (0x180, 0x24f), (0x250, 0x2ff), (0x300, 0x36f), (0x370, 0x3ff), (0x400, 0x52f),
+              (0x530, 0x58f), (0x590, 0x6ff), (0x900, 0x97f), (0xe00, 0xe7f), (0x10a0, 0x10ff), (0x1100, 0x11ff),
+              (0x1e00, 0x1fff), (0x2000, 0x206f), (0x2070, 0x20cf), (0x2100, 0x218f), (0x2190, 0x22ff), (0x2460, 0x24ff),
+              (0x2c00, 0x2dff), (0x3000, 0x30ff), (0x3130, 0x318f), (0x4e00, 0x4e80), (0xa640, 0xa69f), (0xac00, 0xad00),
+              (0xd7a0, 0xd7ff), (0xfb00, 0xfb4f), (0xfe00, 0xfe6f), (0xff00, 0xffef), (0x10400, 0x1044f), (0x1d400, 0x1d4ff),
+              (0x1e900, 0x1e95f), (0x1f300, 0x1f64f), (0x1fa70, 0x1faff), (0xe0000, 0xe007f), (0x0, 0x1f), (0x7f, 0x9f)]
+    own = sorted({ch for t in UNI_STEMS + UNI_PUNCT + STEMS for ch in t.replace("##", "")})
+    for lower, (hf, mine) in uni_toks.items():
+        for it in range(1500):
+            n = int(rng.integers(1, 24))
+            chars = []
+            for _ in range(n):
+                r = rng.random()
+                if r < 0.35:
+                    chars.append(own[int(rng.integers(0, len(own)))])
+                elif r < 0.5:
+                    chars.append(" ")
+                else:
+                    a, b = blocks[int(rng.integers(0, len(blocks)))]
+                    c = int(rng.integers(a, b + 1))
+                    if 0xd800 <= c <= 0xdfff or c == 0:
+                        c = 0x41
+                    chars.append(chr(c))
+            t = "".join(chars)
+            want = hf.encode(t, add_special_tokens=False).ids
+            got = mine.encode(t, False)
+            assert got == want, (lower, [hex(ord(c)) for c in t])
