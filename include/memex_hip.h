@@ -207,11 +207,15 @@ typedef struct mx_encoder_cfg {
     int32_t heads;      /* 12; hidden/heads must be 32 or 64                                 */
     int32_t ffn;        /* 1536 / 3072; multiple of 64                                       */
     int32_t vocab;      /* 30522                                                              */
-    int32_t max_pos;    /* 512                                                                */
+    int32_t max_pos;    /* rows of the position table: 512 (BERT) / 514 (RoBERTa); sequences <= 512 tokens */
     int32_t type_vocab; /* 2                                                                  */
     float ln_eps;       /* 1e-12                                                              */
     int32_t pooling;    /* MX_POOL_MEAN (MiniLM) | MX_POOL_CLS (bge)                          */
     int32_t normalize;  /* 1 = L2-normalise the pooled vector                                 */
+    int32_t pos_offset; /* row of the position table used by a sequence's first token: 0 for BERT
+                           (MiniLM, bge); 2 for RoBERTa-style checkpoints such as all-distilroberta-v1
+                           (embedding.rs:29,159: position ids start at padding_idx + 1; such models also
+                           have max_pos = 514, type_vocab = 1, ln_eps = 1e-5)                  */
 } mx_encoder_cfg;
 
 /*

@@ -57,7 +57,7 @@ class EncoderCfg(ctypes.Structure):
     _fields_ = [("layers", ctypes.c_int32), ("hidden", ctypes.c_int32), ("heads", ctypes.c_int32),
                 ("ffn", ctypes.c_int32), ("vocab", ctypes.c_int32), ("max_pos", ctypes.c_int32),
                 ("type_vocab", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("pooling", ctypes.c_int32),
-                ("normalize", ctypes.c_int32)]
+                ("normalize", ctypes.c_int32), ("pos_offset", ctypes.c_int32)]
 
 
 class EncoderStats(ctypes.Structure):

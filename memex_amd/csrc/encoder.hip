@@ -251,8 +251,9 @@ int check_cfg(const mx_encoder_cfg *c) {
     const int dh = c->hidden / c->heads;
     if (dh != 32 && dh != 64) return fail(MX_EUNSUPPORTED, "head dim %d (need 32 or 64)", dh);
     if (c->ffn < 384 || c->ffn % 384) return fail(MX_EUNSUPPORTED, "ffn %d must be a multiple of 384", c->ffn);
-    if (c->vocab < 1 || c->max_pos < 1 || c->max_pos > 512 || c->type_vocab < 1)
-        return fail(MX_EINVAL, "vocab/max_pos/type_vocab out of range (max_pos <= 512)");
+    if (c->vocab < 1 || c->max_pos < 1 || c->max_pos > 8192 || c->type_vocab < 1)
+        return fail(MX_EINVAL, "vocab/max_pos/type_vocab out of range");
+    if (c->pos_offset < 0 || c->pos_offset >= c->max_pos) return fail(MX_EINVAL, "pos_offset %d outside [0, max_pos)", c->pos_offset);
     if (c->pooling != MX_POOL_MEAN && c->pooling != MX_POOL_CLS) return fail(MX_EINVAL, "pooling %d", c->pooling);
     if (!(c->ln_eps >= 0.0f)) return fail(MX_EINVAL, "ln_eps");
     return MX_OK;
@@ -321,6 +322,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     } while (0)
     MX_TRY(upload_f32(e, take((size_t)cfg->vocab * H), (size_t)cfg->vocab * H, &e->word));
     MX_TRY(upload_f32(e, take((size_t)cfg->max_pos * H), (size_t)cfg->max_pos * H, &e->pos));
+    e->pos += (size_t)cfg->pos_offset * H;  // RoBERTa-style tables: token t of a sequence uses row pos_offset + t
     {
         const float *ty = take((size_t)cfg->type_vocab * H);
         MX_TRY(upload_f32(e, ty, H, &e->type0));  // token_type 0 only (single-segment inputs)
@@ -370,7 +372,9 @@ void mx_encoder_destroy(mx_encoder *e) {
 static int check_call(mx_encoder *e, const void *ids, const void *lens, int B, int S, const void *out) {
     if (!e) return fail(MX_ESEARCH, "null encoder");
     if (B < 0 || S < 1) return fail(MX_EINVAL, "bad batch shape B=%d S=%d", B, S);
-    if (S > e->cfg.max_pos) return fail(MX_EINVAL, "S=%d exceeds max_pos=%d", S, e->cfg.max_pos);
+    if (S > 512) return fail(MX_EUNSUPPORTED, "S=%d: sequences are limited to 512 tokens", S);
+    if (S + e->cfg.pos_offset > e->cfg.max_pos)
+        return fail(MX_EINVAL, "S=%d (+ pos_offset %d) exceeds max_pos=%d", S, e->cfg.pos_offset, e->cfg.max_pos);
     if (B > 0 && (!ids || !lens || !out)) return fail(MX_EINVAL, "null argument");
     return MX_OK;
 }

@@ -67,6 +67,7 @@ class EmbeddingsModelType(enum.Enum):
 _ENCODER_CONFIGS = {
     EmbeddingsModelType.AllMiniLmL12V2: W.ALL_MINILM_L12_V2,
     EmbeddingsModelType.AllMiniLmL6V2: W.ALL_MINILM_L6_V2,
+    EmbeddingsModelType.AllDistilrobertaV1: W.ALL_DISTILROBERTA_V1,
 }
 
 

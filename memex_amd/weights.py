@@ -30,6 +30,7 @@ class EncoderConfig:
     pooling: str = "mean"      # "mean" (MiniLM) | "cls" (bge)
     normalize: bool = True
     max_seq_length: int = 256  # sentence_bert_config.json truncation
+    pos_offset: int = 0        # 0 = BERT; 2 = RoBERTa-style (position ids start at padding_idx + 1)
 
     def as_dict(self) -> dict:
         return asdict(self)
@@ -38,6 +39,11 @@ class EncoderConfig:
 ALL_MINILM_L6_V2 = EncoderConfig(layers=6, hidden=384, heads=12, ffn=1536, max_seq_length=256)
 ALL_MINILM_L12_V2 = EncoderConfig(layers=12, hidden=384, heads=12, ffn=1536, max_seq_length=128)
 BGE_BASE_EN = EncoderConfig(layers=12, hidden=768, heads=12, ffn=3072, pooling="cls", max_seq_length=512)
+# all-distilroberta-v1 (embedding.rs:29): DistilRoBERTa = 6 RoBERTa layers.  Same encoder stack as
+# BERT; the embeddings differ: one token type, 514 positions used from row 2 on, LayerNorm eps 1e-5.
+# (Its byte-level BPE tokenizer is not covered: segment_text rejects the model too, embedding.rs:156-161.)
+ALL_DISTILROBERTA_V1 = EncoderConfig(layers=6, hidden=768, heads=12, ffn=3072, vocab=50265, max_pos=514, type_vocab=1,
+                                     ln_eps=1e-5, max_seq_length=512, pos_offset=2)
 
 
 def tensor_order(cfg: EncoderConfig) -> List[Tuple[str, Tuple[int, ...]]]:
@@ -63,7 +69,7 @@ def pack_weights(state: Mapping[str, object], cfg: EncoderConfig) -> np.ndarray:
     parts = []
     for name, shape in tensor_order(cfg):
         t = None
-        for key in (name, "bert." + name, "0.auto_model." + name, "model." + name):
+        for key in (name, "bert." + name, "roberta." + name, "0.auto_model." + name, "model." + name):
             if key in state:
                 t = state[key]
                 break

@@ -6,7 +6,8 @@ un-vendored crates -- rust-bert 0.21.0 (Cargo.lock:3467-3469) on tch 0.13.0 / li
 follows the published BERT / sentence-transformers semantics those crates implement
 (SURVEY.md App. A.1):
 
-* embeddings = word[id] + position[t] + token_type[0]  -> LayerNorm(eps)
+* embeddings = word[id] + position[pos_offset + t] + token_type[0]  -> LayerNorm(eps)
+  (pos_offset = 0 for BERT; 2 for RoBERTa-style checkpoints: positions start at padding_idx + 1)
 * per layer: Q,K,V = x W^T + b ; scores = QK^T/sqrt(d_head) + (1-mask)*(-10000) ; softmax ; PV ;
   dense ; +residual ; LayerNorm ; dense(H->F) ; GELU(erf) ; dense(F->H) ; +residual ; LayerNorm
 * pooling: masked mean  sum(h*m)/max(sum(m), 1e-9)   (all-MiniLM-*)   or CLS (bge-*)
@@ -58,7 +59,7 @@ def encode(weights: dict, cfg: dict, ids: np.ndarray, lens: np.ndarray, dtype=np
     mask = (np.arange(S)[None, :] < lens[:, None]).astype(dtype)  # [B,S]
 
     x = (W["embeddings.word_embeddings.weight"][ids]
-         + W["embeddings.position_embeddings.weight"][None, :S]
+         + W["embeddings.position_embeddings.weight"][None, cfg.get("pos_offset", 0):cfg.get("pos_offset", 0) + S]
          + W["embeddings.token_type_embeddings.weight"][0][None, None, :])
     x = layer_norm(x, W["embeddings.LayerNorm.weight"], W["embeddings.LayerNorm.bias"], eps)
     add_mask = (1.0 - mask)[:, None, None, :] * -10000.0

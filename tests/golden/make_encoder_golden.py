@@ -20,6 +20,9 @@ CASES = {  # name: (cfg kwargs, B, S, seed)
     "l2_h384": (dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=2000), 4, 32, 101),
     "l6_h384": (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=2000), 4, 128, 102),
     "l2_h768_cls": (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=2000, pooling="cls"), 4, 64, 103),
+    # RoBERTa-style embeddings (all-distilroberta-v1, embedding.rs:29): checked against transformers.RobertaModel
+    "l2_h768_roberta": (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=2000, max_pos=514, type_vocab=1,
+                             ln_eps=1e-5, pos_offset=2), 4, 64, 104),
 }
 
 
@@ -33,12 +36,15 @@ def inputs(cfg, B, S, seed):
 
 
 def hf_forward(cfg, w, ids, lens):
-    from transformers import BertConfig, BertModel
-    hc = BertConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
+    from transformers import BertConfig, BertModel, RobertaConfig, RobertaModel
+    roberta = cfg.pos_offset != 0
+    Config, Model = (RobertaConfig, RobertaModel) if roberta else (BertConfig, BertModel)
+    extra = dict(pad_token_id=cfg.pos_offset - 1) if roberta else {}   # position ids = padding_idx + 1 + t
+    hc = Config(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
                     num_attention_heads=cfg.heads, intermediate_size=cfg.ffn, max_position_embeddings=cfg.max_pos,
                     type_vocab_size=cfg.type_vocab, layer_norm_eps=cfg.ln_eps, hidden_act="gelu",
-                    hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    m = BertModel(hc, add_pooling_layer=False).double().eval()
+                    hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **extra)
+    m = Model(hc, add_pooling_layer=False).double().eval()
     sd = {k: torch.from_numpy(v).double() for k, v in w.items()}
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not [k for k in missing if "position_ids" not in k], missing

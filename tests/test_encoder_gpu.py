@@ -30,6 +30,8 @@ def test_encoder_vs_transformers_golden(lib_built):
     (dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 3, 160, 4),  # bge-base shape
     (dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000, normalize=False), 5, 33, 5),
     (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000), 9, 77, 6),          # mean pooling at H=768
+    (dict(layers=6, hidden=768, heads=12, ffn=3072, vocab=3000, max_pos=514, type_vocab=1, ln_eps=1e-5, pos_offset=2),
+     3, 512, 7),                                                                     # all-distilroberta-v1 shape (embedding.rs:29)
 ])
 def test_encoder_vs_oracle(kw, B, S, seed, lib_built):
     from memex_amd.encoder import Encoder

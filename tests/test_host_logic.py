@@ -50,3 +50,14 @@ def test_partition_covers_all_rows():
         assert all(a[1] == b[0] for a, b in zip(p, p[1:]))
         sizes = [b - a for a, b in p]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_every_supported_model_type_has_an_encoder_config():
+    """embedding.rs:25-33,159: the sentence-transformer checkpoints whose encoder this path covers."""
+    from memex_amd import embedding as E
+    from memex_amd import weights as W
+    assert E._ENCODER_CONFIGS[E.EmbeddingsModelType.AllMiniLmL12V2] is W.ALL_MINILM_L12_V2     # the default (embedding.rs:67)
+    assert E._ENCODER_CONFIGS[E.EmbeddingsModelType.AllMiniLmL6V2] is W.ALL_MINILM_L6_V2
+    rb = E._ENCODER_CONFIGS[E.EmbeddingsModelType.AllDistilrobertaV1]
+    assert (rb.layers, rb.hidden, rb.pos_offset, rb.type_vocab, rb.max_pos) == (6, 768, 2, 1, 514)
+    assert rb.max_seq_length + rb.pos_offset <= rb.max_pos
