@@ -89,25 +89,66 @@ class HipFlatStore : public VectorStore {
     std::string storage_path;
     std::map<size_t, std::string> _id_map;  // local.rs:24 (usize -> _id)
 
-    explicit HipFlatStore(const std::string &path, int device = 0) : storage_path(path), device_(device) {}  // ::new, local.rs:95
+    // devices: empty = one index on `device`; several ordinals = the in-library sharded index
+    // (mx_index_open_sharded: rows dealt to the GPUs in blocks, one exchange + merge per search)
+    explicit HipFlatStore(const std::string &path, int device = 0, std::vector<int> devices = {})
+        : storage_path(path), device_(device), devices_(std::move(devices)) {}  // ::new, local.rs:95
     ~HipFlatStore() override {
         if (idx_) mx_index_close(idx_);
     }
     HipFlatStore(const HipFlatStore &) = delete;
     HipFlatStore &operator=(const HipFlatStore &) = delete;
 
+    // Process-wide registry of resident stores keyed by storage path.  The reference builds a store
+    // per request / per task (handlers.rs:61-63, worker/lib.rs:190) and reloads the index each time
+    // (storage/mod.rs:115-116); here every handle on a collection shares ONE store object -- GPU index
+    // AND id map -- as long as the files it last wrote / read are unchanged on disk.
+    static std::map<std::string, std::shared_ptr<HipFlatStore>> &registry() {
+        static std::map<std::string, std::shared_ptr<HipFlatStore>> r;
+        return r;
+    }
+    static std::mutex &registry_mu() {
+        static std::mutex m;
+        return m;
+    }
+    static void evict_resident() {
+        std::lock_guard<std::mutex> lk(registry_mu());
+        registry().clear();
+    }
+    static std::shared_ptr<HipFlatStore> create(const std::string &path, int device = 0, std::vector<int> devices = {}) {
+        auto st = std::make_shared<HipFlatStore>(path, device, std::move(devices));
+        std::lock_guard<std::mutex> lk(registry_mu());
+        registry()[path] = st;
+        return st;
+    }
+
     static bool has_store(const std::string &path) {  // local.rs:110-113
         struct stat sb;
         return stat((path + "/" + META_FILE).c_str(), &sb) == 0;
     }
 
-    static std::unique_ptr<HipFlatStore> load(const std::string &path, int device = 0) {  // local.rs:115-141
+    static std::shared_ptr<HipFlatStore> load(const std::string &path, int device = 0, std::vector<int> devices = {}) {  // local.rs:115-141
+        {   // resident and unchanged on disk: attach in O(1) (mx_index_load is O(1) too in that case)
+            std::lock_guard<std::mutex> lk(registry_mu());
+            auto it = registry().find(path);
+            if (it != registry().end()) {
+                auto &st = it->second;
+                std::lock_guard<std::mutex> l2(st->mu_);
+                if (st->meta_known_ && file_sig(path + "/" + META_FILE) == st->meta_sig_ && st->_id_map.size() == st->meta_ids_) {
+                    if (st->_id_map.empty()) return st;
+                    if (st->idx_ && mx_index_load(st->idx_, path.c_str()) == MX_OK && st->nb_point() == st->_id_map.size()) return st;
+                }
+            }
+        }
         std::ifstream f(path + "/" + META_FILE);
         if (!f) throw VectorStoreError(VectorStoreError::FileIOError, "cannot open " + path + "/" + META_FILE);
         std::stringstream ss;
         ss << f.rdbuf();
-        auto store = std::make_unique<HipFlatStore>(path, device);
+        auto store = std::make_shared<HipFlatStore>(path, device, std::move(devices));
         store->_id_map = parse_id_map(ss.str());
+        store->meta_sig_ = file_sig(path + "/" + META_FILE);
+        store->meta_ids_ = store->_id_map.size();
+        store->meta_known_ = true;
         if (!store->_id_map.empty()) {
             int dim = 0;
             uint64_t n = 0;
@@ -118,25 +159,49 @@ class HipFlatStore : public VectorStore {
             if (rc != MX_OK) throw from_status(rc, VectorStoreError::FileIOError);
             if (n != store->_id_map.size()) throw VectorStoreError(VectorStoreError::FileIOError, "vector / id count mismatch");
         }
+        std::lock_guard<std::mutex> lk(registry_mu());
+        registry()[path] = store;
         return store;
     }
 
-    void save(const std::string &path_in = "") {  // local.rs:143-165
+    // local.rs:143-165.  The reference calls this after EVERY insert (local.rs:67) and rewrites both
+    // files; a save into the store's own directory appends instead: mx_index_save adds the new rows to
+    // vectors.mxflat, and the new "id":"_id" pairs are spliced in before the JSON object's closing brace.
+    void save(const std::string &path_in = "") {
+        std::lock_guard<std::mutex> lk(mu_);
         const std::string path = path_in.empty() ? storage_path : path_in;
-        mkdir(path.c_str(), 0755);
+        make_dirs(path);
         if (idx_) {
             int rc = mx_index_save(idx_, path.c_str());
             if (rc != MX_OK) throw VectorStoreError(VectorStoreError::SaveError, mx_last_error());
         }
-        std::ofstream f(path + "/" + META_FILE);
-        if (!f) throw VectorStoreError(VectorStoreError::FileIOError, "cannot write " + path + "/" + META_FILE);
-        f << "{";
-        bool first = true;
-        for (auto &kv : _id_map) {
-            f << (first ? "" : ",") << "\"" << kv.first << "\":\"" << escape(kv.second) << "\"";
-            first = false;
+        const std::string meta = path + "/" + META_FILE;
+        const bool own = path == storage_path;
+        const size_t n = _id_map.size();
+        if (own && meta_known_ && file_sig(meta) == meta_sig_ && meta_ids_ > 0 && meta_ids_ <= n) {
+            if (meta_ids_ < n) {
+                std::fstream f(meta, std::ios::in | std::ios::out | std::ios::binary);
+                if (!f) throw VectorStoreError(VectorStoreError::FileIOError, "cannot append to " + meta);
+                f.seekp(-1, std::ios::end);  // over the closing brace
+                for (size_t i = meta_ids_ + 1; i <= n; ++i) f << ",\"" << i << "\":\"" << escape(_id_map[i]) << "\"";
+                f << "}";
+            }
+        } else {
+            std::ofstream f(meta);
+            if (!f) throw VectorStoreError(VectorStoreError::FileIOError, "cannot write " + meta);
+            f << "{";
+            bool first = true;
+            for (auto &kv : _id_map) {
+                f << (first ? "" : ",") << "\"" << kv.first << "\":\"" << escape(kv.second) << "\"";
+                first = false;
+            }
+            f << "}";
         }
-        f << "}";
+        if (own) {
+            meta_sig_ = file_sig(meta);
+            meta_ids_ = n;
+            meta_known_ = true;
+        }
     }
 
     void delete_(const std::string &) override {  // local.rs:29-32: unimplemented!()
@@ -148,12 +213,22 @@ class HipFlatStore : public VectorStore {
         if (mx_index_remove_files(storage_path.c_str()) != MX_OK) throw VectorStoreError(VectorStoreError::DeleteError, mx_last_error());
         if (idx_ && mx_index_clear(idx_) != MX_OK) throw VectorStoreError(VectorStoreError::DeleteError, mx_last_error());
         _id_map.clear();
+        meta_known_ = false;
+        meta_ids_ = 0;
     }
 
-    void bulk_insert(const std::vector<VectorData> &data) override {  // local.rs:55-60, one transfer
+    // local.rs:55-69 semantics (ids in order, store persisted before returning), one transfer and
+    // one incremental save instead of a save per vector
+    void bulk_insert(const std::vector<VectorData> &data) override {
         if (data.empty()) return;
         const size_t d = data[0].vector.size();
-        if (!idx_) open((int)d);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!idx_) {
+                open((int)d);
+                if (nb_point() != _id_map.size()) mx_index_clear(idx_);  // a stale resident index under this key
+            }
+        }
         std::vector<float> flat;
         flat.reserve(data.size() * d);
         for (auto &v : data) {
@@ -163,10 +238,17 @@ class HipFlatStore : public VectorStore {
         uint64_t first = 0;
         int rc = mx_index_add(idx_, flat.data(), data.size(), &first);
         if (rc != MX_OK) throw from_status(rc, VectorStoreError::InsertionError);
-        for (size_t i = 0; i < data.size(); ++i) _id_map[(size_t)first + i] = data[i]._id;  // next_id = len + 1 (local.rs:63)
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t i = 0; i < data.size(); ++i) _id_map[(size_t)first + i] = data[i]._id;  // next_id = len + 1 (local.rs:63)
+        }
+        try {
+            save();  // local.rs:67 `let _ = self.save(..)`: errors are ignored there too
+        } catch (const VectorStoreError &) {
+        }
     }
 
-    void insert(const VectorData &data) override { bulk_insert({data}); }  // local.rs:62-69 (no save-per-insert)
+    void insert(const VectorData &data) override { bulk_insert({data}); }  // local.rs:62-69
 
     std::vector<VectorSearchResult> search(const std::vector<float> &vec, size_t limit) override {  // local.rs:71-91
         std::vector<VectorSearchResult> out;
@@ -194,10 +276,35 @@ class HipFlatStore : public VectorStore {
 
   private:
     int device_ = 0, dim_ = 0;
+    std::vector<int> devices_;
     mx_index *idx_ = nullptr;
+    std::mutex mu_;
+    // (mtime ns, size) of vectors.meta.json as last written / read, and how many ids it holds
+    std::pair<long long, long long> meta_sig_{0, 0};
+    size_t meta_ids_ = 0;
+    bool meta_known_ = false;
 
+    static std::pair<long long, long long> file_sig(const std::string &p) {
+        struct stat sb;
+        if (stat(p.c_str(), &sb) != 0) return {-1, -1};
+        return {(long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec, (long long)sb.st_size};
+    }
+    static void make_dirs(const std::string &dir) {  // create_dir_all (local.rs:144)
+        std::string partial;
+        for (size_t i = 0; i <= dir.size(); ++i)
+            if (i == dir.size() || dir[i] == '/') {
+                if (!partial.empty()) mkdir(partial.c_str(), 0755);
+                if (i < dir.size()) partial += '/';
+            } else {
+                partial += dir[i];
+            }
+    }
+
+    // keyed by the collection's path: every handle on this collection shares ONE resident GPU index
     void open(int dim) {
-        int rc = mx_index_open(nullptr, dim, device_, &idx_);
+        const std::string key = storage_path + "@" + (devices_.empty() ? std::to_string(device_) : std::string("sharded"));
+        int rc = devices_.empty() ? mx_index_open(key.c_str(), dim, device_, &idx_)
+                                  : mx_index_open_sharded(key.c_str(), dim, (int)devices_.size(), devices_.data(), 0, &idx_);
         if (rc != MX_OK) throw from_status(rc, VectorStoreError::ConnectionError);
         dim_ = dim;
     }
@@ -265,7 +372,10 @@ class VectorStorage {  // mod.rs:69-93
     std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
 };
 
-inline VectorStorage get_vector_storage(const std::string &uri, const std::string &collection, int device = 0) {  // mod.rs:95-139
+// mod.rs:95-139.  Called per request like the reference's; a collection that is already resident is
+// attached, not reloaded.
+inline VectorStorage get_vector_storage(const std::string &uri, const std::string &collection, int device = 0,
+                                        std::vector<int> devices = {}) {
     const size_t p = uri.find("://");
     if (p == std::string::npos || p == 0) throw VectorStoreError(VectorStoreError::Unsupported, uri);
     const std::string scheme = uri.substr(0, p);
@@ -280,8 +390,17 @@ inline VectorStorage get_vector_storage(const std::string &uri, const std::strin
                 partial += storage[i];
             }
         std::shared_ptr<VectorStore> store;
-        if (HipFlatStore::has_store(storage)) store = HipFlatStore::load(storage, device);
-        else store = std::make_shared<HipFlatStore>(storage, device);
+        if (HipFlatStore::has_store(storage)) {
+            store = HipFlatStore::load(storage, device, devices);
+        } else {
+            std::shared_ptr<HipFlatStore> res;
+            {
+                std::lock_guard<std::mutex> lk(HipFlatStore::registry_mu());
+                auto it = HipFlatStore::registry().find(storage);
+                if (it != HipFlatStore::registry().end() && it->second->_id_map.empty()) res = it->second;
+            }
+            store = res ? res : HipFlatStore::create(storage, device, devices);
+        }
         return VectorStorage(store);
     }
     throw VectorStoreError(VectorStoreError::Unsupported, uri);  // opensearch+https is a remote client: out of scope

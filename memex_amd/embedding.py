@@ -187,7 +187,17 @@ class SentenceEmbedder:
 
     @classmethod
     def spawn(cls, model_config: ModelConfig = ModelConfig(), weights=None, tokenizer=None, device: int = 0,
-              encoder_config: Optional[W.EncoderConfig] = None, seed: int = 0):
+              encoder_config: Optional[W.EncoderConfig] = None, seed: int = 0, allow_synthetic: bool = False):
+        """``weights``: HF tensor mapping / packed blob of the checkpoint; ``tokenizer``: path to its
+        ``vocab.txt`` (native WordPiece) or ``tokenizer.json``, or a tokenizer object.  Like the
+        reference (``create_model()`` / ``Tokenizer::from_pretrained`` failing -> SetupError,
+        embedding.rs:99-100,163-169) a missing checkpoint or vocabulary is an error; the seeded
+        stand-ins (synthetic weights, whitespace-hash tokenizer) used by tests and benchmarks must be
+        asked for with ``allow_synthetic=True``."""
+        if (weights is None or tokenizer is None) and not allow_synthetic:
+            what = "weights" if weights is None else "tokenizer"
+            raise SetupError(f"Unable to load model <{model_config.model.value}>: no {what} given "
+                             "(pass allow_synthetic=True for the seeded stand-ins)")
         q: "queue.Queue" = queue.Queue(maxsize=100)                              # sync_channel(100), :87
         ready: "queue.Queue" = queue.Queue(maxsize=1)
         th = threading.Thread(target=cls._runner, args=(q, ready, model_config, weights, tokenizer, device,

@@ -101,6 +101,38 @@ static void test_factory_and_errors(const std::string &tmp) {  // mod.rs:95-139
     CHECK(dim_err);
 }
 
+// The reference's flow (tasks.rs:59 / handlers.rs:63,81): the worker adds vectors through ITS
+// get_vector_storage() handle, the API handler searches through ANOTHER one; neither calls save().
+static void test_per_request_handles(const std::string &tmp) {
+    const std::string uri = "hnsw://" + tmp + "/flow";
+    {
+        auto worker = get_vector_storage(uri, "docs");
+        worker.add_vectors(test_data());
+    }
+    auto api = get_vector_storage(uri, "docs");
+    auto r = api.search({0.3f, 0.2f, 0.1f}, 1);
+    CHECK(r.size() == 1 && r[0].first == "test-three");
+    {
+        auto worker2 = get_vector_storage(uri, "docs");  // next task appends (incremental save)
+        worker2.add_vectors({{"test-four", "d", "", {0.9f, 0.0f, -0.1f}, 3}});
+    }
+    CHECK(get_vector_storage(uri, "docs").search({0.9f, 0.0f, -0.1f}, 1)[0].first == "test-four");
+    HipFlatStore::evict_resident();  // "restart": everything comes back from vectors.mxflat + vectors.meta.json
+    auto again = get_vector_storage(uri, "docs");
+    CHECK(again.search({0.9f, 0.0f, -0.1f}, 1)[0].first == "test-four");
+    CHECK(again.search({0.0f, 0.1f, 0.2f}, 1)[0].first == "test-one");
+    CHECK(std::dynamic_pointer_cast<HipFlatStore>(again.client)->_id_map.size() == 4);
+    again.delete_collection();
+    // the same surface over the in-library sharded index (3 logical shards on device 0)
+    auto sh = get_vector_storage("hip://" + tmp + "/sharded", "docs", 0, {0, 0, 0});
+    sh.add_vectors(test_data());
+    auto rs = sh.search({0.1f, 0.1f, 0.1f}, 3);
+    CHECK(rs.size() == 3 && rs[0].first == "test-two" && rs[1].first == "test-three" && rs[2].first == "test-one");
+    CHECK(rs[0].second == 1.0f && rs[1].second == 0.9258201f && rs[2].second == 0.7745967f);
+    sh.delete_collection();
+    HipFlatStore::evict_resident();
+}
+
 static void test_embedder_actor() {  // embedding.rs:78-152 with a seeded 1-layer MiniLM-shaped encoder
     mx_encoder_cfg cfg{1, 384, 12, 1536, 30522, 512, 2, 1e-12f, MX_POOL_MEAN, 1};
     const size_t n = mx_encoder_weight_bytes(&cfg) / sizeof(float);
@@ -140,7 +172,8 @@ int main(int argc, char **argv) {
     test_save_load(tmp);
     test_delete_all(tmp);
     test_factory_and_errors(tmp);
+    test_per_request_handles(tmp);
     test_embedder_actor();
-    std::printf("OK 5 tests\n");
+    std::printf("OK 6 tests\n");
     return 0;
 }

@@ -27,4 +27,4 @@ def test_cpp_reference_tests(tmp_path, lib_built):
     exe = _build(tmp_path, lib_built)
     r = subprocess.run([exe, str(tmp_path / "work")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "OK 5 tests" in r.stdout
+    assert "OK 6 tests" in r.stdout

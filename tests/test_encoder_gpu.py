@@ -107,7 +107,7 @@ def test_embed_then_search_pipeline_matches_cpu_path(oracle, lib_built, tmp_path
     rng = np.random.default_rng(11)
     words = [f"tok{i}" for i in range(400)]
     doc = " ".join(rng.choice(words, size=3000))
-    th, emb = E.SentenceEmbedder.spawn(E.ModelConfig(), weights=w, encoder_config=cfg)
+    th, emb = E.SentenceEmbedder.spawn(E.ModelConfig(), weights=w, encoder_config=cfg, allow_synthetic=True)
     segs = emb.encode(doc)
     assert len(segs) == 1 + int(np.ceil((3000 - 256) / 170))
     qres = emb.encode_single("tok1 tok2 tok3 tok17")
@@ -167,7 +167,7 @@ def test_embedder_batches_concurrent_requests(lib_built):
     rng = np.random.default_rng(13)
     words = [f"tok{i}" for i in range(300)]
     texts = [" ".join(rng.choice(words, size=int(n))) for n in rng.integers(3, 700, 40)]
-    th, emb = E.SentenceEmbedder.spawn(E.ModelConfig(), weights=w, encoder_config=cfg)
+    th, emb = E.SentenceEmbedder.spawn(E.ModelConfig(), weights=w, encoder_config=cfg, allow_synthetic=True)
     alone = [emb.encode(t) for t in texts]                          # one at a time
     got = [None] * len(texts)
     errs = []
