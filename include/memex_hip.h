@@ -147,6 +147,25 @@ int mx_index_set_search_mode(mx_index *idx, int mode);
 int mx_index_set_filter_copy(mx_index *idx, int on);
 
 /*
+ * Corpus mode (compressed corpus).  MX_CORPUS_F32 (default): the f32 rows are
+ * kept and results are bit-identical to the reference's arithmetic on them.  MX_CORPUS_BF16: the index
+ * keeps ONLY bf16(c / |c|) -- 2 bytes per element instead of 4 (+2 for the filter copy), i.e. a third
+ * of the default footprint: 7.7 GB for 10M x 384, ~110M x 384-d rows per 288 GB GPU.  Searches are then
+ * EXACT with respect to the stored (rounded) rows: same pipeline, the rescoring stages read the
+ * stored rows, and the answer is bit-identical to the reference's arithmetic applied to
+ * mx_index_get_rows() -- each cosine is within ~2e-3 of the f32 one, so recall@10 against the f32
+ * corpus stays ~0.99 while the scan is unchanged.  Choose the mode while the index is empty.
+ * dim <= 768.  mx_index_save marks such a store in the file header; loading it into an index of
+ * either mode reproduces the stored rows exactly.
+ */
+enum { MX_CORPUS_F32 = 0, MX_CORPUS_BF16 = 1 };
+int mx_index_set_corpus_mode(mx_index *idx, int mode);
+/* Rows [first_row, first_row + n) (0-based, insertion order) as stored, into out [n, dim] f32: the
+ * inserted values (F32 mode) or the stored near-unit bf16 values widened to f32 (BF16 mode; zero-norm
+ * rows come back as zeros).  Also how a collection is re-exported / rebuilt elsewhere. */
+int mx_index_get_rows(mx_index *idx, uint64_t first_row, uint64_t n, float *out);
+
+/*
  * Persistence.  Replaces HnswStore::save / load / has_store (storage/local.rs:110-165).  Files in
  * `dir`: `vectors.mxflat` (header + raw f32 rows).  The string-id map `vectors.meta.json`
  * (local.rs:19,156-163) stays on the Rust side unchanged.

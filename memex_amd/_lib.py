@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 MX_OK = 0
 MX_EINVAL, MX_EDEVICE, MX_EINSERT, MX_ESEARCH, MX_EIO, MX_EUNSUPPORTED, MX_ENOMEM = -1, -2, -3, -4, -5, -6, -7
 MX_SEARCH_AUTO, MX_SEARCH_EXACT = 0, 1
+MX_CORPUS_F32, MX_CORPUS_BF16 = 0, 1
 MX_POOL_MEAN, MX_POOL_CLS = 0, 1
 
 # every symbol include/memex_hip.h declares (checked by tests/test_abi.py)
@@ -24,7 +25,7 @@ EXPORTS = [
     "mx_last_error", "mx_version", "mx_device_count",
     "mx_index_open", "mx_index_open_sharded", "mx_index_n_shards", "mx_index_wait_stream", "mx_index_close", "mx_index_dim", "mx_index_size", "mx_index_reserve",
     "mx_index_set_id_offset", "mx_index_add", "mx_index_add_device", "mx_index_clear",
-    "mx_index_search", "mx_index_search_device", "mx_index_set_search_mode", "mx_index_set_filter_copy",
+    "mx_index_search", "mx_index_search_device", "mx_index_set_search_mode", "mx_index_set_filter_copy", "mx_index_set_corpus_mode", "mx_index_get_rows",
     "mx_index_save", "mx_index_load", "mx_index_has_store", "mx_index_store_info", "mx_index_remove_files",
     "mx_index_set_profiling", "mx_index_get_stats", "mx_index_reset_stats", "mx_topk_merge_device", "mx_topk_merge_packed_device", "mx_topk_merge_packed_async",
     "mx_encoder_weight_bytes", "mx_encoder_create", "mx_encoder_destroy", "mx_encoder_encode",
@@ -104,6 +105,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "mx_index_search_device": [vp, vp, i32, i32, vp, vp, vp, vp],
         "mx_index_set_search_mode": [vp, i32],
         "mx_index_set_filter_copy": [vp, i32],
+        "mx_index_set_corpus_mode": [vp, i32],
+        "mx_index_get_rows": [vp, u64, u64, vp],
         "mx_index_save": [vp, cp],
         "mx_index_load": [vp, cp],
         "mx_index_has_store": [cp, P(i32)],

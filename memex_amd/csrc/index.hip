@@ -125,6 +125,12 @@ struct mx_index {
     float *scale = nullptr;
     void *xh = nullptr;          // bf16 filter copy (fragment order), cap/32 tiles; null = not kept
     bool want_filter = true;     // keep a filter copy when HBM allows (mx_index_set_filter_copy)
+    // compressed corpus (mx_index_set_corpus_mode): xh is the ONLY copy of the rows; x / scale are not
+    // allocated, appends pass through the small f32 staging window xs / ss
+    bool compressed = false;
+    bool raw_ingest = false;     // rows being appended are stored values coming back from disk: no renormalisation
+    float *xs = nullptr, *ss = nullptr;
+    uint64_t xs_rows = 0;
     uint64_t n = 0, cap = 0;
     IdMap idmap{0, 0, 1, 0};
     uint32_t *flags = nullptr;  // device: [0] non-finite rows, [1] out-of-range-norm rows (last add), [2] ec_max (float bits)
@@ -214,7 +220,7 @@ int free_index(mx_index *idx) {
     auto F = [](void *p) {
         if (p) (void)hipFree(p);
     };
-    F(idx->x); F(idx->scale); F(idx->xh); F(idx->flags);
+    F(idx->x); F(idx->scale); F(idx->xh); F(idx->flags); F(idx->xs); F(idx->ss);
     Scratch &s = idx->s;
     F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.theta_retry); F(s.todo); F(s.dev_flags);
     if (s.host_flags) (void)hipHostFree(s.host_flags);
@@ -321,6 +327,19 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
     if (rows <= idx->cap) return MX_OK;
     uint64_t want = std::max<uint64_t>(rows, idx->cap + idx->cap / 2);
     want = round_up(std::max<uint64_t>(want, 1024), kTileRows);
+    if (idx->compressed) {  // the bf16 copy is the corpus: it must grow, there is nothing to fall back to
+        DevBuf nh2;
+        const size_t hb = (size_t)want * idx->ds * 2;
+        MX_HIP(hipMalloc(&nh2.p, hb));
+        const size_t used = idx->xh ? (size_t)round_up(idx->n, kTileRows) * idx->ds * 2 : 0;
+        if (used) MX_HIP(hipMemcpyAsync(nh2.p, idx->xh, used, hipMemcpyDeviceToDevice, idx->stream));
+        MX_HIP(hipMemsetAsync(static_cast<char *>(nh2.p) + used, 0, hb - used, idx->stream));
+        MX_HIP(hipStreamSynchronize(idx->stream));
+        if (idx->xh) (void)hipFree(idx->xh);
+        idx->xh = nh2.release();
+        idx->cap = want;
+        return MX_OK;
+    }
     DevBuf nx, nsc, nh;
     const size_t rowb = (size_t)idx->ds * sizeof(float);
     MX_HIP(hipMalloc(&nx.p, want * rowb));
@@ -369,6 +388,34 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
     int rc = ensure_capacity(idx, idx->n + n);
     if (rc != MX_OK) return rc;
     MX_HIP(hipMemsetAsync(idx->flags, 0, 2 * sizeof(uint32_t), idx->stream));
+    if (idx->compressed) {
+        // rows -> f32 staging window (validated, padded, 1/|c|) -> bf16 fragments.  The window is aligned
+        // to the tile of the first new row; rows of that tile that are already stored are not touched.
+        constexpr uint64_t kWin = 65536;
+        if (!idx->xs) {
+            MX_HIP(hipMalloc(reinterpret_cast<void **>(&idx->xs), (size_t)(kWin + kTileRows) * idx->ds * sizeof(float)));
+            MX_HIP(hipMalloc(reinterpret_cast<void **>(&idx->ss), (size_t)(kWin + kTileRows) * sizeof(float)));
+            idx->xs_rows = kWin + kTileRows;
+        }
+        uint32_t fl[2] = {0, 0};
+        for (uint64_t done = 0; done < n; done += kWin) {
+            const uint64_t m = std::min(kWin, n - done), g0 = idx->n + done;     // global rows [g0, g0 + m)
+            const uint64_t t0 = g0 / kTileRows, off = g0 % kTileRows;
+            MX_HIP(launch_ingest(idx->stream, d_rows + (size_t)done * idx->dim, m, idx->dim, idx->xs, idx->ss, off, idx->ds, idx->flags,
+                                 idx->raw_ingest ? 1 : 0));
+            MX_HIP(launch_shadow(idx->stream, idx->xs, idx->ss, idx->ds, (uint32_t)t0, (uint32_t)((g0 + m + kTileRows - 1) / kTileRows),
+                                 idx->xh, idx->flags + 2, (uint32_t)t0, g0, g0 + m));
+        }
+        MX_HIP(hipMemcpyAsync(fl, idx->flags, sizeof(fl), hipMemcpyDeviceToHost, idx->stream));
+        MX_HIP(hipStreamSynchronize(idx->stream));
+        if (fl[0] != 0) {  // rows past idx->n are never read by a search; the next append overwrites them
+            return fail(MX_EINVAL, "%u row(s) contain non-finite values; nothing inserted", fl[0]);
+        }
+        idx->wild_rows += fl[1];
+        if (first_id) *first_id = idx->idmap.id_of((uint32_t)idx->n);
+        idx->n += n;
+        return MX_OK;
+    }
     MX_HIP(launch_ingest(idx->stream, d_rows, n, idx->dim, idx->x, idx->scale, idx->n, idx->ds, idx->flags));
     if (idx->xh)  // tiles touched by this append (the first one may already be partly filled)
         MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, (uint32_t)(idx->n / kTileRows),
@@ -414,7 +461,7 @@ int run_exact(mx_index *idx, const std::vector<int> &qs, int k, uint64_t *d_ids,
     if (rc != MX_OK) return rc;
     Scratch &s = idx->s;
     for (int b : qs)
-        MX_HIP(launch_exact_query(idx->stream, k, idx->dim, idx->ds, idx->x, idx->n, idx->idmap,
+        MX_HIP(launch_exact_query(idx->stream, k, idx->dim, idx->ds, idx->compressed ? nullptr : idx->x, idx->xh, idx->n, idx->idmap,
                                   s.qpad + (size_t)b * idx->ds, s.exact_keys, s.sel_state, d_ids + (size_t)b * k,
                                   d_scores + (size_t)b * k, d_dists ? d_dists + (size_t)b * k : nullptr, d_nfound + b));
     return MX_OK;
@@ -431,6 +478,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     MX_HIP(launch_prep_queries(st, d_q, B, idx->dim, idx->ds, s.qfrag, s.qpad, s.qnorm2, s.theta, s.e1,
                                idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags));
     const bool trivial = idx->n == 0 || k == 0;
+    if (idx->compressed && idx->kc > kMaxKC && !trivial)
+        return fail(MX_EUNSUPPORTED, "a compressed corpus supports dim <= %d", kMaxKC * kChunkFloats);
     const bool fast = !trivial && idx->mode == MX_SEARCH_AUTO && idx->kc <= kMaxKC && idx->wild_rows == 0 && k <= 256;
     const uint32_t *h_ovf = s.host_flags, *h_cnt = s.host_flags + kMaxBatch, *h_qfl = s.host_flags + 3 * kMaxBatch;
     bool timed = false;
@@ -439,7 +488,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     fp.k = k;
     fp.ds = idx->ds;
     fp.nwg = idx->nwg;
-    fp.x = idx->x;
+    fp.x = idx->compressed ? nullptr : idx->x;
+    fp.xh = idx->xh;
     fp.scale = idx->scale;
     fp.n_rows = trivial ? 0 : idx->n;
     fp.idmap = idx->idmap;
@@ -744,23 +794,37 @@ bool disk_in_sync(mx_index *idx, const char *dir) {  // vectors.mxflat in dir is
            sb.st_mtim.tv_nsec == idx->disk_mtime.tv_nsec;
 }
 
-// rows [r0, r0 + m) of the index in global order -> host buffer [m, dim]
-int fetch_rows(mx_index *idx, uint64_t r0, uint64_t m, float *out, std::vector<float> &tmp) {
-    if (!idx->composite()) {
-        DeviceGuard dg(idx->device);
+// local rows [r0, r0 + m) of a plain index -> host buffer [m, dim].  A compressed corpus hands out its stored
+// (bf16, near-unit) rows widened to f32.
+int fetch_local(mx_index *idx, uint64_t r0, uint64_t m, float *out) {
+    DeviceGuard dg(idx->device);
+    if (!idx->compressed) {
         MX_HIP(hipMemcpy2D(out, (size_t)idx->dim * 4, idx->x + (size_t)r0 * idx->ds, (size_t)idx->ds * 4, (size_t)idx->dim * 4, m,
                            hipMemcpyDeviceToHost));
         return MX_OK;
     }
+    const uint64_t chunk = std::max<uint64_t>(1, (idx->xs_rows ? idx->xs_rows : 1) * (uint64_t)idx->ds / (uint64_t)idx->dim);
+    if (!idx->xs) return fail(MX_EINVAL, "empty compressed index");
+    for (uint64_t done = 0; done < m; done += chunk) {
+        const uint64_t c = std::min(chunk, m - done);
+        MX_HIP(launch_unshadow(idx->stream, idx->xh, idx->ds, idx->dim, r0 + done, c, idx->xs));
+        MX_HIP(hipMemcpyAsync(out + (size_t)done * idx->dim, idx->xs, (size_t)c * idx->dim * 4, hipMemcpyDeviceToHost, idx->stream));
+        MX_HIP(hipStreamSynchronize(idx->stream));
+    }
+    return MX_OK;
+}
+
+// rows [r0, r0 + m) of the index in global order -> host buffer [m, dim]
+int fetch_rows(mx_index *idx, uint64_t r0, uint64_t m, float *out, std::vector<float> &tmp) {
     (void)tmp;
+    if (!idx->composite()) return fetch_local(idx, r0, m, out);
     const uint64_t R = idx->block_rows, G = idx->shards.size();
     for (uint64_t r = r0, done = 0; done < m;) {
         const uint64_t b = r / R, take = std::min(m - done, R - r % R);
         mx_index *sh = idx->shards[b % G];
         const uint64_t lrow = (b / G) * R + r % R;
-        DeviceGuard dg(sh->device);
-        MX_HIP(hipMemcpy2D(out + (size_t)done * idx->dim, (size_t)idx->dim * 4, sh->x + (size_t)lrow * sh->ds, (size_t)sh->ds * 4,
-                           (size_t)idx->dim * 4, take, hipMemcpyDeviceToHost));
+        int rc = fetch_local(sh, lrow, take, out + (size_t)done * idx->dim);
+        if (rc != MX_OK) return rc;
         r += take;
         done += take;
     }
@@ -768,6 +832,11 @@ int fetch_rows(mx_index *idx, uint64_t r0, uint64_t m, float *out, std::vector<f
 }
 
 uint64_t rows_of(mx_index *idx) { return idx->composite() ? idx->total : idx->n; }
+bool is_compressed(mx_index *idx) { return idx->composite() ? idx->shards[0]->compressed : idx->compressed; }
+void set_raw_ingest(mx_index *idx, bool on) {
+    idx->raw_ingest = on;
+    for (mx_index *sh : idx->shards) sh->raw_ingest = on;
+}
 
 int clear_locked(mx_index *idx) {
     if (idx->composite()) {
@@ -1225,6 +1294,7 @@ int mx_index_set_filter_copy(mx_index *idx, int on) {
         return MX_OK;
     }
     DeviceGuard g(idx->device);
+    if (idx->compressed) return on ? MX_OK : fail(MX_EINVAL, "a compressed corpus has no f32 rows to fall back to");
     idx->want_filter = on != 0;
     if (!on) {
         if (idx->xh) {
@@ -1246,6 +1316,43 @@ int mx_index_set_filter_copy(mx_index *idx, int on) {
     MX_HIP(hipStreamSynchronize(idx->stream));
     idx->xh = nh;
     return MX_OK;
+}
+
+int mx_index_set_corpus_mode(mx_index *idx, int mode) {
+    if (!idx) return fail(MX_EINVAL, "null index");
+    if (mode != MX_CORPUS_F32 && mode != MX_CORPUS_BF16) return fail(MX_EINVAL, "unknown corpus mode %d", mode);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (rows_of(idx) != 0) return fail(MX_EINVAL, "the corpus mode can only be chosen while the index is empty");
+    if (idx->composite()) {
+        for (mx_index *sh : idx->shards) {
+            int rc = mx_index_set_corpus_mode(sh, mode);
+            if (rc != MX_OK) return rc;
+        }
+        return MX_OK;
+    }
+    if (mode == MX_CORPUS_BF16 && idx->kc > kMaxKC)
+        return fail(MX_EUNSUPPORTED, "a compressed corpus supports dim <= %d", kMaxKC * kChunkFloats);
+    DeviceGuard g(idx->device);
+    MX_HIP(hipStreamSynchronize(idx->stream));
+    auto F = [](void *p) {
+        if (p) (void)hipFree(p);
+    };
+    F(idx->x); F(idx->scale); F(idx->xh);
+    idx->x = nullptr; idx->scale = nullptr; idx->xh = nullptr;
+    idx->cap = 0;
+    idx->compressed = mode == MX_CORPUS_BF16;
+    idx->want_filter = true;
+    return MX_OK;
+}
+
+int mx_index_get_rows(mx_index *idx, uint64_t first_row, uint64_t n, float *out) {
+    if (!idx || (!out && n)) return fail(MX_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (first_row + n > rows_of(idx)) return fail(MX_EINVAL, "rows [%llu, %llu) outside the index", (unsigned long long)first_row,
+                                                 (unsigned long long)(first_row + n));
+    if (n == 0) return MX_OK;
+    std::vector<float> tmp;
+    return fetch_rows(idx, first_row, n, out, tmp);
 }
 
 int mx_index_set_profiling(mx_index *idx, int on) {
@@ -1346,7 +1453,7 @@ int mx_index_save(mx_index *idx, const char *dir) {
     const std::string tmp = path + ".tmp";
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return fail(MX_EIO, "cannot open %s for writing", tmp.c_str());
-    uint32_t hdr[2] = {(uint32_t)idx->dim, 0};
+    uint32_t hdr[2] = {(uint32_t)idx->dim, is_compressed(idx) ? 1u : 0u};  // [1] = rows are the stored values of a compressed corpus
     int rc = (fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, sizeof(hdr), 1, f) == 1 && fwrite(&n, sizeof(n), 1, f) == 1)
                  ? MX_OK : fail(MX_EIO, "write to %s failed", tmp.c_str());
     if (rc == MX_OK) rc = write_rows(f, 0);
@@ -1391,6 +1498,7 @@ int mx_index_load(mx_index *idx, const char *dir) {
         return MX_OK;
     }
     clear_locked(idx);
+    set_raw_ingest(idx, hdr[1] == 1);  // stored values of a compressed corpus go back in unchanged
     const uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / ((uint64_t)idx->dim * 4));
     std::vector<float> host((size_t)std::min<uint64_t>(chunk, std::max<uint64_t>(n, 1)) * idx->dim);
     int rc = MX_OK;
@@ -1403,6 +1511,7 @@ int mx_index_load(mx_index *idx, const char *dir) {
         rc = add_host_locked(idx, host.data(), m, nullptr);
     }
     fclose(f);
+    set_raw_ingest(idx, false);
     if (rc != MX_OK) {
         const std::string keep = last_error_slot();
         clear_locked(idx);

@@ -88,13 +88,18 @@ hipError_t launch_scan16(hipStream_t s, int kc, bool collect, int nwg, const Sca
 // 32t + (l&31), dims 16s + 8(l>>5) .. +7: exactly the A operand of v_mfma_f32_32x32x16_bf16.
 // Values are bf16(c_i * 1/|c|) (NaN for a zero-norm row: it must pass every filter).
 // ec_max: device word, atomicMax'ed with the float bits of the largest |bf16(c/|c|) - c/|c|| built.
+// src_tile0: x / scale hold the rows of tiles src_tile0 .. (a staging window; 0 = the whole store).
+// Only rows in [row_lo, row_hi) are (re)written: a 16-byte fragment belongs to ONE row, so rows of a
+// tile that are already in the copy stay untouched.
 hipError_t launch_shadow(hipStream_t s, const float *x, const float *scale, int ds, uint32_t tile0, uint32_t tile1,
-                         void *xh, uint32_t *ec_max);
+                         void *xh, uint32_t *ec_max, uint32_t src_tile0 = 0, uint64_t row_lo = 0, uint64_t row_hi = ~0ull);
+// compressed corpus -> f32 rows [n, d]
+hipError_t launch_unshadow(hipStream_t s, const void *xh, int ds, int d, uint64_t row0, uint64_t n, float *out);
 
 // rows [n, d] (device) -> x[first.., ds] zero-padded + scale; flags[0] += non-finite rows,
 // flags[1] += rows whose norm is outside the range the bf16 scan is certified for
 hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, float *x, float *scale,
-                         uint64_t first, int ds, uint32_t *flags);
+                         uint64_t first, int ds, uint32_t *flags, int raw = 0);
 
 // queries [B, d] (device) -> qfrag (normalised bf16 fragments), qpad [256, ds] f32 original
 // values zero padded, qnorm2 [256] f64 (sequential DistCosine accumulation), theta init, e1 [256]
@@ -113,8 +118,9 @@ hipError_t launch_theta(hipStream_t s, int B, int k, int nwg, const float *lane_
 // >= 2 = answer on the EXACT path.
 struct FinishParams {
     int k, ds, nwg;
-    const float *x;             // [cap_rows, ds]
-    const float *scale;         // [cap_rows] 1/|c|
+    const float *x;             // [cap_rows, ds] f32 rows; null = compressed corpus (rows are read from xh)
+    const void *xh;             // bf16 filter copy (fragment order)
+    const float *scale;         // [cap_rows] 1/|c| (f32 rows only)
     uint64_t n_rows;
     IdMap idmap;
     const float *qpad;          // [256, ds]
@@ -138,7 +144,7 @@ hipError_t launch_finish(hipStream_t s, int B, const FinishParams &p);
 hipError_t launch_retry_setup(hipStream_t s, float *theta, const float *theta_retry, uint32_t *overflow, uint32_t *todo);
 
 // EXACT path: one query against every row in f64, then a 64-step radix select on (dist,row) keys
-hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *x, uint64_t n_rows,
+hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *x, const void *xh, uint64_t n_rows,
                               const IdMap &idmap, const float *qpad_row, uint64_t *keys,
                               uint64_t *sel_state, uint64_t *ids, float *scores, float *dists,
                               int32_t *n_found);

@@ -132,9 +132,11 @@ __device__ __forceinline__ uint32_t block_kth_largest(const uint32_t (&key)[PER]
 // ---------------------------------------------------------------------------------------------
 // ingest: copy rows into the padded store and compute 1/|c|   (replaces hnsw.insert, local.rs:65)
 // ---------------------------------------------------------------------------------------------
+// raw != 0: the rows are stored values of a compressed corpus coming back from disk (unit length up to
+// bf16 rounding): they must be stored as they are, so 1/|c| is replaced by 1.
 __global__ __launch_bounds__(256) void ingest_kernel(const float *__restrict__ src, uint64_t n, int d,
                                                      float *__restrict__ x, float *__restrict__ scale,
-                                                     uint64_t first, int ds, uint32_t *flags) {
+                                                     uint64_t first, int ds, uint32_t *flags, int raw) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float *__restrict__ s
         if (lane == 0) {
             float sc;
             if (acc > 0.0) {
-                sc = (float)(1.0 / sqrt(acc));
+                sc = raw ? 1.0f : (float)(1.0 / sqrt(acc));
                 if (acc < 1e-30 || acc > 1e30) atomicAdd(&flags[1], 1u);
             } else {
                 sc = INFINITY;  // zero-norm row: exact dist is 0 for every query (DistCosine else-branch)
@@ -167,11 +169,11 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float *__restrict__ s
 }
 
 hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, float *x, float *scale,
-                         uint64_t first, int ds, uint32_t *flags) {
+                         uint64_t first, int ds, uint32_t *flags, int raw) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(ingest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, n, d, x, scale, first, ds, flags);
+    hipLaunchKernelGGL(ingest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, n, d, x, scale, first, ds, flags, raw);
     return hipGetLastError();
 }
 
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
         float e = kApproxErr;
         if (ec_max) {
             const float ec = __uint_as_float(*ec_max) * 1.01f + 1e-6f;
-            e = fminf(kApproxErr, ec + eq + ec * eq + kAccSlack);
+            e = fminf(kApproxErr + ec * ec, ec + eq + ec * eq + kAccSlack);
         }
         e1[b] = e;
     }
@@ -317,6 +319,44 @@ hipError_t launch_retry_setup(hipStream_t s, float *theta, const float *theta_re
 // finish: gather a query's candidates, prune by approximate score, rescore in f32, prune again,
 // exact DistCosine on the survivors, order by (dist, id), emit            (K7)
 // ---------------------------------------------------------------------------------------------
+// 4 consecutive dims (4*c4 ..) of a row.  CMP = false: the f32 store.  CMP = true (compressed corpus:
+// the bf16 filter copy is the ONLY copy): the 8-byte half of the 16-byte MFMA fragment holding those
+// dims (layout: launch_shadow), widened to f32 exactly; a zero-norm row is stored as NaN and reads as 0.
+template <bool CMP>
+__device__ __forceinline__ float4 row_load4(const float *__restrict__ x, const void *__restrict__ xh, int ds, uint32_t row,
+                                            int c4) {
+    if (!CMP) return reinterpret_cast<const float4 *>(x + (size_t)row * ds)[c4];
+    const uint32_t t = row >> 5, ks = (uint32_t)c4 >> 2, hh = ((uint32_t)c4 >> 1) & 1u, l = (row & 31u) + 32u * hh;
+    const uint2 v = reinterpret_cast<const uint2 *>(xh)[(((size_t)t * (uint32_t)(ds >> 4) + ks) * 64 + l) * 2 + (c4 & 1)];
+    float4 f;
+    f.x = __uint_as_float(v.x << 16);
+    f.y = __uint_as_float(v.x & 0xffff0000u);
+    f.z = __uint_as_float(v.y << 16);
+    f.w = __uint_as_float(v.y & 0xffff0000u);
+    f.x = f.x == f.x ? f.x : 0.0f;
+    f.y = f.y == f.y ? f.y : 0.0f;
+    f.z = f.z == f.z ? f.z : 0.0f;
+    f.w = f.w == f.w ? f.w : 0.0f;
+    return f;
+}
+
+// exact DistCosine of query qv (LDS) against a stored row, read through row_load4
+template <bool CMP>
+__device__ __forceinline__ float exact_dist_stored(const float *__restrict__ qv, const float *__restrict__ x,
+                                                   const void *__restrict__ xh, int ds, uint32_t row, double na) {
+    double dot = 0.0, nb = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < ds / 4; ++i) {
+        const float4 c = row_load4<CMP>(x, xh, ds, row, i);
+        const float4 a = *reinterpret_cast<const float4 *>(qv + 4 * i);
+        dot += (double)__fmul_rn(a.x, c.x); nb += (double)__fmul_rn(c.x, c.x);
+        dot += (double)__fmul_rn(a.y, c.y); nb += (double)__fmul_rn(c.y, c.y);
+        dot += (double)__fmul_rn(a.z, c.z); nb += (double)__fmul_rn(c.z, c.z);
+        dot += (double)__fmul_rn(a.w, c.w); nb += (double)__fmul_rn(c.w, c.w);
+    }
+    return dist_from_sums(dot, na, nb);
+}
+
 __device__ __forceinline__ float exact_dist_row(const float *__restrict__ qv, const float *__restrict__ row, int ds,
                                                 double na, double *cos_out) {
     // sequential f64 accumulation of f32 products, element order 0..d-1 (zero padding adds +0.0)
@@ -363,6 +403,7 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *lds_w,
     return base + inc - v;
 }
 
+template <bool CMP>
 __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams p) {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     Cand *ent = reinterpret_cast<Cand *>(fsm);                                        // [kCandCap]
@@ -497,13 +538,13 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     float err = 0.0f;
     for (uint32_t base = (uint32_t)wave * 4; base < m1; base += kFinWaves * 4) {
         float dot[4];
-        float sc[4];
+        float sc[4];   // f32 store: 1/|c| of the row; compressed: sum of squares of the stored (near-unit) row
         uint32_t rr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t i = base + j < m1 ? base + j : base;
             rr[j] = ent[i].row;
-            sc[j] = p.scale[rr[j]];
+            sc[j] = CMP ? 0.0f : p.scale[rr[j]];
             dot[j] = 0.0f;
         }
         // ds <= 768: at most 3 float4 per lane and row; all 12 row loads are in flight together (the rows
@@ -514,7 +555,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
             const int c4 = lane + 64 * t;
             if (c4 < nc4) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x[j][t] = reinterpret_cast<const float4 *>(p.x + (size_t)rr[j] * ds)[c4];
+                for (int j = 0; j < 4; ++j) x[j][t] = row_load4<CMP>(p.x, p.xh, ds, rr[j], c4);
             }
         }
 #pragma unroll
@@ -524,23 +565,30 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
                 const float4 a = *reinterpret_cast<const float4 *>(qv + 4 * c4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    dot[j] = fmaf(a.x * invq, x[j][t].x * sc[j], dot[j]);
-                    dot[j] = fmaf(a.y * invq, x[j][t].y * sc[j], dot[j]);
-                    dot[j] = fmaf(a.z * invq, x[j][t].z * sc[j], dot[j]);
-                    dot[j] = fmaf(a.w * invq, x[j][t].w * sc[j], dot[j]);
+                    const float m = CMP ? 1.0f : sc[j];
+                    dot[j] = fmaf(a.x * invq, x[j][t].x * m, dot[j]);
+                    dot[j] = fmaf(a.y * invq, x[j][t].y * m, dot[j]);
+                    dot[j] = fmaf(a.z * invq, x[j][t].z * m, dot[j]);
+                    dot[j] = fmaf(a.w * invq, x[j][t].w * m, dot[j]);
+                    if (CMP) sc[j] = fmaf(x[j][t].x, x[j][t].x, fmaf(x[j][t].y, x[j][t].y, fmaf(x[j][t].z, x[j][t].z, fmaf(x[j][t].w, x[j][t].w, sc[j]))));
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) dot[j] += __shfl_xor(dot[j], o);
+            for (int o = 32; o > 0; o >>= 1) {
+                dot[j] += __shfl_xor(dot[j], o);
+                if (CMP) sc[j] += __shfl_xor(sc[j], o);
+            }
         }
         if (lane < 4 && base + lane < m1) {
             const float d0 = lane == 0 ? dot[0] : lane == 1 ? dot[1] : lane == 2 ? dot[2] : dot[3];
             const float s0 = lane == 0 ? sc[0] : lane == 1 ? sc[1] : lane == 2 ? sc[2] : sc[3];
-            const float s2 = isinf(s0) ? 1.0f : d0;  // zero-norm row: dist 0
-            if (p.max_err && !isinf(s0)) err = fmaxf(err, fabsf(s2 - ent[base + lane].score));
+            // zero-norm row (f32 store: 1/|c| = inf; compressed: every element reads as 0): dist 0
+            const bool zero_row = CMP ? !(s0 > 0.0f) : isinf(s0);
+            const float s2 = zero_row ? 1.0f : (CMP ? d0 * __frsqrt_rn(s0) : d0);
+            if (p.max_err && !zero_row) err = fmaxf(err, fabsf(s2 - ent[base + lane].score));
             ent[base + lane].score = s2;
         }
     }
@@ -628,8 +676,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
         const uint32_t nc4s = (uint32_t)ds >> 2;
         for (uint32_t i = tid; i < m2 * nc4s; i += kFinThreads) {
             const uint32_t r = i / nc4s, c4 = i - r * nc4s;
-            *reinterpret_cast<float4 *>(stage + (size_t)r * pitch + 4 * c4) =
-                reinterpret_cast<const float4 *>(p.x + (size_t)srow[r] * ds)[c4];
+            *reinterpret_cast<float4 *>(stage + (size_t)r * pitch + 4 * c4) = row_load4<CMP>(p.x, p.xh, ds, srow[r], (int)c4);
         }
         __syncthreads();
         if (tid < (int)m2) {
@@ -639,7 +686,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     } else {
         for (uint32_t cI = tid; cI < m2; cI += kFinThreads) {
             const uint32_t r = ent[cI].row;
-            const float d = exact_dist_row(qv, p.x + (size_t)r * ds, ds, na, nullptr);
+            const float d = exact_dist_stored<CMP>(qv, p.x, p.xh, ds, r, na);
             keys[cI] = ((uint64_t)__float_as_uint(d) << 32) | r;
         }
     }
@@ -683,22 +730,27 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
 }
 
 hipError_t finish_setup() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)kMaxKC * kChunkFloats + 128));
+    const int lds = (int)(sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)kMaxKC * kChunkFloats + 128);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 hipError_t launch_finish(hipStream_t s, int B, const FinishParams &p) {
     if (B <= 0) return hipSuccess;
     const size_t lds = sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)p.ds + 128;  // candidates | query | staged row ids
-    hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(kFinThreads), lds, s, p);
+    if (p.x) hipLaunchKernelGGL(finish_kernel<false>, dim3(B), dim3(kFinThreads), lds, s, p);
+    else hipLaunchKernelGGL(finish_kernel<true>, dim3(B), dim3(kFinThreads), lds, s, p);  // compressed corpus: rows come from xh
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
 // EXACT path: f64 DistCosine on every row, then a 64-step MSB-first select on (dist,row) keys
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void exact_keys_kernel(int ds, const float *__restrict__ x, uint64_t n_rows,
-                                                         const float *__restrict__ qrow, uint64_t *__restrict__ keys) {
+template <bool CMP>
+__global__ __launch_bounds__(256) void exact_keys_kernel(int ds, const float *__restrict__ x, const void *__restrict__ xh,
+                                                         uint64_t n_rows, const float *__restrict__ qrow,
+                                                         uint64_t *__restrict__ keys) {
     // all LDS in the dynamic region (a static __shared__ in front would misalign the float4 reads)
     extern __shared__ __attribute__((aligned(16))) char esm[];
     float *qv = reinterpret_cast<float *>(esm);
@@ -713,7 +765,7 @@ __global__ __launch_bounds__(256) void exact_keys_kernel(int ds, const float *__
     __syncthreads();
     const double na = *s_na;
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * 256) {
-        const float d = exact_dist_row(qv, x + r * (uint64_t)ds, ds, na, nullptr);
+        const float d = exact_dist_stored<CMP>(qv, x, xh, ds, (uint32_t)r, na);
         keys[r] = ((uint64_t)__float_as_uint(d) << 32) | (uint32_t)r;
     }
 }
@@ -768,7 +820,7 @@ __global__ __launch_bounds__(256) void exact_emit_kernel(int k, uint64_t kk, IdM
     }
 }
 
-hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *x, uint64_t n_rows,
+hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *x, const void *xh, uint64_t n_rows,
                               const IdMap &idmap, const float *qpad_row, uint64_t *keys, uint64_t *sel_state,
                               uint64_t *ids, float *scores, float *dists, int32_t *n_found) {
     (void)d;
@@ -779,8 +831,8 @@ hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *
     if (kk > 0) {
         unsigned blocks = (unsigned)((n_rows + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(exact_keys_kernel, dim3(blocks), dim3(256), sizeof(float) * (size_t)ds + 16, s, ds, x, n_rows,
-                           qpad_row, keys);
+        if (x) hipLaunchKernelGGL(exact_keys_kernel<false>, dim3(blocks), dim3(256), sizeof(float) * (size_t)ds + 16, s, ds, x, xh, n_rows, qpad_row, keys);
+        else hipLaunchKernelGGL(exact_keys_kernel<true>, dim3(blocks), dim3(256), sizeof(float) * (size_t)ds + 16, s, ds, x, xh, n_rows, qpad_row, keys);
         unsigned cblocks = blocks > 1024 ? 1024 : blocks;
         for (int bit = 63; bit >= 0; --bit) {
             hipLaunchKernelGGL(exact_count_kernel, dim3(cblocks), dim3(256), 0, s, keys, n_rows, bit, sel_state);
@@ -830,6 +882,30 @@ __global__ __launch_bounds__(256) void merge_kernel(const char *__restrict__ ids
             if (out_scores) out_scores[(size_t)b * k + rank] = score_from_dist(d);
         }
     }
+}
+
+// compressed corpus -> rows [row0, row0 + n) as f32 [n, d] (exact widening; zero-norm rows come out as zeros)
+__global__ __launch_bounds__(256) void unshadow_kernel(const void *__restrict__ xh, int ds, int d, uint64_t row0, uint64_t n,
+                                                       float *__restrict__ out) {
+    const int nc4 = (d + 3) / 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n * (uint64_t)nc4; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = i / nc4;
+        const int c4 = (int)(i - r * nc4);
+        const float4 v = row_load4<true>(nullptr, xh, ds, (uint32_t)(row0 + r), c4);
+        float *o = out + r * (uint64_t)d + 4 * c4;
+        if (4 * c4 + 0 < d) o[0] = v.x;
+        if (4 * c4 + 1 < d) o[1] = v.y;
+        if (4 * c4 + 2 < d) o[2] = v.z;
+        if (4 * c4 + 3 < d) o[3] = v.w;
+    }
+}
+
+hipError_t launch_unshadow(hipStream_t s, const void *xh, int ds, int d, uint64_t row0, uint64_t n, float *out) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n * (uint64_t)((d + 3) / 4) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(unshadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xh, ds, d, row0, n, out);
+    return hipGetLastError();
 }
 
 __global__ void fill_nfound_kernel(int32_t *nf, int B, int32_t v) {

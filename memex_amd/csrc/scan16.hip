@@ -233,49 +233,61 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void shadow_kernel(const float *__restrict__ x, const float *__restrict__ scale,
                                                      int ds, uint32_t tile0, uint32_t tile1,
-                                                     bf16x8 *__restrict__ xh, uint32_t *__restrict__ ec_max) {
-    __shared__ float s_r2[kTileRows];  // per row: |bf16(c/|c|) - c/|c||^2, the row's share of the scan's error bound
+                                                     bf16x8 *__restrict__ xh, uint32_t *__restrict__ ec_max,
+                                                     uint32_t src_tile0, uint64_t row_lo, uint64_t row_hi) {
+    // per row: |bf16(c/|c|) - c/|c||^2 (the row's share of the scan's error bound) and |bf16(c/|c|)|^2
+    __shared__ float s_r2[kTileRows], s_n2[kTileRows];
     const uint32_t frags = (uint32_t)(ds / 16) * 64u;  // fragments per tile
     float worst = 0.0f;
     for (uint32_t t = tile0 + blockIdx.x; t < tile1; t += gridDim.x) {
-        const float *xt = x + (size_t)t * kTileRows * ds;
+        const float *xt = x + (size_t)(t - src_tile0) * kTileRows * ds;
         bf16x8 *ot = xh + (size_t)t * frags;
-        if (threadIdx.x < kTileRows) s_r2[threadIdx.x] = 0.0f;
+        if (threadIdx.x < kTileRows) s_r2[threadIdx.x] = 0.0f, s_n2[threadIdx.x] = 0.0f;
         __syncthreads();
         for (uint32_t f = threadIdx.x; f < frags; f += 256) {
             const uint32_t ks = f >> 6, l = f & 63, mm = l & 31, hh = l >> 5;
+            const uint64_t grow = (uint64_t)t * kTileRows + mm;
+            if (grow < row_lo || grow >= row_hi) continue;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(xt + (size_t)mm * ds + ks * 16 + hh * 8);
-            const float sc = scale[(size_t)t * kTileRows + mm];  // 1/|c|; +inf for a zero row -> 0*inf = NaN
+            const float sc = scale[(size_t)(t - src_tile0) * kTileRows + mm];  // 1/|c|; +inf for a zero row -> 0*inf = NaN
             const f32x4 lo = src[0] * sc, hi = src[1] * sc;
             bf16x8 o;
             o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
             o[4] = (__bf16)hi[0]; o[5] = (__bf16)hi[1]; o[6] = (__bf16)hi[2]; o[7] = (__bf16)hi[3];
             ot[f] = o;
-            float r2 = 0.0f;
+            float r2 = 0.0f, n2 = 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float a = (float)o[i] - lo[i], b = (float)o[4 + i] - hi[i];
                 r2 += a * a + b * b;
+                n2 += (float)o[i] * (float)o[i] + (float)o[4 + i] * (float)o[4 + i];
             }
-            if (r2 == r2) atomicAdd(&s_r2[mm], r2);  // NaN: zero-norm row, handled exactly (no error)
+            if (r2 == r2) {  // NaN: zero-norm row, handled exactly (no error)
+                atomicAdd(&s_r2[mm], r2);
+                atomicAdd(&s_n2[mm], n2);
+            }
         }
         __syncthreads();
-        if (threadIdx.x < kTileRows) worst = fmaxf(worst, s_r2[threadIdx.x]);
+        if (threadIdx.x < kTileRows) {
+            // the stored row is not exactly unit: ||c^| - 1| enters the bound when the copy is the corpus
+            const float dev = s_n2[threadIdx.x] > 0.0f ? fabsf(sqrtf(s_n2[threadIdx.x]) - 1.0f) : 0.0f;
+            worst = fmaxf(worst, fmaxf(sqrtf(s_r2[threadIdx.x]), dev));
+        }
         __syncthreads();
     }
     if (threadIdx.x < kTileRows) {
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
-        if (threadIdx.x == 0 && worst > 0.0f) atomicMax(ec_max, __float_as_uint(sqrtf(worst)));
+        if (threadIdx.x == 0 && worst > 0.0f) atomicMax(ec_max, __float_as_uint(worst));
     }
 }
 
 hipError_t launch_shadow(hipStream_t s, const float *x, const float *scale, int ds, uint32_t tile0, uint32_t tile1,
-                         void *xh, uint32_t *ec_max) {
+                         void *xh, uint32_t *ec_max, uint32_t src_tile0, uint64_t row_lo, uint64_t row_hi) {
     if (tile1 <= tile0) return hipSuccess;
     const uint32_t blocks = tile1 - tile0 < 16384u ? tile1 - tile0 : 16384u;
     hipLaunchKernelGGL(shadow_kernel, dim3(blocks), dim3(256), 0, s, x, scale, ds, tile0, tile1,
-                       reinterpret_cast<bf16x8 *>(xh), ec_max);
+                       reinterpret_cast<bf16x8 *>(xh), ec_max, src_tile0, row_lo, row_hi);
     return hipGetLastError();
 }
 

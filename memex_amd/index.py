@@ -97,6 +97,17 @@ class FlatIndex:
         """Keep (default) or drop the bf16 filter copy the scan streams; results do not change."""
         check(lib().mx_index_set_filter_copy(self._h, 1 if on else 0))
 
+    def set_corpus_mode(self, mode: str) -> None:
+        """``"f32"`` (default) or ``"bf16"``: keep only the bf16 rows (a third of the HBM); searches are
+        then exact with respect to the stored rows (``get_rows``).  Only while the index is empty."""
+        check(lib().mx_index_set_corpus_mode(self._h, {"f32": _lib.MX_CORPUS_F32, "bf16": _lib.MX_CORPUS_BF16}[mode]))
+
+    def get_rows(self, first_row: int, n: int) -> np.ndarray:
+        """Rows as stored (0-based, insertion order) -> f32 [n, dim]."""
+        out = np.zeros((int(n), self.dim), dtype=np.float32)
+        check(lib().mx_index_get_rows(self._h, int(first_row), int(n), _ptr(out)))
+        return out
+
     def set_profiling(self, on: bool) -> None:
         check(lib().mx_index_set_profiling(self._h, 1 if on else 0))
 
