@@ -55,7 +55,14 @@ def main():
     if enc:
         with open(enc) as f, open(os.path.join(prof, f"{tag}_encoder_kernel_stats.csv"), "w") as g:
             g.write(f.read())
-    for name in ("bench.json", "bench_under_rocprof.json", "bench_default.json"):
+    st768 = find(os.path.join(out_dir, "stats768"), "_kernel_stats.csv")
+    if st768:
+        with open(st768) as f, open(os.path.join(prof, f"{tag}_bench768_kernel_stats.csv"), "w") as g:
+            g.write(f.read())
+    for name in glob.glob(os.path.join(out_dir, "power_*.log")):
+        with open(name) as f, open(os.path.join(prof, f"{tag}_" + os.path.basename(name)), "w") as g:
+            g.write(f.read())
+    for name in ("bench.json", "bench_under_rocprof.json", "bench_default.json", "bench768_under_rocprof.json"):
         src = os.path.join(out_dir, name)
         if os.path.exists(src):
             lines = [ln for ln in open(src).read().splitlines() if ln.startswith("{")]
@@ -67,17 +74,21 @@ def main():
         bench = json.loads(open(os.path.join(prof, f"{tag}_bench.json")).read())
     except Exception:
         pass
-    for label, want, fname in (("bf16", "scan16_kernel<3, 1>", f"{tag}_scan16_traffic.json"),
-                               ("f32", "scan_kernel<3, 1>", f"{tag}_scan_traffic.json")):
+    for label, want, fname, pat in (("bf16", "scan16_kernel<3, 1>", f"{tag}_scan16_traffic.json", "pmc_*"),
+                                    ("f32", "scan_kernel<3, 1>", f"{tag}_scan_traffic.json", "pmc_*"),
+                                    ("768", "scan16_kernel<6, 1>", f"{tag}_scan16_768_traffic.json", "pmc768_*")):
         c = {}
-        for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
+        for d in sorted(glob.glob(os.path.join(out_dir, pat))):
             if os.path.isdir(d):
                 c.update(counters(d, want))
         if "FETCH_SIZE" not in c:
             continue
         fetch = c["FETCH_SIZE"][0] * 1024.0 * 2.0
         write = c.get("WRITE_SIZE", (0.0, 0, 0.0))[0] * 1024.0
-        rf = bench.get("roofline", {}) if bench.get("scan") == label else bench.get("other_scan", {}).get("roofline", {})
+        if label == "768":
+            rf = bench.get("cfg4_shard_10Mx768", {}).get("roofline", {})
+        else:
+            rf = bench.get("roofline", {}) if bench.get("scan") == label else bench.get("other_scan", {}).get("roofline", {})
         algo = rf.get("bytes_per_launch")
         res = {
             "kernel": "mx::" + want.replace(", ", ","),

@@ -1,20 +1,33 @@
 #!/bin/bash
-# Profiles the search bench on the GPU box: one --kernel-trace --stats pass, then separate --pmc
-# passes (never combined with other trace domains), then scripts/profile_reduce.py writes the
-# summaries that get copied into profiles/.  Usage: scripts/profile_search.sh [tag]
+# Profiles the search bench on the GPU box: --kernel-trace --stats passes (10M x 384 with its side legs;
+# 10M x 768 alone), then separate --pmc passes (never combined with other trace domains), package
+# power / clock logs of the scan kernel and its ablations, the encoder kernels and the default bench
+# line; scripts/profile_reduce.py writes the summaries that get copied into profiles/.
+# Usage: scripts/profile_search.sh [tag]
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --ingest-chunks 0 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --steps 50 --warmup 10 --alt-steps 20 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
-for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
-  D=$OUT/pmc_$(echo $C | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$D" -- $BENCH --steps 6 --warmup 2 --alt-steps 6 > "$D.json" 2> "$D.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --steps 50 --warmup 10 --alt-steps 20 --side-steps 20 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats768" -- $BENCH --dim 768 --steps 30 --warmup 5 --alt-steps 0 --side-steps 0 > "$OUT/bench768_under_rocprof.json" 2> "$OUT/stats768.log"
+for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"; do
+  D=$OUT/pmc_$(echo $C | tr ' ' '_' | cut -c1-60)
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$D" -- $BENCH --steps 6 --warmup 2 --alt-steps 6 --side-steps 0 > "$D.json" 2> "$D.log"
+  D=$OUT/pmc768_$(echo $C | tr ' ' '_' | cut -c1-60)
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$D" -- $BENCH --dim 768 --steps 6 --warmup 2 --alt-steps 0 --side-steps 0 > "$D.json" 2> "$D.log"
 done
 $BENCH > "$OUT/bench.json" 2> "$OUT/bench.log"
+# package power and shader clock while the scan kernel (and its ablations: 1 = DMA stream only,
+# 4 = fragment reads + MFMA without the DMA) runs back to back for >= 5 s
+if [ -x $ROOT/build_ub/scan16_ub_0 ]; then
+  for V in 0 1 4; do
+    python $ROOT/scripts/power_sampler.py "$OUT/power_scan16_ablate$V.log" -- $ROOT/build_ub/scan16_ub_$V 10000000 384 3000 > /dev/null 2>&1
+  done
+  python $ROOT/scripts/power_sampler.py "$OUT/power_scan16_768.log" -- $ROOT/build_ub/scan16_ub_0 10000000 768 1500 > /dev/null 2>&1
+fi
 # encoder kernels (MiniLM-L6 shape, 2048 x 512-token chunks) and the default bench line (all legs)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/enc_stats" -- python $ROOT/scripts/gpu_encoder_prof.py l6 > /dev/null 2> "$OUT/enc_stats.log"
 python $ROOT/bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.log"

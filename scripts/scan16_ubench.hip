@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
   fill16<<<4096, 256>>>((unsigned short*)xh, rows * ds, 1); fillf<<<1024, 256>>>(scale, rows); fill16<<<64, 256>>>((unsigned short*)qf, 256 * ds, 3);
   std::vector<float> th(256, INFINITY); CK(hipMemcpy(theta, th.data(), 1024, hipMemcpyHostToDevice));
   CK(scan16_setup());
-  ScanParams p; p.x = nullptr; p.xh = xh; p.scale = scale; p.qfrag = qf; p.theta = theta; p.n_rows = rows; p.tile_begin = 0; p.tile_end = rows / 32; p.ds = ds; p.lane_buf = lb; p.lane_cnt = lc; p.overflow = ovf;
+  ScanParams p; p.x = nullptr; p.xh = xh; p.scale = scale; p.qfrag = qf; p.theta = theta; p.n_rows = rows; p.tile_begin = 0; p.tile_end = rows / 32; p.tile_stride = 1; p.ds = ds; p.lane_max = (float*)lc; p.lane_buf = lb; p.lane_cnt = lc; p.overflow = ovf;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) CK(launch_scan16(0, kc, true, nwg, p));
   CK(hipDeviceSynchronize());
