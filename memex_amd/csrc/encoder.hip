@@ -168,7 +168,6 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
     int rc = ensure_ws(e, t_pad, B, 0);
     if (rc != MX_OK) return rc;
     hipStream_t st = e->stream;
-    if (e->profiling) MX_HIP(hipEventRecord(e->ev0, st));
     MX_HIP(launch_token_map(st, d_lens, B, S, e->cu, e->tok_seq, e->tok_pos, t_pad));
     MX_HIP(launch_embed_ln(st, d_ids, S, e->tok_seq, e->tok_pos, t_pad, H, e->word, e->pos, e->type0, e->eg, e->eb,
                            c.ln_eps, c.vocab, e->x));
@@ -204,13 +203,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         MX_HIP(launch_gemm(st, EPI_BIAS_RES_LN, f2));
     }
     MX_HIP(launch_pool(st, e->x, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
-    if (e->profiling) MX_HIP(hipEventRecord(e->ev1, st));
-    MX_HIP(hipStreamSynchronize(st));
-    if (e->profiling) {
-        float ms = 0.f;
-        MX_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-        e->stats.gpu_ms += ms;
-    }
+    // no synchronisation here: the passes of one call queue up on the stream (same workspace, stream order)
     e->stats.sequences += (uint64_t)B;
     e->stats.tokens += tokens;
     e->stats.flops += (double)c.layers * ((double)tokens * (8.0 * H * H + 4.0 * (double)H * F) + attn_flops);
@@ -222,6 +215,7 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
                float *d_out) {
     for (int b = 0; b < B; ++b)
         if (h_lens[b] < 1 || h_lens[b] > S) return fail(MX_EINVAL, "lens[%d] = %d outside [1, %d]", b, h_lens[b], S);
+    if (e->profiling) MX_HIP(hipEventRecord(e->ev0, e->stream));
     int b0 = 0;
     while (b0 < B) {
         int nb = 0;
@@ -237,6 +231,13 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
                              d_out + (size_t)b0 * e->cfg.hidden);
         if (rc != MX_OK) return rc;
         b0 += nb;
+    }
+    if (e->profiling) MX_HIP(hipEventRecord(e->ev1, e->stream));
+    MX_HIP(hipStreamSynchronize(e->stream));  // results complete in d_out when the call returns
+    if (e->profiling) {
+        float ms = 0.f;
+        MX_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->stats.gpu_ms += ms;
     }
     e->stats.calls += 1;
     return MX_OK;

@@ -357,8 +357,9 @@ hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void token_map_kernel(const int32_t *__restrict__ lens, int B, int S, int32_t *cu,
                                                          int32_t *tok_seq, int32_t *tok_pos, int t_pad) {
-    // single block of 1024 threads (B <= 1024): parallel exclusive scan of the aligned lengths, then every
-    // packed row finds its sequence by binary search in the scanned starts
+    // blocks of 1024 threads (B <= 1024): every block scans the aligned lengths itself (1024 elements: cheaper
+    // than a second launch), then the packed rows, dealt over the grid, find their sequence by binary
+    // search in the scanned starts
     __shared__ int s_cu[1025];
     __shared__ int s_len[1024];
     const int tid = threadIdx.x;
@@ -378,9 +379,9 @@ __global__ __launch_bounds__(1024) void token_map_kernel(const int32_t *__restri
         s_cu[tid + 1] += v;
         __syncthreads();
     }
-    if (tid <= B) cu[tid] = s_cu[tid];
+    if (blockIdx.x == 0 && tid <= B) cu[tid] = s_cu[tid];
     const int total = s_cu[B];
-    for (int t = tid; t < t_pad; t += 1024) {
+    for (int t = blockIdx.x * 1024 + tid; t < t_pad; t += gridDim.x * 1024) {
         int seq = -1, pos = 0;
         if (t < total) {
             int lo = 0, hi = B - 1;  // last b with s_cu[b] <= t
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(1024) void token_map_kernel(const int32_t *__restri
 hipError_t launch_token_map(hipStream_t s, const int32_t *lens, int B, int S, int32_t *cu, int32_t *tok_seq,
                             int32_t *tok_pos, int t_pad) {
     if (B > 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(token_map_kernel, dim3(1), dim3(1024), 0, s, lens, B, S, cu, tok_seq, tok_pos, t_pad);
+    const int blocks = t_pad / 1024 < 1 ? 1 : (t_pad / 1024 > 256 ? 256 : t_pad / 1024);
+    hipLaunchKernelGGL(token_map_kernel, dim3(blocks), dim3(1024), 0, s, lens, B, S, cu, tok_seq, tok_pos, t_pad);
     return hipGetLastError();
 }
 
