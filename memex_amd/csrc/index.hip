@@ -58,7 +58,8 @@ struct Scratch {
     uint32_t *host_flags = nullptr;  // pinned mirror, one async D2H per batch
     uint32_t *overflow = nullptr, *cand_cnt = nullptr, *qflags = nullptr;  // views into dev_flags
     float *e1 = nullptr;
-    Cand *lane_buf = nullptr;
+    float *lane_rec = nullptr;       // records of the collect launch (ScanParams)
+    uint32_t *lane_tile = nullptr;
     uint32_t *lane_cnt = nullptr;
     float *lane_max = nullptr;
     float *qstage = nullptr;       // [256, dim] host->device query staging
@@ -133,8 +134,10 @@ struct mx_index {
     uint64_t xs_rows = 0;
     uint64_t n = 0, cap = 0;
     IdMap idmap{0, 0, 1, 0};
-    uint32_t *flags = nullptr;  // device: [0] non-finite rows, [1] out-of-range-norm rows (last add), [2] ec_max (float bits)
+    uint32_t *flags = nullptr;  // device: [0] non-finite rows, [1] out-of-range-norm rows (last add), [2] ec_max (float bits), [3] zero-norm rows
     uint64_t wild_rows = 0;
+    uint32_t *zero_rows = nullptr;  // device: [kZeroCap] local rows with zero norm, ascending (finish_kernel adds them to every query)
+    uint64_t n_zero = 0;            // zero-norm rows in the index; more than kZeroCap -> EXACT path
     int mode = MX_SEARCH_AUTO;
     bool profiling = false;
     int n_cu = 0, nwg = 0;
@@ -220,13 +223,13 @@ int free_index(mx_index *idx) {
     auto F = [](void *p) {
         if (p) (void)hipFree(p);
     };
-    F(idx->x); F(idx->scale); F(idx->xh); F(idx->flags); F(idx->xs); F(idx->ss);
+    F(idx->x); F(idx->scale); F(idx->xh); F(idx->flags); F(idx->xs); F(idx->ss); F(idx->zero_rows);
     Scratch &s = idx->s;
     F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.theta_retry); F(s.todo); F(s.dev_flags);
     if (s.host_flags) (void)hipHostFree(s.host_flags);
     for (void *hp : {(void *)s.h_q, (void *)s.h_ids, (void *)s.h_scores, (void *)s.h_dists, (void *)s.h_nf})
         if (hp) (void)hipHostFree(hp);
-    F(s.lane_buf); F(s.lane_cnt); F(s.lane_max); F(s.qstage); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
+    F(s.lane_rec); F(s.lane_tile); F(s.lane_cnt); F(s.lane_max); F(s.qstage); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
     F(s.exact_keys); F(s.sel_state); F(s.max_err);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
@@ -253,7 +256,8 @@ int ensure_scratch(mx_index *idx) {
     s.e1 = reinterpret_cast<float *>(s.dev_flags + 2 * kMaxBatch);
     s.qflags = s.dev_flags + 3 * kMaxBatch;
     MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.host_flags), kFlagWords * sizeof(uint32_t), hipHostMallocDefault));
-    MX_HIP(hipMalloc(&s.lane_buf, (size_t)idx->nwg * kScanThreads * kLaneCap * sizeof(Cand)));
+    MX_HIP(hipMalloc(&s.lane_rec, (size_t)idx->nwg * kScanThreads * kRecCap * 16 * sizeof(float)));
+    MX_HIP(hipMalloc(&s.lane_tile, (size_t)idx->nwg * kScanThreads * kRecCap * sizeof(uint32_t)));
     MX_HIP(hipMalloc(&s.lane_cnt, (size_t)idx->nwg * kScanThreads * sizeof(uint32_t)));
     MX_HIP(hipMalloc(&s.lane_max, (size_t)idx->nwg * kScanThreads * sizeof(float)));
     MX_HIP(hipMalloc(&s.qstage, (size_t)kMaxBatch * idx->dim * sizeof(float)));
@@ -378,6 +382,30 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
     return MX_OK;
 }
 
+// reads the ingest flags back; a batch with non-finite rows is rejected (zero-row list rolled back),
+// otherwise the zero-norm rows it brought are committed (list kept ascending for finish_kernel)
+int commit_ingest(mx_index *idx, uint32_t (&fl)[4]) {
+    MX_HIP(hipMemcpyAsync(fl, idx->flags, sizeof(fl), hipMemcpyDeviceToHost, idx->stream));
+    MX_HIP(hipStreamSynchronize(idx->stream));
+    if (fl[0] != 0) {
+        const uint32_t keep = (uint32_t)idx->n_zero;
+        MX_HIP(hipMemcpyAsync(idx->flags + 3, &keep, sizeof(keep), hipMemcpyHostToDevice, idx->stream));
+        MX_HIP(hipStreamSynchronize(idx->stream));
+        return fail(MX_EINVAL, "%u row(s) contain non-finite values; nothing inserted", fl[0]);
+    }
+    if (fl[3] != idx->n_zero) {
+        const size_t have = std::min<size_t>(fl[3], kZeroCap);
+        if (have > std::min<uint64_t>(idx->n_zero, kZeroCap)) {  // new entries arrive in atomic order: sort
+            std::vector<uint32_t> z(have);
+            MX_HIP(hipMemcpy(z.data(), idx->zero_rows, have * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            std::sort(z.begin(), z.end());
+            MX_HIP(hipMemcpy(idx->zero_rows, z.data(), have * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        idx->n_zero = fl[3];
+    }
+    return MX_OK;
+}
+
 // rows already on the device ([n, dim]); appends and validates
 int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *first_id) {
     if (n == 0) {
@@ -397,38 +425,37 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
             MX_HIP(hipMalloc(reinterpret_cast<void **>(&idx->ss), (size_t)(kWin + kTileRows) * sizeof(float)));
             idx->xs_rows = kWin + kTileRows;
         }
-        uint32_t fl[2] = {0, 0};
+        uint32_t fl[4] = {0, 0, 0, 0};
         for (uint64_t done = 0; done < n; done += kWin) {
             const uint64_t m = std::min(kWin, n - done), g0 = idx->n + done;     // global rows [g0, g0 + m)
             const uint64_t t0 = g0 / kTileRows, off = g0 % kTileRows;
             MX_HIP(launch_ingest(idx->stream, d_rows + (size_t)done * idx->dim, m, idx->dim, idx->xs, idx->ss, off, idx->ds, idx->flags,
-                                 idx->raw_ingest ? 1 : 0));
+                                 idx->raw_ingest ? 1 : 0, idx->zero_rows, g0));
             MX_HIP(launch_shadow(idx->stream, idx->xs, idx->ss, idx->ds, (uint32_t)t0, (uint32_t)((g0 + m + kTileRows - 1) / kTileRows),
                                  idx->xh, idx->flags + 2, (uint32_t)t0, g0, g0 + m));
         }
-        MX_HIP(hipMemcpyAsync(fl, idx->flags, sizeof(fl), hipMemcpyDeviceToHost, idx->stream));
-        MX_HIP(hipStreamSynchronize(idx->stream));
-        if (fl[0] != 0) {  // rows past idx->n are never read by a search; the next append overwrites them
-            return fail(MX_EINVAL, "%u row(s) contain non-finite values; nothing inserted", fl[0]);
-        }
+        int rc2 = commit_ingest(idx, fl);
+        if (rc2 != MX_OK) return rc2;  // rows past idx->n are never read by a search; the next append overwrites them
         idx->wild_rows += fl[1];
         if (first_id) *first_id = idx->idmap.id_of((uint32_t)idx->n);
         idx->n += n;
         return MX_OK;
     }
-    MX_HIP(launch_ingest(idx->stream, d_rows, n, idx->dim, idx->x, idx->scale, idx->n, idx->ds, idx->flags));
+    MX_HIP(launch_ingest(idx->stream, d_rows, n, idx->dim, idx->x, idx->scale, idx->n, idx->ds, idx->flags, 0, idx->zero_rows, idx->n));
     if (idx->xh)  // tiles touched by this append (the first one may already be partly filled)
         MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, (uint32_t)(idx->n / kTileRows),
                              (uint32_t)((idx->n + n + kTileRows - 1) / kTileRows), idx->xh, idx->flags + 2));
-    uint32_t fl[2] = {0, 0};
-    MX_HIP(hipMemcpyAsync(fl, idx->flags, sizeof(fl), hipMemcpyDeviceToHost, idx->stream));
-    MX_HIP(hipStreamSynchronize(idx->stream));
-    if (fl[0] != 0) {
+    uint32_t fl[4] = {0, 0, 0, 0};
+    rc = commit_ingest(idx, fl);
+    if (rc != MX_OK) {
         // rows past idx->n are never read, but the filter copy's tile of row n may now hold garbage: rebuild it
-        if (idx->xh)
+        if (idx->xh) {
+            const std::string keep = last_error_slot();
             MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, (uint32_t)(idx->n / kTileRows),
                                  (uint32_t)(idx->n / kTileRows + 1), idx->xh, idx->flags + 2));
-        return fail(MX_EINVAL, "%u row(s) contain non-finite values; nothing inserted", fl[0]);
+            last_error_slot() = keep;
+        }
+        return rc;
     }
     idx->wild_rows += fl[1];
     if (first_id) *first_id = idx->idmap.id_of((uint32_t)idx->n);  // local.rs:63: next_id = len + 1
@@ -480,7 +507,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     const bool trivial = idx->n == 0 || k == 0;
     if (idx->compressed && idx->kc > kMaxKC && !trivial)
         return fail(MX_EUNSUPPORTED, "a compressed corpus supports dim <= %d", kMaxKC * kChunkFloats);
-    const bool fast = !trivial && idx->mode == MX_SEARCH_AUTO && idx->kc <= kMaxKC && idx->wild_rows == 0 && k <= 256;
+    const bool fast = !trivial && idx->mode == MX_SEARCH_AUTO && idx->kc <= kMaxKC && idx->wild_rows == 0 && k <= 256 &&
+                      idx->n_zero <= (uint64_t)kZeroCap;
     const uint32_t *h_ovf = s.host_flags, *h_cnt = s.host_flags + kMaxBatch, *h_qfl = s.host_flags + 3 * kMaxBatch;
     bool timed = false;
 
@@ -497,8 +525,12 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     fp.qnorm2 = s.qnorm2;
     fp.e1 = s.e1;
     fp.e2 = (float)(idx->ds + 8) * 5.9604645e-8f + 1e-6f;  // f32 fma dot of <= ds terms of unit vectors, any order
-    fp.lane_buf = s.lane_buf;
+    fp.lane_rec = s.lane_rec;
+    fp.lane_tile = s.lane_tile;
     fp.lane_cnt = s.lane_cnt;
+    fp.theta = s.theta;
+    fp.zero_rows = idx->zero_rows;
+    fp.n_zero = (uint32_t)std::min<uint64_t>(idx->n_zero, kZeroCap);
     fp.overflow = s.overflow;
     fp.todo = nullptr;
     fp.theta_retry = s.theta_retry;
@@ -527,7 +559,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         p.theta = s.theta;
         p.n_rows = idx->n;
         p.ds = (uint32_t)idx->ds;
-        p.lane_buf = s.lane_buf;
+        p.lane_rec = s.lane_rec;
+        p.lane_tile = s.lane_tile;
         p.lane_cnt = s.lane_cnt;
         p.lane_max = s.lane_max;
         p.overflow = s.overflow;
@@ -848,9 +881,10 @@ int clear_locked(mx_index *idx) {
     } else {
         idx->n = 0;  // ids restart at 1 (local.rs:50,63); HBM is kept for reuse
         idx->wild_rows = 0;
+        idx->n_zero = 0;
         if (idx->flags) {
             DeviceGuard dg(idx->device);
-            (void)hipMemsetAsync(idx->flags + 2, 0, sizeof(uint32_t), idx->stream);  // ec_max
+            (void)hipMemsetAsync(idx->flags + 2, 0, 2 * sizeof(uint32_t), idx->stream);  // ec_max, zero-row count
         }
     }
     idx->disk_dir.clear();
@@ -918,6 +952,7 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
     MX_HIP(hipEventCreateWithFlags(&idx->ev_wait, hipEventDisableTiming));
     MX_HIP(hipMalloc(&idx->flags, 4 * sizeof(uint32_t)));
     MX_HIP(hipMemset(idx->flags, 0, 4 * sizeof(uint32_t)));
+    MX_HIP(hipMalloc(&idx->zero_rows, kZeroCap * sizeof(uint32_t)));
     *out = idx.release();
     return MX_OK;
 }

@@ -28,9 +28,10 @@ constexpr int kRing16 = 16;        // 16 x 8 KiB = 128 KiB ring, 15 slots in fli
 constexpr int kScan16LdsBytes = kRing16 * kSlot16Bytes;
 
 constexpr int kMaxBatch = 256;     // queries per scan pass (8 waves x 32 MFMA columns)
-constexpr int kLaneCap = 32;       // lane-private candidate slots per scan launch
+constexpr int kRecCap = 32;        // lane-private records per collect launch: one record = the lane's 16 scores of a tile
 constexpr int kMaxScanWGs = 256;   // persistent workgroups (<= CUs)
-constexpr int kCandCap = 2 * kLaneCap * kMaxScanWGs;  // everything one query can collect in a launch (2 lanes per workgroup)
+constexpr int kCandCap = 16384;    // candidates finish_kernel holds per query (LDS); more = rescan with a tight threshold
+constexpr int kZeroCap = 1024;     // zero-norm rows an index tracks in its list (more: EXACT path)
 
 // cosine-unit bounds on |approx - exact| of the bf16 scan.
 //   a priori:  two bf16 roundings (unit roundoff 2^-8 each) of unit vectors, Cauchy-Schwarz:
@@ -42,7 +43,7 @@ constexpr float kApproxErr = 0.0081f;
 constexpr float kAccSlack = 2.7e-4f;
 
 struct Cand {
-    float score;   // approximate cosine (NaN / +2 = "zero-norm row": exact dist is 0)
+    float score;   // approximate cosine
     uint32_t row;  // local row
 };
 
@@ -70,8 +71,11 @@ struct ScanParams {
     uint32_t tile_end;
     uint32_t tile_stride;    // 1 = every tile; > 1 = the evenly spread sample
     uint32_t ds;             // floats per stored row
-    Cand *lane_buf;          // [512][nwg][kLaneCap]  (thread-in-workgroup major)
-    uint32_t *lane_cnt;      // [512][nwg]
+    // collect launch: a lane whose 16 scores of a tile contain one >= theta stores ALL 16 (one record =
+    // 64 bytes + the tile index); finish_kernel picks the passing rows.  No per-row code on the stream.
+    float *lane_rec;         // [512][nwg][kRecCap][16]  (thread-in-workgroup major)
+    uint32_t *lane_tile;     // [512][nwg][kRecCap] tile index of each record
+    uint32_t *lane_cnt;      // [512][nwg] records written
     float *lane_max;         // [512][nwg] sample mode: running maximum of each lane
     uint32_t *overflow;      // [256]
 };
@@ -96,10 +100,11 @@ hipError_t launch_shadow(hipStream_t s, const float *x, const float *scale, int 
 // compressed corpus -> f32 rows [n, d]
 hipError_t launch_unshadow(hipStream_t s, const void *xh, int ds, int d, uint64_t row0, uint64_t n, float *out);
 
-// rows [n, d] (device) -> x[first.., ds] zero-padded + scale; flags[0] += non-finite rows,
-// flags[1] += rows whose norm is outside the range the bf16 scan is certified for
+// rows [n, d] (device) -> x[first.., ds] zero-padded + scale (0 for a zero-norm row); flags[0] += non-finite
+// rows, flags[1] += rows whose norm is outside the range the bf16 scan is certified for, flags[3] +=
+// zero-norm rows, whose local row numbers (row_base + r) go to zero_rows[] (first kZeroCap)
 hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, float *x, float *scale,
-                         uint64_t first, int ds, uint32_t *flags, int raw = 0);
+                         uint64_t first, int ds, uint32_t *flags, int raw, uint32_t *zero_rows, uint64_t row_base);
 
 // queries [B, d] (device) -> qfrag (normalised bf16 fragments), qpad [256, ds] f32 original
 // values zero padded, qnorm2 [256] f64 (sequential DistCosine accumulation), theta init, e1 [256]
@@ -127,8 +132,12 @@ struct FinishParams {
     const double *qnorm2;       // [256]
     const float *e1;            // [256]
     float e2;                   // bound on |f32 rescoring - cosine|
-    const Cand *lane_buf;
+    const float *lane_rec;      // records of the collect launch (ScanParams)
+    const uint32_t *lane_tile;
     const uint32_t *lane_cnt;
+    const float *theta;         // [256] the collect launch's pass threshold
+    const uint32_t *zero_rows;  // [kZeroCap] zero-norm rows of the index (their stored scores are 0: they enter here)
+    uint32_t n_zero;
     uint32_t *overflow;         // [256]
     const uint32_t *todo;       // null = every query; else only queries with todo[q] != 0
     float *theta_retry;         // [256]

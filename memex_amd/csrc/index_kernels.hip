@@ -13,6 +13,8 @@
 
 namespace mx {
 
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
@@ -136,7 +138,8 @@ __device__ __forceinline__ uint32_t block_kth_largest(const uint32_t (&key)[PER]
 // bf16 rounding): they must be stored as they are, so 1/|c| is replaced by 1.
 __global__ __launch_bounds__(256) void ingest_kernel(const float *__restrict__ src, uint64_t n, int d,
                                                      float *__restrict__ x, float *__restrict__ scale,
-                                                     uint64_t first, int ds, uint32_t *flags, int raw) {
+                                                     uint64_t first, int ds, uint32_t *flags, int raw,
+                                                     uint32_t *__restrict__ zero_rows, uint64_t row_base) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
@@ -160,7 +163,14 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float *__restrict__ s
                 sc = raw ? 1.0f : (float)(1.0 / sqrt(acc));
                 if (acc < 1e-30 || acc > 1e30) atomicAdd(&flags[1], 1u);
             } else {
-                sc = INFINITY;  // zero-norm row: exact dist is 0 for every query (DistCosine else-branch)
+                // zero-norm row: exact dist is 0 for every query (DistCosine else-branch).  It is stored as
+                // zeros (scan score 0) and remembered in the index's zero-row list, from which
+                // finish_kernel adds it to every query's candidates.
+                sc = 0.0f;
+                if (!anybad && acc == 0.0) {
+                    const uint32_t at = atomicAdd(&flags[3], 1u);
+                    if (at < (uint32_t)kZeroCap) zero_rows[at] = (uint32_t)(row_base + r);
+                }
             }
             if (anybad || !isfinite(acc)) atomicAdd(&flags[0], 1u);
             scale[first + r] = sc;
@@ -169,11 +179,11 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float *__restrict__ s
 }
 
 hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, float *x, float *scale,
-                         uint64_t first, int ds, uint32_t *flags, int raw) {
+                         uint64_t first, int ds, uint32_t *flags, int raw, uint32_t *zero_rows, uint64_t row_base) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(ingest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, n, d, x, scale, first, ds, flags, raw);
+    hipLaunchKernelGGL(ingest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, n, d, x, scale, first, ds, flags, raw, zero_rows, row_base);
     return hipGetLastError();
 }
 
@@ -449,43 +459,71 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     const float e1 = p.e1[q];
     for (int i = tid; i < ds; i += kFinThreads) qv[i] = p.qpad[(size_t)q * ds + i];
 
-    // ---- gather: scan workgroup w kept this query's candidates in lanes L0 and L0+32 of wave q/32
-    // ([thread-in-workgroup][workgroup] layout, scan16.hip).  All loads of a lane buffer are issued
-    // before the first store (16-byte vectors, 2 entries each).
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    // ---- gather.  Scan workgroup w kept this query's records in lanes L0 and L0+32 of wave q/32
+    // ([thread-in-workgroup][workgroup] layout): a record = the lane's 16 scores of one tile, rows
+    // tile*32 + 4*hh + (r&3) + 8*(r>>2).  Thread i < 2*nwg owns one lane buffer: count the scores
+    // >= theta (what the old per-row append code did on the stream), scan, then write (score, row).
+    // The index's zero-norm rows score 0 in the scan (stored as zeros); their exact dist is 0, so they
+    // join every query's candidates here with cosine 1 -- and are dropped from the records, should a
+    // threshold <= 0 have let them through.
     const int nwg = p.nwg;
-    uint32_t c = 0;
+    const float th = p.theta[q];
+    const uint32_t nz = p.n_zero;
+    auto is_zero_row = [&](uint32_t row) {  // the list is ascending (rows are appended in insertion order)
+        uint32_t lo = 0, hi = nz;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (p.zero_rows[mid] < row) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo < nz && p.zero_rows[lo] == row;
+    };
+    uint32_t nrec = 0, hh = 0;
     size_t l = 0;
     if (tid < 2 * nwg) {
-        const int hh = tid / nwg, w = tid - hh * nwg;
+        hh = (uint32_t)(tid / nwg);
+        const int w = tid - (int)hh * nwg;
         l = (size_t)((uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31) + 32u * hh) * nwg + w;
-        c = p.lane_cnt[l];
-        c = c > (uint32_t)kLaneCap ? (uint32_t)kLaneCap : c;
+        nrec = p.lane_cnt[l];
+        nrec = nrec > (uint32_t)kRecCap ? (uint32_t)kRecCap : nrec;
     }
-    uint32_t M;
-    const uint32_t pos = block_scan_1024(c, s_w, &M);
-    if (c) {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(p.lane_buf + l * kLaneCap);
-        u32x4 v[kLaneCap / 2];
+    const f32x4 *rec = reinterpret_cast<const f32x4 *>(p.lane_rec + l * (kRecCap * 16));
+    auto for_each_pass = [&](auto &&fn) {
+        for (uint32_t e = 0; e < nrec; ++e) {
+            const uint32_t rowb = p.lane_tile[l * kRecCap + e] * kTileRows + 4u * hh;
+            const f32x4 a = rec[e * 4], b = rec[e * 4 + 1], c = rec[e * 4 + 2], d = rec[e * 4 + 3];
+            const float v[16] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
 #pragma unroll
-        for (int e = 0; e < kLaneCap / 2; ++e)
-            if ((uint32_t)(2 * e) < c) v[e] = src[e];
-#pragma unroll
-        for (int e = 0; e < kLaneCap / 2; ++e) {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const uint32_t i = 2 * e + hh;
-                if (i < c) {
-                    Cand cd;
-                    cd.score = __uint_as_float(v[e][2 * hh]);
-                    cd.row = v[e][2 * hh + 1];
-                    // NaN = zero-norm row: its exact dist is 0, i.e. cosine 1 with no error
-                    if (!(cd.score == cd.score)) cd.score = 1.0f;
-                    ent[pos + i] = cd;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
+                if (v[r] >= th && (uint64_t)row < p.n_rows && !(v[r] == 0.0f && nz && is_zero_row(row))) fn(v[r], row);
             }
         }
+    };
+    uint32_t cnt = 0;
+    for_each_pass([&](float, uint32_t) { ++cnt; });
+    // the zero-norm rows: thread i adds list entries i, i + 1024, ...
+    for (uint32_t z = tid; z < nz; z += kFinThreads)
+        if ((uint64_t)p.zero_rows[z] < p.n_rows) ++cnt;
+    uint32_t M;
+    uint32_t pos = block_scan_1024(cnt, s_w, &M);
+    bool too_many = M > (uint32_t)kCandCap;  // more than the block can hold: keep a prefix (any subset yields a valid
+                                              // rescan threshold) and flag the query for the rescan
+    {
+        auto put = [&](float sc, uint32_t row) {
+            if (pos < (uint32_t)kCandCap) {
+                Cand cd;
+                cd.score = sc;
+                cd.row = row;
+                ent[pos] = cd;
+            }
+            ++pos;
+        };
+        for_each_pass(put);
+        for (uint32_t z = tid; z < nz; z += kFinThreads)
+            if ((uint64_t)p.zero_rows[z] < p.n_rows) put(1.0f, p.zero_rows[z]);
     }
+    if (too_many) M = kCandCap;
     __syncthreads();
     if (M < (uint32_t)want) {  // cannot happen unless candidates were lost: leave it to the host
         if (tid == 0) p.overflow[q] = lane_ovf ? 3u : 2u;
@@ -585,8 +623,8 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
         if (lane < 4 && base + lane < m1) {
             const float d0 = lane == 0 ? dot[0] : lane == 1 ? dot[1] : lane == 2 ? dot[2] : dot[3];
             const float s0 = lane == 0 ? sc[0] : lane == 1 ? sc[1] : lane == 2 ? sc[2] : sc[3];
-            // zero-norm row (f32 store: 1/|c| = inf; compressed: every element reads as 0): dist 0
-            const bool zero_row = CMP ? !(s0 > 0.0f) : isinf(s0);
+            // zero-norm row (f32 store: its 1/|c| is kept as 0; compressed: every element is 0): dist 0
+            const bool zero_row = !(s0 > 0.0f);
             const float s2 = zero_row ? 1.0f : (CMP ? d0 * __frsqrt_rn(s0) : d0);
             if (p.max_err && !zero_row) err = fmaxf(err, fabsf(s2 - ent[base + lane].score));
             ent[base + lane].score = s2;
@@ -639,7 +677,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
             p.theta_retry[q] = L - p.e2 - e1 - 1e-6f;
             s_cnt = 0;
         }
-        if (lane_ovf) {  // incomplete candidate set: the host rescans this query with theta_retry
+        if (lane_ovf || too_many) {  // incomplete candidate set: the host rescans this query with theta_retry
             if (tid == 0) p.overflow[q] = 1;
             return;
         }

@@ -14,9 +14,9 @@
 //      32 queries, held as register-resident B-fragments for the whole launch.
 // Steps 2 (slot j+1) and 3 (slot j) are independent and interleave.
 // With A = corpus rows and B = queries every lane ends a tile holding 16 corpus-row scores of ONE
-// query: scale by 1/|c|, compare with that query's pass threshold, append the (rare) survivors to
-// a lane-private buffer in HBM.  No top-k bookkeeping, atomics or cross-lane traffic on the
-// streaming path.
+// query: scale by 1/|c|, take their maximum, compare with that query's pass threshold; a passing lane
+// stores the 16 scores as one record in HBM.  No top-k bookkeeping, atomics or cross-lane traffic on
+// the streaming path.
 //
 // Algorithmic bytes: rows * ds * 4 per launch (+ rows*4 for 1/|c|); MFMA work 2*256*rows*ds flop
 // (512 MFMA cycles per SIMD per slot vs ~1250 cycles of HBM time per slot per CU: HBM-bound).
@@ -132,7 +132,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
 
     // lane buffers are laid out [thread-in-workgroup][workgroup]: everything one query ever receives
     // (2 lanes x all workgroups) is contiguous for the gather in update_kernel
-    Cand *mybuf = p.lane_buf + ((size_t)tid * gridDim.x + blockIdx.x) * kLaneCap;
+    const size_t mylane = (size_t)tid * gridDim.x + blockIdx.x;
+    f32x4 *myrec = reinterpret_cast<f32x4 *>(p.lane_rec + mylane * (kRecCap * 16));
+    uint32_t *mytile = p.lane_tile + mylane * kRecCap;
     uint32_t cnt = 0;
     uint32_t ovf = 0;
     float best = -INFINITY;  // MODE 0 (sample): running maximum of this lane's scores (scan16.hip)
@@ -219,29 +221,29 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         const f32x4 s2 = *reinterpret_cast<const f32x4 *>(sc + 16);
         const f32x4 s3 = *reinterpret_cast<const f32x4 *>(sc + 24);
         float v[16];
-        bool any = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const f32x4 sv = (r >> 2) == 0 ? s0 : (r >> 2) == 1 ? s1 : (r >> 2) == 2 ? s2 : s3;
-            v[r] = acc[r] * sv[r & 3];
-            if (MODE == 0) best = fmaxf(best, v[r]);  // NaN (zero-norm row) is dropped: only weakens the bound
-            any |= !(v[r] < theta);  // NaN (zero-norm row: 0 * inf) passes on purpose
+            v[r] = acc[r] * sv[r & 3];  // 1/|c| is 0 for a zero-norm row: score 0 (see scan16.hip)
         }
-        if (MODE == 1 && __builtin_amdgcn_ballot_w64(any) != 0) {
-            const uint32_t rowb = (t0 + ti * tstep) * kTileRows + 4 * h;
+        float mx = fmaxf(fmaxf(v[0], v[1]), v[2]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
-                if (!(v[r] < theta) && (uint64_t)row < p.n_rows) {
-                    if (cnt < (uint32_t)kLaneCap) {
-                        Cand c;
-                        c.score = v[r];
-                        c.row = row;
-                        mybuf[cnt] = c;
-                        ++cnt;
-                    } else {
-                        ovf = 1;
-                    }
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, v[r]), v[r + 1]);
+        mx = fmaxf(mx, v[15]);
+        if (MODE == 0) {
+            best = fmaxf(best, mx);
+        } else if (__builtin_amdgcn_ballot_w64(mx >= theta) != 0) {
+            if (mx >= theta) {  // one 64-byte record per passing lane and tile (scan16.hip)
+                if (cnt < (uint32_t)kRecCap) {
+                    f32x4 *dst = myrec + cnt * 4;
+                    dst[0] = f32x4{v[0], v[1], v[2], v[3]};
+                    dst[1] = f32x4{v[4], v[5], v[6], v[7]};
+                    dst[2] = f32x4{v[8], v[9], v[10], v[11]};
+                    dst[3] = f32x4{v[12], v[13], v[14], v[15]};
+                    mytile[cnt] = t0 + ti * tstep;
+                    ++cnt;
+                } else {
+                    ovf = 1;
                 }
             }
         }

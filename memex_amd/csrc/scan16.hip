@@ -8,8 +8,8 @@
 //   |approx - cos| <= (2^-7 + 2^-16) * |q^||c^|   two bf16 roundings (unit roundoff 2^-8) + Cauchy-Schwarz
 //                     + ~1e-4                      f32 normalisation and accumulation over <= 768 terms
 //                  <  kApproxErr = 0.0081          (the same certificate as scan.hip; index.hip relies on it)
-// A zero-norm row is stored as NaN, so it passes every threshold (its exact dist is 0: DistCosine's
-// else-branch), exactly like scan.hip's 0 * inf.
+// A zero-norm row is stored as zeros (score 0); its exact dist is 0 (DistCosine's else-branch), so the
+// index keeps such rows in a short list that finish_kernel adds to every query's candidates.
 //
 // One persistent 512-thread workgroup per CU.  Per 8 KiB slot (32 rows x 128 dims):
 //   1. each wave issues ONE 1 KiB LDS-DMA (16 B per lane, nt policy): wave w moves k-step w of the
@@ -23,8 +23,9 @@
 //      for dim_pad <= 512, R = 4 above: the B fragments of 768 dims take 192 of the 256 VGPRs), so
 //      LDS reads, DMA issue and scalar bookkeeping all issue in the shadow of the MFMA pipe.
 // Epilogue per 32-row tile, by MODE:
-//   MODE 1 (collect): compare with the query's pass threshold, append survivors to a lane-private
-//                     buffer.
+//   MODE 1 (collect): v_max3 tree over the lane's 16 scores, ONE compare with the query's pass
+//                     threshold; a passing lane stores all 16 scores as a 64-byte record (no per-row
+//                     code on the stream: finish_kernel picks the rows).
 //   MODE 0 (sample):  keep only the lane's running maximum.  The k-th largest of a query's lane
 //                     maxima (2 lanes per workgroup) is a certified lower bound of its k-th best
 //                     approximate score: index.hip turns it into the pass threshold of the collect
@@ -82,8 +83,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 31;  // query column of B and D
-    const int h = lane >> 5;
+    const int m = lane & 31;  // query column of B and D (lane >> 5 selects which 16 of the tile's 32 rows the lane scores)
 
     // ---- register-resident query fragments (B operand), loaded once per launch
     bf16x8 qf[KC * 8];
@@ -124,7 +124,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
 #endif
     };
 
-    Cand *mybuf = p.lane_buf + ((size_t)tid * gridDim.x + blockIdx.x) * kLaneCap;
+    const size_t mylane = (size_t)tid * gridDim.x + blockIdx.x;
+    f32x4 *myrec = reinterpret_cast<f32x4 *>(p.lane_rec + mylane * (kRecCap * 16));
+    uint32_t *mytile = p.lane_tile + mylane * kRecCap;
     uint32_t cnt = 0;
     uint32_t ovf = 0;
     float best = -INFINITY;  // MODE 0: running maximum of this lane's scores
@@ -182,35 +184,32 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
 
         // ---- tile epilogue: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*h.  The copy
         // holds c/|c|, so the accumulator already is the approximate cosine (NaN for a zero-norm row).
+        // The copy holds c/|c|, so the accumulator already is the approximate cosine (a zero-norm row is
+        // stored as zeros and scores 0: such rows reach finish_kernel through the index's zero-row list).
         float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = DUAL ? acc[r] + acc1[r] : acc[r];
+        float mx = fmaxf(fmaxf(v[0], v[1]), v[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, v[r]), v[r + 1]);
+        mx = fmaxf(mx, v[15]);
         if (MODE == 0) {
-            // sample: only full tiles are sampled (index.hip), so every row is a real row.  fmaxf drops
-            // NaN (zero-norm rows): ignoring a row only weakens the bound.
-#pragma unroll
-            for (int r = 0; r < 16; ++r) best = fmaxf(best, DUAL ? acc[r] + acc1[r] : acc[r]);
-        } else {
-            bool any = false;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                v[r] = DUAL ? acc[r] + acc1[r] : acc[r];
-                any |= !(v[r] < theta);  // NaN passes on purpose
-            }
-            if (__builtin_amdgcn_ballot_w64(any) != 0) {
-                const uint32_t rowb = (t0 + ti * tstep) * kTileRows + 4 * h;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
-                    if (!(v[r] < theta) && (uint64_t)row < p.n_rows) {
-                        if (cnt < (uint32_t)kLaneCap) {
-                            Cand c;
-                            c.score = v[r];
-                            c.row = row;
-                            mybuf[cnt] = c;
-                            ++cnt;
-                        } else {
-                            ovf = 1;
-                        }
-                    }
+            // sample: only full tiles are sampled (index.hip), so every row is a real row
+            best = fmaxf(best, mx);
+        } else if (__builtin_amdgcn_ballot_w64(mx >= theta) != 0) {
+            // a few percent of the tiles: the lanes that pass store their 16 scores as ONE record
+            // (4 x 16 bytes + the tile index); which rows pass is sorted out by finish_kernel
+            if (mx >= theta) {
+                if (cnt < (uint32_t)kRecCap) {
+                    f32x4 *dst = myrec + cnt * 4;
+                    dst[0] = f32x4{v[0], v[1], v[2], v[3]};
+                    dst[1] = f32x4{v[4], v[5], v[6], v[7]};
+                    dst[2] = f32x4{v[8], v[9], v[10], v[11]};
+                    dst[3] = f32x4{v[12], v[13], v[14], v[15]};
+                    mytile[cnt] = t0 + ti * tstep;
+                    ++cnt;
+                } else {
+                    ovf = 1;
                 }
             }
         }
@@ -249,7 +248,7 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float *__restrict__ x
             const uint64_t grow = (uint64_t)t * kTileRows + mm;
             if (grow < row_lo || grow >= row_hi) continue;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(xt + (size_t)mm * ds + ks * 16 + hh * 8);
-            const float sc = scale[(size_t)(t - src_tile0) * kTileRows + mm];  // 1/|c|; +inf for a zero row -> 0*inf = NaN
+            const float sc = scale[(size_t)(t - src_tile0) * kTileRows + mm];  // 1/|c|; 0 for a zero-norm row -> stored as zeros
             const f32x4 lo = src[0] * sc, hi = src[1] * sc;
             bf16x8 o;
             o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
@@ -262,10 +261,8 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float *__restrict__ x
                 r2 += a * a + b * b;
                 n2 += (float)o[i] * (float)o[i] + (float)o[4 + i] * (float)o[4 + i];
             }
-            if (r2 == r2) {  // NaN: zero-norm row, handled exactly (no error)
-                atomicAdd(&s_r2[mm], r2);
-                atomicAdd(&s_n2[mm], n2);
-            }
+            atomicAdd(&s_r2[mm], r2);
+            atomicAdd(&s_n2[mm], n2);
         }
         __syncthreads();
         if (threadIdx.x < kTileRows) {

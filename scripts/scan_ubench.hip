@@ -20,13 +20,13 @@ __global__ void fill(float* p, size_t n, unsigned seed) {
 int main(int argc, char** argv) {
   size_t rows = argc > 1 ? atoll(argv[1]) : 10000000; int ds = argc > 2 ? atoi(argv[2]) : 384; int reps = argc > 3 ? atoi(argv[3]) : 10; int nwg = argc > 4 ? atoi(argv[4]) : 256;
   int kc = ds / 128; rows = rows / 32 * 32;
-  float *x, *scale, *theta; void* qf; Cand* lb; uint32_t *lc, *ovf;
+  float *x, *scale, *theta; void* qf; float* lb; uint32_t *lc, *ovf;
   CK(hipMalloc(&x, rows * ds * 4)); CK(hipMalloc(&scale, rows * 4)); CK(hipMalloc(&theta, 1024)); CK(hipMalloc(&qf, 256 * ds * 2));
-  CK(hipMalloc(&lb, (size_t)256 * 512 * kLaneCap * 8)); CK(hipMalloc(&lc, 256 * 512 * 4)); CK(hipMalloc(&ovf, 1024));
+  CK(hipMalloc(&lb, (size_t)256 * 512 * kRecCap * 64)); uint32_t* lt; CK(hipMalloc(&lt, (size_t)256 * 512 * kRecCap * 4)); CK(hipMalloc(&lc, 256 * 512 * 4)); CK(hipMalloc(&ovf, 1024));
   fill<<<4096, 256>>>(x, rows * ds, 1); fill<<<1024, 256>>>(scale, rows, 2); fill<<<64, 256>>>((float*)qf, 256 * ds / 2, 3);
   std::vector<float> th(256, INFINITY); CK(hipMemcpy(theta, th.data(), 1024, hipMemcpyHostToDevice));
   CK(scan_setup());
-  ScanParams p; p.x = x; p.scale = scale; p.qfrag = qf; p.theta = theta; p.n_rows = rows; p.tile_begin = 0; p.tile_end = rows / 32; p.ds = ds; p.lane_buf = lb; p.lane_cnt = lc; p.overflow = ovf;
+  ScanParams p; p.x = x; p.scale = scale; p.qfrag = qf; p.theta = theta; p.n_rows = rows; p.tile_begin = 0; p.tile_end = rows / 32; p.tile_stride = 1; p.ds = ds; p.lane_max = (float*)lc; p.lane_rec = lb; p.lane_tile = lt; p.lane_cnt = lc; p.overflow = ovf;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) CK(launch_scan(0, kc, true, nwg, p));
   CK(hipDeviceSynchronize());

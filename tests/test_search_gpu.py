@@ -181,12 +181,12 @@ def _rows_with_cosine(rng, q, cosines):
 def test_lane_overflow_is_rescanned_with_a_tight_threshold(oracle, lib_built):
     """A dense neighbourhood the sample cannot see: every tile of ONE scan workgroup is filled with
     rows close to the query (cosines 0.99 .. 0.79, all distinct).  Only 2 of a query's 512 lanes see
-    them, so the sample threshold stays at background level, those lanes overflow (> 32 survivors),
-    and the query must be rescanned with the threshold derived from what it did collect.  Still
-    bit-exact, and no EXACT fallback."""
+    them, so the sample threshold stays at background level, those lanes overflow (> 32 records: a
+    lane stores one record per tile with a passing row), and the query must be rescanned with the
+    threshold derived from what it did collect.  Still bit-exact, and no EXACT fallback."""
     from memex_amd.index import FlatIndex
     rng = np.random.default_rng(123)
-    n, d = 120000, 384
+    n, d = 320000, 384
     X = rng.standard_normal((n, d), dtype=np.float32)
     Q = rng.standard_normal((6, d), dtype=np.float32)
     tiles = [t for t in range(n // 32) if t % 256 == 5]          # one workgroup's tiles (256 CUs)
@@ -200,9 +200,9 @@ def test_lane_overflow_is_rescanned_with_a_tight_threshold(oracle, lib_built):
 
 
 def test_rescan_overflow_falls_back_to_exact_and_stays_bit_exact(oracle, lib_built):
-    """More exact duplicates than a query's lane buffers hold (40000 copies; a lane holds 32): the
-    rescan overflows as well -- no threshold separates exact ties -- and the query is answered on the
-    EXACT path, still bit-exact (lowest ids among the ties win)."""
+    """More exact duplicates (40000 copies) than finish_kernel holds candidates for (16384): the rescan
+    overflows as well -- no threshold separates exact ties -- and the query is answered on the EXACT
+    path, still bit-exact (lowest ids among the ties win)."""
     from memex_amd.index import FlatIndex
     rng = np.random.default_rng(223)
     X = rng.standard_normal((60000, 384), dtype=np.float32)
