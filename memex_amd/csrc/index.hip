@@ -467,14 +467,15 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
 // useful threshold (expected survivors of the collect launch ~ k * N / sample, times the margin's
 // share) and small enough to stay a few percent of the pass
 uint32_t sample_stride(uint64_t full_tiles, int nwg, int k) {
-    // 1/32 of the tiles for k <= 10.  Measured at 10M x 384 (B = 256): a smaller sample is cheaper (60 us at 1/32,
-    // 35 at 1/64, 22 at 1/128) but its weaker threshold sends more tiles of the collect launch down the
-    // append path (1.92 / 1.99 / 2.06 ms): 1/32 is the fastest end to end.  MEMEX_HIP_SAMPLE_DIV
-    // overrides the 32 (a tuning knob: results do not depend on it).
+    // 1/64 of the tiles for k <= 10.  Measured at 10M x 384 (B = 256): the sample launch costs 65 / 38 / 24 /
+    // 17 us at 1/32, 1/64, 1/128, 1/256; a weaker threshold means more records for finish_kernel to sift
+    // (62 / 63 / 72 us, and at 1/256 lanes start to overflow their 32 records), while the collect launch
+    // hardly notices since appends became whole-record stores (1.76 / 1.77 / 1.79 ms).  1/64 is the
+    // fastest end to end.  MEMEX_HIP_SAMPLE_DIV overrides the 64 (a tuning knob: results do not depend on it).
     static const double div = [] {
         const char *e = getenv("MEMEX_HIP_SAMPLE_DIV");
-        const double v = e ? atof(e) : 32.0;
-        return v >= 2.0 && v <= 4096.0 ? v : 32.0;
+        const double v = e ? atof(e) : 64.0;
+        return v >= 2.0 && v <= 4096.0 ? v : 64.0;
     }();
     const double f = std::min(0.5, std::max(1.0 / div, (double)k / (10.0 * div)));
     const uint64_t target = std::max<uint64_t>((uint64_t)nwg, (uint64_t)((double)full_tiles * f));

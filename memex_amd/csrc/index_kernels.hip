@@ -386,6 +386,7 @@ __device__ __forceinline__ float exact_dist_row(const float *__restrict__ qv, co
 }
 
 constexpr int kFinThreads = 1024;
+constexpr int kFinishTailBytes = 128 + (2 * kMaxScanWGs + 1 + 3) * 4;  // staged row ids [32] + scanned record counts
 constexpr int kFinWaves = kFinThreads / 64;
 constexpr int kFinPer = kCandCap / kFinThreads;  // candidates held per thread
 static_assert(kCandCap % kFinThreads == 0, "candidate capacity must divide over the block");
@@ -478,51 +479,64 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
         }
         return lo < nz && p.zero_rows[lo] == row;
     };
-    uint32_t nrec = 0, hh = 0;
-    size_t l = 0;
+    // (a) record counts of this query's 2*nwg lane buffers -> exclusive scan in LDS
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(qv + ds) + 32;  // [2*kMaxScanWGs + 1], behind the staged-row ids
+    uint32_t nrec = 0;
     if (tid < 2 * nwg) {
-        hh = (uint32_t)(tid / nwg);
-        const int w = tid - (int)hh * nwg;
-        l = (size_t)((uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31) + 32u * hh) * nwg + w;
-        nrec = p.lane_cnt[l];
+        const uint32_t hh0 = (uint32_t)(tid / nwg);
+        const int w = tid - (int)hh0 * nwg;
+        nrec = p.lane_cnt[(size_t)((uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31) + 32u * hh0) * nwg + w];
         nrec = nrec > (uint32_t)kRecCap ? (uint32_t)kRecCap : nrec;
     }
-    const f32x4 *rec = reinterpret_cast<const f32x4 *>(p.lane_rec + l * (kRecCap * 16));
-    auto for_each_pass = [&](auto &&fn) {
-        for (uint32_t e = 0; e < nrec; ++e) {
-            const uint32_t rowb = p.lane_tile[l * kRecCap + e] * kTileRows + 4u * hh;
-            const f32x4 a = rec[e * 4], b = rec[e * 4 + 1], c = rec[e * 4 + 2], d = rec[e * 4 + 3];
-            const float v[16] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
-                if (v[r] >= th && (uint64_t)row < p.n_rows && !(v[r] == 0.0f && nz && is_zero_row(row))) fn(v[r], row);
-            }
+    uint32_t R;
+    const uint32_t roff = block_scan_1024(nrec, s_w, &R);
+    if (tid <= 2 * nwg) s_off[tid] = tid < 2 * nwg ? roff : R;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    // (b) one record per thread and trip (all of a query's records are in flight together): find its
+    // lane buffer by binary search in the scanned counts, test the 16 scores, append the passing rows
+    auto put = [&](uint32_t at, float sc, uint32_t row) {
+        if (at < (uint32_t)kCandCap) {
+            Cand cd;
+            cd.score = sc;
+            cd.row = row;
+            ent[at] = cd;
         }
     };
-    uint32_t cnt = 0;
-    for_each_pass([&](float, uint32_t) { ++cnt; });
-    // the zero-norm rows: thread i adds list entries i, i + 1024, ...
-    for (uint32_t z = tid; z < nz; z += kFinThreads)
-        if ((uint64_t)p.zero_rows[z] < p.n_rows) ++cnt;
-    uint32_t M;
-    uint32_t pos = block_scan_1024(cnt, s_w, &M);
-    bool too_many = M > (uint32_t)kCandCap;  // more than the block can hold: keep a prefix (any subset yields a valid
-                                              // rescan threshold) and flag the query for the rescan
-    {
-        auto put = [&](float sc, uint32_t row) {
-            if (pos < (uint32_t)kCandCap) {
-                Cand cd;
-                cd.score = sc;
-                cd.row = row;
-                ent[pos] = cd;
-            }
-            ++pos;
-        };
-        for_each_pass(put);
-        for (uint32_t z = tid; z < nz; z += kFinThreads)
-            if ((uint64_t)p.zero_rows[z] < p.n_rows) put(1.0f, p.zero_rows[z]);
+    for (uint32_t j = tid; j < R; j += kFinThreads) {
+        uint32_t lo = 0, hi = (uint32_t)(2 * nwg) - 1;  // last lane buffer i with s_off[i] <= j
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= j) lo = mid;
+            else hi = mid - 1;
+        }
+        const uint32_t e = j - s_off[lo], hh = lo / (uint32_t)nwg, w = lo - hh * (uint32_t)nwg;
+        const size_t l = (size_t)((uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31) + 32u * hh) * nwg + w;
+        const f32x4 *rec = reinterpret_cast<const f32x4 *>(p.lane_rec + l * (kRecCap * 16)) + e * 4;
+        const uint32_t rowb = p.lane_tile[l * kRecCap + e] * kTileRows + 4u * hh;
+        const f32x4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+        const float v[16] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
+        uint32_t mask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
+            const bool pass = v[r] >= th && (uint64_t)row < p.n_rows && !(v[r] == 0.0f && nz && is_zero_row(row));
+            mask |= pass ? (1u << r) : 0u;
+        }
+        if (mask) {
+            uint32_t at = atomicAdd(&s_cnt, (uint32_t)__popc(mask));
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mask & (1u << r)) put(at++, v[r], rowb + (r & 3) + 8 * (r >> 2));
+        }
     }
+    // the zero-norm rows
+    for (uint32_t z = tid; z < nz; z += kFinThreads)
+        if ((uint64_t)p.zero_rows[z] < p.n_rows) put(atomicAdd(&s_cnt, 1u), 1.0f, p.zero_rows[z]);
+    __syncthreads();
+    uint32_t M = s_cnt;
+    const bool too_many = M > (uint32_t)kCandCap;  // more than the block can hold: keep what fits (any subset yields a
+                                                    // valid rescan threshold) and flag the query for the rescan
     if (too_many) M = kCandCap;
     __syncthreads();
     if (M < (uint32_t)want) {  // cannot happen unless candidates were lost: leave it to the host
@@ -768,7 +782,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
 }
 
 hipError_t finish_setup() {
-    const int lds = (int)(sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)kMaxKC * kChunkFloats + 128);
+    const int lds = (int)(sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)kMaxKC * kChunkFloats + kFinishTailBytes);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -776,7 +790,7 @@ hipError_t finish_setup() {
 
 hipError_t launch_finish(hipStream_t s, int B, const FinishParams &p) {
     if (B <= 0) return hipSuccess;
-    const size_t lds = sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)p.ds + 128;  // candidates | query | staged row ids
+    const size_t lds = sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)p.ds + kFinishTailBytes;  // candidates | query | staged row ids | record offsets
     if (p.x) hipLaunchKernelGGL(finish_kernel<false>, dim3(B), dim3(kFinThreads), lds, s, p);
     else hipLaunchKernelGGL(finish_kernel<true>, dim3(B), dim3(kFinThreads), lds, s, p);  // compressed corpus: rows come from xh
     return hipGetLastError();
