@@ -254,7 +254,19 @@ size_t mx_encoder_weight_bytes(const mx_encoder_cfg *cfg);
 /* Replaces SentenceEmbeddingsBuilder::remote(..).create_model() (embedding.rs:99-100). */
 int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nbytes, int device,
                       mx_encoder **out);
-void mx_encoder_destroy(mx_encoder *enc);
+void mx_encoder_destroy(mx_encoder *enc); /* drops one reference; frees HBM when the last one goes */
+/*
+ * Keyed, ref-counted form: the reference spawns an embedder -- loads the
+ * checkpoint -- for every HTTP search and every ingest task (collections/handlers.rs:61-63,
+ * worker/tasks.rs:17).  The first mx_encoder_open(key, ...) uploads the weights; later opens of the
+ * same key return the SAME resident encoder in O(1) (weights may then be NULL).  Calls on a shared
+ * handle are serialised inside.  key NULL / "" = mx_encoder_create.
+ */
+int mx_encoder_open(const char *key, const mx_encoder_cfg *cfg, const void *weights, size_t nbytes, int device,
+                    mx_encoder **out);
+/* Stream contract as for the index (mx_index_wait_stream): order the next *_device call after the
+ * work enqueued so far on `hip_stream`. */
+int mx_encoder_wait_stream(mx_encoder *enc, void *hip_stream);
 
 /*
  * Replaces model.encode(&segments) (embedding.rs:109) after tokenisation: ids [B, S] row-major

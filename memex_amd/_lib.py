@@ -28,7 +28,7 @@ EXPORTS = [
     "mx_index_search", "mx_index_search_device", "mx_index_set_search_mode", "mx_index_set_filter_copy", "mx_index_set_corpus_mode", "mx_index_get_rows",
     "mx_index_save", "mx_index_load", "mx_index_has_store", "mx_index_store_info", "mx_index_remove_files",
     "mx_index_set_profiling", "mx_index_get_stats", "mx_index_reset_stats", "mx_topk_merge_device", "mx_topk_merge_packed_device", "mx_topk_merge_packed_async",
-    "mx_encoder_weight_bytes", "mx_encoder_create", "mx_encoder_destroy", "mx_encoder_encode",
+    "mx_encoder_weight_bytes", "mx_encoder_create", "mx_encoder_open", "mx_encoder_wait_stream", "mx_encoder_destroy", "mx_encoder_encode",
     "mx_encoder_encode_device", "mx_encoder_set_profiling", "mx_encoder_get_stats",
     "mx_encoder_reset_stats",
     "mx_tokenizer_create", "mx_tokenizer_create_from_memory", "mx_tokenizer_destroy", "mx_tokenizer_vocab_size",
@@ -119,6 +119,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "mx_topk_merge_packed_device": [i32, vp, i32, i32, i32, vp, vp, vp],
         "mx_topk_merge_packed_async": [i32, vp, vp, i32, i32, i32, vp, vp, vp],
         "mx_encoder_create": [P(EncoderCfg), vp, ctypes.c_size_t, i32, P(vp)],
+        "mx_encoder_open": [cp, P(EncoderCfg), vp, ctypes.c_size_t, i32, P(vp)],
+        "mx_encoder_wait_stream": [vp, vp],
         "mx_encoder_encode": [vp, vp, vp, i32, i32, vp],
         "mx_encoder_encode_device": [vp, vp, vp, i32, i32, vp],
         "mx_encoder_set_profiling": [vp, i32],

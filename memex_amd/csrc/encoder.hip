@@ -14,7 +14,9 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "encoder_kernels.h"
@@ -45,6 +47,8 @@ struct Layer {
 
 std::once_flag g_enc_once;
 hipError_t g_enc_setup = hipSuccess;
+std::mutex g_enc_reg_mu;
+std::map<std::string, mx_encoder *> g_enc_registry;
 
 }  // namespace
 
@@ -63,8 +67,10 @@ struct mx_encoder {
     float *out_dev = nullptr;
     bool profiling = false;
     bool fused_mlp = false;  // MLP block as one kernel (hidden 384); MEMEX_HIP_UNFUSED_MLP=1 keeps the two GEMMs
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
     mx_encoder_stats stats{};
+    std::string key;  // registry key (mx_encoder_open); empty = private
+    int refs = 1;
 };
 
 namespace {
@@ -262,6 +268,8 @@ int check_cfg(const mx_encoder_cfg *c) {
 
 }  // namespace
 
+static void destroy_impl(mx_encoder *e);
+
 extern "C" {
 
 size_t mx_encoder_weight_bytes(const mx_encoder_cfg *c) {
@@ -302,11 +310,12 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         e->fused_mlp = mlp_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
     }
     auto bail = [&](int code) {
-        mx_encoder_destroy(e);
+        destroy_impl(e);
         return code;
     };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess)
+        hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_wait, hipEventDisableTiming) != hipSuccess)
         return bail(fail(MX_EDEVICE, "stream/event creation failed"));
 
     const size_t H = (size_t)cfg->hidden, F = (size_t)cfg->ffn;
@@ -355,7 +364,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     return MX_OK;
 }
 
-void mx_encoder_destroy(mx_encoder *e) {
+static void destroy_impl(mx_encoder *e) {
     if (!e) return;
     DeviceGuard g(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -366,8 +375,61 @@ void mx_encoder_destroy(mx_encoder *e) {
         if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev_wait) (void)hipEventDestroy(e->ev_wait);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+}
+
+void mx_encoder_destroy(mx_encoder *e) {
+    if (!e) return;
+    {
+        std::lock_guard<std::mutex> lk(g_enc_reg_mu);
+        if (--e->refs > 0) return;
+        if (!e->key.empty()) g_enc_registry.erase(e->key);
+    }
+    {   // nobody may still be inside a call on this handle
+        std::lock_guard<std::mutex> lk(e->mu);
+    }
+    destroy_impl(e);
+}
+
+// Replaces the per-request / per-task `create_model()` (the reference spawns an embedder, i.e. loads the
+// checkpoint, for every HTTP search and every ingest task: handlers.rs:61-63, tasks.rs:17): the first
+// open of `key` uploads the weights, later opens return the SAME resident encoder (ref-counted; calls
+// on it are serialised inside).  weights may be NULL when the key is expected to be resident.
+int mx_encoder_open(const char *key, const mx_encoder_cfg *cfg, const void *weights, size_t nbytes, int device,
+                    mx_encoder **out) {
+    if (!out) return fail(MX_EINVAL, "out is null");
+    *out = nullptr;
+    const std::string k = key ? key : "";
+    if (k.empty()) return mx_encoder_create(cfg, weights, nbytes, device, out);
+    std::lock_guard<std::mutex> lk(g_enc_reg_mu);
+    auto it = g_enc_registry.find(k);
+    if (it != g_enc_registry.end()) {
+        mx_encoder *e = it->second;
+        if (cfg && memcmp(cfg, &e->cfg, sizeof(*cfg)) != 0) return fail(MX_EINVAL, "encoder '%s' is resident with another configuration", k.c_str());
+        if (e->device != device) return fail(MX_EINVAL, "encoder '%s' lives on device %d, not %d", k.c_str(), e->device, device);
+        e->refs += 1;
+        *out = e;
+        return MX_OK;
+    }
+    if (!weights) return fail(MX_EINVAL, "encoder '%s' is not resident and no weights were given", k.c_str());
+    mx_encoder *e = nullptr;
+    int rc = mx_encoder_create(cfg, weights, nbytes, device, &e);
+    if (rc != MX_OK) return rc;
+    e->key = k;
+    g_enc_registry[k] = e;
+    *out = e;
+    return MX_OK;
+}
+
+int mx_encoder_wait_stream(mx_encoder *e, void *stream) {
+    if (!e) return fail(MX_EINVAL, "null encoder");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    MX_HIP(hipEventRecord(e->ev_wait, static_cast<hipStream_t>(stream)));
+    MX_HIP(hipStreamWaitEvent(e->stream, e->ev_wait, 0));
+    return MX_OK;
 }
 
 static int check_call(mx_encoder *e, const void *ids, const void *lens, int B, int S, const void *out) {

@@ -187,7 +187,8 @@ class SentenceEmbedder:
 
     @classmethod
     def spawn(cls, model_config: ModelConfig = ModelConfig(), weights=None, tokenizer=None, device: int = 0,
-              encoder_config: Optional[W.EncoderConfig] = None, seed: int = 0, allow_synthetic: bool = False):
+              encoder_config: Optional[W.EncoderConfig] = None, seed: int = 0, allow_synthetic: bool = False,
+              encoder_key: Optional[str] = None):
         """``weights``: HF tensor mapping / packed blob of the checkpoint; ``tokenizer``: path to its
         ``vocab.txt`` (native WordPiece) or ``tokenizer.json``, or a tokenizer object.  Like the
         reference (``create_model()`` / ``Tokenizer::from_pretrained`` failing -> SetupError,
@@ -201,7 +202,7 @@ class SentenceEmbedder:
         q: "queue.Queue" = queue.Queue(maxsize=100)                              # sync_channel(100), :87
         ready: "queue.Queue" = queue.Queue(maxsize=1)
         th = threading.Thread(target=cls._runner, args=(q, ready, model_config, weights, tokenizer, device,
-                                                        encoder_config, seed), daemon=True)
+                                                        encoder_config, seed, encoder_key), daemon=True)
         th.start()
         err = ready.get()
         if err is not None:
@@ -209,7 +210,7 @@ class SentenceEmbedder:
         return th, cls(q)
 
     @staticmethod
-    def _runner(q, ready, model_config, weights, tokenizer, device, encoder_config, seed):
+    def _runner(q, ready, model_config, weights, tokenizer, device, encoder_config, seed, encoder_key=None):
         try:
             cfg = encoder_config or _ENCODER_CONFIGS.get(model_config.model)
             if cfg is None:
@@ -217,7 +218,9 @@ class SentenceEmbedder:
             if weights is None:  # no pretrained checkpoint offline: seeded synthetic weights of the real shape
                 weights = W.synthetic_weights(cfg, seed)
             tok = _as_tokenizer(tokenizer, cfg.vocab)
-            enc = Encoder(cfg, weights, device)                                  # create_model(), :99-100
+            # create_model(), :99-100 -- keyed: embedders spawned per request / per task (handlers.rs:61-63,
+            # tasks.rs:17) share one resident copy of the weights instead of re-uploading them
+            enc = Encoder(cfg, weights, device, key=encoder_key)
         except Exception as e:  # surfaces like RustBertError from runner
             ready.put(e if isinstance(e, EmbeddingError) else SetupError(str(e)))
             return

@@ -19,16 +19,22 @@ def _cfg_struct(cfg: EncoderConfig) -> EncoderCfg:
 
 
 class Encoder:
-    def __init__(self, cfg: EncoderConfig, weights, device: int = 0):
-        """``weights``: packed f32 blob (np.ndarray) or a mapping of HF tensor names."""
-        blob = weights if isinstance(weights, np.ndarray) else pack_weights(weights, cfg)
-        blob = np.ascontiguousarray(blob, dtype=np.float32)
+    def __init__(self, cfg: EncoderConfig, weights, device: int = 0, key: str | None = None):
+        """``weights``: packed f32 blob (np.ndarray) or a mapping of HF tensor names (None = attach to
+        the resident encoder ``key``).  ``key``: register / attach under that name: every Encoder opened
+        with the same key shares ONE resident set of weights (the reference reloads the checkpoint per
+        request, handlers.rs:61-63)."""
         self.cfg = cfg
         self.device = device
         c = _cfg_struct(cfg)
         h = ctypes.c_void_p()
-        check(lib().mx_encoder_create(ctypes.byref(c), blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes, device,
-                                      ctypes.byref(h)))
+        if weights is None:
+            check(lib().mx_encoder_open(key.encode() if key else None, ctypes.byref(c), None, 0, device, ctypes.byref(h)))
+        else:
+            blob = weights if isinstance(weights, np.ndarray) else pack_weights(weights, cfg)
+            blob = np.ascontiguousarray(blob, dtype=np.float32)
+            check(lib().mx_encoder_open(key.encode() if key else None, ctypes.byref(c), blob.ctypes.data_as(ctypes.c_void_p),
+                                        blob.nbytes, device, ctypes.byref(h)))
         self._h = h
 
     @staticmethod
@@ -67,6 +73,11 @@ class Encoder:
     def encode_device(self, ids, lens, out) -> None:
         """Device tensors: ids int32 [B,S], lens int32 [B], out f32 [B,hidden] (blocks until done)."""
         B, S = int(ids.shape[0]), int(ids.shape[1])
+        try:  # inputs were produced on torch's current stream (stream contract, include/memex_hip.h)
+            import torch
+            check(lib().mx_encoder_wait_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream(ids.device).cuda_stream)))
+        except ImportError:
+            pass
         check(lib().mx_encoder_encode_device(self._h, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(lens.data_ptr()),
                                              B, S, ctypes.c_void_p(out.data_ptr())))
 

@@ -190,3 +190,35 @@ def test_embedder_batches_concurrent_requests(lib_built):
         want = alone[i] if i % 3 else [single[i]]
         assert [r.content for r in got[i]] == [r.content for r in want]
         np.testing.assert_array_equal(np.float32([r.vector for r in got[i]]), np.float32([r.vector for r in want]))
+
+
+def test_keyed_encoder_is_shared_and_refcounted(lib_built):
+    """mx_encoder_open(key): embedders spawned per request / per task (handlers.rs:61-63, tasks.rs:17)
+    attach to ONE resident encoder instead of re-uploading the checkpoint."""
+    import time
+    from memex_amd import _lib
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    cfg = EncoderConfig(layers=6, hidden=384, heads=12, ffn=1536, vocab=30522)
+    w = synthetic_weights(cfg, 31)
+    rng = np.random.default_rng(31)
+    ids = rng.integers(1000, cfg.vocab, size=(3, 40)).astype(np.int32)
+    lens = np.array([40, 7, 23], dtype=np.int32)
+    a = Encoder(cfg, w, key="all-MiniLM-L6-v2@0")
+    want = a.encode(ids, lens)
+    t0 = time.perf_counter()
+    for _ in range(50):                                             # the per-request pattern
+        b = Encoder(cfg, None, key="all-MiniLM-L6-v2@0")           # attach: no weights needed, O(1)
+        got = b.encode(ids, lens)
+        b.close()
+    dt = time.perf_counter() - t0
+    np.testing.assert_array_equal(got, want)
+    assert dt < 1.0, f"50 attach+encode+close took {dt:.2f} s"
+    a.close()                                                       # last reference: the weights leave HBM
+    with pytest.raises(_lib.MemexHipError):
+        Encoder(cfg, None, key="all-MiniLM-L6-v2@0")
+    other = EncoderConfig(layers=2, hidden=384, heads=12, ffn=1536, vocab=30522)
+    c = Encoder(cfg, w, key="k2")
+    with pytest.raises(_lib.MemexHipError):
+        Encoder(other, synthetic_weights(other, 1), key="k2")      # same key, different configuration
+    c.close()
