@@ -568,9 +568,12 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(const bf16_t
                 sc[r] = key < len ? sc[r] : -1e30f;  // reference: additive -10000 mask == exclusion in f32
             }
         }
-        float bm = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        // the softmax arithmetic is what bounds this kernel at d = 32 (VALU issue, not MFMA): keep it to
+        // v_max3 chains and packed f32 adds / subtracts (2 scores per instruction)
+        float bm = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
 #pragma unroll
-        for (int r = 4; r < 16; r += 4) bm = fmaxf(bm, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
+        for (int r = 3; r < 15; r += 2) bm = fmaxf(fmaxf(bm, sc[r]), sc[r + 1]);
+        bm = fmaxf(bm, sc[15]);
         bm = fmaxf(bm, __shfl_xor(bm, 32));
         if (__builtin_amdgcn_ballot_w64(bm > m_run) != 0) {  // some query's max grew: rescale (rare later on)
             const float m_new = fmaxf(m_run, bm);
@@ -582,12 +585,18 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(const bf16_t
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
         }
-        float ps = 0.0f;
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const f32x2 mm = {m_run, m_run};
+        f32x2 ps2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_run);
-            ps += sc[r];
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 t = f32x2{sc[r], sc[r + 1]} - mm;
+            const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            sc[r] = e[0];
+            sc[r + 1] = e[1];
+            ps2 += e;
         }
+        const float ps = ps2[0] + ps2[1];
         l_run += ps;
         // O^T += V^T P^T: k16 step s uses this lane's p[8s .. 8s+7] = keys 16s + 8(i>>2) + 4h + (i&3),
         // stored contiguously in the permuted V^T tile at physical key offset 16s + 8h
