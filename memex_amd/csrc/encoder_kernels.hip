@@ -477,7 +477,7 @@ hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32
 // ([0-3, 8-11, 4-7, 12-15]) -- exactly the keys a lane's P registers hold for one k16 step -- so a
 // PV A-fragment is ONE ds_read_b128.
 // ---------------------------------------------------------------------------------------------
-constexpr int kAttnWaves = 8;
+constexpr int kAttnWaves = 16;
 constexpr int kAttnQ = kAttnWaves * 32;  // queries per workgroup
 
 template <int D>
