@@ -146,7 +146,7 @@ struct FinishParams {
     float *scores, *dists;
     int32_t *n_found;
     float *max_err;             // null unless profiling
-    int debug_stop;             // 0; 1..4 = return after that stage (MEMEX_HIP_FINISH_STOP: timing probes only, results are garbage)
+    int debug_stop;             // 0; 1..8 = return after that stage (MEMEX_HIP_FINISH_STOP: timing probes only, results are garbage)
 };
 hipError_t finish_setup();
 hipError_t launch_finish(hipStream_t s, int B, const FinishParams &p);

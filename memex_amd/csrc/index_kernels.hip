@@ -430,6 +430,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     if (p.todo && !p.todo[q]) return;
+    if (p.debug_stop == 8) return;
     const int k = p.k, ds = p.ds;
     const uint64_t want64 = p.n_rows < (uint64_t)k ? p.n_rows : (uint64_t)k;
     const int want = (int)want64;
@@ -493,6 +494,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     if (tid <= 2 * nwg) s_off[tid] = tid < 2 * nwg ? roff : R;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
+    if (p.debug_stop == 5) return;
     // (b) one record per thread and trip (all of a query's records are in flight together): find its
     // lane buffer by binary search in the scanned counts, test the 16 scores, append the passing rows
     auto put = [&](uint32_t at, float sc, uint32_t row) {
@@ -503,28 +505,45 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
             ent[at] = cd;
         }
     };
-    for (uint32_t j = tid; j < R; j += kFinThreads) {
-        uint32_t lo = 0, hi = (uint32_t)(2 * nwg) - 1;  // last lane buffer i with s_off[i] <= j
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if (s_off[mid] <= j) lo = mid;
-            else hi = mid - 1;
-        }
-        const uint32_t e = j - s_off[lo], hh = lo / (uint32_t)nwg, w = lo - hh * (uint32_t)nwg;
-        const size_t l = (size_t)((uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31) + 32u * hh) * nwg + w;
-        const f32x4 *rec = reinterpret_cast<const f32x4 *>(p.lane_rec + l * (kRecCap * 16)) + e * 4;
-        const uint32_t rowb = p.lane_tile[l * kRecCap + e] * kTileRows + 4u * hh;
-        const f32x4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
-        const float v[16] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
-        uint32_t mask = 0;
+    for (uint32_t j0 = 0; j0 < R; j0 += kFinThreads) {  // block-uniform trip count
+        const uint32_t j = j0 + tid;
+        uint32_t mask = 0, rowb = 0;
+        float v[16];
+        if (j < R) {
+            uint32_t lo = 0, hi = (uint32_t)(2 * nwg) - 1;  // last lane buffer i with s_off[i] <= j
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (s_off[mid] <= j) lo = mid;
+                else hi = mid - 1;
+            }
+            const uint32_t e = j - s_off[lo], hh = lo / (uint32_t)nwg, w = lo - hh * (uint32_t)nwg;
+            const size_t l = (size_t)((uint32_t)(q >> 5) * 64 + (uint32_t)(q & 31) + 32u * hh) * nwg + w;
+            const f32x4 *rec = reinterpret_cast<const f32x4 *>(p.lane_rec + l * (kRecCap * 16)) + e * 4;
+            rowb = p.lane_tile[l * kRecCap + e] * kTileRows + 4u * hh;
+            const f32x4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
-            const bool pass = v[r] >= th && (uint64_t)row < p.n_rows && !(v[r] == 0.0f && nz && is_zero_row(row));
-            mask |= pass ? (1u << r) : 0u;
+            for (int r = 0; r < 4; ++r) v[r] = a[r], v[4 + r] = b[r], v[8 + r] = c[r], v[12 + r] = d[r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
+                const bool pass = v[r] >= th && (uint64_t)row < p.n_rows && !(v[r] == 0.0f && nz && is_zero_row(row));
+                mask |= pass ? (1u << r) : 0u;
+            }
         }
+        // one LDS atomic per WAVE (a per-thread atomicAdd on the one counter serialises: ~1800 of them
+        // cost 19 us against 13 this way): wave-inclusive scan of the pass counts, lane 63 reserves the range
+        const uint32_t cnt = (uint32_t)__popc(mask);
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        uint32_t wbase = 0;
+        if (lane == 63 && inc) wbase = atomicAdd(&s_cnt, inc);
+        wbase = __shfl(wbase, 63);
+        uint32_t at = wbase + inc - cnt;
         if (mask) {
-            uint32_t at = atomicAdd(&s_cnt, (uint32_t)__popc(mask));
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (mask & (1u << r)) put(at++, v[r], rowb + (r & 3) + 8 * (r >> 2));
@@ -534,6 +553,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     for (uint32_t z = tid; z < nz; z += kFinThreads)
         if ((uint64_t)p.zero_rows[z] < p.n_rows) put(atomicAdd(&s_cnt, 1u), 1.0f, p.zero_rows[z]);
     __syncthreads();
+    if (p.debug_stop == 6) return;
     uint32_t M = s_cnt;
     const bool too_many = M > (uint32_t)kCandCap;  // more than the block can hold: keep what fits (any subset yields a
                                                     // valid rescan threshold) and flag the query for the rescan
@@ -562,6 +582,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     }
     {
         const uint32_t kth = block_kth_largest<kFinPer>(key, valid, (uint32_t)want, s_hist, s_pick);
+        if (p.debug_stop == 7) return;
         const uint32_t keep = f32_key(key_f32(kth) - 2.0f * e1);
         if (tid == 0) s_cnt = 0;
         __syncthreads();  // also: every thread has its entries in registers, ent[] may be overwritten

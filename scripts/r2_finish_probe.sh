@@ -5,7 +5,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/${1:-fp}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for STOP in 0 1 2 3 4; do
+for STOP in ${STOPS:-0 1 2 3 4}; do
   export MEMEX_HIP_FINISH_STOP=$STOP
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/s$STOP" -- python $ROOT/bench.py --ingest-chunks 0 --no-cpu-baseline --steps 30 --warmup 3 --alt-steps 0 --side-steps 0 --recall-queries 0 --rows ${ROWS:-10000000} > "$OUT/b$STOP.json" 2> "$OUT/b$STOP.err"
   python - "$OUT/s$STOP" $STOP <<'PY'
