@@ -69,13 +69,14 @@ class ShardedFlatIndex:
         g_block = torch.zeros((self.world, block.numel()), dtype=torch.uint8, device=dev)
         # list-of-views form: accepted by both RCCL ("nccl") and gloo (CPU tests)
         dist.all_gather(list(g_block.unbind(0)), block, group=self.group)
-        if dev.type == "cuda":
-            torch.cuda.synchronize(dev)
         m_ids = torch.zeros((B, k), dtype=torch.int64, device=dev)
         m_dists = torch.zeros((B, k), dtype=torch.float32, device=dev)
         m_scores = torch.zeros((B, k), dtype=torch.float32, device=dev)
         if self._merge is None:
-            merge_topk_packed_device(self.device, g_block, self.world, B, k, m_ids, m_dists, m_scores)
+            # the merge is enqueued on torch's stream, behind the collective and the zero-fills above
+            # (stream contract: include/memex_hip.h); the caller synchronises when it reads the results
+            merge_topk_packed_device(self.device, g_block, self.world, B, k, m_ids, m_dists, m_scores,
+                                     stream=torch.cuda.current_stream(dev).cuda_stream)
         else:  # injected merge (tests): takes the unpacked [G, B, k] arrays
             g_ids = g_block[:, : B * k * 8].contiguous().view(torch.int64).view(self.world, B, k)
             g_dists = g_block[:, B * k * 8:].contiguous().view(torch.float32).view(self.world, B, k)
