@@ -42,6 +42,7 @@ struct Layer {
     bf16_t *wi = nullptr;    // [F, H]
     float *bi = nullptr;
     bf16_t *wo2 = nullptr;   // [H, F]
+    bf16_t *wf = nullptr;    // wi and wo2 once more, as mlp2_kernel's per-wave fragment streams (fused MLP only)
     float *bo2 = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 
@@ -91,6 +92,16 @@ int upload_weight(mx_encoder *e, const float *src, size_t rows, size_t k, bf16_t
     MX_HIP(hipMalloc(dst, tmp.size() * sizeof(uint16_t)));
     e->allocs.push_back(*dst);
     MX_HIP(hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return MX_OK;
+}
+
+// wi [F, H] and wo2 [H, F] -> the fused MLP kernel's per-wave fragment streams (encoder_mlp2.hip)
+int upload_mlp_stream(mx_encoder *e, const float *wi, const float *wo2, size_t F, bf16_t **dst) {
+    std::vector<uint16_t> st(2 * F * (size_t)e->cfg.hidden);
+    mlp2_stream_layout(wi, wo2, (int)F, st.data(), &f32_to_bf16);
+    MX_HIP(hipMalloc(dst, st.size() * sizeof(uint16_t)));
+    e->allocs.push_back(*dst);
+    MX_HIP(hipMemcpy(*dst, st.data(), st.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return MX_OK;
 }
 
@@ -194,9 +205,9 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         MX_HIP(launch_gemm(st, EPI_BIAS_RES_LN, o));
         if (e->fused_mlp && t_pad >= kFusedMlpMinRows) {
             MlpParams mp{};
-            mp.x = e->x1; mp.ldx = H; mp.w1 = L.wi; mp.b1 = L.bi; mp.w2 = L.wo2; mp.b2 = L.bo2; mp.f = F; mp.m = t_pad;
+            mp.x = e->x1; mp.ldx = H; mp.wf = L.wf; mp.b1 = L.bi; mp.b2 = L.bo2; mp.f = F; mp.m = t_pad;
             mp.out = e->x; mp.ldo = H; mp.gamma = L.ln2g; mp.beta = L.ln2b; mp.eps = c.ln_eps;
-            MX_HIP(launch_mlp(st, mp));
+            MX_HIP(launch_mlp2(st, mp));
             continue;
         }
         GemmParams f1{};
@@ -297,7 +308,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
     std::call_once(g_enc_once, [] {
         g_enc_setup = encoder_kernels_setup();
-        if (g_enc_setup == hipSuccess) g_enc_setup = mlp_setup();
+        if (g_enc_setup == hipSuccess) g_enc_setup = mlp2_setup();
     });
     if (g_enc_setup != hipSuccess)
         return fail(MX_EDEVICE, "encoder kernel setup failed: %s", hipGetErrorString(g_enc_setup));
@@ -307,7 +318,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     e->device = device;
     {
         const char *ev = getenv("MEMEX_HIP_UNFUSED_MLP");
-        e->fused_mlp = mlp_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
+        e->fused_mlp = mlp2_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
     }
     auto bail = [&](int code) {
         destroy_impl(e);
@@ -352,9 +363,12 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         MX_TRY(upload_f32(e, take(H), H, &L.bo));
         MX_TRY(upload_f32(e, take(H), H, &L.ln1g));
         MX_TRY(upload_f32(e, take(H), H, &L.ln1b));
-        MX_TRY(upload_weight(e, take(F * H), F, H, &L.wi));
+        const float *wi_src = take(F * H);
+        MX_TRY(upload_weight(e, wi_src, F, H, &L.wi));
         MX_TRY(upload_f32(e, take(F), F, &L.bi));
-        MX_TRY(upload_weight(e, take(H * F), H, F, &L.wo2));
+        const float *wo2_src = take(H * F);
+        MX_TRY(upload_weight(e, wo2_src, H, F, &L.wo2));
+        if (e->fused_mlp) MX_TRY(upload_mlp_stream(e, wi_src, wo2_src, F, &L.wf));
         MX_TRY(upload_f32(e, take(H), H, &L.bo2));
         MX_TRY(upload_f32(e, take(H), H, &L.ln2g));
         MX_TRY(upload_f32(e, take(H), H, &L.ln2b));

@@ -61,8 +61,16 @@ struct MlpParams {
     int ldo;
     const float *gamma, *beta;
     float eps;
+    // mlp2_kernel (encoder_mlp2.hip): W1 and W2 as one bf16 stream per wave in consumption order
+    // (mlp2_stream_layout), 2 * f * 384 elements
+    const bf16_t *wf;
 };
 hipError_t mlp_setup();
+hipError_t mlp2_setup();
+bool mlp2_supported(int hidden, int ffn);
+hipError_t launch_mlp2(hipStream_t s, const MlpParams &p);
+// w1 [f][384], w2 [384][f] (nn.Linear layouts, f32) -> out [2 * f * 384] bf16 in mlp2_kernel's stream order
+void mlp2_stream_layout(const float *w1, const float *w2, int F, uint16_t *out, uint16_t (*to_bf16)(float));
 bool mlp_supported(int hidden, int ffn);
 hipError_t launch_mlp(hipStream_t s, const MlpParams &p);
 

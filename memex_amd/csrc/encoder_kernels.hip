@@ -11,6 +11,7 @@
 //   K5 pool_kernel         masked mean / CLS + L2 normalise
 // All matrix math is v_mfma_f32_32x32x16_bf16; LayerNorm / softmax / GELU statistics are f32.
 #include "encoder_kernels.h"
+#include "mx_gelu.h"
 
 #include <cmath>
 
@@ -56,16 +57,6 @@ struct GemmGeom {
     static constexpr int LDS = (S * STAGE > OUT_BYTES) ? S * STAGE : OUT_BYTES;
     static_assert(ROWS % 16 == 0 && ((32 * MI) % GR == 0 || GR % (32 * MI) == 0), "piece / group split");
 };
-
-// erf to ~1.5e-7 absolute (Abramowitz-Stegun 7.1.26): the result is rounded to bf16 (2^-9) anyway
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erfv = x < 0.0f ? -e : e;
-    return 0.5f * x * (1.0f + erfv);
-}
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -233,10 +224,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                             const int mrow = wrow0 - g0 + i * 32 + l31;
                             bf16x4 pk;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float t = acc[i][j][rg * 4 + e] + b4[e];
-                                if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
-                                pk[e] = (__bf16)(t * oscale);
+                            for (int e = 0; e < 4; e += 2) {
+                                gelu_f32x2 t = {acc[i][j][rg * 4 + e] + b4[e], acc[i][j][rg * 4 + e + 1] + b4[e + 1]};
+                                if (EPI == EPI_BIAS_GELU) t = gelu_erf2(t);
+                                pk[e] = (__bf16)(t[0] * oscale);
+                                pk[e + 1] = (__bf16)(t[1] * oscale);
                             }
                             *reinterpret_cast<bf16x4 *>(smem + mrow * G::PO + nloc * 2) = pk;
                         }
