@@ -42,7 +42,7 @@ struct Layer {
     bf16_t *wi = nullptr;    // [F, H]
     float *bi = nullptr;
     bf16_t *wo2 = nullptr;   // [H, F]
-    bf16_t *wf = nullptr;    // wi and wo2 once more, as mlp2_kernel's per-wave fragment streams (fused MLP only)
+    bf16_t *wf = nullptr;    // wo, wi and wo2 once more, as tail_kernel's per-wave fragment streams (fused tail only)
     float *bo2 = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 
@@ -95,10 +95,10 @@ int upload_weight(mx_encoder *e, const float *src, size_t rows, size_t k, bf16_t
     return MX_OK;
 }
 
-// wi [F, H] and wo2 [H, F] -> the fused MLP kernel's per-wave fragment streams (encoder_mlp2.hip)
-int upload_mlp_stream(mx_encoder *e, const float *wi, const float *wo2, size_t F, bf16_t **dst) {
-    std::vector<uint16_t> st(2 * F * (size_t)e->cfg.hidden);
-    mlp2_stream_layout(wi, wo2, (int)F, st.data(), &f32_to_bf16);
+// wo [H, H], wi [F, H] and wo2 [H, F] -> the fused tail kernel's per-wave fragment streams (encoder_tail.hip)
+int upload_tail_stream(mx_encoder *e, const float *wo, const float *wi, const float *wo2, size_t F, bf16_t **dst) {
+    std::vector<uint16_t> st(tail_stream_elems((int)F));
+    tail_stream_layout(wo, wi, wo2, (int)F, st.data(), &f32_to_bf16);
     MX_HIP(hipMalloc(dst, st.size() * sizeof(uint16_t)));
     e->allocs.push_back(*dst);
     MX_HIP(hipMemcpy(*dst, st.data(), st.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -199,17 +199,19 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         gv.k = H; gv.out_vt = e->vt; gv.ldvt = t_pad; gv.hidden = H;
         MX_HIP(launch_gemm(st, EPI_VT, gv));
         MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->cu, d_lens, B, max_len, heads, dh, H, e->ctx));
+        if (e->fused_mlp && t_pad >= kFusedMlpMinRows) {
+            // out-projection + Add&Norm + MLP + Add&Norm in one kernel, in place on e->x
+            TailParams tp{};
+            tp.ctx = e->ctx; tp.ldc = H; tp.x = e->x; tp.ldx = H; tp.wf = L.wf; tp.bo = L.bo; tp.ln1g = L.ln1g; tp.ln1b = L.ln1b;
+            tp.b1 = L.bi; tp.b2 = L.bo2; tp.f = F; tp.m = t_pad; tp.out = e->x; tp.ldo = H; tp.gamma = L.ln2g; tp.beta = L.ln2b;
+            tp.eps = c.ln_eps;
+            MX_HIP(launch_tail(st, tp));
+            continue;
+        }
         GemmParams o{};
         o.a = e->ctx; o.lda = H; o.w = L.wo; o.w_rows = H; o.w_row0 = 0; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = H;
         o.out = e->x1; o.ldo = H; o.res = e->x; o.ldres = H; o.gamma = L.ln1g; o.beta = L.ln1b; o.eps = c.ln_eps;
         MX_HIP(launch_gemm(st, EPI_BIAS_RES_LN, o));
-        if (e->fused_mlp && t_pad >= kFusedMlpMinRows) {
-            MlpParams mp{};
-            mp.x = e->x1; mp.ldx = H; mp.wf = L.wf; mp.b1 = L.bi; mp.b2 = L.bo2; mp.f = F; mp.m = t_pad;
-            mp.out = e->x; mp.ldo = H; mp.gamma = L.ln2g; mp.beta = L.ln2b; mp.eps = c.ln_eps;
-            MX_HIP(launch_mlp2(st, mp));
-            continue;
-        }
         GemmParams f1{};
         f1.a = e->x1; f1.lda = H; f1.w = L.wi; f1.w_rows = F; f1.w_row0 = 0; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = H;
         f1.out = e->hbuf; f1.ldo = F;
@@ -308,7 +310,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
     std::call_once(g_enc_once, [] {
         g_enc_setup = encoder_kernels_setup();
-        if (g_enc_setup == hipSuccess) g_enc_setup = mlp2_setup();
+        if (g_enc_setup == hipSuccess) g_enc_setup = tail_setup();
     });
     if (g_enc_setup != hipSuccess)
         return fail(MX_EDEVICE, "encoder kernel setup failed: %s", hipGetErrorString(g_enc_setup));
@@ -318,7 +320,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     e->device = device;
     {
         const char *ev = getenv("MEMEX_HIP_UNFUSED_MLP");
-        e->fused_mlp = mlp2_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
+        e->fused_mlp = tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
     }
     auto bail = [&](int code) {
         destroy_impl(e);
@@ -359,7 +361,8 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         }
         MX_TRY(upload_weight(e, wqkv.data(), 3 * H, H, &L.wqkv));
         MX_TRY(upload_f32(e, bqkv.data(), 3 * H, &L.bqkv));
-        MX_TRY(upload_weight(e, take(H * H), H, H, &L.wo));
+        const float *wo_src = take(H * H);
+        MX_TRY(upload_weight(e, wo_src, H, H, &L.wo));
         MX_TRY(upload_f32(e, take(H), H, &L.bo));
         MX_TRY(upload_f32(e, take(H), H, &L.ln1g));
         MX_TRY(upload_f32(e, take(H), H, &L.ln1b));
@@ -368,7 +371,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         MX_TRY(upload_f32(e, take(F), F, &L.bi));
         const float *wo2_src = take(H * F);
         MX_TRY(upload_weight(e, wo2_src, H, F, &L.wo2));
-        if (e->fused_mlp) MX_TRY(upload_mlp_stream(e, wi_src, wo2_src, F, &L.wf));
+        if (e->fused_mlp) MX_TRY(upload_tail_stream(e, wo_src, wi_src, wo2_src, F, &L.wf));
         MX_TRY(upload_f32(e, take(H), H, &L.bo2));
         MX_TRY(upload_f32(e, take(H), H, &L.ln2g));
         MX_TRY(upload_f32(e, take(H), H, &L.ln2b));

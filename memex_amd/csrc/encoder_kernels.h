@@ -47,32 +47,32 @@ struct GemmParams {
     float eps;
 };
 
-// fused MLP block (encoder_mlp.hip): out = LayerNorm(x + W2 gelu(W1 x + b1) + b2), hidden = 384
-struct MlpParams {
-    const bf16_t *x;      // [M, 384] input and residual, row pitch ldx
+// the layer tail (encoder_tail.hip), hidden = 384:
+//     x1 = LayerNorm1(x + Wo ctx + bo);  out = LayerNorm2(x1 + W2 gelu(W1 x1 + b1) + b2)
+// ctx == nullptr: the MLP block alone with x = x1
+struct TailParams {
+    const bf16_t *ctx;    // [M, 384] attention output, row pitch ldc (nullptr: MLP block only)
+    int ldc;
+    const bf16_t *x;      // [M, 384] layer input = residual of LayerNorm1 (MLP only: x1), row pitch ldx
     int ldx;
-    const bf16_t *w1;     // intermediate weights, K-blocked [384/32][f][32]
+    const bf16_t *wf;     // Wo, W1, W2 as one bf16 stream per wave in consumption order (tail_stream_layout)
+    const float *bo;      // [384] out-projection bias
+    const float *ln1g, *ln1b;
     const float *b1;      // [f]
-    const bf16_t *w2;     // output weights, K-blocked [f/32][384][32]
     const float *b2;      // [384]
-    int f;                // ffn width, multiple of 128
-    int m;                // rows, multiple of 128
-    bf16_t *out;          // [M, 384] pitch ldo
+    int f;                // ffn width, multiple of 128, 256 .. 1536
+    int m;                // rows, multiple of 64
+    bf16_t *out;          // [M, 384] pitch ldo (may alias x: a workgroup reads its 64 rows before it writes them)
     int ldo;
-    const float *gamma, *beta;
+    const float *gamma, *beta;  // LayerNorm2
     float eps;
-    // mlp2_kernel (encoder_mlp2.hip): W1 and W2 as one bf16 stream per wave in consumption order
-    // (mlp2_stream_layout), 2 * f * 384 elements
-    const bf16_t *wf;
 };
-hipError_t mlp_setup();
-hipError_t mlp2_setup();
-bool mlp2_supported(int hidden, int ffn);
-hipError_t launch_mlp2(hipStream_t s, const MlpParams &p);
-// w1 [f][384], w2 [384][f] (nn.Linear layouts, f32) -> out [2 * f * 384] bf16 in mlp2_kernel's stream order
-void mlp2_stream_layout(const float *w1, const float *w2, int F, uint16_t *out, uint16_t (*to_bf16)(float));
-bool mlp_supported(int hidden, int ffn);
-hipError_t launch_mlp(hipStream_t s, const MlpParams &p);
+hipError_t tail_setup();
+bool tail_supported(int hidden, int ffn);
+hipError_t launch_tail(hipStream_t s, const TailParams &p);
+// wo [384][384], w1 [f][384], w2 [384][f] (nn.Linear layouts, f32) -> out [tail_stream_elems(f)] bf16
+size_t tail_stream_elems(int F);
+void tail_stream_layout(const float *wo, const float *w1, const float *w2, int F, uint16_t *out, uint16_t (*to_bf16)(float));
 
 hipError_t encoder_kernels_setup();
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p);

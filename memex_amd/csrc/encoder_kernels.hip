@@ -12,6 +12,7 @@
 // All matrix math is v_mfma_f32_32x32x16_bf16; LayerNorm / softmax / GELU statistics are f32.
 #include "encoder_kernels.h"
 #include "mx_gelu.h"
+#include "mx_layernorm.h"
 
 #include <cmath>
 
@@ -243,7 +244,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
             static_assert(G::BN % (TPR * 8) == 0 && NT % G::GR == 0, "row split");
             const int row = tid / TPR, prt = tid % TPR;
             float y[CPT * 8];
-            float sum = 0.0f;
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 // interleave the threads of a row chunk-wise: consecutive threads read consecutive 16 B
@@ -251,23 +251,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                 const bf16x8 o = *reinterpret_cast<const bf16x8 *>(smem + row * G::PO + col * 2);
                 const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res + (size_t)(mg + row) * p.ldres + n0 + col);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    y[c * 8 + e] = (float)o[e] + (float)rs[e];
-                    sum += y[c * 8 + e];
-                }
+                for (int e = 0; e < 8; ++e) y[c * 8 + e] = (float)o[e] + (float)rs[e];
             }
-#pragma unroll
-            for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum / (float)G::BN;
-            float sq = 0.0f;
-#pragma unroll
-            for (int e = 0; e < CPT * 8; ++e) {
-                const float dlt = y[e] - mean;
-                sq += dlt * dlt;
-            }
-#pragma unroll
-            for (int o = 1; o < TPR; o <<= 1) sq += __shfl_xor(sq, o);
-            const float rstd = 1.0f / sqrtf(sq / (float)G::BN + p.eps);
+            float mean, rstd;
+            ln_row_stats<TPR, CPT * 8>(y, p.eps, mean, rstd);
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 const int col = (c * TPR + prt) * 8;
@@ -278,8 +265,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = (__bf16)((y[c * 8 + e] - mean) * rstd * g0v[e] + b0v[e]);
-                    o[4 + e] = (__bf16)((y[c * 8 + 4 + e] - mean) * rstd * g1v[e] + b1v[e]);
+                    o[e] = (__bf16)ln_affine(y[c * 8 + e], mean, rstd, g0v[e], b0v[e]);
+                    o[4 + e] = (__bf16)ln_affine(y[c * 8 + 4 + e], mean, rstd, g1v[e], b1v[e]);
                 }
                 *reinterpret_cast<bf16x8 *>(p.out + (size_t)(mg + row) * p.ldo + n0 + col) = o;
             }

@@ -7,8 +7,8 @@
 // 13 issue slots per value against 20 for the 7.1.26 form (rcp + exp + select) it replaces.  |gelu - exact|
 // <= 5e-7 + f32 rounding; the result is rounded to bf16 (2^-9 relative) by every caller.  For negative x the
 // first term is exactly 0 and the result is -0.5 |x| q with q computed without cancellation.
-// All three users (gemm_kernel's GELU epilogue, mlp_kernel, mlp2_kernel) call this one function with
-// explicit fma's, so the fused and two-GEMM MLP paths stay bit-identical.
+// Both users (gemm_kernel's GELU epilogue and tail_kernel) call this one function with explicit fma's, so
+// the fused and the GEMM-by-GEMM paths stay bit-identical.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -1,8 +1,8 @@
 #!/bin/bash
-# PMC counters of the two fused-MLP kernels on the microbenchmark (build_ub/mlp2_ub): where do the
+# PMC counters of the two fused-MLP kernels on the microbenchmark (build_ub/tail_ub): where do the
 # wave-cycles go, and what does the weight stream cost in L1/L2?
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/mlp2_pmc; rm -rf $OUT; mkdir -p $OUT
+OUT=$ROOT/gpurun_out/tail_pmc; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
@@ -11,7 +11,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
          "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCC_TAG_STALL_sum TCP_PENDING_STALL_CYCLES_sum"; do
   i=$((i+1))
-  timeout 90 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- $ROOT/build_ub/mlp2_ub 131072 1536 3 > /dev/null 2> $OUT/p$i.log
+  timeout 90 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- $ROOT/build_ub/tail_ub 131072 1536 3 > /dev/null 2> $OUT/p$i.log
 done
 python - $OUT <<'PY'
 import csv, glob, os, sys
@@ -20,7 +20,7 @@ for path in glob.glob(os.path.join(sys.argv[1], "p*", "**", "*_counter_collectio
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
-            name = "mlp2" if "mlp2_kernel" in k else None
+            name = "tail" if "tail_kernel" in k else None
             if not name: continue
             a = acc.setdefault((name, row["Counter_Name"]), {})
             a[row["Dispatch_Id"]] = a.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Package power and sclk (rocm-smi rows of scripts/power_sampler.py; the hwmon files can belong to another
 # GPU of the host) while ablation variants of the fused-MLP microbenchmark run for ~5 s each.
-#   bash scripts/r2_mlp2_power.sh 0 4 13      (builds build_ub/mlp2_ub_aN if missing)
+#   bash scripts/r2_tail_power.sh 0 4 13      (builds build_ub/tail_ub_aN if missing)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/mlp2_power; rm -rf $OUT; mkdir -p $OUT
+OUT=$ROOT/gpurun_out/tail_power; rm -rf $OUT; mkdir -p $OUT
 for a in "$@"; do
-  [ -x $ROOT/build_ub/mlp2_ub_a$a ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMX_MLP2_ABLATE=$a -I $ROOT/memex_amd/csrc $ROOT/scripts/mlp2_ubench.hip $ROOT/memex_amd/csrc/encoder_mlp2.hip -o $ROOT/build_ub/mlp2_ub_a$a
-  timeout 90 python $ROOT/scripts/power_sampler.py $OUT/a$a.log -- $ROOT/build_ub/mlp2_ub_a$a 131072 1536 ${REPS:-15000} > $OUT/a$a.txt 2>&1
-  grep "^mlp2" $OUT/a$a.txt
+  [ -x $ROOT/build_ub/tail_ub_a$a ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMX_TAIL_ABLATE=$a -I $ROOT/memex_amd/csrc $ROOT/scripts/tail_ubench.hip $ROOT/memex_amd/csrc/encoder_tail.hip -o $ROOT/build_ub/tail_ub_a$a
+  timeout 90 python $ROOT/scripts/power_sampler.py $OUT/a$a.log -- $ROOT/build_ub/tail_ub_a$a 131072 1536 ${REPS:-15000} > $OUT/a$a.txt 2>&1
+  grep "^tail" $OUT/a$a.txt
   python - $OUT/a$a.log <<'PY'
 import re, sys
 rows = []

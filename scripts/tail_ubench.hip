@@ -1,9 +1,10 @@
-// scripts/mlp2_ubench.hip -- standalone microbenchmark of the fused MLP kernel (encoder_mlp2.hip) on random
+// scripts/tail_ubench.hip -- standalone microbenchmark of the fused layer-tail kernel (encoder_tail.hip;
+// argv[4] = 0: the MLP block alone) on random
 // bf16 data (MiniLM shape: hidden 384, ffn 1536), with a checksum of the output so that two builds can be
 // compared (bit-equality with the two-GEMM path is tests/test_encoder_gpu.py's job).  Use >= 1000 reps:
-// the first milliseconds run at ramp-up clocks.  -DMX_MLP2_ABLATE=N selects the ablations of the kernel.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I memex_amd/csrc scripts/mlp2_ubench.hip \
-//        memex_amd/csrc/encoder_mlp2.hip -o build_ub/mlp2_ub
+// the first milliseconds run at ramp-up clocks.  -DMX_TAIL_ABLATE=N selects the ablations of the kernel.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I memex_amd/csrc scripts/tail_ubench.hip \
+//        memex_amd/csrc/encoder_tail.hip -o build_ub/tail_ub
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -11,8 +12,8 @@
 #include <vector>
 #include "encoder_kernels.h"
 using namespace mx;
-#ifndef MX_MLP2_ABLATE
-#define MX_MLP2_ABLATE 0
+#ifndef MX_TAIL_ABLATE
+#define MX_TAIL_ABLATE 0
 #endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 __global__ void fill16(unsigned short* p, size_t n, unsigned seed) {
@@ -29,32 +30,33 @@ static void to_logical(const std::vector<unsigned short>& kb, size_t rows, size_
 }
 static uint16_t bf16_exact(float f) { unsigned int u; memcpy(&u, &f, 4); return (uint16_t)(u >> 16); }
 int main(int argc, char** argv) {
-  int m = argc > 1 ? atoi(argv[1]) : 131072; int f = argc > 2 ? atoi(argv[2]) : 1536; int reps = argc > 3 ? atoi(argv[3]) : 2000;
-  bf16_t *x, *w1, *w2, *wf, *out2; float *b1, *b2, *g, *b;
+  int m = argc > 1 ? atoi(argv[1]) : 131072; int f = argc > 2 ? atoi(argv[2]) : 1536; int reps = argc > 3 ? atoi(argv[3]) : 2000; int po = argc > 4 ? atoi(argv[4]) : 1;
+  bf16_t *x, *ctx, *w1, *w2, *wo, *wf, *out2; float *b1, *b2, *g, *b;
   CK(hipMalloc(&x, (size_t)m * 384 * 2)); CK(hipMalloc(&out2, (size_t)m * 384 * 2));
-  CK(hipMalloc(&w1, (size_t)f * 384 * 2)); CK(hipMalloc(&w2, (size_t)f * 384 * 2)); CK(hipMalloc(&wf, (size_t)f * 384 * 4));
+  CK(hipMalloc(&w1, (size_t)f * 384 * 2)); CK(hipMalloc(&w2, (size_t)f * 384 * 2)); CK(hipMalloc(&wf, tail_stream_elems(f) * 2)); CK(hipMalloc(&wo, 384 * 384 * 2)); CK(hipMalloc(&ctx, (size_t)m * 384 * 2));
   CK(hipMalloc(&b1, f * 4)); CK(hipMalloc(&b2, 384 * 4)); CK(hipMalloc(&g, 384 * 4)); CK(hipMalloc(&b, 384 * 4));
-  fill16<<<4096, 256>>>((unsigned short*)x, (size_t)m * 384, 1); fill16<<<256, 256>>>((unsigned short*)w1, (size_t)f * 384, 2); fill16<<<256, 256>>>((unsigned short*)w2, (size_t)f * 384, 3);
+  fill16<<<4096, 256>>>((unsigned short*)x, (size_t)m * 384, 1); fill16<<<4096, 256>>>((unsigned short*)ctx, (size_t)m * 384, 7); fill16<<<64, 256>>>((unsigned short*)wo, (size_t)384 * 384, 5); fill16<<<256, 256>>>((unsigned short*)w1, (size_t)f * 384, 2); fill16<<<256, 256>>>((unsigned short*)w2, (size_t)f * 384, 3);
   fillf<<<8, 256>>>(b1, f, 0.01f, 0.003f); fillf<<<2, 256>>>(b2, 384, 0.01f, -0.002f); fillf<<<2, 256>>>(g, 384, 1.0f, 0.01f); fillf<<<2, 256>>>(b, 384, 0.0f, 0.005f);
   CK(hipDeviceSynchronize());
-  { std::vector<unsigned short> kb((size_t)f * 384); std::vector<float> l1, l2; std::vector<uint16_t> st((size_t)f * 384 * 2);
+  { std::vector<unsigned short> kb((size_t)f * 384), kbo((size_t)384 * 384); std::vector<float> l1, l2, lo; std::vector<uint16_t> st(tail_stream_elems(f));
     CK(hipMemcpy(kb.data(), w1, kb.size() * 2, hipMemcpyDeviceToHost)); to_logical(kb, f, 384, l1);
     CK(hipMemcpy(kb.data(), w2, kb.size() * 2, hipMemcpyDeviceToHost)); to_logical(kb, 384, f, l2);
-    mlp2_stream_layout(l1.data(), l2.data(), f, st.data(), bf16_exact); CK(hipMemcpy(wf, st.data(), st.size() * 2, hipMemcpyHostToDevice)); }
-  CK(mlp2_setup());
-  MlpParams p2{}; p2.x = x; p2.ldx = 384; p2.b1 = b1; p2.b2 = b2; p2.f = f; p2.m = m; p2.out = out2; p2.ldo = 384; p2.gamma = g; p2.beta = b; p2.eps = 1e-12f; p2.wf = wf;
+    CK(hipMemcpy(kbo.data(), wo, kbo.size() * 2, hipMemcpyDeviceToHost)); to_logical(kbo, 384, 384, lo);
+    tail_stream_layout(lo.data(), l1.data(), l2.data(), f, st.data(), bf16_exact); CK(hipMemcpy(wf, st.data(), st.size() * 2, hipMemcpyHostToDevice)); }
+  CK(tail_setup());
+  TailParams p2{}; p2.ctx = po ? ctx : nullptr; p2.ldc = 384; p2.bo = b2; p2.ln1g = g; p2.ln1b = b; p2.x = x; p2.ldx = 384; p2.b1 = b1; p2.b2 = b2; p2.f = f; p2.m = m; p2.out = out2; p2.ldo = 384; p2.gamma = g; p2.beta = b; p2.eps = 1e-12f; p2.wf = wf;
   CK(hipMemset(out2, 0xff, (size_t)m * 384 * 2));
-  CK(launch_mlp2(0, p2)); CK(hipDeviceSynchronize());
+  CK(launch_tail(0, p2)); CK(hipDeviceSynchronize());
   { std::vector<unsigned short> c((size_t)m * 384);
     CK(hipMemcpy(c.data(), out2, c.size() * 2, hipMemcpyDeviceToHost));
     unsigned long long h = 1469598103934665603ull; for (unsigned short v : c) { h ^= v; h *= 1099511628211ull; }
     printf("output checksum %016llx\n", h); }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  double fl = 4.0 * (double)m * 384 * f;
-  for (int i = 0; i < 3; ++i) CK(launch_mlp2(0, p2));
+  double fl = 4.0 * (double)m * 384 * f + (po ? 2.0 * (double)m * 384 * 384 : 0.0);
+  for (int i = 0; i < 3; ++i) CK(launch_tail(0, p2));
   CK(hipDeviceSynchronize());
-  CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) CK(launch_mlp2(0, p2)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) CK(launch_tail(0, p2)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-  printf("mlp2 ablate=%d m=%d f=%d: %.1f us  %.0f TFLOP/s (%.1f%% of 2.5 PF)\n", MX_MLP2_ABLATE, m, f, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
+  printf("tail po=%d ablate=%d m=%d f=%d: %.1f us  %.0f TFLOP/s (%.1f%% of 2.5 PF)\n", po, MX_TAIL_ABLATE, m, f, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
   return 0;
 }
