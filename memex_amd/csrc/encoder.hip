@@ -67,7 +67,7 @@ struct mx_encoder {
     int32_t *cu = nullptr, *tok_seq = nullptr, *tok_pos = nullptr, *lens_dev = nullptr, *ids_dev = nullptr;
     float *out_dev = nullptr;
     bool profiling = false;
-    bool fused_mlp = false;  // MLP block as one kernel (hidden 384); MEMEX_HIP_UNFUSED_MLP=1 keeps the two GEMMs
+    bool fused_mlp = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_UNFUSED_MLP=1 keeps the three GEMMs
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
     mx_encoder_stats stats{};
     std::string key;  // registry key (mx_encoder_open); empty = private
@@ -114,26 +114,23 @@ void free_ws(mx_encoder *e) {
     e->ws_rows = 0;
 }
 
-// The fused MLP kernel owns 128 token rows per workgroup at one workgroup per CU: below ~one wave of
-// workgroups (256 CUs) the two-GEMM path with its 128 x 192 tiles fills the chip better (measured:
-// 64 x 128-token sequences 85k vs 73k chunks/s), and a single query is two workgroups.
-constexpr int kFusedMlpMinRows = 256 * 128;
-
 int ensure_ws(mx_encoder *e, int rows, int seqs, int n_ids) {
     const int H = e->cfg.hidden, F = e->cfg.ffn;
     if (rows > e->ws_rows) {
         free_ws(e);
         const size_t r = (size_t)rows;
-        bf16_t **bufs[] = {&e->x, &e->x1, &e->q, &e->k, &e->vt, &e->ctx};
+        bf16_t **bufs[] = {&e->x, &e->q, &e->k, &e->vt, &e->ctx};
         for (bf16_t **b : bufs) {
             MX_HIP(hipMalloc(b, r * H * sizeof(uint16_t)));
             MX_HIP(hipMemsetAsync(*b, 0, r * H * sizeof(uint16_t), e->stream));
         }
-        {   // [rows, ffn] intermediate of the two-GEMM MLP.  The fused MLP keeps it on chip and only
-            // falls back to the two GEMMs for small passes (see encode_pass), so it needs few rows.
-            const size_t hr = e->fused_mlp ? std::min<size_t>(r, (size_t)kFusedMlpMinRows) : r;
-            MX_HIP(hipMalloc(&e->hbuf, hr * F * sizeof(uint16_t)));
-            MX_HIP(hipMemsetAsync(e->hbuf, 0, hr * F * sizeof(uint16_t), e->stream));
+        if (!e->fused_mlp) {  // x1 [rows, H] and the [rows, ffn] MLP intermediate only exist GEMM by GEMM:
+            // the fused tail kernel keeps both on chip (and is the faster path at every pass size, a
+            // single short query included: 0.49 vs 0.58 ms)
+            MX_HIP(hipMalloc(&e->x1, r * H * sizeof(uint16_t)));
+            MX_HIP(hipMemsetAsync(e->x1, 0, r * H * sizeof(uint16_t), e->stream));
+            MX_HIP(hipMalloc(&e->hbuf, r * F * sizeof(uint16_t)));
+            MX_HIP(hipMemsetAsync(e->hbuf, 0, r * F * sizeof(uint16_t), e->stream));
         }
         MX_HIP(hipMalloc(&e->tok_seq, r * sizeof(int32_t)));
         MX_HIP(hipMalloc(&e->tok_pos, r * sizeof(int32_t)));
@@ -199,7 +196,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         gv.k = H; gv.out_vt = e->vt; gv.ldvt = t_pad; gv.hidden = H;
         MX_HIP(launch_gemm(st, EPI_VT, gv));
         MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->cu, d_lens, B, max_len, heads, dh, H, e->ctx));
-        if (e->fused_mlp && t_pad >= kFusedMlpMinRows) {
+        if (e->fused_mlp) {
             // out-projection + Add&Norm + MLP + Add&Norm in one kernel, in place on e->x
             TailParams tp{};
             tp.ctx = e->ctx; tp.ldc = H; tp.x = e->x; tp.ldx = H; tp.wf = L.wf; tp.bo = L.bo; tp.ln1g = L.ln1g; tp.ln1b = L.ln1b;
