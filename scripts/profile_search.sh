@@ -1,7 +1,8 @@
 #!/bin/bash
 # Profiles the search bench on the GPU box: --kernel-trace --stats passes (10M x 384 with its side legs;
 # 10M x 768 alone), then separate --pmc passes (never combined with other trace domains), package
-# power / clock logs of the scan kernel and its ablations, the encoder kernels and the default bench
+# power / clock logs of the scan kernel, of the encoder's tail kernel and of their ablations, the encoder
+# kernels and the default bench
 # line; scripts/profile_reduce.py writes the summaries that get copied into profiles/.
 # Usage: scripts/profile_search.sh [tag]
 set -u
@@ -28,6 +29,13 @@ if [ -x $ROOT/build_ub/scan16_ub_0 ]; then
   done
   python $ROOT/scripts/power_sampler.py "$OUT/power_scan16_768.log" -- $ROOT/build_ub/scan16_ub_0 10000000 768 1500 > /dev/null 2>&1
 fi
+# the encoder's layer-tail kernel alone (131072 tokens, ffn 1536) and two ablations (4 = no GELU arithmetic,
+# 13 = no weight loads, no LDS fragment reads, no GELU): time per launch + package power / clock over >= 5 s
+: > "$OUT/tail_ubench.txt"
+for V in 0 4 13; do
+  [ -x $ROOT/build_ub/tail_ub_a$V ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMX_TAIL_ABLATE=$V -I $ROOT/memex_amd/csrc $ROOT/scripts/tail_ubench.hip $ROOT/memex_amd/csrc/encoder_tail.hip -o $ROOT/build_ub/tail_ub_a$V
+  timeout 120 python $ROOT/scripts/power_sampler.py "$OUT/power_tail_ablate$V.log" -- $ROOT/build_ub/tail_ub_a$V 131072 1536 12000 2>&1 | grep "^tail" >> "$OUT/tail_ubench.txt"
+done
 # encoder kernels (MiniLM-L6 shape, 2048 x 512-token chunks) and the default bench line (all legs)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/enc_stats" -- python $ROOT/scripts/gpu_encoder_prof.py l6 > /dev/null 2> "$OUT/enc_stats.log"
 python $ROOT/bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.log"
