@@ -1,4 +1,4 @@
-"""A/B of the fused MLP kernel against the two-GEMM path (not a test): output agreement + throughput."""
+"""A/B of the fused layer-tail kernel against the GEMM-by-GEMM path (not a test): output agreement + throughput."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -15,7 +15,7 @@ for path in glob.glob(os.path.join(sys.argv[1], "p*", "**", "*_counter_collectio
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
-            name = "attention" if "attention" in k else "mlp" if "mlp_kernel" in k else "gemm" + k[k.find("<") : k.find("<") + 3] if "gemm_kernel" in k else None
+            name = "attention" if "attention" in k else "tail" if "tail_kernel" in k else "gemm" + k[k.find("<") : k.find("<") + 3] if "gemm_kernel" in k else None
             if not name: continue
             a = acc.setdefault((name, row["Counter_Name"]), {})
             a[row["Dispatch_Id"]] = a.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
