@@ -67,7 +67,7 @@ struct mx_encoder {
     int32_t *cu = nullptr, *tok_seq = nullptr, *tok_pos = nullptr, *lens_dev = nullptr, *ids_dev = nullptr;
     float *out_dev = nullptr;
     bool profiling = false;
-    bool fused_mlp = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_UNFUSED_MLP=1 keeps the three GEMMs
+    bool fused_tail = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_UNFUSED_TAIL=1 keeps the three GEMMs
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
     mx_encoder_stats stats{};
     std::string key;  // registry key (mx_encoder_open); empty = private
@@ -124,7 +124,7 @@ int ensure_ws(mx_encoder *e, int rows, int seqs, int n_ids) {
             MX_HIP(hipMalloc(b, r * H * sizeof(uint16_t)));
             MX_HIP(hipMemsetAsync(*b, 0, r * H * sizeof(uint16_t), e->stream));
         }
-        if (!e->fused_mlp) {  // x1 [rows, H] and the [rows, ffn] MLP intermediate only exist GEMM by GEMM:
+        if (!e->fused_tail) {  // x1 [rows, H] and the [rows, ffn] MLP intermediate only exist GEMM by GEMM:
             // the fused tail kernel keeps both on chip (and is the faster path at every pass size, a
             // single short query included: 0.49 vs 0.58 ms)
             MX_HIP(hipMalloc(&e->x1, r * H * sizeof(uint16_t)));
@@ -196,7 +196,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         gv.k = H; gv.out_vt = e->vt; gv.ldvt = t_pad; gv.hidden = H;
         MX_HIP(launch_gemm(st, EPI_VT, gv));
         MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->cu, d_lens, B, max_len, heads, dh, H, e->ctx));
-        if (e->fused_mlp) {
+        if (e->fused_tail) {
             // out-projection + Add&Norm + MLP + Add&Norm in one kernel, in place on e->x
             TailParams tp{};
             tp.ctx = e->ctx; tp.ldc = H; tp.x = e->x; tp.ldx = H; tp.wf = L.wf; tp.bo = L.bo; tp.ln1g = L.ln1g; tp.ln1b = L.ln1b;
@@ -316,8 +316,8 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     e->cfg = *cfg;
     e->device = device;
     {
-        const char *ev = getenv("MEMEX_HIP_UNFUSED_MLP");
-        e->fused_mlp = tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
+        const char *ev = getenv("MEMEX_HIP_UNFUSED_TAIL");
+        e->fused_tail = tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
     }
     auto bail = [&](int code) {
         destroy_impl(e);
@@ -368,7 +368,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         MX_TRY(upload_f32(e, take(F), F, &L.bi));
         const float *wo2_src = take(H * F);
         MX_TRY(upload_weight(e, wo2_src, H, F, &L.wo2));
-        if (e->fused_mlp) MX_TRY(upload_tail_stream(e, wo_src, wi_src, wo2_src, F, &L.wf));
+        if (e->fused_tail) MX_TRY(upload_tail_stream(e, wo_src, wi_src, wo2_src, F, &L.wf));
         MX_TRY(upload_f32(e, take(H), H, &L.bo2));
         MX_TRY(upload_f32(e, take(H), H, &L.ln2g));
         MX_TRY(upload_f32(e, take(H), H, &L.ln2b));

@@ -134,7 +134,7 @@ def test_embed_then_search_pipeline_matches_cpu_path(oracle, lib_built, tmp_path
 
 def test_fused_layer_tail_equals_gemm_by_gemm_path(lib_built, monkeypatch):
     """tail_kernel (attention out-projection + Add&Norm + MLP + Add&Norm in one launch) rounds at the same
-    points and accumulates in the same k order as the three GEMMs it replaces (MEMEX_HIP_UNFUSED_MLP=1):
+    points and accumulates in the same k order as the three GEMMs it replaces (MEMEX_HIP_UNFUSED_TAIL=1):
     outputs must be bit-identical -- full passes, ragged lengths, a single short query and a non-default ffn
     width included."""
     from memex_amd.encoder import Encoder
@@ -150,7 +150,7 @@ def test_fused_layer_tail_equals_gemm_by_gemm_path(lib_built, monkeypatch):
         lens = rng.integers(S // 2 + S // 4, S + 1, B).astype(np.int32)
         outs = []
         for unfused in ("1", "0"):
-            monkeypatch.setenv("MEMEX_HIP_UNFUSED_MLP", unfused)
+            monkeypatch.setenv("MEMEX_HIP_UNFUSED_TAIL", unfused)
             with Encoder(cfg, w) as enc:
                 outs.append(enc.encode(ids, lens))
         np.testing.assert_array_equal(outs[0], outs[1])
