@@ -22,6 +22,17 @@ def test_cpp_mirror_compiles_and_links(tmp_path, lib_built):
     assert os.path.exists(_build(tmp_path, lib_built))
 
 
+def test_tail_weight_stream_layout(tmp_path, lib_built):
+    """encoder_tail.hip's per-wave weight streams: a permutation of Wo, W1, W2 with every fragment where the
+    kernel's addressing expects it (host code inside the library: runs without a GPU)."""
+    exe = str(tmp_path / "test_tail_stream")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "cpp", "test_tail_stream.cpp"),
+                           "-o", exe, "-L", os.path.join(ROOT, "memex_amd"), "-lmemex_hip", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "memex_amd")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK tail stream layout" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_reference_tests(tmp_path, lib_built):
     exe = _build(tmp_path, lib_built)
