@@ -10,6 +10,9 @@
 //   K3 attention_kernel    QK^T -> masked softmax -> PV, scores never leave registers
 //   K5 pool_kernel         masked mean / CLS + L2 normalise
 // All matrix math is v_mfma_f32_32x32x16_bf16; LayerNorm / softmax / GELU statistics are f32.
+#include <cstdlib>
+#include <type_traits>
+
 #include "encoder_kernels.h"
 #include "mx_gelu.h"
 #include "mx_layernorm.h"
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(const bf16_t
                                                                     const bf16_t *__restrict__ vt, int ldvt,
                                                                     const int32_t *__restrict__ cu,
                                                                     const int32_t *__restrict__ lens, int hidden,
-                                                                    bf16_t *__restrict__ ctx) {
+                                                                    bf16_t *__restrict__ ctx, int safe_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = kAttnWaves * 64;
     constexpr int KP = D * 2 + 16;  // K row pitch (bytes)
@@ -530,66 +533,89 @@ __global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(const bf16_t
     const int nkb = sb / 32;
     const int full_blocks = len / 32;  // key blocks without padding keys
 
-    for (int kb = 0; kb < nkb; ++kb) {
-        // S^T tile: rows = keys kb*32 + (r&3) + 8*(r>>2) + 4h, col = query l31
-        f32x16 sc;
+    // SAFE: the textbook running maximum (max + cross-half exchange + compare per 32-key block, rescale when
+    // it grows).  !SAFE: the shift is the maximum of key block 0 and stays there -- softmax is shift-invariant
+    // and P, l, O are floating point, so later scores above the shift only make P > 1; what can go wrong is
+    // exp2 overflowing (a score more than 127 above block 0's maximum), which leaves l_run non-finite and
+    // sends the wave through the SAFE loop afterwards.  The max chain is 13 of ~105 VALU issue slots per
+    // block in a loop that is VALU-bound, and it sits on the MFMA -> exp dependency chain.
+    auto key_loop = [&](auto safe_tag) __attribute__((always_inline)) {
+        constexpr bool SAFE = decltype(safe_tag)::value;
+        for (int kb = 0; kb < nkb; ++kb) {
+            // S^T tile: rows = keys kb*32 + (r&3) + 8*(r>>2) + 4h, col = query l31
+            f32x16 sc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < D / 16; ++s) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(ks + (kb * 32 + l31) * KP + s * 32 + h * 16);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
-        }
-        if (kb >= full_blocks) {  // wave-uniform: only the last block can hold padding keys
+            for (int s = 0; s < D / 16; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(ks + (kb * 32 + l31) * KP + s * 32 + h * 16);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
+            }
+            if (kb >= full_blocks) {  // wave-uniform: only the last block can hold padding keys
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                sc[r] = key < len ? sc[r] : -1e30f;  // reference: additive -10000 mask == exclusion in f32
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    sc[r] = key < len ? sc[r] : -1e30f;  // reference: additive -10000 mask == exclusion in f32
+                }
+            }
+            // the softmax arithmetic is what bounds this kernel at d = 32 (VALU issue, not MFMA): keep it to
+            // v_max3 chains and packed f32 adds / subtracts (2 scores per instruction)
+            if (SAFE || kb == 0) {
+                float bm = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) bm = fmaxf(fmaxf(bm, sc[r]), sc[r + 1]);
+                bm = fmaxf(bm, sc[15]);
+                bm = fmaxf(bm, __shfl_xor(bm, 32));
+                if (__builtin_amdgcn_ballot_w64(bm > m_run) != 0) {  // some query's max grew: rescale (rare later on)
+                    const float m_new = fmaxf(m_run, bm);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    l_run *= alpha;
+                    m_run = m_new;
+#pragma unroll
+                    for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                }
+            }
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            const f32x2 mm = {m_run, m_run};
+            f32x2 ps2 = {0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = f32x2{sc[r], sc[r + 1]} - mm;
+                const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                sc[r] = e[0];
+                sc[r + 1] = e[1];
+                ps2 += e;
+            }
+            const float ps = ps2[0] + ps2[1];
+            l_run += ps;
+            // O^T += V^T P^T: k16 step s uses this lane's p[8s .. 8s+7] = keys 16s + 8(i>>2) + 4h + (i&3),
+            // stored contiguously in the permuted V^T tile at physical key offset 16s + 8h
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s + e];
+#pragma unroll
+                for (int t = 0; t < D / 32; ++t) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(vs + (t * 32 + l31) * VP + (kb * 32 + 16 * s + 8 * h) * 2);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
+                }
             }
         }
-        // the softmax arithmetic is what bounds this kernel at d = 32 (VALU issue, not MFMA): keep it to
-        // v_max3 chains and packed f32 adds / subtracts (2 scores per instruction)
-        float bm = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+    };
+    if (!safe_only) key_loop(std::false_type{});
+    // 1 <= l_run here (block 0's maximum contributes exp2(0)); a row sum beyond 1e30 means some score sat
+    // ~100 above the shift: exp2 may have overflowed (inf) or P * v may have -> redo with the running maximum
+    if (safe_only || __builtin_amdgcn_ballot_w64(!(l_run + __shfl_xor(l_run, 32) < 1.0e30f)) != 0) {
 #pragma unroll
-        for (int r = 3; r < 15; r += 2) bm = fmaxf(fmaxf(bm, sc[r]), sc[r + 1]);
-        bm = fmaxf(bm, sc[15]);
-        bm = fmaxf(bm, __shfl_xor(bm, 32));
-        if (__builtin_amdgcn_ballot_w64(bm > m_run) != 0) {  // some query's max grew: rescale (rare later on)
-            const float m_new = fmaxf(m_run, bm);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-            m_run = m_new;
+        for (int t = 0; t < D / 32; ++t)
 #pragma unroll
-            for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-        }
-        typedef __attribute__((ext_vector_type(2))) float f32x2;
-        const f32x2 mm = {m_run, m_run};
-        f32x2 ps2 = {0.0f, 0.0f};
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const f32x2 t = f32x2{sc[r], sc[r + 1]} - mm;
-            const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-            sc[r] = e[0];
-            sc[r + 1] = e[1];
-            ps2 += e;
-        }
-        const float ps = ps2[0] + ps2[1];
-        l_run += ps;
-        // O^T += V^T P^T: k16 step s uses this lane's p[8s .. 8s+7] = keys 16s + 8(i>>2) + 4h + (i&3),
-        // stored contiguously in the permuted V^T tile at physical key offset 16s + 8h
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 pf;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s + e];
-#pragma unroll
-            for (int t = 0; t < D / 32; ++t) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(vs + (t * 32 + l31) * VP + (kb * 32 + 16 * s + 8 * h) * 2);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
-            }
-        }
+            for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+        m_run = -1e30f;
+        l_run = 0.0f;
+        key_loop(std::true_type{});
     }
     l_run += __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_run;
@@ -619,10 +645,15 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
     if (max_len > 512 || max_len < 1) return hipErrorInvalidValue;
     dim3 grid((max_len + kAttnQ - 1) / kAttnQ, heads, B);
     const size_t lds = attn_lds(max_len, d_head);
+    // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path)
+    const int safe_only = [] {
+        const char *ev = getenv("MEMEX_HIP_ATTN_SAFE");
+        return ev && ev[0] == '1' ? 1 : 0;
+    }();
     if (d_head == 32)
-        hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx);
+        hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, safe_only);
     else if (d_head == 64)
-        hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx);
+        hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, safe_only);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -156,6 +156,42 @@ def test_fused_layer_tail_equals_gemm_by_gemm_path(lib_built, monkeypatch):
         np.testing.assert_array_equal(outs[0], outs[1])
 
 
+def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
+    """attention_kernel keeps the maximum of key block 0 as its softmax shift and only falls back to the
+    running maximum when a row sum says an exp2 may have overflowed.  (a) ordinary weights: fast path ==
+    running-maximum loop (MEMEX_HIP_ATTN_SAFE=1) up to bf16 rounding of P, both within tolerance of the
+    oracle; (b) query / key projections scaled so that scores reach several hundred and later key blocks
+    tower over block 0 by far more than 2^127: every exp2 of the fast path overflows there, so finite
+    outputs that agree with the running-maximum loop mean the fallback ran and is right."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    from oracle import bert_oracle
+    cfg = EncoderConfig(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000)
+    rng = np.random.default_rng(21)
+    B, S = 6, 256
+    ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
+    lens = np.array([256, 200, 97, 256, 33, 160], dtype=np.int32)
+    for scale in (1.0, 24.0):
+        w = synthetic_weights(cfg, 21)
+        for name in list(w):
+            if name.endswith("attention.self.query.weight") or name.endswith("attention.self.key.weight"):
+                w[name] = (w[name] * scale).astype(np.float32)
+        outs = []
+        for safe in ("0", "1"):
+            monkeypatch.setenv("MEMEX_HIP_ATTN_SAFE", safe)
+            with Encoder(cfg, w) as enc:
+                outs.append(enc.encode(ids, lens))
+        for o in outs:
+            assert np.isfinite(o).all(), scale
+        if scale == 1.0:  # (with scores in the hundreds bf16 q / k decide the arg max: no oracle comparison there)
+            ref = bert_oracle.encode(w, cfg.as_dict(), ids, lens)
+            for o in outs:
+                cos = (o * ref).sum(1) / np.linalg.norm(o, axis=1) / np.linalg.norm(ref, axis=1)
+                assert (1.0 - cos).max() <= TOL, cos
+        cos = (outs[0] * outs[1]).sum(1) / np.linalg.norm(outs[0], axis=1) / np.linalg.norm(outs[1], axis=1)
+        assert (1.0 - cos).max() <= 1e-4, (scale, cos)
+
+
 def test_embedder_batches_concurrent_requests(lib_built):
     """Concurrent encode / encode_single calls on one embedder are embedded together; every caller
     still receives exactly what a lone call returns (a row's embedding is batch-independent)."""
