@@ -463,7 +463,7 @@ constexpr int kAttnWaves = 16;
 constexpr int kAttnQ = kAttnWaves * 32;  // queries per workgroup
 
 template <int D>
-__global__ __launch_bounds__(kAttnWaves * 64) void attention_kernel(const bf16_t *__restrict__ q,
+__global__ __launch_bounds__(kAttnWaves * 64, D == 32 ? 8 : 4) void attention_kernel(const bf16_t *__restrict__ q,
                                                                     const bf16_t *__restrict__ k,
                                                                     const bf16_t *__restrict__ vt, int ldvt,
                                                                     const int32_t *__restrict__ cu,
