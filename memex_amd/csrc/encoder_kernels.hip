@@ -534,11 +534,12 @@ __global__ __launch_bounds__(kAttnWaves * 64, D == 32 ? 8 : 4) void attention_ke
     const int full_blocks = len / 32;  // key blocks without padding keys
 
     // SAFE: the textbook running maximum (max + cross-half exchange + compare per 32-key block, rescale when
-    // it grows).  !SAFE: the shift is the maximum of key block 0 and stays there -- softmax is shift-invariant
-    // and P, l, O are floating point, so later scores above the shift only make P > 1; what can go wrong is
-    // exp2 overflowing (a score more than 127 above block 0's maximum), which leaves l_run non-finite and
-    // sends the wave through the SAFE loop afterwards.  The max chain is 13 of ~105 VALU issue slots per
-    // block in a loop that is VALU-bound, and it sits on the MFMA -> exp dependency chain.
+    // it grows).  !SAFE: NO shift at all, P = exp2(score) -- softmax is shift-invariant and P, l, O are floating
+    // point, so scores away from 0 only move the exponents; what can go wrong is exp2 overflowing (a score
+    // above 127; the pre-scaled logits of the models this runs stay within a few tens) or a whole row
+    // underflowing, and both leave the row sum outside (1e-30, 1e30), which sends the wave through the SAFE
+    // loop afterwards.  The max chain and the subtraction are 21 of ~105 VALU issue slots per block in a loop
+    // that is VALU-bound, and the max sits on the MFMA -> exp dependency chain.
     auto key_loop = [&](auto safe_tag) __attribute__((always_inline)) {
         constexpr bool SAFE = decltype(safe_tag)::value;
         for (int kb = 0; kb < nkb; ++kb) {
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, D == 32 ? 8 : 4) void attention_ke
             }
             // the softmax arithmetic is what bounds this kernel at d = 32 (VALU issue, not MFMA): keep it to
             // v_max3 chains and packed f32 adds / subtracts (2 scores per instruction)
-            if (SAFE || kb == 0) {
+            if (SAFE) {
                 float bm = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) bm = fmaxf(fmaxf(bm, sc[r]), sc[r + 1]);
@@ -582,7 +583,8 @@ __global__ __launch_bounds__(kAttnWaves * 64, D == 32 ? 8 : 4) void attention_ke
             f32x2 ps2 = {0.0f, 0.0f};
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const f32x2 t = f32x2{sc[r], sc[r + 1]} - mm;
+                f32x2 t = {sc[r], sc[r + 1]};
+                if (SAFE) t -= mm;
                 const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
                 sc[r] = e[0];
                 sc[r + 1] = e[1];
@@ -606,9 +608,10 @@ __global__ __launch_bounds__(kAttnWaves * 64, D == 32 ? 8 : 4) void attention_ke
         }
     };
     if (!safe_only) key_loop(std::false_type{});
-    // 1 <= l_run here (block 0's maximum contributes exp2(0)); a row sum beyond 1e30 means some score sat
-    // ~100 above the shift: exp2 may have overflowed (inf) or P * v may have -> redo with the running maximum
-    if (safe_only || __builtin_amdgcn_ballot_w64(!(l_run + __shfl_xor(l_run, 32) < 1.0e30f)) != 0) {
+    // a row sum outside (1e-30, 1e30): an exp2 (or P * v) may have overflowed, or the whole row underflowed
+    // -> redo with the running maximum (the comparison is false for NaN as well)
+    const float l_row = l_run + __shfl_xor(l_run, 32);
+    if (safe_only || __builtin_amdgcn_ballot_w64(!(l_row > 1.0e-30f && l_row < 1.0e30f)) != 0) {
 #pragma unroll
         for (int t = 0; t < D / 32; ++t)
 #pragma unroll

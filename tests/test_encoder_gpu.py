@@ -157,12 +157,12 @@ def test_fused_layer_tail_equals_gemm_by_gemm_path(lib_built, monkeypatch):
 
 
 def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
-    """attention_kernel keeps the maximum of key block 0 as its softmax shift and only falls back to the
-    running maximum when a row sum says an exp2 may have overflowed.  (a) ordinary weights: fast path ==
-    running-maximum loop (MEMEX_HIP_ATTN_SAFE=1) up to bf16 rounding of P, both within tolerance of the
-    oracle; (b) query / key projections scaled so that scores reach several hundred and later key blocks
-    tower over block 0 by far more than 2^127: every exp2 of the fast path overflows there, so finite
-    outputs that agree with the running-maximum loop mean the fallback ran and is right."""
+    """attention_kernel's fast path applies no softmax shift (P = exp2(score)) and only falls back to the
+    running maximum when a row sum says an exp2 may have overflowed or a row underflowed.  (a) ordinary
+    weights: fast path == running-maximum loop (MEMEX_HIP_ATTN_SAFE=1) up to bf16 rounding of P, both within
+    tolerance of the oracle; (b) query / key projections scaled so that scores reach several hundred either
+    side of 0: every row of the fast path overflows or underflows there, so finite outputs that agree with
+    the running-maximum loop mean the fallback ran and is right."""
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, synthetic_weights
     from oracle import bert_oracle
