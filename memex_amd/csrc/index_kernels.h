@@ -147,6 +147,15 @@ struct FinishParams {
     int32_t *n_found;
     float *max_err;             // null unless profiling
     int debug_stop;             // 0; 1..8 = return after that stage (MEMEX_HIP_FINISH_STOP: timing probes only, results are garbage)
+    // completion signal: the LAST workgroup of the launch writes a 4-word summary of the batch's flag block
+    // (dev_flags: [overflow 256 | cand_cnt 256 | e1 256 | qbad 256]) into host-mapped memory and then stores
+    // seq behind it (system scope) -- the host polls that word instead of queueing a D2H copy and sleeping in
+    // hipStreamSynchronize.  host_flags == nullptr: no signal.
+    uint32_t *done_ctr;         // device word, 0 between launches
+    const uint32_t *dev_flags;
+    uint32_t *host_flags;       // [5]: max overflow code, sum of cand_cnt, any bad query, e1[0], seq
+    int n_queries;              // B
+    uint32_t seq;
 };
 hipError_t finish_setup();
 hipError_t launch_finish(hipStream_t s, int B, const FinishParams &p);

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
     float *s_row = reinterpret_cast<float *>(psm);  // [d] this query (coalesced load; the chain reads LDS)
     __shared__ float s_inv;
     __shared__ uint32_t s_red[4];
+    __shared__ uint32_t s_bad[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const bool live = b < B;
@@ -241,9 +242,15 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
     const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0;
-    if ((tid & 63) == 0) s_red[tid >> 6] = __float_as_uint(r2);
+    if ((tid & 63) == 0) {
+        s_red[tid >> 6] = __float_as_uint(r2);
+        s_bad[tid >> 6] = anybad ? 1u : 0u;
+    }
     __syncthreads();
     if (tid == 0) {
+        // non-finite query: the call fails with MX_EINVAL.  One word per query slot, written by every launch:
+        // nothing to clear between calls
+        flags[b] = live ? (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) : 0u;
         // |approx - cos| <= |c^ - c| + |q^ - q| + |c^ - c||q^ - q| + f32 accumulation (unit vectors,
         // Cauchy-Schwarz).  ec_max is the largest row residual the filter copy holds (shadow_kernel);
         // without a filter copy (f32 scan: rows are rounded unnormalised) the a-priori bound is used.
@@ -256,7 +263,6 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
         }
         e1[b] = e;
     }
-    if (live && anybad && (tid & 63) == 0) atomicOr(&flags[0], 1u);  // non-finite query: the call fails with MX_EINVAL
 }
 
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag, float *qpad,
@@ -415,7 +421,7 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *lds_w,
 }
 
 template <bool CMP>
-__global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams p) {
+__device__ __forceinline__ void finish_query(const FinishParams &p) {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     Cand *ent = reinterpret_cast<Cand *>(fsm);                                        // [kCandCap]
     uint64_t *keys = reinterpret_cast<uint64_t *>(fsm);                               // same storage, later
@@ -799,6 +805,44 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
             osc[rank] = score_from_dist(d);
             if (odi) odi[rank] = d;
         }
+    }
+}
+
+// One workgroup per query (finish_query above), then the completion signal of FinishParams.
+template <bool CMP>
+__global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams p) {
+    finish_query<CMP>(p);  // every exit of it is workgroup-uniform
+    if (!p.host_flags) return;
+    __shared__ uint32_t s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();  // this workgroup's results and flag words before its tick
+        s_last = atomicAdd(p.done_ctr, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // summary of the batch for the host (4 words + seq: one small write over PCIe; the per-query words stay
+    // in HBM and are only fetched when the summary says some query overflowed)
+    __shared__ uint32_t s_sum[3];
+    if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+    __threadfence();
+    __syncthreads();
+    if ((int)threadIdx.x < p.n_queries) {
+        const uint32_t ovf = __hip_atomic_load(&p.dev_flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t cnt = __hip_atomic_load(&p.dev_flags[kMaxBatch + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t bad = __hip_atomic_load(&p.dev_flags[3 * kMaxBatch + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ovf) atomicMax(&s_sum[0], ovf);
+        atomicAdd(&s_sum[1], cnt);
+        if (bad) atomicOr(&s_sum[2], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p.host_flags[0] = s_sum[0];  // 0: nobody overflowed; 1: some need the retry pass; >= 2: some need EXACT
+        p.host_flags[1] = s_sum[1];  // candidates rescored in f32, whole batch
+        p.host_flags[2] = s_sum[2];  // a query held non-finite values
+        p.host_flags[3] = __hip_atomic_load(&p.dev_flags[2 * kMaxBatch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // e1 of query 0
+        *p.done_ctr = 0;
+        __hip_atomic_store(&p.host_flags[4], p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
