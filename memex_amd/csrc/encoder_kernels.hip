@@ -392,57 +392,83 @@ hipError_t launch_token_map(hipStream_t s, const int32_t *lens, int B, int S, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1: embeddings + LayerNorm, one wave per packed row
+// K1: embeddings + LayerNorm, half a wave per packed row
 // ---------------------------------------------------------------------------------------------
+// hidden = 128 * PER (384, 768: what mx_encoder_create accepts).  HALF a wave per token, 16-byte loads of the
+// three table rows (lane l of the half owns columns 4l + 128j .. +3), 8-byte stores; 8 tokens per workgroup:
+// 58 us per 131k tokens = 5.2 TB/s (the one-wave-per-token form with 4-byte loads it replaces: 123 us).
+template <int PER>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict__ ids, int S,
-                                                       const int32_t *__restrict__ tok_seq,
-                                                       const int32_t *__restrict__ tok_pos, int t_pad, int hidden,
-                                                       const float *__restrict__ word, const float *__restrict__ pos,
-                                                       const float *__restrict__ type0, const float *__restrict__ gamma,
-                                                       const float *__restrict__ beta, float eps, int vocab,
-                                                       bf16_t *__restrict__ x) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                        const int32_t *__restrict__ tok_seq,
+                                                        const int32_t *__restrict__ tok_pos, int t_pad,
+                                                        const float *__restrict__ word, const float *__restrict__ pos,
+                                                        const float *__restrict__ type0, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, float eps, int vocab,
+                                                        bf16_t *__restrict__ x) {
+    constexpr int H = 128 * PER;
+    const int l = threadIdx.x & 31;
+    const int t = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (t >= t_pad) return;
     const int b = tok_seq[t];
-    bf16_t *xo = x + (size_t)t * hidden;
+    bf16_t *xo = x + (size_t)t * H;
     if (b < 0) {  // padding row: keep it finite
-        for (int c = lane; c < hidden; c += 64) xo[c] = (__bf16)0.0f;
+        const bf16x4 z = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+#pragma unroll
+        for (int j = 0; j < PER; ++j) *reinterpret_cast<bf16x4 *>(xo + 4 * l + 128 * j) = z;
         return;
     }
     const int ps = tok_pos[t];
     int id = ids[(size_t)b * S + ps];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    const float *w = word + (size_t)id * hidden;
-    const float *pp = pos + (size_t)ps * hidden;
-    float v[16];  // hidden <= 1024
+    const float *w = word + (size_t)id * H;
+    const float *pp = pos + (size_t)ps * H;
+    f32x4 v[PER];
     float sum = 0.0f;
-    const int per = hidden / 64;
-    for (int i = 0; i < per; ++i) {
-        const int c = lane + i * 64;
-        v[i] = w[c] + pp[c] + type0[c];
-        sum += v[i];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = 4 * l + 128 * j;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(w + c);
+        const f32x4 p4 = *reinterpret_cast<const f32x4 *>(pp + c);
+        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(type0 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[j][e] = a[e] + p4[e] + t4[e];
+            sum += v[j][e];
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float mean = sum / (float)hidden;
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)H;
     float sq = 0.0f;
-    for (int i = 0; i < per; ++i) sq += (v[i] - mean) * (v[i] - mean);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    const float rstd = 1.0f / sqrtf(sq / (float)hidden + eps);
-    for (int i = 0; i < per; ++i) {
-        const int c = lane + i * 64;
-        xo[c] = (__bf16)((v[i] - mean) * rstd * gamma[c] + beta[c]);
+    for (int j = 0; j < PER; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sq += (v[j][e] - mean) * (v[j][e] - mean);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = 4 * l + 128 * j;
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(gamma + c);
+        const f32x4 bt = *reinterpret_cast<const f32x4 *>(beta + c);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)((v[j][e] - mean) * rstd * g[e] + bt[e]);
+        *reinterpret_cast<bf16x4 *>(xo + c) = o;
     }
 }
 
 hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32_t *tok_seq, const int32_t *tok_pos,
                            int t_pad, int hidden, const float *word, const float *pos, const float *type0,
                            const float *gamma, const float *beta, float eps, int vocab, bf16_t *x) {
-    if (hidden % 64 || hidden > 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(embed_ln_kernel, dim3((t_pad + 3) / 4), dim3(256), 0, s, ids, S, tok_seq, tok_pos, t_pad, hidden,
-                       word, pos, type0, gamma, beta, eps, vocab, x);
+    const dim3 g8((t_pad + 7) / 8);
+    if (hidden == 384)
+        hipLaunchKernelGGL(embed_ln_kernel<3>, g8, dim3(256), 0, s, ids, S, tok_seq, tok_pos, t_pad, word, pos, type0, gamma, beta, eps, vocab, x);
+    else if (hidden == 768)
+        hipLaunchKernelGGL(embed_ln_kernel<6>, g8, dim3(256), 0, s, ids, S, tok_seq, tok_pos, t_pad, word, pos, type0, gamma, beta, eps, vocab, x);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
