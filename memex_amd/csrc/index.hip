@@ -574,8 +574,13 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     auto finish_and_wait = [&]() -> int {
         fp.seq = ++s.flag_seq;
         MX_HIP(launch_finish(st, B, fp));
+        // MEMEX_HIP_NO_SPIN=1: sleep in hipStreamSynchronize instead (no core kept busy for the ~2 ms of a batch)
+        static const bool no_spin = [] {
+            const char *ev = getenv("MEMEX_HIP_NO_SPIN");
+            return ev && ev[0] == '1';
+        }();
         const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 1;; ++spins) {
+        for (unsigned spins = 1; !no_spin; ++spins) {
             if (__atomic_load_n(&s.host_sum[4], __ATOMIC_ACQUIRE) == fp.seq) return MX_OK;
             if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
             __builtin_ia32_pause();
