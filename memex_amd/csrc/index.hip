@@ -567,9 +567,9 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     fp.host_flags = s.host_sum;
     fp.n_queries = B;
     // finish + completion: the kernel's last workgroup writes the batch summary into pinned host memory and
-    // stores the launch's sequence number behind it; the host spins on that word (no D2H copy command, no
-    // memset, no sleep in hipStreamSynchronize between batches: the host gap between two batches drops from
-    // 45 to 22 us, the kernel grows by 8: measured with scripts/r2_step_gaps.sh).  A kernel that never signals (fault) is
+    // stores the launch's sequence number behind it; the host spins on that word (no D2H copy command and no
+    // memset between batches: the host gap between two batches drops from 45 to 22 us, the kernel grows by
+    // 8: scripts/r2_step_gaps.sh; waiting in hipStreamSynchronize is as fast, see MEMEX_HIP_NO_SPIN below).  A kernel that never signals (fault) is
     // caught by the synchronize after the spin budget.  -> the summary's overflow code
     auto finish_and_wait = [&]() -> int {
         fp.seq = ++s.flag_seq;
