@@ -149,7 +149,7 @@ struct FinishParams {
     int debug_stop;             // 0; 1..8 = return after that stage (MEMEX_HIP_FINISH_STOP: timing probes only, results are garbage)
     // completion signal: the LAST workgroup of the launch writes a 4-word summary of the batch's flag block
     // (dev_flags: [overflow 256 | cand_cnt 256 | e1 256 | qbad 256]) into host-mapped memory and then stores
-    // seq behind it (system scope) -- the host polls that word instead of queueing a D2H copy and sleeping in
+    // seq behind it (system scope) -- the host polls that word instead of queueing a D2H copy (and a flag memset) and waiting in
     // hipStreamSynchronize.  host_flags == nullptr: no signal.
     uint32_t *done_ctr;         // device word, 0 between launches
     const uint32_t *dev_flags;
