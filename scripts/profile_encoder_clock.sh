@@ -3,7 +3,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/encpmc
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/encpmc -- python $ROOT/scripts/gpu_encoder_prof.py l6 > /dev/null 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/encpmc -- python $ROOT/scripts/gpu_encoder_prof.py l6 > /dev/null 2>&1
 python - <<PY
 import csv, glob, collections
 f = glob.glob("/tmp/encpmc/**/*_counter_collection.csv", recursive=True)[0]

@@ -62,6 +62,10 @@ def main():
     for name in glob.glob(os.path.join(out_dir, "power_*.log")):
         with open(name) as f, open(os.path.join(prof, f"{tag}_" + os.path.basename(name)), "w") as g:
             g.write(f.read())
+    ec = os.path.join(out_dir, "encoder_clock_mfma.txt")
+    if os.path.exists(ec):
+        with open(ec) as f, open(os.path.join(prof, f"{tag}_encoder_clock_mfma.txt"), "w") as g:
+            g.write(f.read())
     tu = os.path.join(out_dir, "tail_ubench.txt")
     if os.path.exists(tu):
         with open(tu) as f, open(os.path.join(prof, f"{tag}_tail_ubench.txt"), "w") as g:

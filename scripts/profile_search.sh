@@ -38,5 +38,7 @@ for V in 0 4 13; do
 done
 # encoder kernels (MiniLM-L6 shape, 2048 x 512-token chunks) and the default bench line (all legs)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/enc_stats" -- python $ROOT/scripts/gpu_encoder_prof.py l6 > /dev/null 2> "$OUT/enc_stats.log"
+# effective shader clock and MFMA-busy fraction of every encoder kernel (PMC pass of its own)
+timeout 300 bash $ROOT/scripts/profile_encoder_clock.sh > "$OUT/encoder_clock_mfma.txt" 2>&1
 python $ROOT/bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.log"
 python "$ROOT/scripts/profile_reduce.py" "$OUT" "$TAG"
