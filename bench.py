@@ -7,19 +7,24 @@ synthetic corpus resident in HBM, query batch 256, top-10, exact cosine search t
 sample scan, threshold, collect scan, candidate select + f32/f64 rescoring + ordering; plus the RCCL
 all-gather + merge when N > 1).  Inputs are resident in HBM before the timed region.
 
-N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`): STRONG scaling on the same 10M-row
-corpus (north_star: "on a 10M x 384-d corpus ... queries/sec at 1/2/4/8 GPUs") -- rank r owns rows
-[r*10M/N, (r+1)*10M/N) with global ids, every rank answers the same 256 queries on its shard, ONE
-all-gather of the per-shard top-10 blocks (ids + dists) and a merge kernel give every rank the
-global answer.
+N > 1: STRONG scaling on the same 10M-row corpus (north_star: "on a 10M x 384-d corpus ... queries/sec at
+1/2/4/8 GPUs"), in either of two forms with identical arithmetic:
+  * `python bench.py --gpus N` (one plain process, WORLD_SIZE unset): the form memex itself would run -- its
+    api and worker are tasks of ONE process (bin/memex/src/main.rs) -- through the in-library sharded index
+    (`mx_index_open_sharded`): rows dealt to the N GPUs in 64k-row blocks, one helper thread + stream per
+    shard, ONE RCCL all-gather of the per-shard top-10 blocks, merge on device 0;
+  * `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (one process per GPU): rank r owns
+    rows [r*10M/N, (r+1)*10M/N) with global ids, every rank answers the same 256 queries on its shard, ONE
+    `all_gather_into_tensor` of the packed blocks and the merge kernel give every rank the global answer.
 
 Printed JSON (one line, rank 0): metric/value/unit per the contract + `roofline` for the collect-scan
 kernel (algorithmic bytes / HIP-event time of the kernel on the library's stream) + `cpu_baseline`
 (rank 0 at N = 1 only): the C oracle's exact brute force on all host cores AND the reference's real
 algorithm, HNSW with memex's parameters, on one thread with its recall@10.  Reported beside the
 headline at N = 1: the same job on clustered data (dense neighbourhoods, duplicates), the host-pointer
-API the Rust shim binds, BASELINE configs[3]'s per-GPU shard (10M x 768), and the ingest leg
-(configs[4]).
+API the Rust shim binds, BASELINE configs[3]'s per-GPU shard (10M x 768), configs[1] end to end (`cfg2`:
+100k segments embedded on the GPU, appended from HBM, searched), and the ingest legs (configs[4] on the
+all-MiniLM-L6-v2 shape, and the bge-base-en shape that configs[3] embeds with).
 """
 from __future__ import annotations
 
@@ -61,6 +66,10 @@ def parse():
     ap.add_argument("--hnsw-rows", type=int, default=100_000, help="corpus size of the HNSW CPU baseline (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=4, help="queries re-answered on the EXACT path")
     ap.add_argument("--ingest-chunks", type=int, default=262_144, help="512-token chunks per GPU for the ingest leg (0 = skip)")
+    ap.add_argument("--bge-chunks", type=int, default=24_576, help="N=1 only: 512-token chunks of the bge-base-en ingest leg (0 = skip)")
+    ap.add_argument("--cfg2-segments", type=int, default=100_000, help="N=1 only: segments of the configs[1] end-to-end leg (0 = skip)")
+    ap.add_argument("--per-process", action="store_true",
+                    help="N>1: insist on the one-process-per-GPU form (must be started by torch.distributed.run)")
     return ap.parse_args()
 
 
@@ -220,42 +229,62 @@ def encoder_cpu_baseline(cfg, chunks: int = 16):
 # ------------------------------------------------------------------------------------------------
 # ingest leg (BASELINE.json configs[4])
 # ------------------------------------------------------------------------------------------------
-def ingest_leg(chunks: int, dev: int, world: int, cpu_too: bool = True):
-    """512-token chunks, all-MiniLM-L6-v2 architecture with seeded synthetic weights (no checkpoints
-    offline), bf16 MFMA encoder, data-parallel replicas (no collective).  The timed region starts
-    from token ids in HOST memory and ends with the f32 embeddings back in host memory (H2D of ids,
-    D2H of outputs included: what the worker's embed step sees), in calls of 16384 chunks.
-    Reported next to the headline metric; not part of `value`."""
-    import torch
-    import torch.distributed as dist
-    from memex_amd import weights as W
-    from memex_amd.encoder import Encoder
-
-    cfg = W.ALL_MINILM_L6_V2
-    enc = Encoder(cfg, W.synthetic_weights(cfg, 0), device=dev)
-    call = 16384
-    rng = np.random.default_rng(77)
-    ids = rng.integers(1000, cfg.vocab, size=(call, 512), dtype=np.int32)   # one call's worth, reused (content does not matter)
-    lens = np.full((call,), 512, dtype=np.int32)
-    enc.encode(ids[:256], lens[:256])  # warm-up
-    enc.reset_stats()
-    enc.set_profiling(True)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
+def _ingest_calls(enc, ids, lens, chunks: int, call: int):
     done = 0
     while done < chunks:
         n = min(call, chunks - done)
         enc.encode(ids[:n], lens[:n])
         done += n
-    dt = time.perf_counter() - t0
+
+
+def ingest_leg(chunks: int, dev: int, world: int, cpu_too: bool = True, model: str = "all-MiniLM-L6-v2", devices=None):
+    """512-token chunks, the named architecture with seeded synthetic weights (no checkpoints offline), bf16
+    MFMA encoder, data-parallel replicas (no collective).  The timed region starts from token ids in HOST
+    memory and ends with the f32 embeddings back in host memory (H2D of ids, D2H of outputs included: what
+    the worker's embed step sees), in calls of `call` chunks.  `devices` (plain-process N > 1): one replica
+    and one host thread per device.  Reported next to the headline metric; not part of `value`."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    from memex_amd import weights as W
+    from memex_amd.encoder import Encoder
+
+    cfg = {"all-MiniLM-L6-v2": W.ALL_MINILM_L6_V2, "bge-base-en": W.BGE_BASE_EN}[model]
+    call = 16384 if cfg.hidden == 384 else 4096
+    wts = W.pack_weights(W.synthetic_weights(cfg, 0), cfg)
+    rng = np.random.default_rng(77)
+    ids = rng.integers(1000, cfg.vocab, size=(call, 512), dtype=np.int32)   # one call's worth, reused (content does not matter)
+    lens = np.full((call,), 512, dtype=np.int32)
+    devs = list(devices) if devices else [dev]
+    encs = [Encoder(cfg, wts, device=d) for d in devs]
+    for e in encs:
+        e.encode(ids[:256], lens[:256])  # warm-up
+        e.reset_stats()
+        e.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    if len(encs) == 1:
+        t0 = time.perf_counter()
+        _ingest_calls(encs[0], ids, lens, chunks, call)
+        dt = time.perf_counter() - t0
+    else:  # ctypes releases the GIL inside mx_encoder_encode: the replicas run concurrently
+        gate = threading.Barrier(len(encs) + 1)
+        th = [threading.Thread(target=lambda e=e: (gate.wait(), _ingest_calls(e, ids, lens, chunks, call))) for e in encs]
+        for t in th:
+            t.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    enc = encs[0]
     st = enc.stats()
     ragged = None
-    if world == 1:  # lengths U[64, 512] (BASELINE configs[4]'s ragged variant); reported only
+    if world == 1 and len(encs) == 1 and cfg.hidden == 384:  # lengths U[64, 512] (BASELINE configs[4]'s ragged variant); reported only
         rl = rng.integers(64, 513, size=(call,), dtype=np.int32)
         enc.reset_stats()
         tr = time.perf_counter()
@@ -266,21 +295,90 @@ def ingest_leg(chunks: int, dev: int, world: int, cpu_too: bool = True):
         ragged = {"value": 4 * call / dr, "unit": "chunks/s", "tokens_per_s": sr.tokens / dr,
                   "tflops": sr.flops / (sr.gpu_ms / 1e3) / 1e12 if sr.gpu_ms > 0 else 0.0,
                   "lengths": "uniform in [64, 512]"}
-    enc.close()
+    for e in encs:
+        e.close()
     tf = st.flops / (st.gpu_ms / 1e3) / 1e12 if st.gpu_ms > 0 else 0.0
-    cpu = encoder_cpu_baseline(cfg) if (world == 1 and cpu_too) else None
+    cpu = encoder_cpu_baseline(cfg) if (world == 1 and len(encs) == 1 and cpu_too and cfg.hidden == 384) else None
+    replicas = world * len(encs)
     return {
         "cpu_baseline": cpu,
-        "metric": "ingest chunks/sec (512-token chunks, all-MiniLM-L6-v2 shape, bf16 MFMA; host ids in, host embeddings out)",
-        "value": chunks * world / dt,
+        "metric": f"ingest chunks/sec (512-token chunks, {model} shape, bf16 MFMA; host ids in, host embeddings out)",
+        "value": chunks * replicas / dt,
         "unit": "chunks/s",
+        "replicas": replicas,
         "chunks_per_gpu": chunks,
         "gflop_per_chunk": st.flops / max(1, st.sequences) / 1e9,
         "gpu_only_chunks_per_s": st.sequences / (st.gpu_ms / 1e3) if st.gpu_ms > 0 else 0.0,
         "ragged": ragged,
         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tf / MFMA_PEAK_TFLOPS, "note": "rank-0 GPU time by HIP events on the encoder stream"},
+                     "frac": tf / MFMA_PEAK_TFLOPS, "note": "GPU time of replica 0 by HIP events on the encoder stream"},
     }
+
+
+def cfg2_leg(n_seg: int, batch: int, k: int, steps: int):
+    """BASELINE.json configs[1] end to end on one GPU: all-MiniLM-L6-v2 shape (seeded weights), `n_seg`
+    synthetic segments with lengths U[16, 256] -> mx_encoder_encode_device -> mx_index_add_device (the
+    embeddings never leave HBM: embedding.rs:109 -> tasks.rs:59) -> `batch` encoded queries -> top-k
+    (local.rs:71-91).  The 100k x 384 corpus (154 MB) sits in the 256 MiB Infinity Cache: the search rate
+    is reported only, not read as an HBM roofline point.  Parity of this flow
+    against the oracle: tests/test_cfg2_gpu.py."""
+    import torch
+    from memex_amd import _lib
+    from memex_amd import weights as W
+    from memex_amd.encoder import Encoder
+    from memex_amd.index import FlatIndex
+
+    cfg = W.ALL_MINILM_L6_V2
+    S = 256
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2024)
+    ids = torch.randint(1000, cfg.vocab, (n_seg, S), device="cuda", dtype=torch.int32, generator=g)
+    lens = torch.randint(16, S + 1, (n_seg,), device="cuda", dtype=torch.int32, generator=g)
+    qids = torch.randint(1000, cfg.vocab, (batch, 32), device="cuda", dtype=torch.int32, generator=g)
+    qlens = torch.randint(4, 33, (batch,), device="cuda", dtype=torch.int32, generator=g)
+    vec = torch.zeros((n_seg, cfg.hidden), device="cuda")
+    q = torch.zeros((batch, cfg.hidden), device="cuda")
+    enc = Encoder(cfg, W.pack_weights(W.synthetic_weights(cfg, 0), cfg))
+    idx = FlatIndex(cfg.hidden)
+    call = 16384
+    enc.encode_device(ids[:256], lens[:256], vec[:256])  # warm-up
+    enc.reset_stats()
+    enc.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b0 in range(0, n_seg, call):
+        enc.encode_device(ids[b0:b0 + call], lens[b0:b0 + call], vec[b0:b0 + call])
+    t_embed = time.perf_counter() - t0
+    st = enc.stats()
+    t0 = time.perf_counter()
+    idx.add_device(vec)
+    t_add = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    enc.encode_device(qids, qlens, q)
+    t_q = time.perf_counter() - t0
+    bufs = SearchBuffers(batch, k)
+
+    def step():
+        idx.search_device(q, k, bufs.ids, bufs.scores, bufs.dists, bufs.nf)
+    dt, sst = timed_steps(idx, step, torch.cuda.synchronize, 3, steps, 1)
+    nq = min(4, batch)
+    e = SearchBuffers(nq, k)
+    idx.set_search_mode(_lib.MX_SEARCH_EXACT)
+    idx.search_device(q[:nq].contiguous(), k, e.ids, e.scores, e.dists, e.nf)
+    same = bool(torch.equal(bufs.ids[:nq], e.ids))
+    idx.close()
+    enc.close()
+    tf = st.flops / (st.gpu_ms / 1e3) / 1e12 if st.gpu_ms > 0 else 0.0
+    out = {"workload": f"all-MiniLM-L6-v2 shape, {n_seg} synthetic segments (lengths U[16,256]) embedded on the GPU, "
+                       f"appended from HBM, {batch} encoded queries, top-{k}",
+           "embed_segments_per_s": n_seg / t_embed, "embed_tokens_per_s": st.tokens / t_embed, "embed_tflops": tf,
+           "embed_mfma_frac": tf / MFMA_PEAK_TFLOPS, "add_device_ms": t_add * 1e3, "encode_queries_ms": t_q * 1e3,
+           "search_value": batch * steps / dt, "search_unit": "queries/s", "search_ms_per_step": dt / steps * 1e3,
+           "search_note": "corpus is Infinity-Cache resident (154 MB): report only, not an HBM roofline point",
+           "fallback_queries": int(sst.fallback_queries), "ids_equal_exact_path": same}
+    del ids, lens, vec, q, bufs
+    torch.cuda.empty_cache()
+    return out
 
 
 def traffic_from_profile(rows_total: int, dim: int, world: int, scan: str):
@@ -398,13 +496,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    # one plain process and N > 1: the in-library sharded index drives all N GPUs (the form the single-process
+    # Rust host would run); under torch.distributed.run (WORLD_SIZE set): one process per GPU
+    in_library = a.gpus > 1 and world == 1
+    if in_library and a.per_process:
+        raise SystemExit("--per-process needs: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    shards = a.gpus if in_library else 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    # MEMEX_BENCH_ONE_DEVICE=1 is a wiring check for boxes with a single GPU: all ranks share device 0
-    # and the collectives go through gloo (RCCL refuses two ranks on one device).  Never a benchmark.
+    # MEMEX_BENCH_ONE_DEVICE=1 is a wiring check for boxes with a single GPU: all ranks / shards share device 0
+    # (gloo for the per-process collectives: RCCL refuses two ranks on one device).  Never a benchmark.
     one_device = os.environ.get("MEMEX_BENCH_ONE_DEVICE") == "1"
+    if in_library and not one_device and torch.cuda.device_count() < a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but only {torch.cuda.device_count()} device(s) are visible")
     dev = local_rank if (world > 1 and not one_device) else 0
     torch.cuda.set_device(dev)
     if world > 1:
@@ -413,16 +517,19 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    if "MEMEX_HIP_SPIN" not in os.environ and "MEMEX_HIP_NO_SPIN" not in os.environ:
+        os.environ["MEMEX_HIP_SPIN"] = "1"  # a benchmark owns its core: poll the completion word (servers sleep by default)
 
     # ---- corpus shard in HBM (generated on device in blocks; ids are global)
     rows_total = a.rows
     lo = rows_total * rank // world
     hi = rows_total * (rank + 1) // world
-    n_local = hi - lo
-    idx = FlatIndex(a.dim, key=None, device=dev)
+    n_local = (hi - lo) // shards
+    shard_devs = ([0] * shards if one_device else list(range(shards))) if in_library else None
+    idx = FlatIndex(a.dim, key=None, device=dev, devices=shard_devs)
     if a.scan == "f32":
         idx.set_filter_copy(False)
-    idx.reserve(n_local)
+    idx.reserve(hi - lo)
     idx.set_id_offset(lo)
     fill_index(idx, rows_total, a.dim, lo, hi, a.data)
     q = make_queries(a.batch, a.dim, a.data)
@@ -436,7 +543,8 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        idx.search_device(q, k, bufs.ids, bufs.scores, bufs.dists, bufs.nf)  # blocks until results are in HBM
+        # blocks until results are in HBM; on a sharded index: every shard's scan, the exchange and the merge
+        idx.search_device(q, k, bufs.ids, bufs.scores, bufs.dists, bufs.nf)
         if world > 1:
             if one_device:  # gloo: gather through host memory
                 parts = [torch.empty_like(bufs.block, device="cpu") for _ in range(world)]
@@ -451,12 +559,15 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        for d in sorted(set(shard_devs or [dev])):
+            torch.cuda.synchronize(d)
 
     dt, st = timed_steps(idx, step, fence, a.warmup, a.steps, world)
     ids_main = bufs.ids.clone()
+    exchange = idx.exchange
     alt = None
-    if world == 1 and a.alt_steps > 0:
+    single = world == 1 and not in_library
+    if single and a.alt_steps > 0:
         # the same job on the other scan kernel (results must be identical: same certificate, same rescoring)
         other = "f32" if a.scan == "bf16" else "bf16"
         idx.set_filter_copy(other == "bf16")
@@ -467,7 +578,7 @@ def main():
         idx.set_filter_copy(a.scan == "bf16")
         step()
     host_api = None
-    if world == 1 and a.side_steps > 0:
+    if single and a.side_steps > 0:
         # the entry point the Rust shim binds: host pointers in and out (queries H2D, results D2H inside the step)
         qh = q.cpu().numpy()
         dt3, st3 = timed_steps(idx, lambda: idx.search(qh, k), fence, 3, a.side_steps, world)
@@ -480,7 +591,7 @@ def main():
     if rank == 0 and a.recall_queries > 0:
         nq = min(a.recall_queries, a.batch)
         final_ids = (m_ids if world > 1 else bufs.ids)[:nq].clone()
-        if world == 1:
+        if world == 1:  # (on the in-library sharded index too: the EXACT mode reaches every shard)
             e = SearchBuffers(nq, k)
             idx.set_search_mode(_lib.MX_SEARCH_EXACT)
             idx.search_device(q[:nq].contiguous(), k, e.ids, e.scores, e.dists, e.nf)
@@ -501,20 +612,27 @@ def main():
     torch.cuda.empty_cache()
 
     sides = {}
-    if world == 1 and a.side_steps > 0:
+    if single and a.side_steps > 0:
         sides["host_api"] = host_api
         other_data = "clustered" if a.data == "gaussian" else "gaussian"
         sides[other_data] = side_leg(rows_total, a.dim, a.batch, k, a.side_steps, other_data)
         sides["cfg4_shard_10Mx768"] = side_leg(10_000_000, 768, a.batch, k, a.side_steps, "gaussian")
-    ingest = ingest_leg(a.ingest_chunks, dev, world, not a.no_cpu_baseline) if a.ingest_chunks > 0 else None
+        if a.cfg2_segments > 0:
+            sides["cfg2"] = cfg2_leg(a.cfg2_segments, a.batch, k, a.side_steps)
+    ingest = None
+    if a.ingest_chunks > 0:
+        ingest = ingest_leg(a.ingest_chunks, dev, world, not a.no_cpu_baseline, devices=shard_devs if in_library and not one_device else None)
+    if single and a.bge_chunks > 0:
+        sides["ingest_bge_base"] = ingest_leg(a.bge_chunks, dev, 1, False, model="bge-base-en")
 
     if rank == 0:
-        roof = roofline_of(st, a.scan, a.dim, a.batch, n_local, world)
+        n_gpus = world * shards
+        roof = roofline_of(st, a.scan, a.dim, a.batch, n_local, n_gpus)
         out = {
             "metric": "queries/sec, exact cosine top-10 (recall@10 = 1.0) on 10M x 384-d f32",
             "value": a.batch * a.steps / dt,
             "unit": "queries/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
@@ -526,8 +644,13 @@ def main():
             "filter_copy_bytes": int(st.filter_copy_bytes),
             "data": "synthetic" if a.data == "gaussian" else "synthetic (clustered)",
             "config": {"workload": f"{rows_total}x{a.dim} f32 corpus in HBM ({a.data}), query batch {a.batch}, top-{k}",
-                       "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
+                       "rows_per_gpu": n_local,
+                       "parallelism": (f"row-shard x{shards} inside one process (mx_index_open_sharded)" if in_library else
+                                       f"row-shard x{world}, one process per GPU" if world > 1 else "single GPU")},
+            "rccl_ranks": n_gpus if (world > 1 and not one_device) or exchange == "rccl" else 0,
+            "exchange": exchange if in_library else ("rccl" if world > 1 and not one_device else ("gloo" if world > 1 else "none")),
             "recall_at_10": recall,
+            "recall_note": "vs the library's own EXACT path (all-f64) on a few queries; the oracle-based check at this size is tests/test_search_fullsize_gpu.py",
             "ids_equal_exact_path": recall_exact_order,
             "merged_lists_ok": merged_ok,
             "fallback_queries": int(st.fallback_queries),
@@ -542,7 +665,7 @@ def main():
         out.update(sides)
         if ingest is not None:
             out["ingest"] = ingest
-        if world == 1 and not a.no_cpu_baseline:
+        if single and not a.no_cpu_baseline:
             cb = cpu_bruteforce(a.dim, a.batch, k, rows_total, a.cpu_seconds)
             if a.hnsw_rows > 0:
                 try:

@@ -78,6 +78,9 @@ void mx_index_close(mx_index *idx); /* drops one reference; frees HBM when the l
 int mx_index_open_sharded(const char *key, int dim, int n_dev, const int *devices, uint64_t block_rows,
                           mx_index **out);
 int mx_index_n_shards(mx_index *idx, int *n_shards); /* 1 for a plain index */
+/* How the shards exchange their per-shard top-k blocks: 0 = plain index (nothing to exchange), 1 = copies into
+ * a slot per shard on devices[0] (peer-to-peer between devices), 2 = one RCCL all-gather. */
+int mx_index_exchange(mx_index *idx, int *kind);
 
 /*
  * Stream contract of the *_device entry points.  The index works on its own HIP stream and every

@@ -178,24 +178,40 @@ class HipFlatStore : public VectorStore {
         const std::string meta = path + "/" + META_FILE;
         const bool own = path == storage_path;
         const size_t n = _id_map.size();
+        bool appended = false;
         if (own && meta_known_ && file_sig(meta) == meta_sig_ && meta_ids_ > 0 && meta_ids_ <= n) {
-            if (meta_ids_ < n) {
+            appended = meta_ids_ == n;
+            if (!appended) {
                 std::fstream f(meta, std::ios::in | std::ios::out | std::ios::binary);
-                if (!f) throw VectorStoreError(VectorStoreError::FileIOError, "cannot append to " + meta);
-                f.seekp(-1, std::ios::end);  // over the closing brace
-                for (size_t i = meta_ids_ + 1; i <= n; ++i) f << ",\"" << i << "\":\"" << escape(_id_map[i]) << "\"";
+                char last = 0;
+                if (f && f.seekg(-1, std::ios::end) && f.get(last) && last == '}') {  // the file ends the way this store left it
+                    f.seekp(-1, std::ios::end);                                        // over the closing brace
+                    for (size_t i = meta_ids_ + 1; i <= n; ++i) f << ",\"" << i << "\":\"" << escape(_id_map[i]) << "\"";
+                    f << "}";
+                    f.flush();
+                    appended = (bool)f;
+                }
+            }
+        }
+        if (!appended) {
+            // full rewrite through a temporary file: the vectors are already on disk, the id map must never be
+            // left shorter than them (also the way out of a file the splice does not recognise)
+            meta_known_ = false;
+            const std::string tmp = meta + ".tmp";
+            {
+                std::ofstream f(tmp);
+                if (!f) throw VectorStoreError(VectorStoreError::FileIOError, "cannot write " + tmp);
+                f << "{";
+                bool first = true;
+                for (auto &kv : _id_map) {
+                    f << (first ? "" : ",") << "\"" << kv.first << "\":\"" << escape(kv.second) << "\"";
+                    first = false;
+                }
                 f << "}";
+                f.flush();
+                if (!f) throw VectorStoreError(VectorStoreError::FileIOError, "cannot write " + tmp);
             }
-        } else {
-            std::ofstream f(meta);
-            if (!f) throw VectorStoreError(VectorStoreError::FileIOError, "cannot write " + meta);
-            f << "{";
-            bool first = true;
-            for (auto &kv : _id_map) {
-                f << (first ? "" : ",") << "\"" << kv.first << "\":\"" << escape(kv.second) << "\"";
-                first = false;
-            }
-            f << "}";
+            if (std::rename(tmp.c_str(), meta.c_str()) != 0) throw VectorStoreError(VectorStoreError::FileIOError, "cannot replace " + meta);
         }
         if (own) {
             meta_sig_ = file_sig(meta);

@@ -23,7 +23,7 @@ MX_POOL_MEAN, MX_POOL_CLS = 0, 1
 # every symbol include/memex_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mx_last_error", "mx_version", "mx_device_count",
-    "mx_index_open", "mx_index_open_sharded", "mx_index_n_shards", "mx_index_wait_stream", "mx_index_close", "mx_index_dim", "mx_index_size", "mx_index_reserve",
+    "mx_index_open", "mx_index_open_sharded", "mx_index_n_shards", "mx_index_exchange", "mx_index_wait_stream", "mx_index_close", "mx_index_dim", "mx_index_size", "mx_index_reserve",
     "mx_index_set_id_offset", "mx_index_add", "mx_index_add_device", "mx_index_clear",
     "mx_index_search", "mx_index_search_device", "mx_index_set_search_mode", "mx_index_set_filter_copy", "mx_index_set_corpus_mode", "mx_index_get_rows",
     "mx_index_save", "mx_index_load", "mx_index_has_store", "mx_index_store_info", "mx_index_remove_files",
@@ -93,6 +93,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "mx_index_open": [cp, i32, i32, P(vp)],
         "mx_index_open_sharded": [cp, i32, i32, P(i32), u64, P(vp)],
         "mx_index_n_shards": [vp, P(i32)],
+        "mx_index_exchange": [vp, P(i32)],
         "mx_index_wait_stream": [vp, vp],
         "mx_index_dim": [vp, P(i32)],
         "mx_index_size": [vp, P(u64)],

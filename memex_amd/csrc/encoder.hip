@@ -17,6 +17,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "encoder_kernels.h"
@@ -106,6 +107,7 @@ int upload_tail_stream(mx_encoder *e, const float *wo, const float *wi, const fl
 }
 
 void free_ws(mx_encoder *e) {
+    if (e->stream) (void)hipStreamSynchronize(e->stream);  // nothing queued may still use the buffers
     void *ptrs[] = {e->x, e->x1, e->q, e->k, e->vt, e->ctx, e->hbuf, e->tok_seq, e->tok_pos};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -231,9 +233,13 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
                float *d_out) {
     for (int b = 0; b < B; ++b)
         if (h_lens[b] < 1 || h_lens[b] > S) return fail(MX_EINVAL, "lens[%d] = %d outside [1, %d]", b, h_lens[b], S);
-    if (e->profiling) MX_HIP(hipEventRecord(e->ev0, e->stream));
-    int b0 = 0;
-    while (b0 < B) {
+    // the pass split first: the workspace is sized ONCE for the largest pass before anything is launched (the
+    // passes queue on the stream without synchronisation, so a later pass must never reallocate buffers an
+    // earlier one is still using)
+    std::vector<std::pair<int, int>> passes;  // (first sequence, count)
+    long max_rows = 0;
+    int max_nb = 0;
+    for (int b0 = 0; b0 < B;) {
         int nb = 0;
         long rows = 0;
         while (b0 + nb < B && nb < kMaxSeqsPerPass) {
@@ -243,10 +249,18 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
             rows += r;
             ++nb;
         }
-        int rc = encode_pass(e, d_ids + (size_t)b0 * S, h_lens + b0, d_lens + b0, nb, S,
-                             d_out + (size_t)b0 * e->cfg.hidden);
-        if (rc != MX_OK) return rc;
+        passes.push_back({b0, nb});
+        max_rows = std::max(max_rows, rows);
+        max_nb = std::max(max_nb, nb);
         b0 += nb;
+    }
+    int rc = ensure_ws(e, (int)round_up((uint64_t)max_rows + 32, kRowPad), max_nb, 0);
+    if (rc != MX_OK) return rc;
+    if (e->profiling) MX_HIP(hipEventRecord(e->ev0, e->stream));
+    for (const auto &ps : passes) {
+        rc = encode_pass(e, d_ids + (size_t)ps.first * S, h_lens + ps.first, d_lens + ps.first, ps.second, S,
+                         d_out + (size_t)ps.first * e->cfg.hidden);
+        if (rc != MX_OK) return rc;
     }
     if (e->profiling) MX_HIP(hipEventRecord(e->ev1, e->stream));
     MX_HIP(hipStreamSynchronize(e->stream));  // results complete in d_out when the call returns
@@ -461,8 +475,12 @@ int mx_encoder_encode_device(mx_encoder *e, const int32_t *d_ids, const int32_t 
     if (rc != MX_OK || B == 0) return rc;
     std::lock_guard<std::mutex> lk(e->mu);
     DeviceGuard g(e->device);
+    // the lengths decide the pass split and the workspace size on the host: fetch them ON the encoder's stream,
+    // i.e. behind whatever mx_encoder_wait_stream ordered in front of this call (a blocking copy on the null
+    // stream does not wait for a caller's non-blocking stream and could read the lengths before they exist)
     std::vector<int32_t> h_lens((size_t)B);
-    MX_HIP(hipMemcpy(h_lens.data(), d_lens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    MX_HIP(hipMemcpyAsync(h_lens.data(), d_lens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    MX_HIP(hipStreamSynchronize(e->stream));
     return encode_all(e, d_ids, h_lens.data(), d_lens, B, S, d_out);
 }
 

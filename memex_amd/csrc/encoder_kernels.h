@@ -66,6 +66,11 @@ struct TailParams {
     int ldo;
     const float *gamma, *beta;  // LayerNorm2
     float eps;
+    // start-up skew (speed only): workgroups b < skew_hi with bit skew_shift of b set sleep skew_iters x ~4 us
+    // before they start, so that the two workgroups of a CU stop running their load / LayerNorm / store phases
+    // at the same time
+    int skew_shift, skew_hi, skew_iters;
+    unsigned long long *trace;  // scripts/tail_ubench.hip only (MX_TAIL_TRACE): [blocks][8] phase timestamps
 };
 hipError_t tail_setup();
 bool tail_supported(int hidden, int ffn);

@@ -38,6 +38,18 @@
 #ifndef MX_TAIL_ABLATE
 #define MX_TAIL_ABLATE 0
 #endif
+// scripts/tail_ubench.hip only: lane 0 of wave 0 stamps the 100 MHz real-time counter at phase boundaries
+#ifndef MX_TAIL_TRACE
+#define MX_TAIL_TRACE 0
+#endif
+#if MX_TAIL_TRACE
+#define MX_TRACE(i)                                                                                         \
+    do {                                                                                                    \
+        if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();  \
+    } while (0)
+#else
+#define MX_TRACE(i) do { } while (0)
+#endif
 
 namespace mx {
 
@@ -80,6 +92,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int F = p.f;
     const int nch = F / kFC;
     const uint32_t s = (uint32_t)(l31 & 15), sh = s ^ (uint32_t)h;
+#if MX_TAIL_TRACE
+    if (p.trace && tid == 0)  // [7] = where this workgroup runs: XCC id << 16 | HW_ID (se / sh / cu / simd / wave)
+        p.trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                              (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
+    MX_TRACE(0);
+    if ((int)blockIdx.x < p.skew_hi && (((int)blockIdx.x >> p.skew_shift) & 1))
+        for (int i = 0; i < p.skew_iters; ++i) __builtin_amdgcn_s_sleep(127);  // 127 x 64 clocks ~ 4 us
+    MX_TRACE(1);
 
     // ---- the weight stream of this wave (see the header comment): fragment n at byte n * 1024 + lane * 16.
     // Buffer loads: the lane offset is ONE VGPR for the whole kernel, the stream position an SGPR.
@@ -151,6 +172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // pending here, or it drains the fragment ring at the top of every chunk)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __builtin_amdgcn_s_barrier();
+    MX_TRACE(2);
 
     bf16x8 bfr[2][2];  // activation fragments of one k-step, double-buffered: [buf][ii]
     float b1v;         // b1 of this wave's 32 features of the chunk in acc1: lane l holds feature l & 31
@@ -326,6 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         spos += 3 * kTP * 1024;
+        MX_TRACE(3);
         ln_ids();
         bf16x8 rs[CPT];  // the residual rows (layer input), straight from HBM, in flight during pass 1
 #pragma unroll
@@ -351,6 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     // ---- stream order (= the order of p.wf): G1(0) | G1(1) | G2(0) G1(2) | G2(1) G1(3) | ... | G2(nch-2) | G2(nch-1)
+    MX_TRACE(4);
     load_b1(0);
     read_x(0, bfr[0]);
     g1_segment(0u, false);
@@ -390,6 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- LayerNorm2: out = LN(acc2 + b2 + x1).  The residual comes out of the x tile before the staging tile
     // overwrites it.
     __builtin_amdgcn_s_barrier();  // every wave is done with the x and h tiles
+    MX_TRACE(5);
     {
         ln_ids();
         bf16x8 rs[CPT];
@@ -404,6 +429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             *reinterpret_cast<bf16x8 *>(p.out + (size_t)(m0 + ln_row) * p.ldo + (c * TPR + ln_prt) * 8) = o;
         });
     }
+    MX_TRACE(6);
 }
 
 // Host side of the layout.  For wave wn the stream is the segment list

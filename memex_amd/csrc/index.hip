@@ -36,6 +36,7 @@
 
 #include "index_kernels.h"
 #include "mx_common.h"
+#include "shard_pool.h"
 
 namespace mx {
 
@@ -167,6 +168,7 @@ struct mx_index {
     std::vector<float *> sh_q, sh_scores;
     std::vector<int32_t *> sh_nf;
     int sh_kcap = 0;
+    std::unique_ptr<ShardPool> pool;  // helper threads for shards 1 .. G-1 (shards on distinct devices only)
     bool composite() const { return !shards.empty(); }
 };
 
@@ -219,6 +221,7 @@ int free_index(mx_index *idx) {
         std::lock_guard<std::mutex> lk(idx->mu);
     }
     if (idx->composite()) {
+        idx->pool.reset();  // joins the helper threads
         free_composite_buffers(idx);
         for (void *c : idx->comms)
             if (c && g_rccl.ok) (void)g_rccl.CommDestroy(c);
@@ -574,10 +577,13 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     auto finish_and_wait = [&]() -> int {
         fp.seq = ++s.flag_seq;
         MX_HIP(launch_finish(st, B, fp));
-        // MEMEX_HIP_NO_SPIN=1: sleep in hipStreamSynchronize instead (no core kept busy for the ~2 ms of a batch)
+        // Default: wait in hipStreamSynchronize -- a server thread must not burn a core for the ~2 ms of a batch
+        // (measured: 1.902 vs 1.898 ms per step, scripts/r2_spin_vs_sleep.sh).  MEMEX_HIP_SPIN=1 (bench.py sets
+        // it) polls the completion word instead; MEMEX_HIP_NO_SPIN=1 is the older spelling of the default.
         static const bool no_spin = [] {
-            const char *ev = getenv("MEMEX_HIP_NO_SPIN");
-            return ev && ev[0] == '1';
+            const char *sp = getenv("MEMEX_HIP_SPIN"), *ns = getenv("MEMEX_HIP_NO_SPIN");
+            if (ns && ns[0] == '1') return true;
+            return !(sp && sp[0] == '1');
         }();
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 1; !no_spin; ++spins) {
@@ -759,14 +765,9 @@ int composite_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_i
         DeviceGuard dg(idx->shards[0]->device);
         MX_HIP(hipStreamSynchronize(idx->shards[0]->stream));
     }
-    bool distinct = true;
-    for (int g = 1; g < G; ++g) distinct = distinct && idx->shards[g]->device != idx->shards[0]->device;
-    if (G > 1 && distinct) {
-        std::vector<std::thread> th;
-        for (int g = 1; g < G; ++g) th.emplace_back(local, g);
-        local(0);
-        for (auto &t : th) t.join();
-    } else {
+    if (idx->pool) {  // one persistent helper thread per shard >= 1 (shard_pool.h); shard 0 on this thread
+        idx->pool->run(local);
+    } else {          // logical shards on one device: their streams would only take turns on the GPU anyway
         for (int g = 0; g < G; ++g) local(g);
     }
     for (int g = 0; g < G; ++g)
@@ -786,10 +787,8 @@ int composite_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_i
             const int e2 = g_rccl.GroupEnd();
             if (e != 0 || e2 != 0)
                 return fail(MX_EDEVICE, "RCCL all-gather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e ? e : e2) : "?");
-            for (int g = 1; g < G; ++g) {
-                DeviceGuard d2(idx->shards[g]->device);
-                MX_HIP(hipStreamSynchronize(idx->shards[g]->stream));
-            }
+            // no host wait on shards >= 1: their part of the collective is ordered on their own streams (the
+            // next batch's kernels queue behind it), and the merge below follows shard 0's part in stream order
         }
         MX_HIP(launch_merge(s0->stream, idx->sh_gather[0], blk, static_cast<const char *>(idx->sh_gather[0]) + ids_bytes, blk, G, B,
                             k, d_ids, d_dists ? d_dists : reinterpret_cast<float *>(static_cast<char *>(idx->sh_block[0]) + ids_bytes),
@@ -806,6 +805,26 @@ int any_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids, fl
               int32_t *d_nfound) {
     return idx->composite() ? composite_batch(idx, d_q, B, k, d_ids, d_scores, d_dists, d_nfound)
                             : search_batch(idx, d_q, B, k, d_ids, d_scores, d_dists, d_nfound);
+}
+
+// what an append can change in a plain index, and how to undo it: an insert is all-or-nothing, also when it
+// spans several shards or several staging chunks and a later part fails (non-finite device rows, HBM)
+struct RowMark {
+    uint64_t n, n_zero, wild_rows;
+};
+RowMark mark_rows(const mx_index *idx) { return RowMark{idx->n, idx->n_zero, idx->wild_rows}; }
+void rollback_rows(mx_index *idx, const RowMark &m) {
+    if (idx->n == m.n) return;
+    const std::string keep = last_error_slot();
+    DeviceGuard dg(idx->device);
+    idx->n = m.n;  // rows past n are never read by a search (finish_kernel drops them); the next append overwrites them
+    idx->n_zero = m.n_zero;
+    idx->wild_rows = m.wild_rows;
+    const uint32_t zc = (uint32_t)m.n_zero;  // the device-side zero-row count: entries past it are dead
+    (void)hipMemcpyAsync(idx->flags + 3, &zc, sizeof(zc), hipMemcpyHostToDevice, idx->stream);
+    (void)hipStreamSynchronize(idx->stream);
+    idx->disk_dir.clear();
+    last_error_slot() = keep;
 }
 
 // append host rows to a composite: global row r -> block b = r / R, shard b % G
@@ -828,8 +847,9 @@ int composite_add(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_
         for (size_t i = 0; i < totalf; ++i)
             if (!std::isfinite(rows[i])) return fail(MX_EINVAL, "row %zu contains a non-finite value; nothing inserted", i / rowf);
     }
-    for (uint64_t g = 0; g < G; ++g) {
-        if (seg[g].empty()) continue;
+    std::vector<RowMark> marks;
+    for (mx_index *sh : idx->shards) marks.push_back(mark_rows(sh));
+    auto append_to = [&](uint64_t g) -> int {
         mx_index *sh = idx->shards[g];
         std::lock_guard<std::mutex> lk(sh->mu);
         DeviceGuard dg(sh->device);
@@ -845,8 +865,18 @@ int composite_add(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_
                                   on_device ? hipMemcpyDefault : hipMemcpyHostToDevice, sh->stream));
             at += sgm.second;
         }
-        int rc = add_device_locked(sh, stage, cnt, nullptr);
-        if (rc != MX_OK) return rc;  // device rows only: a partial append leaves the composite unusable -> caller clears
+        return add_device_locked(sh, stage, cnt, nullptr);
+    };
+    for (uint64_t g = 0; g < G; ++g) {
+        if (seg[g].empty()) continue;
+        const int rc = append_to(g);
+        if (rc != MX_OK) {  // a non-finite device row or an allocation on shard g: take back what shards < g got
+            for (uint64_t h = 0; h < g; ++h) {
+                std::lock_guard<std::mutex> lk(idx->shards[h]->mu);
+                rollback_rows(idx->shards[h], marks[h]);
+            }
+            return rc;
+        }
     }
     idx->total += n;
     return MX_OK;
@@ -959,6 +989,7 @@ int add_host_locked(mx_index *idx, const float *rows, uint64_t n, uint64_t *firs
     MX_HIP(hipMalloc(&stage, (size_t)std::min(chunk_rows, n) * idx->dim * sizeof(float)));
     int rc = MX_OK;
     uint64_t first = 0;
+    const RowMark mark = mark_rows(idx);
     for (uint64_t done = 0; done < n && rc == MX_OK; done += chunk_rows) {
         const uint64_t m = std::min(chunk_rows, n - done);
         hipError_t e = hipMemcpyAsync(stage, rows + (size_t)done * idx->dim, (size_t)m * idx->dim * sizeof(float),
@@ -972,6 +1003,7 @@ int add_host_locked(mx_index *idx, const float *rows, uint64_t n, uint64_t *firs
         if (done == 0) first = f;
     }
     (void)hipFree(stage);
+    if (rc != MX_OK) rollback_rows(idx, mark);  // a later chunk failed: the earlier ones go too
     if (rc == MX_OK && first_id) *first_id = first;
     return rc;
 }
@@ -1136,9 +1168,23 @@ int mx_index_open_sharded(const char *key, int dim, int n_dev, const int *device
             }
         }
     }
+    {   // helper threads: one per shard >= 1 when every shard has its own device.  MEMEX_HIP_SHARD_THREADS=1
+        // forces them for logical shards on one device too (how the hand-off is tested on a 1-GPU box), =0 never
+        const char *tv = getenv("MEMEX_HIP_SHARD_THREADS");
+        const bool threads = tv ? tv[0] == '1' : distinct;
+        if (threads && n_dev > 1) idx->pool.reset(new ShardPool(n_dev - 1));
+    }
     mx_index *raw = idx.release();
     if (!k.empty()) g_registry[k] = raw;
     *out = raw;
+    return MX_OK;
+}
+
+// how the shards of `idx` exchange their top-k blocks: 0 = not sharded, 1 = copies into a slot per shard on
+// devices[0] (peer-to-peer between devices), 2 = RCCL all-gather
+int mx_index_exchange(mx_index *idx, int *kind) {
+    if (!idx || !kind) return fail(MX_EINVAL, "null argument");
+    *kind = !idx->composite() ? 0 : (idx->use_rccl ? 2 : 1);
     return MX_OK;
 }
 

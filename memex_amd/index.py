@@ -54,6 +54,13 @@ class FlatIndex:
         check(lib().mx_index_n_shards(self._h, ctypes.byref(n)))
         return int(n.value)
 
+    @property
+    def exchange(self) -> str:
+        """How the shards exchange their top-k blocks: "none" (plain index), "p2p" (copies) or "rccl"."""
+        kind = ctypes.c_int(0)
+        check(lib().mx_index_exchange(self._h, ctypes.byref(kind)))
+        return ("none", "p2p", "rccl")[int(kind.value)]
+
     def wait_stream(self, stream) -> None:
         """Order the next operation on this index after everything enqueued on ``stream`` (a raw
         hipStream_t as int / c_void_p, or None for the default stream).  See the stream contract in

@@ -128,7 +128,7 @@ class VectorStore(abc.ABC):
 # SAME store object (GPU index + id map) is handed out as long as the files it last wrote / read are
 # unchanged on disk.  (The Rust shim keeps the equivalent `HashMap<PathBuf, Arc<Mutex<HipFlatStore>>>`,
 # INTEGRATION.md.)
-_RESIDENT: Dict[Tuple[str, int], "HipFlatStore"] = {}
+_RESIDENT: Dict[tuple, "HipFlatStore"] = {}
 _RESIDENT_MU = threading.Lock()
 
 
@@ -145,8 +145,7 @@ def evict_resident(storage_path: str | None = None) -> None:
     with _RESIDENT_MU:
         for key in [k for k in _RESIDENT if storage_path is None or k[0] == os.path.realpath(str(storage_path))]:
             st = _RESIDENT.pop(key)
-            if st._index is not None:
-                st._index.close()
+            with st._lock:      # a search in flight holds its own reference: the handle closes when that one goes
                 st._index = None
 
 
@@ -168,15 +167,13 @@ class HipFlatStore(VectorStore):
     def new(cls, storage_path: str, device: int = 0, devices: Sequence[int] | None = None) -> "HipFlatStore":
         store = cls(storage_path=str(storage_path), device=device, devices=devices)
         with _RESIDENT_MU:
-            old = _RESIDENT.pop(store._rkey(), None)
-            if old is not None and old._index is not None:
-                old._index.close()
-                old._index = None
+            # a store this one replaces is NOT closed under its holders: earlier requests may still be inside
+            # search() on it; its handle on the keyed GPU index goes away with its last reference
             _RESIDENT[store._rkey()] = store
         return store
 
-    def _rkey(self) -> Tuple[str, int]:
-        return (os.path.realpath(self.storage_path), int(self.device))
+    def _rkey(self) -> tuple:
+        return (os.path.realpath(self.storage_path), int(self.device), tuple(int(d) for d in self.devices) if self.devices else None)
 
     @staticmethod
     def has_store(store_path: str) -> bool:
@@ -226,11 +223,7 @@ class HipFlatStore(VectorStore):
             if len(store._index) != len(store._id_map):
                 raise FileIOError(f"{store_path}: {len(store._index)} vectors vs {len(store._id_map)} ids")
         with _RESIDENT_MU:
-            old = _RESIDENT.get(store._rkey())
-            _RESIDENT[store._rkey()] = store
-        if old is not None and old is not store and old._index is not None and old._index is not store._index:
-            old._index.close()
-            old._index = None
+            _RESIDENT[store._rkey()] = store     # (a replaced store keeps its handle for whoever still uses it)
         return store
 
     def save(self, store_path: str | None = None) -> None:
@@ -248,26 +241,41 @@ class HipFlatStore(VectorStore):
                 meta = os.path.join(store_path, META_FILE)
                 own = os.path.realpath(store_path) == os.path.realpath(self.storage_path)
                 n = len(self._id_map)
+                appended = False
                 if own and self._meta_sig is not None and self._meta_sig == _file_sig(meta) and 0 < self._meta_ids <= n:
-                    if self._meta_ids < n:
-                        tail = ",".join(f"{json.dumps(str(i))}: {json.dumps(self._id_map[i])}"
-                                        for i in range(self._meta_ids + 1, n + 1))
-                        with open(meta, "r+b") as f:
-                            f.seek(-1, os.SEEK_END)
-                            if f.read(1) != b"}":
-                                raise OSError(f"{meta}: unexpected tail")
-                            f.seek(-1, os.SEEK_END)
-                            f.write((", " + tail + "}").encode("utf-8"))
-                else:
-                    with open(meta, "w", encoding="utf-8") as f:
+                    appended = self._meta_ids == n or self._append_meta(meta, n)
+                if not appended:
+                    # full rewrite through a temporary file: the vectors are already on disk, so the id map must
+                    # never be left shorter than them (also the way out of a file the splice does not recognise,
+                    # e.g. one that a hand edit ended with a newline)
+                    tmp = meta + ".tmp"
+                    with open(tmp, "w", encoding="utf-8") as f:
                         json.dump({str(k): v for k, v in self._id_map.items()}, f)
+                    os.replace(tmp, meta)
                 if own:
                     self._meta_sig = _file_sig(meta)
                     self._meta_ids = n
             except _lib.MemexHipError as e:
+                self._meta_sig = None
                 raise SaveError(e.msg) from e
             except OSError as e:
+                self._meta_sig = None
                 raise FileIOError(str(e)) from e
+
+    def _append_meta(self, meta: str, n: int) -> bool:
+        """Splice ids _meta_ids+1 .. n in front of the closing brace of vectors.meta.json.  False = the file does
+        not end the way this store left it (nothing written): the caller rewrites it."""
+        tail = ",".join(f"{json.dumps(str(i))}: {json.dumps(self._id_map[i])}" for i in range(self._meta_ids + 1, n + 1))
+        try:
+            with open(meta, "r+b") as f:
+                f.seek(-1, os.SEEK_END)
+                if f.read(1) != b"}":
+                    return False
+                f.seek(-1, os.SEEK_END)
+                f.write((", " + tail + "}").encode("utf-8"))
+            return True
+        except OSError:
+            return False
 
     def _open(self, dim: int) -> None:
         # keyed by the collection's path: every handle on this collection shares ONE resident GPU index
@@ -331,13 +339,15 @@ class HipFlatStore(VectorStore):
         self.bulk_insert([data])
 
     def search(self, vec: Sequence[float], limit: int) -> List[VectorSearchResult]:
-        if self._index is None or limit <= 0:
+        with self._lock:
+            idx = self._index        # own reference: the store may be evicted / replaced while the GPU works
+        if idx is None or limit <= 0:
             return []
         q = np.asarray(vec, dtype=np.float32)
         if q.shape != (self._dim,):
             raise SearchError(f"query dimension {q.shape} != store dimension {self._dim}")
         try:
-            ids, scores, _, nf = self._index.search(q, int(limit))
+            ids, scores, _, nf = idx.search(q, int(limit))      # not under the lock: concurrent callers are combined
         except _lib.MemexHipError as e:
             _raise_from(e, SearchError)
         out: List[VectorSearchResult] = []

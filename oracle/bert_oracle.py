@@ -49,7 +49,7 @@ def encode(weights: dict, cfg: dict, ids: np.ndarray, lens: np.ndarray, dtype=np
     ``weights`` uses HF BertModel tensor names (no ``bert.`` prefix); Linear weights are [out,in].
     ``cfg`` keys: layers, hidden, heads, ffn, ln_eps, pooling ('mean'|'cls'), normalize (bool).
     """
-    W = {k: np.asarray(v, dtype=dtype) for k, v in weights.items()}
+    W = {k: np.asarray(v, dtype=dtype) for k, v in weights.items()}  # no copy when already `dtype` (encode_many)
     ids = np.asarray(ids)
     B, S = ids.shape
     H, nh, L = cfg["hidden"], cfg["heads"], cfg["layers"]
@@ -67,13 +67,17 @@ def encode(weights: dict, cfg: dict, ids: np.ndarray, lens: np.ndarray, dtype=np
     for l in range(L):
         p = f"encoder.layer.{l}."
 
-        def lin(t, name):
-            return t @ W[p + name + ".weight"].T + W[p + name + ".bias"]
+        def lin(t, name):  # one 2-D GEMM (NumPy's batched matmul of a 3-D operand is ~50x slower)
+            w = W[p + name + ".weight"]
+            return (t.reshape(-1, t.shape[-1]) @ w.T + W[p + name + ".bias"]).reshape(t.shape[:-1] + (w.shape[0],))
 
-        q = lin(x, "attention.self.query").reshape(B, S, nh, dh).transpose(0, 2, 1, 3)
-        k = lin(x, "attention.self.key").reshape(B, S, nh, dh).transpose(0, 2, 1, 3)
-        v = lin(x, "attention.self.value").reshape(B, S, nh, dh).transpose(0, 2, 1, 3)
-        s = q @ k.transpose(0, 1, 3, 2) / math.sqrt(dh) + add_mask
+        def heads(t):
+            return np.ascontiguousarray(t.reshape(B, S, nh, dh).transpose(0, 2, 1, 3))
+
+        q = heads(lin(x, "attention.self.query"))
+        k = heads(lin(x, "attention.self.key"))
+        v = heads(lin(x, "attention.self.value"))
+        s = q @ np.ascontiguousarray(k.transpose(0, 1, 3, 2)) / math.sqrt(dh) + add_mask
         s = s - s.max(axis=-1, keepdims=True)
         pr = np.exp(s)
         pr = pr / pr.sum(axis=-1, keepdims=True)
@@ -94,3 +98,35 @@ def encode(weights: dict, cfg: dict, ids: np.ndarray, lens: np.ndarray, dtype=np
     if return_hidden:
         return pooled, x
     return pooled
+
+
+def encode_many(weights: dict, cfg: dict, ids: np.ndarray, lens: np.ndarray, batch: int = 16, workers: int = 0) -> np.ndarray:
+    """:func:`encode` over many sequences: sorted by length, cut into batches trimmed to their longest
+    sequence (padding beyond a row's length does not change its result: it is masked), batches spread over
+    threads (NumPy releases the GIL inside its kernels).  Same arithmetic per sequence as :func:`encode`."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    ids = np.asarray(ids)
+    lens = np.asarray(lens)
+    W = {k: np.asarray(v, dtype=np.float64) for k, v in weights.items()}
+    order = np.argsort(lens, kind="stable")
+    out = np.zeros((ids.shape[0], cfg["hidden"]), dtype=np.float64)
+    jobs = [order[i:i + batch] for i in range(0, len(order), batch)]
+
+    def run(sel):
+        smax = int(lens[sel].max())
+        out[sel] = encode(W, cfg, ids[sel][:, :smax], lens[sel])
+
+    workers = workers or min(32, os.cpu_count() or 1)
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=max(1, (os.cpu_count() or 1) // workers))
+    except Exception:  # pragma: no cover
+        limit = None
+    try:
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(run, jobs))
+    finally:
+        if limit is not None:
+            limit.unregister()
+    return out

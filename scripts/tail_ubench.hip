@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include "encoder_kernels.h"
 using namespace mx;
 #ifndef MX_TAIL_ABLATE
@@ -31,6 +33,7 @@ static void to_logical(const std::vector<unsigned short>& kb, size_t rows, size_
 static uint16_t bf16_exact(float f) { unsigned int u; memcpy(&u, &f, 4); return (uint16_t)(u >> 16); }
 int main(int argc, char** argv) {
   int m = argc > 1 ? atoi(argv[1]) : 131072; int f = argc > 2 ? atoi(argv[2]) : 1536; int reps = argc > 3 ? atoi(argv[3]) : 2000; int po = argc > 4 ? atoi(argv[4]) : 1;
+  const int skew_iters = argc > 5 ? atoi(argv[5]) : 0, skew_shift = argc > 6 ? atoi(argv[6]) : 8, skew_hi = argc > 7 ? atoi(argv[7]) : 512;
   bf16_t *x, *ctx, *w1, *w2, *wo, *wf, *out2; float *b1, *b2, *g, *b;
   CK(hipMalloc(&x, (size_t)m * 384 * 2)); CK(hipMalloc(&out2, (size_t)m * 384 * 2));
   CK(hipMalloc(&w1, (size_t)f * 384 * 2)); CK(hipMalloc(&w2, (size_t)f * 384 * 2)); CK(hipMalloc(&wf, tail_stream_elems(f) * 2)); CK(hipMalloc(&wo, 384 * 384 * 2)); CK(hipMalloc(&ctx, (size_t)m * 384 * 2));
@@ -45,6 +48,7 @@ int main(int argc, char** argv) {
     tail_stream_layout(lo.data(), l1.data(), l2.data(), f, st.data(), bf16_exact); CK(hipMemcpy(wf, st.data(), st.size() * 2, hipMemcpyHostToDevice)); }
   CK(tail_setup());
   TailParams p2{}; p2.ctx = po ? ctx : nullptr; p2.ldc = 384; p2.bo = b2; p2.ln1g = g; p2.ln1b = b; p2.x = x; p2.ldx = 384; p2.b1 = b1; p2.b2 = b2; p2.f = f; p2.m = m; p2.out = out2; p2.ldo = 384; p2.gamma = g; p2.beta = b; p2.eps = 1e-12f; p2.wf = wf;
+  p2.skew_iters = skew_iters; p2.skew_shift = skew_shift; p2.skew_hi = skew_hi; p2.trace = nullptr;
   CK(hipMemset(out2, 0xff, (size_t)m * 384 * 2));
   CK(launch_tail(0, p2)); CK(hipDeviceSynchronize());
   { std::vector<unsigned short> c((size_t)m * 384);
@@ -57,6 +61,32 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) CK(launch_tail(0, p2)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-  printf("tail po=%d ablate=%d m=%d f=%d: %.1f us  %.0f TFLOP/s (%.1f%% of 2.5 PF)\n", po, MX_TAIL_ABLATE, m, f, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
+  printf("tail po=%d ablate=%d skew=%d(bit %d, < %d) m=%d f=%d: %.1f us  %.0f TFLOP/s (%.1f%% of 2.5 PF)\n", po, MX_TAIL_ABLATE, skew_iters, skew_shift, skew_hi, m, f, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
+#if MX_TAIL_TRACE
+  { // one traced launch in steady state: phase durations per dispatch round, and who shares a CU
+    const int nb = m / 64; unsigned long long* tr; CK(hipMalloc(&tr, (size_t)nb * 64)); CK(hipMemset(tr, 0, (size_t)nb * 64));
+    p2.trace = tr; for (int i = 0; i < 20; ++i) CK(launch_tail(0, p2)); CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> t((size_t)nb * 8); CK(hipMemcpy(t.data(), tr, t.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull; for (int b = 0; b < nb; ++b) if (t[b * 8] < t0) t0 = t[b * 8];
+    const char* names[6] = {"skew", "prologue(ctx DMA)", "out-proj", "LN1", "chunk loop", "LN2+store"};
+    for (int r0 = 0; r0 < nb; r0 += 512) {
+      double st = 0, en = 0, d[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
+      for (int b = r0; b < r0 + 512 && b < nb; ++b, ++n) { st += (double)(t[b * 8] - t0); en += (double)(t[b * 8 + 6] - t0); for (int i = 0; i < 6; ++i) d[i] += (double)(t[b * 8 + i + 1] - t[b * 8 + i]); }
+      printf("blocks %4d..%4d: start %.1f us end %.1f us |", r0, r0 + n - 1, st / n / 100, en / n / 100);
+      for (int i = 0; i < 6; ++i) printf(" %s %.1f", names[i], d[i] / n / 100); printf(" us\n");
+    }
+    // start times of the first 520 blocks, and whether block b and b + 256 run on the same CU
+    int same = 0, cnt = 0; for (int b = 0; b + 256 < nb && b < 256; ++b, ++cnt) { const unsigned long long ka = t[b * 8 + 7], kb = t[(b + 256) * 8 + 7]; same += ((ka >> 32) == (kb >> 32)) && ((ka & 0xff00) == (kb & 0xff00)); }
+    printf("block b and b+256 on the same CU: %d of %d\n", same, cnt);
+    { // who shares a CU among the first 512 blocks: histogram of (second block - first block)
+      std::vector<std::pair<unsigned long long, int>> ks; for (int b = 0; b < 512 && b < nb; ++b) ks.push_back({((t[b * 8 + 7] >> 32) << 16) | (t[b * 8 + 7] & 0xff00), b});
+      std::sort(ks.begin(), ks.end()); int ncu = 0, pairs = 0; std::vector<int> deltas;
+      for (size_t i = 0; i < ks.size();) { size_t j = i; while (j < ks.size() && ks[j].first == ks[i].first) ++j; ++ncu; if (j - i == 2) { ++pairs; deltas.push_back(ks[i + 1].second - ks[i].second); } i = j; }
+      std::sort(deltas.begin(), deltas.end()); printf("first 512 blocks sit on %d distinct CUs, %d of them hold exactly two; delta between the two block ids: min %d median %d max %d\n", ncu, pairs, deltas.empty() ? -1 : deltas.front(), deltas.empty() ? -1 : deltas[deltas.size() / 2], deltas.empty() ? -1 : deltas.back()); }
+    for (int b : {0, 1, 8, 255, 256, 257, 264, 511, 512, 513, 767, 768, 1023, 1024}) if (b < nb) printf("  block %4d: xcc %llu hw_id %08llx  start %.1f us end %.1f us\n", b, t[b * 8 + 7] >> 32, t[b * 8 + 7] & 0xffffffffull, (double)(t[b * 8] - t0) / 100, (double)(t[b * 8 + 6] - t0) / 100);
+    unsigned long long tend = 0; for (int b = 0; b < nb; ++b) if (t[b * 8 + 6] > tend) tend = t[b * 8 + 6];
+    printf("traced launch: %.1f us first start -> last end\n", (double)(tend - t0) / 100);
+  }
+#endif
   return 0;
 }

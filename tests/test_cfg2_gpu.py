@@ -1,0 +1,95 @@
+"""BASELINE.json configs[1] end to end on the GPU: all-MiniLM-L6-v2 (384-d) encoder, 100k synthetic
+segments, brute-force cosine top-10, one MI355X --
+    model.encode(&segments)  (lib/libmemex/src/llm/embedding.rs:109)  ->  mx_encoder_encode_device
+    add_vectors              (lib/worker/src/tasks.rs:59)             ->  mx_index_add_device  (embeddings never leave HBM)
+    search                   (lib/libmemex/src/storage/local.rs:71-91) ->  mx_index_search_device
+Bars: ids / dists / scores bit-equal to the search oracle on the GPU-produced f32 vectors; on a
+2000-segment subset the embeddings are within 1e-3 cosine of the f64 encoder oracle and the scores of the
+whole GPU pipeline within 1e-3 of the all-CPU pipeline (oracle embeddings -> oracle search)."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+N_SEG, N_Q, K, S = 100_000, 256, 10, 256
+SUBSET = 2000
+
+
+def _segments(rng, n, lo, hi, vocab):
+    """Token-id segments with lengths U[lo, hi]: [CLS] body [SEP], padding after the length."""
+    lens = rng.integers(lo, hi + 1, size=n).astype(np.int32)
+    ids = rng.integers(1000, vocab, size=(n, S)).astype(np.int32)
+    ids[:, 0] = 101
+    ids[np.arange(n), lens - 1] = 102
+    return ids, lens
+
+
+def test_cfg2_embed_100k_segments_add_on_device_search(oracle, lib_built):
+    import torch
+    from memex_amd import weights as W
+    from memex_amd.encoder import Encoder
+    from memex_amd.index import FlatIndex
+    from oracle import bert_oracle
+
+    cfg = W.ALL_MINILM_L6_V2
+    w = W.synthetic_weights(cfg, 11)
+    rng = np.random.default_rng(11)
+    ids, lens = _segments(rng, N_SEG, 16, 256, cfg.vocab)
+    qids, qlens = _segments(rng, N_Q, 4, 32, cfg.vocab)
+    # queries that have a real neighbourhood: half of them are prefixes of a corpus segment
+    for b in range(0, N_Q, 2):
+        src = int(rng.integers(0, N_SEG))
+        n = int(min(qlens[b], lens[src])) - 1
+        qids[b, :n] = ids[src, :n]
+        qids[b, n] = 102
+        qlens[b] = n + 1
+
+    dev = torch.device("cuda", 0)
+    d_ids, d_lens = torch.from_numpy(ids).to(dev), torch.from_numpy(lens).to(dev)
+    d_vec = torch.zeros((N_SEG, cfg.hidden), device=dev, dtype=torch.float32)
+    d_q = torch.zeros((N_Q, cfg.hidden), device=dev, dtype=torch.float32)
+    with Encoder(cfg, w) as enc, FlatIndex(cfg.hidden) as idx:
+        call = 16384
+        for b0 in range(0, N_SEG, call):                       # the worker's embed step, batch by batch
+            enc.encode_device(d_ids[b0:b0 + call], d_lens[b0:b0 + call], d_vec[b0:b0 + call])
+        first = idx.add_device(d_vec)                          # tasks.rs:59 -- straight from HBM
+        assert first == 1 and len(idx) == N_SEG
+        enc.encode_device(torch.from_numpy(qids).to(dev), torch.from_numpy(qlens).to(dev), d_q)
+        o_ids = torch.zeros((N_Q, K), device=dev, dtype=torch.int64)
+        o_sc = torch.zeros((N_Q, K), device=dev, dtype=torch.float32)
+        o_di = torch.zeros((N_Q, K), device=dev, dtype=torch.float32)
+        o_nf = torch.zeros((N_Q,), device=dev, dtype=torch.int32)
+        idx.search_device(d_q, K, o_ids, o_sc, o_di, o_nf)
+        st = idx.stats()
+        vec, q = d_vec.cpu().numpy(), d_q.cpu().numpy()
+        g_ids, g_sc, g_di = o_ids.cpu().numpy().astype(np.uint64), o_sc.cpu().numpy(), o_di.cpu().numpy()
+        assert (o_nf.cpu().numpy() == K).all()
+        assert st.fallback_queries == 0                        # the MFMA scan answered every query
+
+        # ---- (1) search parity on identical f32 vectors: bit-exact
+        r_ids, r_di, r_sc, _ = oracle.search(vec, q, K)
+        np.testing.assert_array_equal(g_ids, r_ids)
+        np.testing.assert_array_equal(bits(g_di), bits(r_di))
+        np.testing.assert_array_equal(bits(g_sc), bits(r_sc))
+        np.testing.assert_allclose(np.linalg.norm(vec, axis=1), 1.0, atol=1e-5)
+
+        # ---- (2) encoder parity on a subset: f64 oracle
+        sub = np.sort(rng.choice(N_SEG, size=SUBSET, replace=False))
+        ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub]).astype(np.float32)
+        qref = bert_oracle.encode_many(w, cfg.as_dict(), qids, qlens).astype(np.float32)
+        assert (1.0 - (vec[sub] * ref).sum(1)).max() <= TOL
+        assert (1.0 - (q * qref).sum(1)).max() <= TOL
+
+        # ---- (3) whole pipeline vs the all-CPU pipeline on that subset (ranks may swap inside near-ties;
+        # the j-th best score may not move by more than the tolerance)
+        with FlatIndex(cfg.hidden) as small:
+            small.add_device(d_vec[torch.from_numpy(sub).to(dev)].contiguous())
+            s_ids, s_sc, _, _ = small.search(q, K)
+        _, _, c_sc, _ = oracle.search(ref, qref, K)
+        assert np.abs(s_sc - c_sc).max() <= TOL
+        h_ids, _, h_sc, _ = oracle.search(vec[sub], q, K)       # and that small search itself is bit-exact
+        np.testing.assert_array_equal(s_ids, h_ids)
+        np.testing.assert_array_equal(bits(s_sc), bits(h_sc))

@@ -33,6 +33,14 @@ def test_tail_weight_stream_layout(tmp_path, lib_built):
     assert r.returncode == 0 and "OK tail stream layout" in r.stdout, r.stdout + r.stderr
 
 
+def test_shard_pool_hand_off(tmp_path):
+    """The persistent helper threads of the sharded index (memex_amd/csrc/shard_pool.h): plain C++, no GPU."""
+    exe = str(tmp_path / "test_shard_pool")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_shard_pool.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK shard pool" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_reference_tests(tmp_path, lib_built):
     exe = _build(tmp_path, lib_built)

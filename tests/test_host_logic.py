@@ -61,3 +61,35 @@ def test_every_supported_model_type_has_an_encoder_config():
     rb = E._ENCODER_CONFIGS[E.EmbeddingsModelType.AllDistilrobertaV1]
     assert (rb.layers, rb.hidden, rb.pos_offset, rb.type_vocab, rb.max_pos) == (6, 768, 2, 1, 514)
     assert rb.max_seq_length + rb.pos_offset <= rb.max_pos
+
+
+def test_meta_save_appends_and_falls_back_to_a_rewrite(tmp_path):
+    """save() splices new ids in front of the closing brace of vectors.meta.json (O(new ids) per insert, the
+    reference saves after every insert: local.rs:67); a file that does not end the way the store left it --
+    e.g. a hand edit that added a newline -- is rewritten in full instead of leaving fewer ids than vectors."""
+    import json
+    import os
+    s = storage.HipFlatStore.new(str(tmp_path))
+    s._id_map = {1: "a", 2: "b"}
+    s.save()
+    meta = tmp_path / storage.META_FILE
+    assert json.loads(meta.read_text()) == {"1": "a", "2": "b"}
+    s._id_map[3] = 'c "quoted"'
+    s.save()                                               # spliced
+    assert json.loads(meta.read_text()) == {"1": "a", "2": "b", "3": 'c "quoted"'}
+    meta.write_text(meta.read_text() + "\n")               # external edit: trailing newline, still valid JSON
+    s._meta_sig = storage._file_sig(str(meta))             # (as load() would record it)
+    s._id_map[4] = "d"
+    s.save()                                               # no '}' at the end -> full rewrite, nothing lost
+    assert json.loads(meta.read_text()) == {"1": "a", "2": "b", "3": 'c "quoted"', "4": "d"}
+    assert not os.path.exists(str(meta) + ".tmp")
+    s._id_map[5] = "e"
+    s.save()                                               # and the splice works again afterwards
+    assert json.loads(meta.read_text())["5"] == "e"
+
+
+def test_resident_registry_is_keyed_by_device_set(tmp_path):
+    a = storage.HipFlatStore(storage_path=str(tmp_path), device=0)
+    b = storage.HipFlatStore(storage_path=str(tmp_path), device=0, devices=[0, 1])
+    c = storage.HipFlatStore(storage_path=str(tmp_path), device=0, devices=[0, 1])
+    assert a._rkey() != b._rkey() and b._rkey() == c._rkey()

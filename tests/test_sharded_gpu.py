@@ -110,3 +110,51 @@ def test_store_on_sharded_index(tmp_path, lib_built):
     assert vs2.search(vecs[123], 3) == hits
     vs2.delete_collection()
     storage.evict_resident()
+
+
+def test_helper_threads_on_logical_shards(oracle, lib_built):
+    """MEMEX_HIP_SHARD_THREADS=1: the persistent per-shard helper threads (what shards on distinct devices
+    always use) drive 8 logical shards of one GPU; many batches in a row, results as without them."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(10)
+    X = rng.standard_normal((60000, 384), dtype=np.float32)
+    Q = rng.standard_normal((300, 384), dtype=np.float32)        # two batches per call (256 + 44)
+    os.environ["MEMEX_HIP_SHARD_THREADS"] = "1"
+    try:
+        with FlatIndex(384, devices=[0] * 8, block_rows=1024) as idx:
+            assert idx.exchange == "p2p"
+            idx.add(X)
+            for _ in range(5):
+                _same(idx, X, Q, 10, oracle)
+    finally:
+        del os.environ["MEMEX_HIP_SHARD_THREADS"]
+    with FlatIndex(384) as plain:
+        assert plain.exchange == "none"
+
+
+def test_sharded_add_is_all_or_nothing(oracle, lib_built):
+    """A device batch whose bad row lands on a LATER shard: the shards before it had already appended their
+    part when the failure shows (device rows are validated by the ingest kernel) -- they must give it back,
+    or later rows land at wrong offsets and searches return wrong ids."""
+    import torch
+    from memex_amd import _lib
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((5000, 64), dtype=np.float32)
+    X[100] = 0                                                    # a zero-norm row that stays
+    bad = rng.standard_normal((4000, 64), dtype=np.float32)
+    bad[50] = 0                                                   # a zero-norm row that must be rolled back (shard 0)
+    bad[3000, 7] = np.nan                                         # rows 8000.. of the composite: block 7 -> shard 3
+    Q = rng.standard_normal((7, 64), dtype=np.float32)
+    with FlatIndex(64, devices=[0, 0, 0, 0], block_rows=1024) as idx:
+        assert idx.add(X) == 1
+        with pytest.raises(_lib.MemexHipError):
+            idx.add_device(torch.from_numpy(bad).cuda())
+        assert len(idx) == 5000
+        _same(idx, X, Q, 10, oracle)
+        more = rng.standard_normal((3000, 64), dtype=np.float32)
+        assert idx.add_device(torch.from_numpy(more).cuda()) == 5001
+        _same(idx, np.concatenate([X, more]), Q, 10, oracle)
+        with pytest.raises(_lib.MemexHipError):                   # host rows: rejected before anything moves
+            idx.add(bad)
+        _same(idx, np.concatenate([X, more]), Q, 10, oracle)
