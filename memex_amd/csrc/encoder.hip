@@ -44,6 +44,8 @@ struct Layer {
     float *bi = nullptr;
     bf16_t *wo2 = nullptr;   // [H, F]
     bf16_t *wf = nullptr;    // wo, wi and wo2 once more, as tail_kernel's per-wave fragment streams (fused tail only)
+    bf16_t *wf2 = nullptr;   // ... and as tail2_kernel's single fragment stream (large passes)
+    float *pf = nullptr;     // tail2_kernel's parameter block (biases + LayerNorm parameters of the tail)
     float *bo2 = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 
@@ -69,8 +71,10 @@ struct mx_encoder {
     float *out_dev = nullptr;
     bool profiling = false;
     bool fused_tail = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_UNFUSED_TAIL=1 keeps the three GEMMs
+    bool tail2 = false;       // large passes use tail2_kernel (encoder_tail2.hip); MEMEX_HIP_TAIL=1 keeps tail_kernel everywhere
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
     mx_encoder_stats stats{};
+    int tail2_min_rows = 0;
     std::string key;  // registry key (mx_encoder_open); empty = private
     int refs = 1;
 };
@@ -104,6 +108,19 @@ int upload_tail_stream(mx_encoder *e, const float *wo, const float *wi, const fl
     e->allocs.push_back(*dst);
     MX_HIP(hipMemcpy(*dst, st.data(), st.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return MX_OK;
+}
+
+// wo, wi, wo2 -> tail2_kernel's fragment stream; the tail's biases / LayerNorm parameters -> its parameter block
+int upload_tail2(mx_encoder *e, const float *wo, const float *wi, const float *wo2, size_t F, const float *bo, const float *g1,
+                 const float *be1, const float *b1, const float *b2, const float *g2, const float *be2, Layer &L) {
+    std::vector<uint16_t> st(tail2_stream_elems((int)F));
+    tail2_stream_layout(wo, wi, wo2, (int)F, st.data(), &f32_to_bf16);
+    MX_HIP(hipMalloc(&L.wf2, st.size() * sizeof(uint16_t)));
+    e->allocs.push_back(L.wf2);
+    MX_HIP(hipMemcpy(L.wf2, st.data(), st.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    std::vector<float> pf(tail2_param_floats());
+    tail2_param_layout(bo, g1, be1, b1, b2, g2, be2, (int)F, pf.data());
+    return upload_f32(e, pf.data(), pf.size(), &L.pf);
 }
 
 void free_ws(mx_encoder *e) {
@@ -204,7 +221,11 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             tp.ctx = e->ctx; tp.ldc = H; tp.x = e->x; tp.ldx = H; tp.wf = L.wf; tp.bo = L.bo; tp.ln1g = L.ln1g; tp.ln1b = L.ln1b;
             tp.b1 = L.bi; tp.b2 = L.bo2; tp.f = F; tp.m = t_pad; tp.out = e->x; tp.ldo = H; tp.gamma = L.ln2g; tp.beta = L.ln2b;
             tp.eps = c.ln_eps;
-            MX_HIP(launch_tail(st, tp));
+            tp.wf2 = L.wf2; tp.pf = L.pf;
+            // 128-token workgroups, one per CU: worth it once they fill the chip; below that tail_kernel's 64-token
+            // workgroups (two per CU) finish a pass sooner (a query is a few hundred tokens)
+            if (e->tail2 && t_pad >= e->tail2_min_rows) MX_HIP(launch_tail2(st, tp));
+            else MX_HIP(launch_tail(st, tp));
             continue;
         }
         GemmParams o{};
@@ -322,6 +343,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     std::call_once(g_enc_once, [] {
         g_enc_setup = encoder_kernels_setup();
         if (g_enc_setup == hipSuccess) g_enc_setup = tail_setup();
+        if (g_enc_setup == hipSuccess) g_enc_setup = tail2_setup();
     });
     if (g_enc_setup != hipSuccess)
         return fail(MX_EDEVICE, "encoder kernel setup failed: %s", hipGetErrorString(g_enc_setup));
@@ -332,6 +354,11 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     {
         const char *ev = getenv("MEMEX_HIP_UNFUSED_TAIL");
         e->fused_tail = tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
+        const char *tv = getenv("MEMEX_HIP_TAIL");
+        e->tail2 = e->fused_tail && tail2_supported(cfg->hidden, cfg->ffn) && !(tv && tv[0] == '1');
+        hipDeviceProp_t prop;
+        e->tail2_min_rows = hipGetDeviceProperties(&prop, device) == hipSuccess ? 128 * prop.multiProcessorCount : 32768;
+        if (tv && tv[0] == '2') e->tail2_min_rows = 0;  // MEMEX_HIP_TAIL=2: tail2_kernel at every pass size (tests)
     }
     auto bail = [&](int code) {
         destroy_impl(e);
@@ -374,18 +401,22 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         MX_TRY(upload_f32(e, bqkv.data(), 3 * H, &L.bqkv));
         const float *wo_src = take(H * H);
         MX_TRY(upload_weight(e, wo_src, H, H, &L.wo));
-        MX_TRY(upload_f32(e, take(H), H, &L.bo));
-        MX_TRY(upload_f32(e, take(H), H, &L.ln1g));
-        MX_TRY(upload_f32(e, take(H), H, &L.ln1b));
+        const float *bo_src = take(H), *g1_src = take(H), *be1_src = take(H);
+        MX_TRY(upload_f32(e, bo_src, H, &L.bo));
+        MX_TRY(upload_f32(e, g1_src, H, &L.ln1g));
+        MX_TRY(upload_f32(e, be1_src, H, &L.ln1b));
         const float *wi_src = take(F * H);
         MX_TRY(upload_weight(e, wi_src, F, H, &L.wi));
-        MX_TRY(upload_f32(e, take(F), F, &L.bi));
+        const float *b1_src = take(F);
+        MX_TRY(upload_f32(e, b1_src, F, &L.bi));
         const float *wo2_src = take(H * F);
         MX_TRY(upload_weight(e, wo2_src, H, F, &L.wo2));
         if (e->fused_tail) MX_TRY(upload_tail_stream(e, wo_src, wi_src, wo2_src, F, &L.wf));
-        MX_TRY(upload_f32(e, take(H), H, &L.bo2));
-        MX_TRY(upload_f32(e, take(H), H, &L.ln2g));
-        MX_TRY(upload_f32(e, take(H), H, &L.ln2b));
+        const float *b2_src = take(H), *g2_src = take(H), *be2_src = take(H);
+        MX_TRY(upload_f32(e, b2_src, H, &L.bo2));
+        MX_TRY(upload_f32(e, g2_src, H, &L.ln2g));
+        MX_TRY(upload_f32(e, be2_src, H, &L.ln2b));
+        if (e->tail2) MX_TRY(upload_tail2(e, wo_src, wi_src, wo2_src, F, bo_src, g1_src, be1_src, b1_src, b2_src, g2_src, be2_src, L));
     }
 #undef MX_TRY
     *out = e;

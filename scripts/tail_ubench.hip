@@ -3,12 +3,15 @@
 // bf16 data (MiniLM shape: hidden 384, ffn 1536), with a checksum of the output so that two builds can be
 // compared (bit-equality with the two-GEMM path is tests/test_encoder_gpu.py's job).  Use >= 1000 reps:
 // the first milliseconds run at ramp-up clocks.  -DMX_TAIL_ABLATE=N selects the ablations of the kernel.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I memex_amd/csrc scripts/tail_ubench.hip \
-//        memex_amd/csrc/encoder_tail.hip -o build_ub/tail_ub
+// argv: rows ffn reps po skew_iters skew_shift skew_hi.  Then the same for tail2_kernel (encoder_tail2.hip) with the
+// largest difference between the two outputs (different rounding points: a few bf16 ulps).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I memex_amd/csrc scripts/tail_ubench.hip \
+//        memex_amd/csrc/encoder_tail.hip memex_amd/csrc/encoder_tail2.hip -o build_ub/tail_ub
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 #include <algorithm>
 #include <utility>
@@ -88,5 +91,43 @@ int main(int argc, char** argv) {
     printf("traced launch: %.1f us first start -> last end\n", (double)(tend - t0) / 100);
   }
 #endif
+  if (po) { // ---- tail2_kernel on the same inputs
+    bf16_t *wf2, *out3; float *pf;
+    CK(hipMalloc(&wf2, tail2_stream_elems(f) * 2)); CK(hipMalloc(&pf, tail2_param_floats() * 4)); CK(hipMalloc(&out3, (size_t)m * 384 * 2));
+    { std::vector<unsigned short> kb((size_t)f * 384), kbo((size_t)384 * 384); std::vector<float> l1, l2, lo; std::vector<uint16_t> st(tail2_stream_elems(f));
+      CK(hipMemcpy(kb.data(), w1, kb.size() * 2, hipMemcpyDeviceToHost)); to_logical(kb, f, 384, l1);
+      CK(hipMemcpy(kb.data(), w2, kb.size() * 2, hipMemcpyDeviceToHost)); to_logical(kb, 384, f, l2);
+      CK(hipMemcpy(kbo.data(), wo, kbo.size() * 2, hipMemcpyDeviceToHost)); to_logical(kbo, 384, 384, lo);
+      tail2_stream_layout(lo.data(), l1.data(), l2.data(), f, st.data(), bf16_exact); CK(hipMemcpy(wf2, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+      std::vector<float> hb1(f), hb2(384), hg(384), hb(384), pp(tail2_param_floats());
+      CK(hipMemcpy(hb1.data(), b1, f * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb2.data(), b2, 384 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hg.data(), g, 384 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), b, 384 * 4, hipMemcpyDeviceToHost));
+      tail2_param_layout(hb2.data(), hg.data(), hb.data(), hb1.data(), hb2.data(), hg.data(), hb.data(), f, pp.data()); CK(hipMemcpy(pf, pp.data(), pp.size() * 4, hipMemcpyHostToDevice)); }
+    CK(tail2_setup());
+    TailParams p3 = p2; p3.wf2 = wf2; p3.pf = pf; p3.out = out3; p3.trace = nullptr;
+    CK(hipMemset(out3, 0xff, (size_t)m * 384 * 2));
+    CK(launch_tail2(0, p3)); CK(hipDeviceSynchronize());
+    { std::vector<unsigned short> a((size_t)m * 384), c((size_t)m * 384);
+      CK(hipMemcpy(a.data(), out2, a.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(c.data(), out3, c.size() * 2, hipMemcpyDeviceToHost));
+      double mx = 0, sum = 0, ref = 0; size_t bad = 0, worst = 0;
+      for (size_t i = 0; i < a.size(); ++i) { unsigned ua = (unsigned)a[i] << 16, uc = (unsigned)c[i] << 16; float fa, fc; memcpy(&fa, &ua, 4); memcpy(&fc, &uc, 4);
+        const double d = fabs((double)fa - fc); if (!(d <= 1e30)) { ++bad; continue; } if (d > mx) { mx = d; worst = i; } sum += d; ref += fabs(fa); }
+      printf("tail2 vs tail: max |diff| %.5f (row %zu col %zu), mean |diff| %.6f, mean |value| %.4f, non-finite %zu\n", mx, worst / 384, worst % 384, sum / a.size(), ref / a.size(), bad); }
+    for (int i = 0; i < 3; ++i) CK(launch_tail2(0, p3));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) CK(launch_tail2(0, p3)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    printf("tail2 m=%d f=%d: %.1f us  %.0f TFLOP/s (%.1f%% of 2.5 PF)\n", m, f, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
+#if MX_TAIL2_TRACE
+    { const int nb = m / 128; unsigned long long* tr; CK(hipMalloc(&tr, (size_t)nb * 64)); CK(hipMemset(tr, 0, (size_t)nb * 64));
+      p3.trace = tr; for (int i = 0; i < 20; ++i) CK(launch_tail2(0, p3)); CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> t((size_t)nb * 8); CK(hipMemcpy(t.data(), tr, t.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull, tend = 0; for (int b2_ = 0; b2_ < nb; ++b2_) { if (t[b2_ * 8] < t0) t0 = t[b2_ * 8]; if (t[b2_ * 8 + 5] > tend) tend = t[b2_ * 8 + 5]; }
+      const char* names[5] = {"prologue", "out-proj", "LN1", "MLP loop", "LN2+store"};
+      for (int r0 = 0; r0 < nb; r0 += 256) { double st = 0, en = 0, d[5] = {0, 0, 0, 0, 0}; int n = 0;
+        for (int b2_ = r0; b2_ < r0 + 256 && b2_ < nb; ++b2_, ++n) { st += (double)(t[b2_ * 8] - t0); en += (double)(t[b2_ * 8 + 5] - t0); for (int i = 0; i < 5; ++i) d[i] += (double)(t[b2_ * 8 + i + 1] - t[b2_ * 8 + i]); }
+        printf("tail2 blocks %4d..%4d: start %.1f us end %.1f us |", r0, r0 + n - 1, st / n / 100, en / n / 100); for (int i = 0; i < 5; ++i) printf(" %s %.1f", names[i], d[i] / n / 100); printf(" us\n"); }
+      printf("tail2 traced launch: %.1f us first start -> last end\n", (double)(tend - t0) / 100); }
+#endif
+  }
   return 0;
 }
