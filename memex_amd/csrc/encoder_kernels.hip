@@ -320,12 +320,20 @@ static hipError_t gemm_go(hipStream_t s, const GemmParams &p) {
 // 80 KiB 4-stage ring -> TWO workgroups per CU, one's epilogue overlapping the other's MFMAs.  The
 // LayerNorm GEMMs need a full row per tile: 128 x 384 (8 waves, 128 KiB ring) and 64 x 768
 // (3-stage 52 KiB ring); 64 x 384 at 2 workgroups/CU was measured slower (weight re-reads double).
+// Large passes (round 3, scripts/gemm_ubench.hip at 131k tokens): 256 x 384 tiles -- 8 waves, wave tile 128 x 96
+// (12 MFMAs per 7 fragment reads instead of 6 per 5), a 3-stage 120 KiB ring, one workgroup per CU -- run the
+// QK projection in 116 us instead of 133 at K = 384 and 337 instead of 387 at K = 768, the FFN-up GEMM in 742
+// instead of 807 (bit-identical outputs: every configuration sums k in the same order).  Small passes (a
+// query) keep the 128 x 192 tiles: more, shorter workgroups.
+constexpr int kBigTileRows = 32768;
+
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
+    const bool big = p.m >= kBigTileRows && p.n % 384 == 0;
     switch (epi) {
-        case EPI_BIAS: return gemm_go<EPI_BIAS, 2, 2, 2, 32, 4>(s, p);
-        case EPI_BIAS_GELU: return gemm_go<EPI_BIAS_GELU, 2, 2, 2, 32, 4>(s, p);
-        case EPI_QKV: return gemm_go<EPI_QKV, 2, 2, 2, 32, 4>(s, p);
-        case EPI_VT: return gemm_go<EPI_VT, 2, 2, 2, 32, 4>(s, p);
+        case EPI_BIAS: return big ? gemm_go<EPI_BIAS, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_BIAS, 2, 2, 2, 32, 4>(s, p);
+        case EPI_BIAS_GELU: return big ? gemm_go<EPI_BIAS_GELU, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_BIAS_GELU, 2, 2, 2, 32, 4>(s, p);
+        case EPI_QKV: return big ? gemm_go<EPI_QKV, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_QKV, 2, 2, 2, 32, 4>(s, p);
+        case EPI_VT: return big ? gemm_go<EPI_VT, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_VT, 2, 2, 2, 32, 4>(s, p);
         case EPI_BIAS_RES_LN:
             if (p.n == 384) return gemm_go<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>(s, p);
             if (p.n == 768) return gemm_go<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>(s, p);
@@ -746,6 +754,10 @@ hipError_t encoder_kernels_setup() {
     if ((e = gemm_attr<EPI_BIAS_GELU, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_QKV, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_VT, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_BIAS_GELU, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_QKV, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_VT, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>()) != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<32>),

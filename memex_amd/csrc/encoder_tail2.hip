@@ -44,6 +44,12 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 #ifndef MX_TAIL2_TRACE
 #define MX_TAIL2_TRACE 0
 #endif
+// Ablation switch for scripts/tail_ubench.hip only (0 = production kernel; results are wrong with any bit set):
+//   1 = no slot wait / barrier, 2 = no DMA issue in the loops, 4 = no GELU sub-steps under the MFMAs,
+//   8 = no A-fragment reads in the loops (the registers keep the prologue's fragments)
+#ifndef MX_TAIL2_ABLATE
+#define MX_TAIL2_ABLATE 0
+#endif
 #if MX_TAIL2_TRACE
 #define MX_TRACE2(i)                                                                                        \
     do {                                                                                                    \
@@ -110,13 +116,15 @@ __device__ __forceinline__ float gelu_sig5(float v) {
 // accumulator layout (lane = token, 8 consecutive registers = features {0-3, 8-11} + 4 (lane >> 5) of a
 // 16-feature group)  <->  MFMA B-fragment layout (lane holds features 8 (lane >> 5) .. +7 as 4 packed pairs):
 // the same two half-wave swaps in both directions
+// v_permlane32_swap a, b: lanes 32-63 of a <-> lanes 0-31 of b.  Written as inline assembly: hipcc (ROCm 7.2)
+// miscompiles code that combines the two results of __builtin_amdgcn_permlane32_swap (seen: r[0] + r[1] emitted as
+// r[0] + r[0]).  The instruction needs two wait states after a VALU write of either operand; the s_nop covers it.
+__device__ __forceinline__ void lane32_swap(uint32_t &a, uint32_t &b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ void frag_swap(uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t &r3) {
-    auto a = __builtin_amdgcn_permlane32_swap(r0, r2, false, false);
-    r0 = a[0];
-    r2 = a[1];
-    auto b = __builtin_amdgcn_permlane32_swap(r1, r3, false, false);
-    r1 = b[0];
-    r3 = b[1];
+    lane32_swap(r0, r2);
+    lane32_swap(r1, r3);
 }
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     const bf16x2 pk = {(__bf16)lo, (__bf16)hi};
@@ -158,6 +166,15 @@ __device__ __forceinline__ void from_frag(bf16x8 f, float (&v)[8]) {
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(A), "v"(B), "i"(BASE), "i"((BASE) + 15))
 #define MX_ACC_RD(DST, IDX) asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(DST) : "i"(IDX))
 #define MX_ACC_WR(IDX, SRC) asm volatile("v_accvgpr_write_b32 a%c0, %1" ::"i"(IDX), "v"(SRC))
+#define MX_ACC_RD4(D, IDX) /* D[0..3] = a[IDX .. IDX+3]: one statement, one boundary pad */                              \
+    asm volatile("v_accvgpr_read_b32 %0, a%c4\n\tv_accvgpr_read_b32 %1, a%c5\n\tv_accvgpr_read_b32 %2, a%c6\n\tv_accvgpr_read_b32 %3, a%c7" \
+                 : "=v"((D)[0]), "=v"((D)[1]), "=v"((D)[2]), "=v"((D)[3])                                                        \
+                 : "i"(IDX), "i"((IDX) + 1), "i"((IDX) + 2), "i"((IDX) + 3))
+#define MX_ACC_WR4(IDX, S)                                                                                                   \
+    asm volatile("v_accvgpr_write_b32 a%c0, %4\n\tv_accvgpr_write_b32 a%c1, %5\n\tv_accvgpr_write_b32 a%c2, %6\n\tv_accvgpr_write_b32 a%c3, %7" \
+                 ::"i"(IDX), "i"((IDX) + 1), "i"((IDX) + 2), "i"((IDX) + 3), "v"((S)[0]), "v"((S)[1]), "v"((S)[2]), "v"((S)[3]))
+#define MX_MFMA_W(BASE, A, B, ANEXT) /* also waits for the NEXT A fragment: one s_waitcnt per two MFMAs */             \
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(A), "v"(B), "i"(BASE), "i"((BASE) + 15), "v"(ANEXT))
 #define MX_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")  /* the last MFMAs' results are readable */
 
 #define MX_Z1(n) "v_accvgpr_write_b32 a" #n ", 0\n\t"
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t dma_dst = (uint32_t)kRingOff + (uint32_t)(2 * w) * kFrag;
     auto dma_slot = [&](auto postag) __attribute__((always_inline)) {  // ring slot 0..5
         constexpr int pos = decltype(postag)::value;
-        char *dst = smem + __builtin_amdgcn_readfirstlane(dma_dst + (uint32_t)pos * (kSlotFrags * kFrag));
+        char *dst = smem + (dma_dst + (uint32_t)pos * (kSlotFrags * kFrag));  // wave-uniform (w went through readfirstlane)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t *)dst, 16, dma_voff, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t *)(dst + kFrag), 16, dma_voff + kFrag, 0, 0, 0);
         dma_voff += kSlotFrags * kFrag;
@@ -254,14 +271,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // start of a slot (f % 8 == 0): my pieces of the NEXT slot have landed, everyone's are published by the
     // barrier, and everyone is done with the previous slot, whose ring position the DMA below refills
     auto slot_open = [&]() __attribute__((always_inline)) {
+#if !(MX_TAIL2_ABLATE & 1)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#endif
     };
     // the bookkeeping behind MFMA f of a segment: refill the A register, issue the DMA of the slot five ahead
     auto after_mfma = [&](auto ft) __attribute__((always_inline)) {
         constexpr int f = decltype(ft)::value;
+#if !(MX_TAIL2_ABLATE & 8)
         abuf[f % kAhead] = ring_read(ic<f + kAhead>{});
-        if constexpr (f % kSlotFrags == 1) dma_slot(ic<((f % kRingFrags) / kSlotFrags + kRingSlots - 1) % kRingSlots>{});
+#endif
+        if constexpr (f % kSlotFrags == 1 && !(MX_TAIL2_ABLATE & 2)) dma_slot(ic<((f % kRingFrags) / kSlotFrags + kRingSlots - 1) % kRingSlots>{});
     };
 
     // =============== out-projection: y = ctx Wo^T.  6 ring revolutions of 4 k-steps x 12 blocks ===============
@@ -278,7 +299,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (f % kSlotFrags == 0) {
                     if (f != 0 || rev != 0) slot_open();
                 }
-                MX_MFMA(16 * fb, abuf[f % kAhead], bb[ks & 1]);
+                if constexpr (f % 2 == 0) MX_MFMA_W(16 * fb, abuf[f % kAhead], bb[ks & 1], abuf[(f + 1) % kAhead]);
+                else MX_MFMA(16 * fb, abuf[f % kAhead], bb[ks & 1]);
                 after_mfma(ft);
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -294,9 +316,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto par4 = [&](int off, int fb, int rg) __attribute__((always_inline)) -> f32x4 {  // 4 parameters of features fb*32 + 8 rg + 4 h ..
         return *reinterpret_cast<const f32x4 *>(par + off + fb * 32 + rg * 8 + h * 4);
     };
-    auto half_sum = [&](float s) __attribute__((always_inline)) -> float {
-        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, s), __builtin_bit_cast(uint32_t, s), false, false);
-        return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    auto half_sum = [&](float s) __attribute__((always_inline)) -> float {  // s(lane) + s(lane ^ 32) in every lane
+        uint32_t a = __builtin_bit_cast(uint32_t, s), b = a;
+        lane32_swap(a, b);  // lower lanes: a = own, b = partner's; upper lanes: a = partner's, b = own
+        return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
     };
     float ln_mean = 0.0f, ln_rstd = 0.0f;
     auto ln_stats = [&](auto first) __attribute__((always_inline)) {  // first: LayerNorm1 (y += residual rows + bo)
@@ -305,24 +328,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         MX_MFMA_DRAIN();
         static_for<0, 24>([&](auto gt) __attribute__((always_inline)) {
             constexpr int g = decltype(gt)::value, fb = g >> 1, hf = g & 1;
-            float rv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            f32x4 b0 = {0, 0, 0, 0}, b1v = {0, 0, 0, 0};
+            float v[8];  // 8 registers per statement: the eight chains behind it are independent, the compiler interleaves them
+            MX_ACC_RD4(v, 16 * fb + 8 * hf);
+            MX_ACC_RD4(v + 4, 16 * fb + 8 * hf + 4);
             if constexpr (kFirst) {
+                float rv[8];
                 from_frag(xr[g], rv);
-                b0 = par4(kPBo, fb, 2 * hf);
-                b1v = par4(kPBo, fb, 2 * hf + 1);
+                const f32x4 b0 = par4(kPBo, fb, 2 * hf), b1v = par4(kPBo, fb, 2 * hf + 1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = v[i] + rv[i] + (i < 4 ? b0[i & 3] : b1v[i & 3]);
+                MX_ACC_WR4(16 * fb + 8 * hf, v);
+                MX_ACC_WR4(16 * fb + 8 * hf + 4, v + 4);
             }
-            static_for<0, 8>([&](auto it) __attribute__((always_inline)) {
-                constexpr int i = decltype(it)::value;
-                float v;
-                MX_ACC_RD(v, 16 * fb + 8 * hf + i);
-                if constexpr (kFirst) {
-                    v = v + rv[i] + (i < 4 ? b0[i & 3] : b1v[i & 3]);
-                    MX_ACC_WR(16 * fb + 8 * hf + i, v);
-                }
-                s4[i & 3] += v;
-                q4[i & 3] = __builtin_fmaf(v, v, q4[i & 3]);
-            });
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s4[i & 3] += v[i];
+                q4[i & 3] = __builtin_fmaf(v[i], v[i], q4[i & 3]);
+            }
         });
         ln_mean = half_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / kHid);
         const float ex2 = half_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / kHid);
@@ -332,12 +354,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto ln_values = [&](auto gt, int pg, int pbe, float (&v)[8]) __attribute__((always_inline)) {
         constexpr int g = decltype(gt)::value, fb = g >> 1, hf = g & 1;
         const f32x4 g0 = par4(pg, fb, 2 * hf), g1 = par4(pg, fb, 2 * hf + 1), e0 = par4(pbe, fb, 2 * hf), e1 = par4(pbe, fb, 2 * hf + 1);
-        static_for<0, 8>([&](auto it) __attribute__((always_inline)) {
-            constexpr int i = decltype(it)::value;
-            float a;
-            MX_ACC_RD(a, 16 * fb + 8 * hf + i);
-            v[i] = __builtin_fmaf((a - ln_mean) * ln_rstd, i < 4 ? g0[i & 3] : g1[i & 3], i < 4 ? e0[i & 3] : e1[i & 3]);
-        });
+        float a[8];
+        MX_ACC_RD4(a, 16 * fb + 8 * hf);
+        MX_ACC_RD4(a + 4, 16 * fb + 8 * hf + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaf((a[i] - ln_mean) * ln_rstd, i < 4 ? g0[i & 3] : g1[i & 3], i < 4 ? e0[i & 3] : e1[i & 3]);
     };
 
     // x1 = LN1(x + ctx Wo^T + bo) -> this wave's activation fragments (over ctx: only this wave reads them, and
@@ -349,11 +370,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ln_values(gt, kPG1, kPBe1, v);
         *reinterpret_cast<bf16x8 *>(smem + act + g * kFrag) = to_frag(v);
         const f32x4 c0 = par4(kPB2, fb, 2 * hf), c1 = par4(kPB2, fb, 2 * hf + 1);
-        static_for<0, 8>([&](auto it) __attribute__((always_inline)) {
-            constexpr int i = decltype(it)::value;
-            const float y = v[i] + (i < 4 ? c0[i & 3] : c1[i & 3]);
-            MX_ACC_WR(16 * fb + 8 * hf + i, y);
-        });
+        float y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = v[i] + (i < 4 ? c0[i & 3] : c1[i & 3]);
+        MX_ACC_WR4(16 * fb + 8 * hf, y);
+        MX_ACC_WR4(16 * fb + 8 * hf + 4, y + 4);
     });
     asm volatile("s_nop 3" ::: "memory");
     MX_TRACE2(3);
@@ -364,34 +385,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // The epilogue E1(c), one PIECE = one G2 k-step of 16 ffn features: hfr[P][k] = B fragment of
     // gelu(acc1[P] + b1) for features 16 k .. 16 k + 15 of chunk c (P = c & 1).  A single wave hides ~5
     // instructions behind an MFMA, so a piece is cut into kE1Steps sub-steps that the segments below spread
-    // over 24 MFMAs (state between sub-steps: ev, eb, et, ep).
-    constexpr int kE1Steps = 35;  // bias load | 8 values x 4 | pack | swap + store
-    float ev[8], et0 = 0.0f, et1 = 0.0f;
+    // over 24 MFMAs.
+    // Sub-steps of a piece: 24, one behind each MFMA it is spread over.  A step applies ONE operation to FOUR
+    // values (a single wave issues in order: a dependent chain per value would pay the full VALU / transcendental
+    // latency at every instruction; four independent chains issue back to back):
+    //   steps 0 .. 10: values 0-3 (read | + bias | v^2 | clamp | fma | fma | * v | exp2 | + 1 | rcp | * v), 11 .. 21: values
+    //   4-7, 22: pack to bf16, 23: half-wave swaps -> hfr
+    constexpr int kE1Steps = 24;
+    float ev[8], ea[4], et[4];
     f32x4 eba = {0, 0, 0, 0}, ebc = {0, 0, 0, 0};
     uint32_t ep[4] = {0, 0, 0, 0};
     auto e1_step = [&](auto ptag, auto ktag, auto sttag, int chunk) __attribute__((always_inline)) {
         constexpr int P = decltype(ptag)::value, k = decltype(ktag)::value, step = decltype(sttag)::value;
         constexpr int fb = k >> 1, half = k & 1;
-        if constexpr (step == 0) {
-            eba = *reinterpret_cast<const f32x4 *>(par + kPB1 + chunk * kFC + fb * 32 + half * 16 + h * 4);
-            ebc = *reinterpret_cast<const f32x4 *>(par + kPB1 + chunk * kFC + fb * 32 + half * 16 + 8 + h * 4);
-        } else if constexpr (step <= 32) {
-            constexpr int i = (step - 1) >> 2, sub = (step - 1) & 3;
-            if constexpr (sub == 0) {         // v, t = min(v^2, 100)
-                float a;
-                MX_ACC_RD(a, 192 + 32 * P + 16 * fb + 8 * half + i);
-                et0 = a + (i < 4 ? eba[i & 3] : ebc[i & 3]);
-                et1 = fminf(et0 * et0, 100.0f);
-            } else if constexpr (sub == 1) {  // exponent v (C1 + C3 t + C5 t^2)
-                float pl = __builtin_fmaf(et1, kGC5, kGC3);
-                pl = __builtin_fmaf(pl, et1, kGC1);
-                et1 = pl * et0;
-            } else if constexpr (sub == 2) {  // 1 + exp2
-                et1 = 1.0f + __builtin_amdgcn_exp2f(et1);
-            } else {                          // v / (1 + exp)
-                ev[i] = et0 * __builtin_amdgcn_rcpf(et1);
+        if constexpr (step < 22) {
+            constexpr int grp = step / 11, op = step % 11;  // values 4 grp .. 4 grp + 3
+            if constexpr (op == 0) {
+                if constexpr (grp == 0) {
+                    eba = *reinterpret_cast<const f32x4 *>(par + kPB1 + chunk * kFC + fb * 32 + half * 16 + h * 4);
+                    ebc = *reinterpret_cast<const f32x4 *>(par + kPB1 + chunk * kFC + fb * 32 + half * 16 + 8 + h * 4);
+                }
+                MX_ACC_RD4(ea, 192 + 32 * P + 16 * fb + 8 * half + 4 * grp);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (op == 1) ea[j] += grp == 0 ? eba[j] : ebc[j];
+                    else if constexpr (op == 2) et[j] = ea[j] * ea[j];
+                    else if constexpr (op == 3) et[j] = fminf(et[j], 100.0f);
+                    else if constexpr (op == 4) ev[4 * grp + j] = __builtin_fmaf(et[j], kGC5, kGC3);
+                    else if constexpr (op == 5) et[j] = __builtin_fmaf(ev[4 * grp + j], et[j], kGC1);
+                    else if constexpr (op == 6) et[j] = et[j] * ea[j];
+                    else if constexpr (op == 7) et[j] = __builtin_amdgcn_exp2f(et[j]);
+                    else if constexpr (op == 8) et[j] = 1.0f + et[j];
+                    else if constexpr (op == 9) et[j] = __builtin_amdgcn_rcpf(et[j]);
+                    else ev[4 * grp + j] = ea[j] * et[j];
+                }
             }
-        } else if constexpr (step == 33) {
+        } else if constexpr (step == 22) {
             ep[0] = pack2(ev[0], ev[1]); ep[1] = pack2(ev[2], ev[3]); ep[2] = pack2(ev[4], ev[5]); ep[3] = pack2(ev[6], ev[7]);
         } else {
             frag_swap(ep[0], ep[1], ep[2], ep[3]);
@@ -399,10 +429,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             hfr[P][k] = __builtin_bit_cast(bf16x8, o);
         }
     };
-    // the sub-steps of piece k that go behind MFMA g (0..23) of the 24 it is spread over
+    // the sub-step of piece k that goes behind MFMA g (0..23) of the 24 it is spread over
     auto e1_under = [&](auto ptag, auto ktag, auto gtag, int chunk) __attribute__((always_inline)) {
-        constexpr int g = decltype(gtag)::value;
-        static_for<kE1Steps * g / 24, kE1Steps * (g + 1) / 24>([&](auto st) __attribute__((always_inline)) { e1_step(ptag, ktag, st, chunk); });
+        if constexpr (!(MX_TAIL2_ABLATE & 4)) e1_step(ptag, ktag, gtag, chunk);
     };
     auto e1_alone = [&](auto ptag, auto k0tag, int chunk) __attribute__((always_inline)) {  // two pieces with nothing to hide under
         MX_MFMA_DRAIN();
@@ -423,6 +452,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int f = decltype(ft)::value, s = f / 2, fb = f % 2;
             if constexpr (f % kSlotFrags == 0) slot_open();
             if constexpr (s == 0) MX_MFMA_Z(192 + 32 * P + 16 * fb, abuf[f % kAhead], bb[s % 3]);
+            else if constexpr (f % 2 == 0) MX_MFMA_W(192 + 32 * P + 16 * fb, abuf[f % kAhead], bb[s % 3], abuf[(f + 1) % kAhead]);
             else MX_MFMA(192 + 32 * P + 16 * fb, abuf[f % kAhead], bb[s % 3]);
             after_mfma(ft);
             if constexpr (fb == 1 && s + 3 < 24) bb[s % 3] = *reinterpret_cast<const bf16x8 *>(smem + act + (s + 3) * kFrag);
@@ -438,6 +468,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int f = decltype(ft)::value, s2 = f / 12, fb = f % 12;
             if constexpr (f % kSlotFrags == 0) slot_open();
             if constexpr (fb == 0) MX_MFMA_VB(16 * fb, abuf[f % kAhead], hfr[P][s2]);
+            else if constexpr (f % 2 == 0) MX_MFMA_W(16 * fb, abuf[f % kAhead], hfr[P][s2], abuf[(f + 1) % kAhead]);
             else MX_MFMA(16 * fb, abuf[f % kAhead], hfr[P][s2]);
             after_mfma(ft);
             if constexpr (E1) e1_under(ic<1 - P>{}, ic<f / 24>{}, ic<f % 24>{}, chunk + 1);

@@ -54,6 +54,8 @@ int main(int argc, char** argv) {
   { GemmParams p{}; p.a = x; p.lda = H; p.w = w1; p.w_rows = F; p.w_row0 = 0; p.bias = bias; p.m = m; p.n = F; p.k = H; p.out = out; p.ldo = F;
     run<EPI_BIAS_GELU, 2, 2, 2, 4>("ffn1", p, reps, (size_t)m * F * 2, out); run<EPI_BIAS_GELU, 2, 4, 2, 4>("ffn1", p, reps, (size_t)m * F * 2, out);
     run<EPI_BIAS_GELU, 4, 2, 2, 4>("ffn1", p, reps, (size_t)m * F * 2, out); run<EPI_BIAS_GELU, 2, 4, 4, 3>("ffn1", p, reps, (size_t)m * F * 2, out); run<EPI_BIAS_GELU, 2, 2, 4, 2>("ffn1", p, reps, (size_t)m * F * 2, out); }
+  { GemmParams p{}; p.a = x; p.lda = H; p.w = wqkv; p.w_rows = 3 * H; p.w_row0 = 2 * H; p.bias = bias; p.m = m; p.n = H; p.k = H; p.out_vt = q; p.ldvt = m; p.hidden = H;
+    run<EPI_VT, 2, 2, 2, 4>("vt", p, reps, (size_t)m * H * 2, q); run<EPI_VT, 2, 4, 4, 3>("vt", p, reps, (size_t)m * H * 2, q); run<EPI_VT, 2, 4, 2, 4>("vt", p, reps, (size_t)m * H * 2, q); }
   if (H == 768) { GemmParams p{}; p.a = hbuf; p.lda = F; p.w = w2; p.w_rows = H; p.w_row0 = 0; p.bias = bias; p.m = m; p.n = H; p.k = F; p.out = out; p.ldo = H; p.res = x; p.ldres = H; p.gamma = g; p.beta = b; p.eps = 1e-12f;
     run<EPI_BIAS_RES_LN, 1, 8, 2, 3>("ffn2+ln", p, reps, (size_t)m * H * 2, out); run<EPI_BIAS_RES_LN, 1, 8, 4, 2>("ffn2+ln", p, reps, (size_t)m * H * 2, out);
     p.a = x; p.lda = H; p.w = wqkv; p.k = H;

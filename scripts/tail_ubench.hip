@@ -21,9 +21,9 @@ using namespace mx;
 #define MX_TAIL_ABLATE 0
 #endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-__global__ void fill16(unsigned short* p, size_t n, unsigned seed) {
+__global__ void fill16(unsigned short* p, size_t n, unsigned seed, unsigned expo) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  for (; i < n; i += (size_t)gridDim.x * blockDim.x) { unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; p[i] = (unsigned short)(0x3a00u + (h & 0x3ff) + ((h >> 16) & 0x8000u)); }
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) { unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; p[i] = (unsigned short)(expo + (h & 0x7f) + ((h >> 16) & 0x8000u)); }
 }
 __global__ void fillf(float* p, size_t n, float v, float step) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; for (; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v + step * (float)(i % 37); }
 // K-blocked bf16 [k/32][rows][32] -> logical f32 [rows][k]
@@ -37,11 +37,14 @@ static uint16_t bf16_exact(float f) { unsigned int u; memcpy(&u, &f, 4); return 
 int main(int argc, char** argv) {
   int m = argc > 1 ? atoi(argv[1]) : 131072; int f = argc > 2 ? atoi(argv[2]) : 1536; int reps = argc > 3 ? atoi(argv[3]) : 2000; int po = argc > 4 ? atoi(argv[4]) : 1;
   const int skew_iters = argc > 5 ? atoi(argv[5]) : 0, skew_shift = argc > 6 ? atoi(argv[6]) : 8, skew_hi = argc > 7 ? atoi(argv[7]) : 512;
+  const int wmask = argc > 8 ? atoi(argv[8]) : 3;  // debugging: bit 0 = Wo non-zero, bit 1 = W1 / W2 non-zero
   bf16_t *x, *ctx, *w1, *w2, *wo, *wf, *out2; float *b1, *b2, *g, *b;
   CK(hipMalloc(&x, (size_t)m * 384 * 2)); CK(hipMalloc(&out2, (size_t)m * 384 * 2));
   CK(hipMalloc(&w1, (size_t)f * 384 * 2)); CK(hipMalloc(&w2, (size_t)f * 384 * 2)); CK(hipMalloc(&wf, tail_stream_elems(f) * 2)); CK(hipMalloc(&wo, 384 * 384 * 2)); CK(hipMalloc(&ctx, (size_t)m * 384 * 2));
   CK(hipMalloc(&b1, f * 4)); CK(hipMalloc(&b2, 384 * 4)); CK(hipMalloc(&g, 384 * 4)); CK(hipMalloc(&b, 384 * 4));
-  fill16<<<4096, 256>>>((unsigned short*)x, (size_t)m * 384, 1); fill16<<<4096, 256>>>((unsigned short*)ctx, (size_t)m * 384, 7); fill16<<<64, 256>>>((unsigned short*)wo, (size_t)384 * 384, 5); fill16<<<256, 256>>>((unsigned short*)w1, (size_t)f * 384, 2); fill16<<<256, 256>>>((unsigned short*)w2, (size_t)f * 384, 3);
+  // activations of magnitude 0.5 .. 1, weights 0.03 .. 0.06 (0.016 .. 0.03 for W2): every term of the tail matters
+  fill16<<<4096, 256>>>((unsigned short*)x, (size_t)m * 384, 1, 0x3f00); fill16<<<4096, 256>>>((unsigned short*)ctx, (size_t)m * 384, 7, 0x3f00); fill16<<<64, 256>>>((unsigned short*)wo, (size_t)384 * 384, 5, 0x3d00); fill16<<<256, 256>>>((unsigned short*)w1, (size_t)f * 384, 2, 0x3d00); fill16<<<256, 256>>>((unsigned short*)w2, (size_t)f * 384, 3, 0x3c80);
+  if (!(wmask & 1)) CK(hipMemset(wo, 0, 384 * 384 * 2)); if (!(wmask & 2)) { CK(hipMemset(w1, 0, (size_t)f * 384 * 2)); CK(hipMemset(w2, 0, (size_t)f * 384 * 2)); }
   fillf<<<8, 256>>>(b1, f, 0.01f, 0.003f); fillf<<<2, 256>>>(b2, 384, 0.01f, -0.002f); fillf<<<2, 256>>>(g, 384, 1.0f, 0.01f); fillf<<<2, 256>>>(b, 384, 0.0f, 0.005f);
   CK(hipDeviceSynchronize());
   { std::vector<unsigned short> kb((size_t)f * 384), kbo((size_t)384 * 384); std::vector<float> l1, l2, lo; std::vector<uint16_t> st(tail_stream_elems(f));
@@ -102,6 +105,23 @@ int main(int argc, char** argv) {
       std::vector<float> hb1(f), hb2(384), hg(384), hb(384), pp(tail2_param_floats());
       CK(hipMemcpy(hb1.data(), b1, f * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb2.data(), b2, 384 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hg.data(), g, 384 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), b, 384 * 4, hipMemcpyDeviceToHost));
       tail2_param_layout(hb2.data(), hg.data(), hb.data(), hb1.data(), hb2.data(), hg.data(), hb.data(), f, pp.data()); CK(hipMemcpy(pf, pp.data(), pp.size() * 4, hipMemcpyHostToDevice)); }
+    // f64 reference of a few rows (exact erf GELU, no intermediate rounding): which kernel is off, and where
+    std::vector<float> rl1, rl2, rlo; { std::vector<unsigned short> kb((size_t)f * 384), kbo((size_t)384 * 384);
+      CK(hipMemcpy(kb.data(), w1, kb.size() * 2, hipMemcpyDeviceToHost)); to_logical(kb, f, 384, rl1);
+      CK(hipMemcpy(kb.data(), w2, kb.size() * 2, hipMemcpyDeviceToHost)); to_logical(kb, 384, f, rl2);
+      CK(hipMemcpy(kbo.data(), wo, kbo.size() * 2, hipMemcpyDeviceToHost)); to_logical(kbo, 384, 384, rlo); }
+    auto bf = [](unsigned short u) { unsigned v = (unsigned)u << 16; float x_; memcpy(&x_, &v, 4); return (double)x_; };
+    auto ref_row = [&](int r, std::vector<double>& outv) {
+      std::vector<unsigned short> xrw(384), crw(384); std::vector<float> hb1(f), hb2(384), hg(384), hb(384);
+      hipMemcpy(xrw.data(), (unsigned short*)x + (size_t)r * 384, 768, hipMemcpyDeviceToHost); hipMemcpy(crw.data(), (unsigned short*)ctx + (size_t)r * 384, 768, hipMemcpyDeviceToHost);
+      hipMemcpy(hb1.data(), b1, f * 4, hipMemcpyDeviceToHost); hipMemcpy(hb2.data(), b2, 384 * 4, hipMemcpyDeviceToHost); hipMemcpy(hg.data(), g, 384 * 4, hipMemcpyDeviceToHost); hipMemcpy(hb.data(), b, 384 * 4, hipMemcpyDeviceToHost);
+      std::vector<double> v(384), x1(384), hh(f), y(384);
+      auto ln = [&](std::vector<double>& a, std::vector<double>& o) { double m_ = 0, q = 0; for (double t : a) m_ += t; m_ /= 384; for (double t : a) q += (t - m_) * (t - m_); q /= 384; for (int i = 0; i < 384; ++i) o[i] = (a[i] - m_) / sqrt(q + 1e-12) * hg[i] + hb[i]; };
+      for (int n = 0; n < 384; ++n) { double a = hb2[n] + bf(xrw[n]); for (int k = 0; k < 384; ++k) a += bf(crw[k]) * rlo[(size_t)n * 384 + k]; v[n] = a; }
+      ln(v, x1);
+      for (int j = 0; j < f; ++j) { double a = hb1[j]; for (int k = 0; k < 384; ++k) a += x1[k] * rl1[(size_t)j * 384 + k]; hh[j] = 0.5 * a * (1.0 + erf(a / sqrt(2.0))); }
+      for (int n = 0; n < 384; ++n) { double a = hb2[n] + x1[n]; for (int j = 0; j < f; ++j) a += hh[j] * rl2[(size_t)n * f + j]; y[n] = a; }
+      outv.resize(384); ln(y, outv); };
     CK(tail2_setup());
     TailParams p3 = p2; p3.wf2 = wf2; p3.pf = pf; p3.out = out3; p3.trace = nullptr;
     CK(hipMemset(out3, 0xff, (size_t)m * 384 * 2));
@@ -111,7 +131,11 @@ int main(int argc, char** argv) {
       double mx = 0, sum = 0, ref = 0; size_t bad = 0, worst = 0;
       for (size_t i = 0; i < a.size(); ++i) { unsigned ua = (unsigned)a[i] << 16, uc = (unsigned)c[i] << 16; float fa, fc; memcpy(&fa, &ua, 4); memcpy(&fc, &uc, 4);
         const double d = fabs((double)fa - fc); if (!(d <= 1e30)) { ++bad; continue; } if (d > mx) { mx = d; worst = i; } sum += d; ref += fabs(fa); }
-      printf("tail2 vs tail: max |diff| %.5f (row %zu col %zu), mean |diff| %.6f, mean |value| %.4f, non-finite %zu\n", mx, worst / 384, worst % 384, sum / a.size(), ref / a.size(), bad); }
+      printf("tail2 vs tail: max |diff| %.5f (row %zu col %zu), mean |diff| %.6f, mean |value| %.4f, non-finite %zu\n", mx, worst / 384, worst % 384, sum / a.size(), ref / a.size(), bad);
+      for (int r : {0, 37, 64, 127, (int)(worst / 384)}) { if (r >= m) continue; std::vector<double> rv; ref_row(r, rv); double e1 = 0, e2 = 0; int w1_ = 0, w2_ = 0;
+        for (int i = 0; i < 384; ++i) { const double d1 = fabs(bf(a[(size_t)r * 384 + i]) - rv[i]), d2 = fabs(bf(c[(size_t)r * 384 + i]) - rv[i]); if (d1 > e1) { e1 = d1; w1_ = i; } if (d2 > e2) { e2 = d2; w2_ = i; } }
+        printf("  row %6d vs f64 reference: tail max err %.5f (col %d)   tail2 max err %.5f (col %d)\n", r, e1, w1_, e2, w2_);
+        if (r == 0) { printf("  row 0 tail2 - ref, features 0..63:"); for (int i = 0; i < 64; ++i) printf("%s%+.3f", i % 16 == 0 ? "\n    " : " ", bf(c[i]) - rv[i]); printf("\n"); } } }
     for (int i = 0; i < 3; ++i) CK(launch_tail2(0, p3));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) CK(launch_tail2(0, p3)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
