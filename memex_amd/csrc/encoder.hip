@@ -71,7 +71,7 @@ struct mx_encoder {
     float *out_dev = nullptr;
     bool profiling = false;
     bool fused_tail = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_UNFUSED_TAIL=1 keeps the three GEMMs
-    bool tail2 = false;       // large passes use tail2_kernel (encoder_tail2.hip); MEMEX_HIP_TAIL=1 keeps tail_kernel everywhere
+    bool tail2 = false;       // MEMEX_HIP_TAIL=2|3: the layer tail runs on tail2_kernel (encoder_tail2.hip)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
     mx_encoder_stats stats{};
     int tail2_min_rows = 0;
@@ -222,8 +222,6 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             tp.b1 = L.bi; tp.b2 = L.bo2; tp.f = F; tp.m = t_pad; tp.out = e->x; tp.ldo = H; tp.gamma = L.ln2g; tp.beta = L.ln2b;
             tp.eps = c.ln_eps;
             tp.wf2 = L.wf2; tp.pf = L.pf;
-            // 128-token workgroups, one per CU: worth it once they fill the chip; below that tail_kernel's 64-token
-            // workgroups (two per CU) finish a pass sooner (a query is a few hundred tokens)
             if (e->tail2 && t_pad >= e->tail2_min_rows) MX_HIP(launch_tail2(st, tp));
             else MX_HIP(launch_tail(st, tp));
             continue;
@@ -354,11 +352,15 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     {
         const char *ev = getenv("MEMEX_HIP_UNFUSED_TAIL");
         e->fused_tail = tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
+        // tail2_kernel (encoder_tail2.hip) is the experimental activation-stationary form of the tail: correct and a
+        // little more accurate, 3-5 % faster than tail_kernel alone on the chip, 1-2 % SLOWER inside the encoder
+        // (scripts/r3_enc_ab.sh).  MEMEX_HIP_TAIL=2 selects it at every pass size, =3 from 128 rows
+        // per CU on; the default (and =1) is tail_kernel.
         const char *tv = getenv("MEMEX_HIP_TAIL");
-        e->tail2 = e->fused_tail && tail2_supported(cfg->hidden, cfg->ffn) && !(tv && tv[0] == '1');
+        e->tail2 = e->fused_tail && tail2_supported(cfg->hidden, cfg->ffn) && tv && (tv[0] == '2' || tv[0] == '3');
         hipDeviceProp_t prop;
         e->tail2_min_rows = hipGetDeviceProperties(&prop, device) == hipSuccess ? 128 * prop.multiProcessorCount : 32768;
-        if (tv && tv[0] == '2') e->tail2_min_rows = 0;  // MEMEX_HIP_TAIL=2: tail2_kernel at every pass size (tests)
+        if (tv && tv[0] == '2') e->tail2_min_rows = 0;
     }
     auto bail = [&](int code) {
         destroy_impl(e);

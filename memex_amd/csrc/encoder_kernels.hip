@@ -320,20 +320,31 @@ static hipError_t gemm_go(hipStream_t s, const GemmParams &p) {
 // 80 KiB 4-stage ring -> TWO workgroups per CU, one's epilogue overlapping the other's MFMAs.  The
 // LayerNorm GEMMs need a full row per tile: 128 x 384 (8 waves, 128 KiB ring) and 64 x 768
 // (3-stage 52 KiB ring); 64 x 384 at 2 workgroups/CU was measured slower (weight re-reads double).
-// Large passes (round 3, scripts/gemm_ubench.hip at 131k tokens): 256 x 384 tiles -- 8 waves, wave tile 128 x 96
-// (12 MFMAs per 7 fragment reads instead of 6 per 5), a 3-stage 120 KiB ring, one workgroup per CU -- run the
-// QK projection in 116 us instead of 133 at K = 384 and 337 instead of 387 at K = 768, the FFN-up GEMM in 742
-// instead of 807 (bit-identical outputs: every configuration sums k in the same order).  Small passes (a
-// query) keep the 128 x 192 tiles: more, shorter workgroups.
+// 256 x 384 tiles (8 waves, wave tile 128 x 96: 12 MFMAs per 7 fragment reads instead of 6 per 5, a 3-stage
+// 120 KiB ring, one workgroup per CU) for large passes.  Round 3: alone on the chip with synthetic operands
+// (scripts/gemm_ubench.hip, 131k tokens) they run the QK projection in 116 us instead of 133 at K = 384, in 337
+// instead of 387 at K = 768, and the FFN-up GEMM in 742 instead of 807 -- bit-identical outputs, every
+// configuration sums k in the same order.  INSIDE the encoder (scripts/r3_enc_ab.sh: same box, same process,
+// real operands, the package at its power cap) the gain is +1.2 % chunks/s for the hidden-768 models with the QK
+// projection alone on big tiles, -1.3 % at hidden 384, and the V projection loses 30 us per layer (its
+// feature-major epilogue): so the default is bit 0 (QK) for K >= 768 only.  MEMEX_HIP_GEMM_BIG=<mask> (bit 0 QK,
+// bit 1 V, bit 2 bias / GELU GEMMs) overrides for A/B runs.
 constexpr int kBigTileRows = 32768;
 
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
-    const bool big = p.m >= kBigTileRows && p.n % 384 == 0;
+    // MEMEX_HIP_GEMM_BIG: bit 0 = QK projection, bit 1 = V projection, bit 2 = bias / GELU GEMMs (A/B switch)
+    static const int big_mask = [] {
+        const char *e = getenv("MEMEX_HIP_GEMM_BIG");
+        return e ? atoi(e) : -1;
+    }();
+    const bool fits = p.m >= kBigTileRows && p.n % 384 == 0;
+    const int mask = big_mask >= 0 ? big_mask : (p.k >= 768 ? 1 : 0);
+    const bool big_qk = fits && (mask & 1), big_vt = fits && (mask & 2), big_ff = fits && (mask & 4);
     switch (epi) {
-        case EPI_BIAS: return big ? gemm_go<EPI_BIAS, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_BIAS, 2, 2, 2, 32, 4>(s, p);
-        case EPI_BIAS_GELU: return big ? gemm_go<EPI_BIAS_GELU, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_BIAS_GELU, 2, 2, 2, 32, 4>(s, p);
-        case EPI_QKV: return big ? gemm_go<EPI_QKV, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_QKV, 2, 2, 2, 32, 4>(s, p);
-        case EPI_VT: return big ? gemm_go<EPI_VT, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_VT, 2, 2, 2, 32, 4>(s, p);
+        case EPI_BIAS: return big_ff ? gemm_go<EPI_BIAS, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_BIAS, 2, 2, 2, 32, 4>(s, p);
+        case EPI_BIAS_GELU: return big_ff ? gemm_go<EPI_BIAS_GELU, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_BIAS_GELU, 2, 2, 2, 32, 4>(s, p);
+        case EPI_QKV: return big_qk ? gemm_go<EPI_QKV, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_QKV, 2, 2, 2, 32, 4>(s, p);
+        case EPI_VT: return big_vt ? gemm_go<EPI_VT, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_VT, 2, 2, 2, 32, 4>(s, p);
         case EPI_BIAS_RES_LN:
             if (p.n == 384) return gemm_go<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>(s, p);
             if (p.n == 768) return gemm_go<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>(s, p);

@@ -1,4 +1,4 @@
-// encoder_tail2.hip -- the layer tail for LARGE passes (>= 32768 packed tokens), hidden = 384:
+// encoder_tail2.hip -- an EXPERIMENTAL second form of the layer tail (MEMEX_HIP_TAIL=2|3; default: encoder_tail.hip), hidden = 384:
 //     x1  = LayerNorm1(x + Wo ctx + bo);   out = LayerNorm2(x1 + W2 gelu(W1 x1 + b1) + b2)
 // Same role as encoder_tail.hip (reference: the BERT self-output / intermediate / output blocks behind
 // `model.encode(&segments)`, lib/libmemex/src/llm/embedding.rs:109; restated in oracle/bert_oracle.py), built
