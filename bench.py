@@ -645,6 +645,7 @@ def main():
             "data": "synthetic" if a.data == "gaussian" else "synthetic (clustered)",
             "config": {"workload": f"{rows_total}x{a.dim} f32 corpus in HBM ({a.data}), query batch {a.batch}, top-{k}",
                        "rows_per_gpu": n_local,
+                       "wait": "poll" if os.environ.get("MEMEX_HIP_SPIN") == "1" else "sleep",
                        "parallelism": (f"row-shard x{shards} inside one process (mx_index_open_sharded)" if in_library else
                                        f"row-shard x{world}, one process per GPU" if world > 1 else "single GPU")},
             "rccl_ranks": n_gpus if (world > 1 and not one_device) or exchange == "rccl" else 0,

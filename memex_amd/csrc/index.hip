@@ -1217,9 +1217,7 @@ int mx_index_size(mx_index *idx, uint64_t *n) {
     return MX_OK;
 }
 
-int mx_index_reserve(mx_index *idx, uint64_t rows) {
-    if (!idx) return fail(MX_EINVAL, "null index");
-    std::lock_guard<std::mutex> lk(idx->mu);
+static int reserve_locked(mx_index *idx, uint64_t rows) {
     if (idx->composite()) {
         const uint64_t G = idx->shards.size();
         for (uint64_t g = 0; g < G; ++g) {
@@ -1233,6 +1231,12 @@ int mx_index_reserve(mx_index *idx, uint64_t rows) {
     }
     DeviceGuard g(idx->device);
     return ensure_capacity(idx, rows);
+}
+
+int mx_index_reserve(mx_index *idx, uint64_t rows) {
+    if (!idx) return fail(MX_EINVAL, "null index");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    return reserve_locked(idx, rows);
 }
 
 int mx_index_set_id_offset(mx_index *idx, uint64_t off) {
@@ -1635,17 +1639,69 @@ int mx_index_load(mx_index *idx, const char *dir) {
     }
     clear_locked(idx);
     set_raw_ingest(idx, hdr[1] == 1);  // stored values of a compressed corpus go back in unchanged
+    // Cold start (a collection after a restart): the file is read in 32 MB pieces into two PINNED buffers; a piece
+    // goes to the device on a copy stream while the next one is being read and the previous one is ingested
+    // (validated on the device like any device-row append): the load runs at the speed of the read, not at the
+    // sum of read + pageable copy + host validation + ingest (round 2).  A sharded index takes its pieces
+    // through composite_add (each shard validates its part).
     const uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / ((uint64_t)idx->dim * 4));
-    std::vector<float> host((size_t)std::min<uint64_t>(chunk, std::max<uint64_t>(n, 1)) * idx->dim);
+    const size_t chunk_bytes = (size_t)chunk * idx->dim * sizeof(float);
+    mx_index *t0 = idx->composite() ? idx->shards[0] : idx;
+    DeviceGuard dg(t0->device);
+    float *pin[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t cs = nullptr;
     int rc = MX_OK;
-    for (uint64_t r = 0; r < n && rc == MX_OK; r += chunk) {
+    auto release = [&] {
+        for (int i = 0; i < 2; ++i) {
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            if (dev[i]) (void)hipFree(dev[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+        if (cs) (void)hipStreamDestroy(cs);
+    };
+    for (int i = 0; i < 2 && rc == MX_OK; ++i) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&pin[i]), chunk_bytes, hipHostMallocDefault) != hipSuccess ||
+            (!idx->composite() && hipMalloc(reinterpret_cast<void **>(&dev[i]), chunk_bytes) != hipSuccess) ||
+            hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
+            rc = fail(MX_ENOMEM, "staging buffers for %s", path.c_str());
+    }
+    if (rc == MX_OK && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) rc = fail(MX_EDEVICE, "stream creation failed");
+    if (rc == MX_OK && n > 0) rc = reserve_locked(idx, n);
+    uint64_t pending_rows = 0;  // rows of the piece that is on its way to dev[pending_buf]
+    int pending_buf = 0;
+    auto ingest_pending = [&]() -> int {
+        if (!pending_rows) return MX_OK;
+        MX_HIP(hipStreamWaitEvent(idx->stream, ev[pending_buf], 0));
+        const int r = add_device_locked(idx, dev[pending_buf], pending_rows, nullptr);
+        pending_rows = 0;
+        return r;
+    };
+    int buf = 0;
+    for (uint64_t r = 0; r < n && rc == MX_OK; r += chunk, buf ^= 1) {
         const uint64_t m = std::min(chunk, n - r);
-        if (fread(host.data(), sizeof(float), (size_t)m * idx->dim, f) != (size_t)m * idx->dim) {
+        if (fread(pin[buf], sizeof(float), (size_t)m * idx->dim, f) != (size_t)m * idx->dim) {
             rc = fail(MX_EIO, "%s: read failed", path.c_str());
             break;
         }
-        rc = add_host_locked(idx, host.data(), m, nullptr);
+        if (idx->composite()) {
+            rc = composite_add(idx, pin[buf], m, nullptr, false);
+            continue;
+        }
+        // dev[buf] was last read by the ingest of the piece before the previous one: that call returned synchronised
+        hipError_t e = hipMemcpyAsync(dev[buf], pin[buf], (size_t)m * idx->dim * sizeof(float), hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess) e = hipEventRecord(ev[buf], cs);
+        if (e != hipSuccess) {
+            rc = fail(MX_EDEVICE, "hipMemcpy H2D: %s", hipGetErrorString(e));
+            break;
+        }
+        rc = ingest_pending();  // the previous piece, while this one is in flight
+        pending_rows = m;
+        pending_buf = buf;
     }
+    if (rc == MX_OK) rc = ingest_pending();
+    if (cs) (void)hipStreamSynchronize(cs);
+    release();
     fclose(f);
     set_raw_ingest(idx, false);
     if (rc != MX_OK) {

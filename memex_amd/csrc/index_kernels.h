@@ -90,7 +90,8 @@ hipError_t launch_scan16(hipStream_t s, int kc, bool collect, int nwg, const Sca
 // (re)build tiles [tile0, tile1) of the bf16 filter copy from the padded f32 store.  Layout: tile t
 // (32 rows), k-step s (16 dims), MFMA lane l -> 8 bf16 at ((t*(ds/16) + s)*64 + l)*8, holding row
 // 32t + (l&31), dims 16s + 8(l>>5) .. +7: exactly the A operand of v_mfma_f32_32x32x16_bf16.
-// Values are bf16(c_i * 1/|c|) (NaN for a zero-norm row: it must pass every filter).
+// Values are bf16(c_i * 1/|c|); a zero-norm row is stored as zeros (it scores 0 in the scan and reaches
+// finish_kernel through the index's zero-row list instead).
 // ec_max: device word, atomicMax'ed with the float bits of the largest |bf16(c/|c|) - c/|c|| built.
 // src_tile0: x / scale hold the rows of tiles src_tile0 .. (a staging window; 0 = the whole store).
 // Only rows in [row_lo, row_hi) are (re)written: a 16-byte fragment belongs to ONE row, so rows of a

@@ -337,7 +337,7 @@ hipError_t launch_retry_setup(hipStream_t s, float *theta, const float *theta_re
 // ---------------------------------------------------------------------------------------------
 // 4 consecutive dims (4*c4 ..) of a row.  CMP = false: the f32 store.  CMP = true (compressed corpus:
 // the bf16 filter copy is the ONLY copy): the 8-byte half of the 16-byte MFMA fragment holding those
-// dims (layout: launch_shadow), widened to f32 exactly; a zero-norm row is stored as NaN and reads as 0.
+// dims (layout: launch_shadow), widened to f32 exactly; a zero-norm row is stored as zeros.
 template <bool CMP>
 __device__ __forceinline__ float4 row_load4(const float *__restrict__ x, const void *__restrict__ xh, int ds, uint32_t row,
                                             int c4) {

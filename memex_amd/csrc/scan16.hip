@@ -34,12 +34,11 @@
 // tile_stride > 1 spreads the sample evenly over the corpus (a contiguous head of the corpus can be
 // unrepresentative: the first documents ingested).
 //
-// Measured (10M x 384, B = 256; scripts/scan16_ubench.hip): 726 shader cycles per slot against 512 of
-// pure MFMA issue per SIMD; DMA alone 1.13 ms (6.8 TB/s), compute alone 1.15 ms at 2.14 GHz, together
-// 1.9 ms at an effective 1.35 GHz: the launch is bound by the 1400 W package power cap (1.97 TFLOP of
-// bf16 MFMA per launch is ~2 J on its own), not by a pipe.  Earlier forms of the kernel -- fragment
-// reads and DMA issue bunched after the barrier, one accumulator, per-tile scale multiply -- took
-// 1050-1150 cycles per slot and 2.25 ms.
+// Measured (10M x 384, B = 256; profiles/r2_scan16_traffic.json, r2_power_scan16_*.log): the collect launch takes
+// 1.73-1.78 ms = 4.3-4.4 TB/s at the 1400 W package power cap, shader clock 1.44-1.46 GHz, MFMA pipe 71 % busy
+// in cycles (81 % at 768-d); the DMA stream alone runs at 7.1 TB/s and the MFMA + fragment-read half alone at
+// 1.86 PFLOP/s, both at full clock and below the cap: together they need more than the cap allows, so what
+// pays is energy per launch, not cycles.
 #include <type_traits>
 
 #include "index_kernels.h"
@@ -182,8 +181,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
             rp = rp1;
         }
 
-        // ---- tile epilogue: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*h.  The copy
-        // holds c/|c|, so the accumulator already is the approximate cosine (NaN for a zero-norm row).
+        // ---- tile epilogue: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*h.
         // The copy holds c/|c|, so the accumulator already is the approximate cosine (a zero-norm row is
         // stored as zeros and scores 0: such rows reach finish_kernel through the index's zero-row list).
         float v[16];

@@ -22,10 +22,30 @@ def read(path):
         return None
 
 
+def leased_hwmon():
+    """hwmon directory of the GPU this container was given: the host has several, /sys shows them all, and card0
+    is not necessarily the leased one (round 2 logged an idle neighbour: 239 W, 95 MHz).  Match the PCI bus id
+    that rocm-smi reports for device 0 against /sys/class/drm/card*/device."""
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+    try:
+        r = subprocess.run(["rocm-smi", "--showbus", "-d", "0"], capture_output=True, text=True, timeout=10)
+        import re
+        m = re.search(r"PCI Bus:\s*([0-9a-fA-F:.]+)", r.stdout)
+        if m:
+            bus = m.group(1).lower()
+            for h in cards:
+                dev = os.path.realpath(os.path.dirname(os.path.dirname(h)))
+                if os.path.basename(dev).lower() == bus:
+                    return [h], bus
+    except Exception:
+        pass
+    return cards[:1], None
+
+
 def main():
     out_path = sys.argv[1]
     cmd = sys.argv[sys.argv.index("--") + 1:]
-    hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+    hw, bus = leased_hwmon()
     stop = threading.Event()
     lines = []
     t0 = time.time()
@@ -67,7 +87,7 @@ def main():
     for t in th:
         t.join(timeout=12)
     with open(out_path, "w") as f:
-        f.write("# hwmon dirs: " + ",".join(hw) + "\n")
+        f.write("# hwmon dirs: " + ",".join(hw) + (f" (matched PCI bus {bus})" if bus else " (NOT matched to the leased device: the S rows may belong to another GPU)") + "\n")
         f.write("\n".join(lines) + "\n")
         f.write("# ---- command stdout ----\n" + r.stdout + "\n# ---- command stderr ----\n" + r.stderr[-2000:] + "\n")
     sys.stdout.write(r.stdout)
