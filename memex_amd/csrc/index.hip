@@ -370,7 +370,7 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
     }
     MX_HIP(hipMemsetAsync(fx + idx->n * (size_t)idx->ds, 0, (want - idx->n) * rowb, idx->stream));
     MX_HIP(hipMemsetAsync(fsc + idx->n, 0, (want - idx->n) * sizeof(float), idx->stream));
-    if (idx->want_filter && idx->kc <= kMaxKC) {
+    if (idx->want_filter && idx->kc <= kMaxKC16) {
         // the filter copy is an accelerator, not a requirement: without HBM for it the index
         // keeps working on the f32 scan
         const size_t hb = (size_t)want * idx->ds * 2;
@@ -517,13 +517,22 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     if (rc != MX_OK) return rc;
     Scratch &s = idx->s;
     hipStream_t st = idx->stream;
+    const bool trivial = idx->n == 0 || k == 0;
+    if (idx->compressed && idx->kc > kMaxKC16 && !trivial)
+        return fail(MX_EUNSUPPORTED, "a compressed corpus supports dim <= %d", kMaxKC16 * kChunkFloats);
+    // wide rows (768 < dim_pad <= 1536) have their own scan kernel over the filter copy: 128 queries per pass
+    const bool wide = idx->kc > kMaxKC;
+    const bool fast = !trivial && idx->mode == MX_SEARCH_AUTO && (wide ? idx->xh != nullptr && idx->kc <= kMaxKC16 : true) &&
+                      idx->wild_rows == 0 && k <= 256 && idx->n_zero <= (uint64_t)kZeroCap;
+    if (fast && wide && B > kWideBatch) {
+        rc = search_batch(idx, d_q, kWideBatch, k, d_ids, d_scores, d_dists, d_nfound);
+        if (rc != MX_OK) return rc;
+        const size_t o = (size_t)kWideBatch * k;
+        return search_batch(idx, d_q + (size_t)kWideBatch * idx->dim, B - kWideBatch, k, d_ids + o, d_scores + o,
+                            d_dists ? d_dists + o : nullptr, d_nfound + kWideBatch);
+    }
     MX_HIP(launch_prep_queries(st, d_q, B, idx->dim, idx->ds, s.qfrag, s.qpad, s.qnorm2, s.theta, s.e1,
                                idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags));
-    const bool trivial = idx->n == 0 || k == 0;
-    if (idx->compressed && idx->kc > kMaxKC && !trivial)
-        return fail(MX_EUNSUPPORTED, "a compressed corpus supports dim <= %d", kMaxKC * kChunkFloats);
-    const bool fast = !trivial && idx->mode == MX_SEARCH_AUTO && idx->kc <= kMaxKC && idx->wild_rows == 0 && k <= 256 &&
-                      idx->n_zero <= (uint64_t)kZeroCap;
     const uint32_t *h_ovf = s.host_flags, *h_qfl = s.host_flags + 3 * kMaxBatch;
     auto any_bad_query = [&] {
         uint32_t bad = 0;
@@ -621,6 +630,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         p.lane_max = s.lane_max;
         p.overflow = s.overflow;
         auto scan = [&](bool collect) {
+            if (wide) return launch_scan16w(st, idx->kc, collect, idx->nwg, p);
             return idx->xh ? launch_scan16(st, idx->kc, collect, idx->nwg, p) : launch_scan(st, idx->kc, collect, idx->nwg, p);
         };
         auto collect = [&](bool first) -> int {
@@ -1019,6 +1029,7 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
     std::call_once(g_scan_once, [] {
         g_scan_setup_err = scan_setup();
         if (g_scan_setup_err == hipSuccess) g_scan_setup_err = scan16_setup();
+        if (g_scan_setup_err == hipSuccess) g_scan_setup_err = scan16w_setup();
         if (g_scan_setup_err == hipSuccess) g_scan_setup_err = finish_setup();
     });
     if (g_scan_setup_err != hipSuccess)
@@ -1026,7 +1037,9 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
     std::unique_ptr<mx_index> idx(new mx_index());
     idx->key = k;
     idx->dim = dim;
-    idx->ds = (int)round_up((uint64_t)dim, kChunkFloats);
+    // stored row width: a multiple of 128 dims (one scan slot); wide rows (> 768) of 256, so that the two waves
+    // that share a row's k-steps in scan16w_kernel get whole slots each
+    idx->ds = (int)round_up((uint64_t)dim, dim > kMaxKC * kChunkFloats ? 2 * kChunkFloats : kChunkFloats);
     idx->kc = idx->ds / kChunkFloats;
     idx->device = device;
     hipDeviceProp_t prop;
@@ -1444,7 +1457,7 @@ int mx_index_set_filter_copy(mx_index *idx, int on) {
         }
         return MX_OK;
     }
-    if (idx->xh || idx->cap == 0 || idx->kc > kMaxKC) return MX_OK;  // present, or built with the first rows
+    if (idx->xh || idx->cap == 0 || idx->kc > kMaxKC16) return MX_OK;  // present, or built with the first rows
     void *nh = nullptr;
     const size_t hb = (size_t)idx->cap * idx->ds * 2;
     hipError_t e = hipMalloc(&nh, hb);
@@ -1470,8 +1483,8 @@ int mx_index_set_corpus_mode(mx_index *idx, int mode) {
         }
         return MX_OK;
     }
-    if (mode == MX_CORPUS_BF16 && idx->kc > kMaxKC)
-        return fail(MX_EUNSUPPORTED, "a compressed corpus supports dim <= %d", kMaxKC * kChunkFloats);
+    if (mode == MX_CORPUS_BF16 && idx->kc > kMaxKC16)
+        return fail(MX_EUNSUPPORTED, "a compressed corpus supports dim <= %d", kMaxKC16 * kChunkFloats);
     DeviceGuard g(idx->device);
     MX_HIP(hipStreamSynchronize(idx->stream));
     auto F = [](void *p) {

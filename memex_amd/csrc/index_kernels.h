@@ -26,6 +26,11 @@ constexpr int kMaxKC = 6;          // k-chunks per row the MFMA scan supports (d
 constexpr int kSlot16Bytes = kTileRows * kChunkFloats * 2;
 constexpr int kRing16 = 16;        // 16 x 8 KiB = 128 KiB ring, 15 slots in flight
 constexpr int kScan16LdsBytes = kRing16 * kSlot16Bytes;
+// wide rows (scan16w_kernel, 768 < dim_pad <= 1536): the k-steps of a row are dealt to two waves, 128 queries per
+// launch; the ring plus 16 KiB in which the even-slot waves hand their partial sums to the odd-slot waves
+constexpr int kMaxKC16 = 12;
+constexpr int kWideBatch = 128;
+constexpr int kScan16WideLdsBytes = kRing16 * kSlot16Bytes + 4 * 64 * 16 * 4;
 
 constexpr int kMaxBatch = 256;     // queries per scan pass (8 waves x 32 MFMA columns)
 constexpr int kRecCap = 32;        // lane-private records per collect launch: one record = the lane's 16 scores of a tile
@@ -86,6 +91,8 @@ hipError_t scan16_setup();
 // collect = false: sample launch (lane maxima only); collect = true: survivors of theta are appended
 hipError_t launch_scan(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
 hipError_t launch_scan16(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
+hipError_t scan16w_setup();
+hipError_t launch_scan16w(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);  // kc in {8, 10, 12}, <= 128 queries
 
 // (re)build tiles [tile0, tile1) of the bf16 filter copy from the padded f32 store.  Layout: tile t
 // (32 rows), k-step s (16 dims), MFMA lane l -> 8 bf16 at ((t*(ds/16) + s)*64 + l)*8, holding row

@@ -626,30 +626,32 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
             sc[j] = CMP ? 0.0f : p.scale[rr[j]];
             dot[j] = 0.0f;
         }
-        // ds <= 768: at most 3 float4 per lane and row; all 12 row loads are in flight together (the rows
-        // are random 1.5-3 KB reads in a multi-GB array: every one is a TLB miss)
-        float4 x[4][kMaxKC / 2];
+        // per pass of 768 dims: at most 3 float4 per lane and row, all 12 row loads in flight together (the rows
+        // are random 1.5-3 KB reads in a multi-GB array: every one is a TLB miss); wide rows take two passes
+        for (int tb = 0; tb * 64 < nc4; tb += kMaxKC / 2) {
+            float4 x[4][kMaxKC / 2];
 #pragma unroll
-        for (int t = 0; t < kMaxKC / 2; ++t) {
-            const int c4 = lane + 64 * t;
-            if (c4 < nc4) {
+            for (int t = 0; t < kMaxKC / 2; ++t) {
+                const int c4 = lane + 64 * (tb + t);
+                if (c4 < nc4) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x[j][t] = row_load4<CMP>(p.x, p.xh, ds, rr[j], c4);
+                    for (int j = 0; j < 4; ++j) x[j][t] = row_load4<CMP>(p.x, p.xh, ds, rr[j], c4);
+                }
             }
-        }
 #pragma unroll
-        for (int t = 0; t < kMaxKC / 2; ++t) {
-            const int c4 = lane + 64 * t;
-            if (c4 < nc4) {
-                const float4 a = *reinterpret_cast<const float4 *>(qv + 4 * c4);
+            for (int t = 0; t < kMaxKC / 2; ++t) {
+                const int c4 = lane + 64 * (tb + t);
+                if (c4 < nc4) {
+                    const float4 a = *reinterpret_cast<const float4 *>(qv + 4 * c4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float m = CMP ? 1.0f : sc[j];
-                    dot[j] = fmaf(a.x * invq, x[j][t].x * m, dot[j]);
-                    dot[j] = fmaf(a.y * invq, x[j][t].y * m, dot[j]);
-                    dot[j] = fmaf(a.z * invq, x[j][t].z * m, dot[j]);
-                    dot[j] = fmaf(a.w * invq, x[j][t].w * m, dot[j]);
-                    if (CMP) sc[j] = fmaf(x[j][t].x, x[j][t].x, fmaf(x[j][t].y, x[j][t].y, fmaf(x[j][t].z, x[j][t].z, fmaf(x[j][t].w, x[j][t].w, sc[j]))));
+                    for (int j = 0; j < 4; ++j) {
+                        const float m = CMP ? 1.0f : sc[j];
+                        dot[j] = fmaf(a.x * invq, x[j][t].x * m, dot[j]);
+                        dot[j] = fmaf(a.y * invq, x[j][t].y * m, dot[j]);
+                        dot[j] = fmaf(a.z * invq, x[j][t].z * m, dot[j]);
+                        dot[j] = fmaf(a.w * invq, x[j][t].w * m, dot[j]);
+                        if (CMP) sc[j] = fmaf(x[j][t].x, x[j][t].x, fmaf(x[j][t].y, x[j][t].y, fmaf(x[j][t].z, x[j][t].z, fmaf(x[j][t].w, x[j][t].w, sc[j]))));
+                    }
                 }
             }
         }
@@ -749,7 +751,9 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     uint32_t *srow = reinterpret_cast<uint32_t *>(qv + ds);                     // [kStageRows] row ids
     float *stage = reinterpret_cast<float *>(fsm) + 2 * kStageRows;            // behind kStageRows keys
     const int pitch = ds + 4;                                                   // +16 B: conflict-free ds_read_b128 across rows
-    if (m2 <= (uint32_t)kStageRows) {
+    // rows that fit behind the keys in ent[]'s storage: 32 up to 1020 dims, 21 at 1536
+    const uint32_t stage_rows = min((uint32_t)kStageRows, (uint32_t)((sizeof(Cand) * kCandCap - 2 * kStageRows * sizeof(float)) / (pitch * sizeof(float))));
+    if (m2 <= stage_rows) {
         if (tid < (int)m2) srow[tid] = ent[tid].row;
         __syncthreads();  // row ids are out of ent[]: its storage becomes keys + staged rows
         const uint32_t nc4s = (uint32_t)ds >> 2;
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
 }
 
 hipError_t finish_setup() {
-    const int lds = (int)(sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)kMaxKC * kChunkFloats + kFinishTailBytes);
+    const int lds = (int)(sizeof(Cand) * (size_t)kCandCap + sizeof(float) * (size_t)kMaxKC16 * kChunkFloats + kFinishTailBytes);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -21,6 +21,14 @@ def run(n, d, B, k, steps=10):
     st = idx.stats()
     print(f"n={n} d={d} B={B} k={k}: {dt*1e3:.3f} ms/step {B/dt:.0f} QPS scan {st.scan_bytes/max(st.scan_ms,1e-9)/1e6:.0f} GB/s fallback={st.fallback_queries} cand/q={st.candidates/max(1,st.queries):.0f}")
     idx.close()
+if len(sys.argv) > 1 and sys.argv[1] == "wide":      # wide rows: scan16w_kernel, 128 queries per pass
+    run(4_000_000, 1024, 128, 10, 6)
+    run(4_000_000, 1024, 256, 10, 6)
+    run(4_000_000, 1536, 128, 10, 6)
+    run(4_000_000, 1536, 256, 10, 6)
+    run(4_000_000, 1280, 128, 10, 6)
+    run(4_000_000, 1024, 1, 10, 6)
+    sys.exit(0)
 run(10_000_000, 768, 256, 10, 6)
 run(10_000_000, 384, 1, 10)
 run(10_000_000, 384, 32, 10)

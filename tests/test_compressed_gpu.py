@@ -21,7 +21,7 @@ def _check_against_stored_rows(idx, Q, k, oracle):
     return rows, ids
 
 
-@pytest.mark.parametrize("n,d,seed", [(50003, 384, 1), (20000, 768, 2), (7001, 100, 3), (40, 384, 4)])
+@pytest.mark.parametrize("n,d,seed", [(50003, 384, 1), (20000, 768, 2), (7001, 100, 3), (40, 384, 4), (20000, 1024, 5), (9000, 1500, 6)])
 def test_compressed_search_is_exact_on_the_stored_rows(n, d, seed, oracle, lib_built, tmp_path):
     from memex_amd import _lib
     from memex_amd.index import FlatIndex

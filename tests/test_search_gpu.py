@@ -501,3 +501,40 @@ def test_concurrent_single_queries_are_combined(oracle, lib_built):
     assert not errors, errors[:3]
     assert st.queries == nthreads * per
     assert st.searches < st.queries, (st.searches, st.queries)     # at least some calls shared a batch
+
+
+@pytest.mark.parametrize("n,d,B,k,seed", [
+    (20000, 1024, 256, 10, 31), (20000, 1536, 200, 10, 32), (30000, 896, 64, 10, 33), (9000, 1300, 5, 100, 34),
+    (50000, 1024, 129, 10, 35), (300, 1536, 4, 10, 36),
+])
+def test_wide_rows_use_the_split_scan(n, d, B, k, seed, oracle, lib_built):
+    """768 < dim <= 1536 (bge-large / e5-large 1024-d, 1536-d API embeddings): scan16w_kernel deals a row's k-steps
+    to two waves, 128 queries per pass; a batch of 129..256 queries is two passes.  Same bar: bit-exact, and the
+    MFMA scan answers every query (before round 3 such rows went query by query through the EXACT path)."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    Q = rng.standard_normal((B, d), dtype=np.float32)
+    Q[0] = X[n // 2] * 2.0
+    X[7] = 0
+    X[100:125] = X[50]                                   # 26 exact ties: more survivors than finish_kernel can stage
+    Q[B - 1] = X[50] * 3.0                               # in LDS at 1536 dims (21 rows) -> its chains read global memory
+    with FlatIndex(d) as idx:
+        assert idx.add(X) == 1 and len(idx) == n
+        oi, od, os_, onf = oracle.search(X, Q, k)
+        ids, sc, di, nf = idx.search(Q, k)
+        np.testing.assert_array_equal(ids, oi)
+        np.testing.assert_array_equal(bits(di), bits(od))
+        np.testing.assert_array_equal(bits(sc), bits(os_))
+        np.testing.assert_array_equal(nf, onf)
+        st = idx.stats()
+        assert st.fallback_queries == 0 and st.scan_launches >= (2 if B > 128 else 1)
+        idx.set_filter_copy(False)                      # no copy: the EXACT path answers, same bits
+        ids2, sc2, _, _ = idx.search(Q[:3], k)
+        np.testing.assert_array_equal(ids2, oi[:3])
+        np.testing.assert_array_equal(bits(sc2), bits(os_[:3]))
+        idx.set_filter_copy(True)                       # rebuilt from the resident rows
+        ids3, sc3, _, _ = idx.search(Q, k)
+        np.testing.assert_array_equal(ids3, oi)
+        np.testing.assert_array_equal(bits(sc3), bits(os_))
+
