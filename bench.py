@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, same guide
+MFMA_PEAK_I8_TOPS = 5000.0  # dense int8 (2x the bf16 rate, same guide)
 BLOCK = 1_000_000          # the corpus is defined by GLOBAL 1M-row blocks: every N sees the same rows
 
 
@@ -55,8 +56,8 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--data", choices=["gaussian", "clustered"], default="gaussian",
                     help="rows of the headline corpus: i.i.d. N(0,1) (BASELINE's synthetic corpus) or clustered")
-    ap.add_argument("--scan", choices=["bf16", "f32"], default="bf16",
-                    help="what the scan kernel streams: the bf16 filter copy (default) or the f32 rows")
+    ap.add_argument("--scan", choices=["i8", "bf16", "f32"], default="i8",
+                    help="what the scan kernel streams: the int8 filter copy, the bf16 filter copy or the f32 rows")
     ap.add_argument("--alt-steps", type=int, default=20,
                     help="N=1 only: extra steps on the OTHER scan kernel, reported beside the main one (0 = skip)")
     ap.add_argument("--side-steps", type=int, default=20,
@@ -385,10 +386,11 @@ def traffic_from_profile(rows_total: int, dim: int, world: int, scan: str):
     """HBM bytes per launch of the collect-scan kernel from the committed PMC pass (profiles/, FETCH_SIZE
     x2 gfx950 correction + WRITE_SIZE, separate --pmc runs).  bench.py cannot collect PMCs itself, so
     this is only reported when a committed profile matches the workload being run."""
-    tag = {(384, "bf16"): "scan16", (384, "f32"): "scan", (768, "bf16"): "scan16_768"}.get((dim, scan))
+    tag = {(384, "bf16"): "scan16", (384, "f32"): "scan", (768, "bf16"): "scan16_768", (384, "i8"): "scan8",
+           (768, "i8"): "scan8_768"}.get((dim, scan))
     if world != 1 or rows_total != 10_000_000 or tag is None:
         return None
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_traffic.json")
         if os.path.exists(path):
             try:
@@ -413,12 +415,14 @@ def roofline_of(st, scan: str, dim: int, batch: int, rows_total: int, world: int
     scan_s = st.scan_ms / 1e3
     achieved = (st.scan_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
     launches = max(1, st.scan_launches)
-    elem = 2 if scan == "bf16" else 4
+    elem = {"i8": 1, "bf16": 2, "f32": 4}[scan]
+    mfma_peak = MFMA_PEAK_I8_TOPS if scan == "i8" else MFMA_PEAK_TFLOPS
     tflops = (2.0 * batch * (st.scan_bytes / elem) / scan_s / 1e12) if scan_s > 0 else 0.0
     kc = (dim + 127) // 128
     return {
         "bound": "hbm",
-        "kernel": f"mx::scan16_kernel<{kc},1> (bf16 filter copy, collect launch)" if scan == "bf16"
+        "kernel": f"mx::scan8_kernel<{kc},1> (int8 filter copy, collect launch)" if scan == "i8"
+                  else f"mx::scan16_kernel<{kc},1> (bf16 filter copy, collect launch)" if scan == "bf16"
                   else f"mx::scan_kernel<{kc},1> (f32 rows, collect launch)",
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
@@ -428,7 +432,7 @@ def roofline_of(st, scan: str, dim: int, batch: int, rows_total: int, world: int
         "ms_per_launch": st.scan_ms / launches,
         "traffic": traffic_from_profile(rows_total, dim, world, scan),
         "mfma_tflops": tflops,
-        "mfma_frac": tflops / MFMA_PEAK_TFLOPS,
+        "mfma_frac": tflops / mfma_peak,
         "power_note": "package power sits at its 1400 W cap during this kernel (profiles/r2_power_*.log)",
     }
 
@@ -527,8 +531,7 @@ def main():
     n_local = (hi - lo) // shards
     shard_devs = ([0] * shards if one_device else list(range(shards))) if in_library else None
     idx = FlatIndex(a.dim, key=None, device=dev, devices=shard_devs)
-    if a.scan == "f32":
-        idx.set_filter_copy(False)
+    idx.set_filter_copy({"f32": False, "bf16": "bf16", "i8": "i8"}[a.scan])
     idx.reserve(hi - lo)
     idx.set_id_offset(lo)
     fill_index(idx, rows_total, a.dim, lo, hi, a.data)
@@ -570,12 +573,12 @@ def main():
     if single and a.alt_steps > 0:
         # the same job on the other scan kernel (results must be identical: same certificate, same rescoring)
         other = "f32" if a.scan == "bf16" else "bf16"
-        idx.set_filter_copy(other == "bf16")
+        idx.set_filter_copy("bf16" if other == "bf16" else False)
         dt2, st2 = timed_steps(idx, step, fence, 3, a.alt_steps, world)
         alt = {"scan": other, "value": a.batch * a.alt_steps / dt2, "unit": "queries/s", "steps": a.alt_steps,
                "ms_per_step": dt2 / a.alt_steps * 1e3, "ids_equal_main_run": bool(torch.equal(bufs.ids, ids_main)),
                "roofline": roofline_of(st2, other, a.dim, a.batch, rows_total, world)}
-        idx.set_filter_copy(a.scan == "bf16")
+        idx.set_filter_copy({"f32": False, "bf16": "bf16", "i8": "i8"}[a.scan])
         step()
     host_api = None
     if single and a.side_steps > 0:

@@ -191,7 +191,9 @@ typedef struct mx_index_stats {
     double max_abs_err;         /* profiling only: max |approx - exact| cosine on candidates */
     uint64_t filter_copy_bytes; /* HBM held by the bf16 filter copy (0 = scanning the f32 rows) */
     uint64_t retry_queries;     /* queries rescanned once with a tightened threshold (lane buffer overflow) */
-    double approx_err_bound;    /* per-query bound e1 on |bf16 score - cosine| in force for the last batch */
+    double approx_err_bound;    /* largest per-query bound e1 on |filter score - cosine| of the last batch */
+    uint64_t filter_kind;       /* what the scan streams now: 0 = the f32 rows, 2 = int8 filter copy, 3 = bf16 filter copy */
+    uint64_t filter_demotions;  /* times an automatically chosen int8 copy was rebuilt as bf16 (dense corpus)   */
 } mx_index_stats;
 int mx_index_set_profiling(mx_index *idx, int on); /* record HIP events around the scan kernel */
 int mx_index_get_stats(mx_index *idx, mx_index_stats *out);

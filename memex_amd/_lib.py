@@ -51,7 +51,8 @@ class IndexStats(ctypes.Structure):
                 ("scan_bytes", ctypes.c_uint64), ("scan_ms", ctypes.c_double),
                 ("candidates", ctypes.c_uint64), ("max_abs_err", ctypes.c_double),
                 ("filter_copy_bytes", ctypes.c_uint64), ("retry_queries", ctypes.c_uint64),
-                ("approx_err_bound", ctypes.c_double)]
+                ("approx_err_bound", ctypes.c_double), ("filter_kind", ctypes.c_uint64),
+                ("filter_demotions", ctypes.c_uint64)]
 
 
 class EncoderCfg(ctypes.Structure):

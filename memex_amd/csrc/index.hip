@@ -51,6 +51,12 @@ namespace {
 // the host a 4-word summary + its sequence number (host_sum); the block itself is only copied when the
 // summary reports an overflow, and on the EXACT path
 constexpr int kFlagWords = 4 * kMaxBatch;
+// Filter copy an f32 corpus keeps unless told otherwise: int8 up to 512 dims, bf16 above.  The int8 certificate is
+// ~0.02-0.026 wide whatever the width (quantisation noise of a unit vector does not depend on its length) while the
+// spread of cosines shrinks like 1/sqrt(dim): measured on Gaussian rows, B = 256, k = 10 (scripts/r3_dims.sh):
+// int8 / bf16 = 444k / 320k QPS at 128 dims, 270k / 181k at 256, 172k / 112k at 384, 134k / 96k at 512,
+// 54k / 68k at 768, 78k / 88k at 1024, 38k / 57k at 1536.
+constexpr int kAutoI8MaxDim = 512;  // filter copy of an f32 corpus: int8 (scan8.hip) or bf16 (scan16.hip)
 constexpr int kSumWords = 5;  // max overflow code, candidates, any bad query, e1 of query 0, seq
 
 struct Scratch {
@@ -71,6 +77,7 @@ struct Scratch {
     uint32_t *lane_cnt = nullptr;
     float *lane_max = nullptr;
     float *qstage = nullptr;       // [256, dim] host->device query staging
+    float *qscale = nullptr;       // [256] quantisation step of each query (8-bit filter copy)
     uint64_t *out_ids = nullptr;   // [256, kcap] device outputs for the host API
     float *out_scores = nullptr;
     float *out_dists = nullptr;
@@ -134,6 +141,11 @@ struct mx_index {
     float *scale = nullptr;
     void *xh = nullptr;          // bf16 filter copy (fragment order), cap/32 tiles; null = not kept
     bool want_filter = true;     // keep a filter copy when HBM allows (mx_index_set_filter_copy)
+    // 8-bit filter copy (scan8.hip): xh holds int8 fragments in 64-row tiles, tsc one quantisation step per 32-row
+    // half tile.  An f32 corpus only; the compressed corpus keeps its bf16 rows.
+    bool filter_i8 = false;
+    bool filter_auto = true;     // the library picks the kind (by row width) and may demote int8 to bf16 when a batch overflows
+    float *tsc = nullptr;
     // compressed corpus (mx_index_set_corpus_mode): xh is the ONLY copy of the rows; x / scale are not
     // allocated, appends pass through the small f32 staging window xs / ss
     bool compressed = false;
@@ -233,14 +245,14 @@ int free_index(mx_index *idx) {
     auto F = [](void *p) {
         if (p) (void)hipFree(p);
     };
-    F(idx->x); F(idx->scale); F(idx->xh); F(idx->flags); F(idx->xs); F(idx->ss); F(idx->zero_rows);
+    F(idx->x); F(idx->scale); F(idx->xh); F(idx->tsc); F(idx->flags); F(idx->xs); F(idx->ss); F(idx->zero_rows);
     Scratch &s = idx->s;
     F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.theta_retry); F(s.todo); F(s.dev_flags); F(s.done_ctr);
     if (s.host_flags) (void)hipHostFree(s.host_flags);
     if (s.host_sum) (void)hipHostFree(s.host_sum);
     for (void *hp : {(void *)s.h_q, (void *)s.h_ids, (void *)s.h_scores, (void *)s.h_dists, (void *)s.h_nf})
         if (hp) (void)hipHostFree(hp);
-    F(s.lane_rec); F(s.lane_tile); F(s.lane_cnt); F(s.lane_max); F(s.qstage); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
+    F(s.lane_rec); F(s.lane_tile); F(s.lane_cnt); F(s.lane_max); F(s.qstage); F(s.qscale); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
     F(s.exact_keys); F(s.sel_state); F(s.max_err);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
@@ -276,6 +288,7 @@ int ensure_scratch(mx_index *idx) {
     MX_HIP(hipMalloc(&s.lane_cnt, (size_t)idx->nwg * kScanThreads * sizeof(uint32_t)));
     MX_HIP(hipMalloc(&s.lane_max, (size_t)idx->nwg * kScanThreads * sizeof(float)));
     MX_HIP(hipMalloc(&s.qstage, (size_t)kMaxBatch * idx->dim * sizeof(float)));
+    MX_HIP(hipMalloc(&s.qscale, kMaxBatch * sizeof(float)));
     MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_q), (size_t)kMaxBatch * idx->dim * sizeof(float), hipHostMallocDefault));
     MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_nf), kMaxBatch * sizeof(int32_t), hipHostMallocDefault));
     MX_HIP(hipMalloc(&s.max_err, sizeof(float)));
@@ -345,7 +358,7 @@ struct DevBuf {
 int ensure_capacity(mx_index *idx, uint64_t rows) {
     if (rows <= idx->cap) return MX_OK;
     uint64_t want = std::max<uint64_t>(rows, idx->cap + idx->cap / 2);
-    want = round_up(std::max<uint64_t>(want, 1024), kTileRows);
+    want = round_up(std::max<uint64_t>(want, 1024), kTile8Rows);
     if (idx->compressed) {  // the bf16 copy is the corpus: it must grow, there is nothing to fall back to
         DevBuf nh2;
         const size_t hb = (size_t)want * idx->ds * 2;
@@ -359,7 +372,7 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
         idx->cap = want;
         return MX_OK;
     }
-    DevBuf nx, nsc, nh;
+    DevBuf nx, nsc, nh, nts;
     const size_t rowb = (size_t)idx->ds * sizeof(float);
     MX_HIP(hipMalloc(&nx.p, want * rowb));
     MX_HIP(hipMalloc(&nsc.p, want * sizeof(float)));
@@ -373,26 +386,40 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
     if (idx->want_filter && idx->kc <= kMaxKC16) {
         // the filter copy is an accelerator, not a requirement: without HBM for it the index
         // keeps working on the f32 scan
-        const size_t hb = (size_t)want * idx->ds * 2;
-        if (hipMalloc(&nh.p, hb) != hipSuccess) {
+        const size_t eb = idx->filter_i8 ? 1 : 2;  // bytes per stored element
+        const size_t hb = (size_t)want * idx->ds * eb, tb = (size_t)(want / kTileRows) * sizeof(float);
+        if (hipMalloc(&nh.p, hb) != hipSuccess || (idx->filter_i8 && hipMalloc(&nts.p, tb) != hipSuccess)) {
             (void)hipGetLastError();
+            if (nh.p) (void)hipFree(nh.release());
             nh.p = nullptr;
         } else {
-            const size_t used = idx->xh ? (size_t)round_up(idx->n, kTileRows) * idx->ds * 2 : 0;
+            const uint64_t used_rows = idx->xh ? round_up(idx->n, kTile8Rows) : 0;
+            const size_t used = (size_t)used_rows * idx->ds * eb;
             if (used) MX_HIP(hipMemcpyAsync(nh.p, idx->xh, used, hipMemcpyDeviceToDevice, idx->stream));
             MX_HIP(hipMemsetAsync(static_cast<char *>(nh.p) + used, 0, hb - used, idx->stream));
-            if (!idx->xh && idx->n)  // (re)enabled on a populated index
-                MX_HIP(launch_shadow(idx->stream, fx, fsc, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh.p,
-                                     idx->flags + 2));
+            if (idx->filter_i8) {
+                const size_t tused = (size_t)(used_rows / kTileRows) * sizeof(float);
+                if (tused) MX_HIP(hipMemcpyAsync(nts.p, idx->tsc, tused, hipMemcpyDeviceToDevice, idx->stream));
+                MX_HIP(hipMemsetAsync(static_cast<char *>(nts.p) + tused, 0, tb - tused, idx->stream));
+            }
+            if (!idx->xh && idx->n) {  // (re)enabled on a populated index
+                const uint32_t t1 = (uint32_t)((idx->n + kTileRows - 1) / kTileRows);
+                if (idx->filter_i8)
+                    MX_HIP(launch_shadow8(idx->stream, fx, fsc, idx->ds, 0, t1, idx->n, nh.p, static_cast<float *>(nts.p), idx->flags + 2));
+                else
+                    MX_HIP(launch_shadow(idx->stream, fx, fsc, idx->ds, 0, t1, nh.p, idx->flags + 2));
+            }
         }
     }
     MX_HIP(hipStreamSynchronize(idx->stream));
     if (idx->x) (void)hipFree(idx->x);
     if (idx->scale) (void)hipFree(idx->scale);
     if (idx->xh) (void)hipFree(idx->xh);
+    if (idx->tsc) (void)hipFree(idx->tsc);
     idx->x = static_cast<float *>(nx.release());
     idx->scale = static_cast<float *>(nsc.release());
     idx->xh = nh.release();
+    idx->tsc = static_cast<float *>(nts.release());
     idx->cap = want;
     return MX_OK;
 }
@@ -457,17 +484,22 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
         return MX_OK;
     }
     MX_HIP(launch_ingest(idx->stream, d_rows, n, idx->dim, idx->x, idx->scale, idx->n, idx->ds, idx->flags, 0, idx->zero_rows, idx->n));
-    if (idx->xh)  // tiles touched by this append (the first one may already be partly filled)
-        MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, (uint32_t)(idx->n / kTileRows),
-                             (uint32_t)((idx->n + n + kTileRows - 1) / kTileRows), idx->xh, idx->flags + 2));
+    // tiles touched by this append (the first one may already be partly filled; an 8-bit half tile is requantised
+    // as a whole: its step depends on all of its rows)
+    auto refilter = [&](uint64_t row_lo, uint64_t row_hi) -> hipError_t {
+        const uint32_t h0 = (uint32_t)(row_lo / kTileRows), h1 = (uint32_t)((row_hi + kTileRows - 1) / kTileRows);
+        if (idx->filter_i8)  // both halves of the last 64-row scan tile: the one past row_hi becomes zeros with step 0
+            return launch_shadow8(idx->stream, idx->x, idx->scale, idx->ds, h0, (uint32_t)round_up(std::max(h1, h0 + 1), 2), row_hi, idx->xh, idx->tsc, idx->flags + 2);
+        return launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, h0, std::max(h1, h0 + 1), idx->xh, idx->flags + 2);
+    };
+    if (idx->xh) MX_HIP(refilter(idx->n, idx->n + n));
     uint32_t fl[4] = {0, 0, 0, 0};
     rc = commit_ingest(idx, fl);
     if (rc != MX_OK) {
         // rows past idx->n are never read, but the filter copy's tile of row n may now hold garbage: rebuild it
         if (idx->xh) {
             const std::string keep = last_error_slot();
-            MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, (uint32_t)(idx->n / kTileRows),
-                                 (uint32_t)(idx->n / kTileRows + 1), idx->xh, idx->flags + 2));
+            MX_HIP(refilter(idx->n, idx->n));
             last_error_slot() = keep;
         }
         return rc;
@@ -481,17 +513,22 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
 // how many tiles the sample launch visits: enough that the k-th largest of 2*nwg lane maxima is a
 // useful threshold (expected survivors of the collect launch ~ k * N / sample, times the margin's
 // share) and small enough to stay a few percent of the pass
-uint32_t sample_stride(uint64_t full_tiles, int nwg, int k) {
+uint32_t sample_stride(uint64_t full_tiles, int nwg, int k, bool filt8, int ds) {
     // 1/64 of the tiles for k <= 10.  Measured at 10M x 384 (B = 256): the sample launch costs 65 / 38 / 24 /
     // 17 us at 1/32, 1/64, 1/128, 1/256; a weaker threshold means more records for finish_kernel to sift
     // (62 / 63 / 72 us, and at 1/256 lanes start to overflow their 32 records), while the collect launch
     // hardly notices since appends became whole-record stores (1.76 / 1.77 / 1.79 ms).  1/64 is the
-    // fastest end to end.  MEMEX_HIP_SAMPLE_DIV overrides the 64 (a tuning knob: results do not depend on it).
-    static const double div = [] {
+    // fastest end to end.  The int8 copy's certificate is five times wider (e1 0.022 against 0.004), so a weak
+    // threshold costs it far more rows: 1/8 of the tiles (1/64: 78 % of the queries overflow their lane buffers and
+    // take the retry pass; 1/16: 3 %; 1/8: none, 1.35 ms per step; 1/4: 1.42 ms -- scripts/r3_i8_sample.sh; at 512
+    // dims 1/8 still overflows and 1/4 does not -- scripts/r3_dims.sh).
+    // MEMEX_HIP_SAMPLE_DIV overrides both (a tuning knob: results do not depend on it).
+    static const double env_div = [] {
         const char *e = getenv("MEMEX_HIP_SAMPLE_DIV");
-        const double v = e ? atof(e) : 64.0;
-        return v >= 2.0 && v <= 4096.0 ? v : 64.0;
+        const double v = e ? atof(e) : 0.0;
+        return v >= 2.0 && v <= 4096.0 ? v : 0.0;
     }();
+    const double div = env_div > 0.0 ? env_div : filt8 ? (ds <= 384 ? 8.0 : 4.0) : 64.0;
     const double f = std::min(0.5, std::max(1.0 / div, (double)k / (10.0 * div)));
     const uint64_t target = std::max<uint64_t>((uint64_t)nwg, (uint64_t)((double)full_tiles * f));
     return (uint32_t)std::max<uint64_t>(1, full_tiles / std::max<uint64_t>(target, 1));
@@ -510,6 +547,29 @@ int run_exact(mx_index *idx, const std::vector<int> &qs, int k, uint64_t *d_ids,
     return MX_OK;
 }
 
+// int8 filter copy -> bf16 filter copy, rebuilt from the f32 rows (an automatic choice that did not suit the data)
+int demote_filter(mx_index *idx) {
+    DevBuf nh;
+    const size_t hb = (size_t)idx->cap * idx->ds * 2;
+    if (hipMalloc(&nh.p, hb) != hipSuccess) {
+        (void)hipGetLastError();
+        return MX_ENOMEM;  // no room for the wider copy: stay on int8
+    }
+    MX_HIP(hipStreamSynchronize(idx->stream));
+    if (idx->xh) (void)hipFree(idx->xh);
+    if (idx->tsc) (void)hipFree(idx->tsc);
+    idx->xh = nullptr;
+    idx->tsc = nullptr;
+    idx->filter_i8 = false;
+    MX_HIP(hipMemsetAsync(nh.p, 0, hb, idx->stream));
+    MX_HIP(hipMemsetAsync(idx->flags + 2, 0, sizeof(uint32_t), idx->stream));
+    MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh.p,
+                         idx->flags + 2));
+    MX_HIP(hipStreamSynchronize(idx->stream));
+    idx->xh = nh.release();
+    return MX_OK;
+}
+
 // one batch (B <= 256) with queries and outputs on the device
 int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids, float *d_scores, float *d_dists,
                  int32_t *d_nfound) {
@@ -521,8 +581,9 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     if (idx->compressed && idx->kc > kMaxKC16 && !trivial)
         return fail(MX_EUNSUPPORTED, "a compressed corpus supports dim <= %d", kMaxKC16 * kChunkFloats);
     // wide rows (768 < dim_pad <= 1536) have their own scan kernel over the filter copy: 128 queries per pass
-    const bool wide = idx->kc > kMaxKC;
-    const bool fast = !trivial && idx->mode == MX_SEARCH_AUTO && (wide ? idx->xh != nullptr && idx->kc <= kMaxKC16 : true) &&
+    const bool filt8 = idx->xh != nullptr && idx->filter_i8 && !idx->compressed;  // 8-bit copy: 256 queries per pass at every width
+    const bool wide = idx->kc > kMaxKC && !filt8;
+    const bool fast = !trivial && idx->mode == MX_SEARCH_AUTO && (idx->kc > kMaxKC ? idx->xh != nullptr && idx->kc <= kMaxKC16 : true) &&
                       idx->wild_rows == 0 && k <= 256 && idx->n_zero <= (uint64_t)kZeroCap;
     if (fast && wide && B > kWideBatch) {
         rc = search_batch(idx, d_q, kWideBatch, k, d_ids, d_scores, d_dists, d_nfound);
@@ -532,7 +593,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                             d_dists ? d_dists + o : nullptr, d_nfound + kWideBatch);
     }
     MX_HIP(launch_prep_queries(st, d_q, B, idx->dim, idx->ds, s.qfrag, s.qpad, s.qnorm2, s.theta, s.e1,
-                               idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags));
+                               idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags, filt8, s.qscale));
     const uint32_t *h_ovf = s.host_flags, *h_qfl = s.host_flags + 3 * kMaxBatch;
     auto any_bad_query = [&] {
         uint32_t bad = 0;
@@ -615,7 +676,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         fp.seq = ++s.flag_seq;
         MX_HIP(launch_finish(st, B, fp));  // n_found = 0, empty slots
     } else if (fast) {
-        const uint64_t tiles = (idx->n + kTileRows - 1) / kTileRows, full = idx->n / kTileRows;
+        const uint64_t trows = filt8 ? kTile8Rows : kTileRows;  // rows per scan tile
+        const uint64_t tiles = (idx->n + trows - 1) / trows, full = idx->n / trows;
         ScanParams p;
         p.x = idx->x;
         p.xh = idx->xh;
@@ -629,7 +691,10 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         p.lane_cnt = s.lane_cnt;
         p.lane_max = s.lane_max;
         p.overflow = s.overflow;
+        p.tscale = idx->tsc;
+        p.qscale = s.qscale;
         auto scan = [&](bool collect) {
+            if (filt8) return launch_scan8(st, idx->kc, collect, idx->nwg, p);
             if (wide) return launch_scan16w(st, idx->kc, collect, idx->nwg, p);
             return idx->xh ? launch_scan16(st, idx->kc, collect, idx->nwg, p) : launch_scan(st, idx->kc, collect, idx->nwg, p);
         };
@@ -646,7 +711,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
             }
             if (first) {
                 idx->stats.scan_launches += 1;
-                idx->stats.scan_bytes += tiles * kTileRows * idx->ds * (idx->xh ? 2ull : 4ull);
+                idx->stats.scan_bytes += tiles * trows * idx->ds * (filt8 ? 1ull : idx->xh ? 2ull : 4ull);
             }
             return MX_OK;
         };
@@ -655,7 +720,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         if (tiles > 2ull * idx->nwg) {
             p.tile_begin = 0;
             p.tile_end = (uint32_t)full;
-            p.tile_stride = sample_stride(full, idx->nwg, k);
+            p.tile_stride = sample_stride(full, idx->nwg, k, filt8, idx->ds);
             MX_HIP(scan(false));
             MX_HIP(launch_theta(st, B, k, idx->nwg, s.lane_max, s.e1, s.theta));
         }
@@ -675,6 +740,15 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
             for (int b = 0; b < B; ++b) {
                 if (h_ovf[b] == 1) ++retry;
                 else if (h_ovf[b] >= 2) exact.push_back(b);
+            }
+            if (filt8 && idx->filter_auto && (size_t)(retry + (int)exact.size()) * 16 > (size_t)B) {
+                // More than 1/16 of the batch did not fit the int8 pass: this corpus is too dense for the int8
+                // certificate (neighbourhoods narrower than ~0.05 in cosine).  Rebuild the copy as bf16 (one pass
+                // over the f32 rows) and answer the batch on it; the index stays on bf16.
+                if (demote_filter(idx) == MX_OK) {
+                    idx->stats.filter_demotions += 1;
+                    return search_batch(idx, d_q, B, k, d_ids, d_scores, d_dists, d_nfound);
+                }
             }
             if (retry) {
                 // ONE more pass for all overflowed queries of the batch, with the threshold finish derived
@@ -1030,6 +1104,7 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
         g_scan_setup_err = scan_setup();
         if (g_scan_setup_err == hipSuccess) g_scan_setup_err = scan16_setup();
         if (g_scan_setup_err == hipSuccess) g_scan_setup_err = scan16w_setup();
+        if (g_scan_setup_err == hipSuccess) g_scan_setup_err = scan8_setup();
         if (g_scan_setup_err == hipSuccess) g_scan_setup_err = finish_setup();
     });
     if (g_scan_setup_err != hipSuccess)
@@ -1041,6 +1116,11 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
     // that share a row's k-steps in scan16w_kernel get whole slots each
     idx->ds = (int)round_up((uint64_t)dim, dim > kMaxKC * kChunkFloats ? 2 * kChunkFloats : kChunkFloats);
     idx->kc = idx->ds / kChunkFloats;
+    {   // which filter copy an f32 corpus keeps (mx_index_set_filter_copy overrides): MEMEX_HIP_FILTER=bf16|i8
+        const char *fk = getenv("MEMEX_HIP_FILTER");
+        idx->filter_auto = !(fk && fk[0]);
+        idx->filter_i8 = idx->filter_auto ? idx->ds <= kAutoI8MaxDim : (fk[0] == 'i' || fk[0] == '8');
+    }
     idx->device = device;
     hipDeviceProp_t prop;
     MX_HIP(hipGetDeviceProperties(&prop, device));
@@ -1438,6 +1518,7 @@ int mx_index_search(mx_index *idx, const float *q, int B, int k, uint64_t *ids, 
 
 int mx_index_set_filter_copy(mx_index *idx, int on) {
     if (!idx) return fail(MX_EINVAL, "null index");
+    if (on < 0 || on > 3) return fail(MX_EINVAL, "filter copy: 0 = none, 1 = kind chosen by the library, 2 = int8, 3 = bf16 (got %d)", on);
     std::lock_guard<std::mutex> lk(idx->mu);
     if (idx->composite()) {
         for (mx_index *sh : idx->shards) {
@@ -1448,26 +1529,42 @@ int mx_index_set_filter_copy(mx_index *idx, int on) {
     }
     DeviceGuard g(idx->device);
     if (idx->compressed) return on ? MX_OK : fail(MX_EINVAL, "a compressed corpus has no f32 rows to fall back to");
-    idx->want_filter = on != 0;
-    if (!on) {
+    const bool i8 = on == 2 || (on == 1 && idx->ds <= kAutoI8MaxDim);
+    auto drop = [&]() -> int {
         if (idx->xh) {
             MX_HIP(hipStreamSynchronize(idx->stream));
             (void)hipFree(idx->xh);
+            if (idx->tsc) (void)hipFree(idx->tsc);
             idx->xh = nullptr;
+            idx->tsc = nullptr;
         }
         return MX_OK;
+    };
+    idx->want_filter = on != 0;
+    if (!on) return drop();
+    if (idx->xh && idx->filter_i8 != i8) {  // the other kind is resident: replace it
+        int rc = drop();
+        if (rc != MX_OK) return rc;
     }
+    idx->filter_i8 = i8;
+    idx->filter_auto = on == 1;
     if (idx->xh || idx->cap == 0 || idx->kc > kMaxKC16) return MX_OK;  // present, or built with the first rows
-    void *nh = nullptr;
-    const size_t hb = (size_t)idx->cap * idx->ds * 2;
-    hipError_t e = hipMalloc(&nh, hb);
+    DevBuf nh, nts;
+    const size_t hb = (size_t)idx->cap * idx->ds * (i8 ? 1 : 2), tb = (size_t)(idx->cap / kTileRows) * sizeof(float);
+    hipError_t e = hipMalloc(&nh.p, hb);
+    if (e == hipSuccess && i8) e = hipMalloc(&nts.p, tb);
     if (e != hipSuccess) return fail(MX_ENOMEM, "hipMalloc(filter copy, %zu bytes): %s", hb, hipGetErrorString(e));
-    MX_HIP(hipMemsetAsync(nh, 0, hb, idx->stream));
+    MX_HIP(hipMemsetAsync(nh.p, 0, hb, idx->stream));
+    if (i8) MX_HIP(hipMemsetAsync(nts.p, 0, tb, idx->stream));
     MX_HIP(hipMemsetAsync(idx->flags + 2, 0, sizeof(uint32_t), idx->stream));
-    MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh,
-                         idx->flags + 2));
+    const uint32_t t1 = (uint32_t)((idx->n + kTileRows - 1) / kTileRows);
+    if (i8)
+        MX_HIP(launch_shadow8(idx->stream, idx->x, idx->scale, idx->ds, 0, t1, idx->n, nh.p, static_cast<float *>(nts.p), idx->flags + 2));
+    else
+        MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, t1, nh.p, idx->flags + 2));
     MX_HIP(hipStreamSynchronize(idx->stream));
-    idx->xh = nh;
+    idx->xh = nh.release();
+    idx->tsc = static_cast<float *>(nts.release());
     return MX_OK;
 }
 
@@ -1490,8 +1587,8 @@ int mx_index_set_corpus_mode(mx_index *idx, int mode) {
     auto F = [](void *p) {
         if (p) (void)hipFree(p);
     };
-    F(idx->x); F(idx->scale); F(idx->xh);
-    idx->x = nullptr; idx->scale = nullptr; idx->xh = nullptr;
+    F(idx->x); F(idx->scale); F(idx->xh); F(idx->tsc);
+    idx->x = nullptr; idx->scale = nullptr; idx->xh = nullptr; idx->tsc = nullptr;
     idx->cap = 0;
     idx->compressed = mode == MX_CORPUS_BF16;
     idx->want_filter = true;
@@ -1534,6 +1631,8 @@ int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
             acc.max_abs_err = std::max(acc.max_abs_err, s1.max_abs_err);
             acc.approx_err_bound = std::max(acc.approx_err_bound, s1.approx_err_bound);
             acc.filter_copy_bytes += s1.filter_copy_bytes;
+            acc.filter_kind = std::max(acc.filter_kind, s1.filter_kind);  // shards choose alike; a demoted one shows as bf16
+            acc.filter_demotions += s1.filter_demotions;
         }
         *out = acc;
         return MX_OK;
@@ -1544,12 +1643,13 @@ int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
         MX_HIP(hipMemcpy(&e, idx->s.max_err, sizeof(float), hipMemcpyDeviceToHost));
         idx->stats.max_abs_err = std::max(idx->stats.max_abs_err, (double)e);
     }
-    if (idx->s.host_sum) {  // e1 of the last batch's first query (all queries share Ec; Eq varies little)
+    if (idx->s.host_sum) {  // largest e1 of the last batch (all queries share Ec; Eq is the query's own)
         float e1 = 0.f;
         memcpy(&e1, idx->s.host_sum + 3, sizeof(float));
         idx->stats.approx_err_bound = e1;
     }
-    idx->stats.filter_copy_bytes = idx->xh ? (uint64_t)idx->cap * idx->ds * 2ull : 0;
+    idx->stats.filter_kind = !idx->xh ? 0u : (idx->filter_i8 && !idx->compressed ? 2u : 3u);
+    idx->stats.filter_copy_bytes = idx->xh ? (uint64_t)idx->cap * idx->ds * (idx->filter_i8 && !idx->compressed ? 1ull : 2ull) : 0;
     *out = idx->stats;
     return MX_OK;
 }

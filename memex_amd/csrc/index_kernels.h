@@ -83,6 +83,9 @@ struct ScanParams {
     uint32_t *lane_cnt;      // [512][nwg] records written
     float *lane_max;         // [512][nwg] sample mode: running maximum of each lane
     uint32_t *overflow;      // [256]
+    // 8-bit filter copy (scan8_kernel): xh holds int8 fragments, tiles are 64 rows
+    const float *tscale = nullptr;  // [cap_rows / 32] quantisation step of each 32-row half tile
+    const float *qscale = nullptr;  // [256] quantisation step of each query
 };
 
 // launches ---------------------------------------------------------------------------------
@@ -91,6 +94,17 @@ hipError_t scan16_setup();
 // collect = false: sample launch (lane maxima only); collect = true: survivors of theta are appended
 hipError_t launch_scan(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
 hipError_t launch_scan16(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
+// scan over the 8-bit filter copy: kc = ds / 128 in 1 .. 12, tile_begin / tile_end / tile_stride count 64-row tiles
+constexpr int kTile8Rows = 64;
+constexpr int kScaleRing8 = 32;  // tiles whose scales can be in flight (15 slots ahead at one slot per tile, + the tile being multiplied)
+constexpr int kScan8LdsBytes = kRing16 * kSlot16Bytes + kScaleRing8 * 256;
+hipError_t scan8_setup();
+hipError_t launch_scan8(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
+// (re)build half tiles [half0, half1) (32 rows each) of the 8-bit filter copy from the padded f32 store: per half
+// tile one quantisation step tscale[h] = max |c_i/|c|| / 127 over its rows below row_hi (rows at or above row_hi,
+// and zero-norm rows, are stored as zeros); ec_max as launch_shadow
+hipError_t launch_shadow8(hipStream_t s, const float *x, const float *scale, int ds, uint32_t half0, uint32_t half1,
+                          uint64_t row_hi, void *x8, float *tscale, uint32_t *ec_max);
 hipError_t scan16w_setup();
 hipError_t launch_scan16w(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);  // kc in {8, 10, 12}, <= 128 queries
 
@@ -120,7 +134,9 @@ hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, flo
 // residual as float bits, or null = a-priori bound); flags[0] |= 1 when a query is not finite
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag,
                                float *qpad, double *qnorm2, float *theta, float *e1, const uint32_t *ec_max,
-                               uint32_t *overflow, uint32_t *flags);
+                               uint32_t *overflow, uint32_t *flags, bool filt8 = false, float *qscale = nullptr);
+// filt8: fragments for the 8-bit filter copy (scan8.hip: int8 [8 waves][ds/32][64 lanes][16]) and qscale[256] = the
+// query's quantisation step (0 for an unusable query); ec_max then is that copy's residual word (required)
 
 // theta[q] = (k-th largest of query q's lane maxima) - 2*e1[q]
 hipError_t launch_theta(hipStream_t s, int B, int k, int nwg, const float *lane_max, const float *e1, float *theta);

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
                                                            __bf16 *__restrict__ qfrag, float *__restrict__ qpad,
                                                            double *__restrict__ qnorm2, float *__restrict__ theta,
                                                            float *__restrict__ e1, const uint32_t *__restrict__ ec_max,
-                                                           uint32_t *__restrict__ overflow, uint32_t *__restrict__ flags) {
+                                                           uint32_t *__restrict__ overflow, uint32_t *__restrict__ flags,
+                                                           int filt8, float *__restrict__ qscale) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
     float *s_row = reinterpret_cast<float *>(psm);  // [d] this query (coalesced load; the chain reads LDS)
     __shared__ float s_inv;
@@ -224,20 +225,48 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
     }
     __syncthreads();
     const float inv = s_inv;
-    const int ksteps = ds / 16;
     const int w = b >> 5, col = b & 31;
-    float r2 = 0.0f;  // |bf16(q/|q|) - q/|q||^2: this query's share of the scan's error bound
-    for (int dim = tid; dim < ds; dim += 256) {
-        const float v = dim < d ? s_row[dim] : 0.0f;
-        qpad[(size_t)b * ds + dim] = v;
-        // MFMA 32x32x16 B-operand: lane l holds B[k = 8*(l>>5)+i][n = l&31]
-        const int ks = dim >> 4, hh = (dim >> 3) & 1, i = dim & 7;
-        const int lane = hh * 32 + col;
-        const float vn = v * inv;
-        const __bf16 vb = (__bf16)vn;
-        qfrag[(((size_t)w * ksteps + ks) * 64 + lane) * 8 + i] = vb;
-        const float r = (float)vb - vn;
-        r2 += r * r;
+    float r2 = 0.0f;  // |stored(q/|q|) - q/|q||^2: this query's share of the scan's error bound
+    if (filt8) {
+        // 8-bit filter copy (scan8.hip): q8 = rint((q/|q|) / s_q), s_q = max |q_i/|q|| / 127
+        float mx = 0.0f;
+        for (int dim = tid; dim < d; dim += 256) mx = fmaxf(mx, fabsf(s_row[dim] * inv));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((tid & 63) == 0) s_red[tid >> 6] = __float_as_uint(mx);
+        __syncthreads();
+        mx = fmaxf(fmaxf(__uint_as_float(s_red[0]), __uint_as_float(s_red[1])), fmaxf(__uint_as_float(s_red[2]), __uint_as_float(s_red[3])));
+        __syncthreads();  // s_red is reused for the residual below
+        const float sq = mx / 127.0f, qinv = mx > 0.0f ? 127.0f / mx : 0.0f;
+        if (tid == 0) qscale[b] = sq;
+        const int ksteps = ds / 32;
+        int8_t *q8 = reinterpret_cast<int8_t *>(qfrag);
+        for (int dim = tid; dim < ds; dim += 256) {
+            const float v = dim < d ? s_row[dim] : 0.0f;
+            qpad[(size_t)b * ds + dim] = v;
+            // v_mfma_i32_32x32x32_i8 B-operand: lane l holds B[k = 16*(l>>5)+i][n = l&31], 16 int8
+            const int ks = dim >> 5, hh = (dim >> 4) & 1, i = dim & 15;
+            const int lane = hh * 32 + col;
+            const float vn = v * inv;
+            const float qv = fminf(fmaxf(rintf(vn * qinv), -127.0f), 127.0f);
+            q8[(((size_t)w * ksteps + ks) * 64 + lane) * 16 + i] = (int8_t)(int)qv;
+            const float r = qv * sq - vn;
+            r2 += r * r;
+        }
+    } else {
+        const int ksteps = ds / 16;
+        for (int dim = tid; dim < ds; dim += 256) {
+            const float v = dim < d ? s_row[dim] : 0.0f;
+            qpad[(size_t)b * ds + dim] = v;
+            // MFMA 32x32x16 B-operand: lane l holds B[k = 8*(l>>5)+i][n = l&31]
+            const int ks = dim >> 4, hh = (dim >> 3) & 1, i = dim & 7;
+            const int lane = hh * 32 + col;
+            const float vn = v * inv;
+            const __bf16 vb = (__bf16)vn;
+            qfrag[(((size_t)w * ksteps + ks) * 64 + lane) * 8 + i] = vb;
+            const float r = (float)vb - vn;
+            r2 += r * r;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
@@ -259,7 +288,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
         float e = kApproxErr;
         if (ec_max) {
             const float ec = __uint_as_float(*ec_max) * 1.01f + 1e-6f;
-            e = fminf(kApproxErr + ec * ec, ec + eq + ec * eq + kAccSlack);
+            e = ec + eq + ec * eq + kAccSlack;
+            if (!filt8) e = fminf(kApproxErr + ec * ec, e);  // two bf16 roundings have an a-priori bound as well
         }
         e1[b] = e;
     }
@@ -267,9 +297,9 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
 
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag, float *qpad,
                                double *qnorm2, float *theta, float *e1, const uint32_t *ec_max, uint32_t *overflow,
-                               uint32_t *flags) {
+                               uint32_t *flags, bool filt8, float *qscale) {
     hipLaunchKernelGGL(prep_queries_kernel, dim3(kMaxBatch), dim3(256), sizeof(float) * (size_t)d, s, q, B, d, ds,
-                       (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags);
+                       (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags, filt8 ? 1 : 0, qscale);
     return hipGetLastError();
 }
 
@@ -827,8 +857,8 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     if (!s_last) return;
     // summary of the batch for the host (4 words + seq: one small write over PCIe; the per-query words stay
     // in HBM and are only fetched when the summary says some query overflowed)
-    __shared__ uint32_t s_sum[3];
-    if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+    __shared__ uint32_t s_sum[4];
+    if (threadIdx.x < 4) s_sum[threadIdx.x] = 0;
     __threadfence();
     __syncthreads();
     if ((int)threadIdx.x < p.n_queries) {
@@ -838,13 +868,15 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
         if (ovf) atomicMax(&s_sum[0], ovf);
         atomicAdd(&s_sum[1], cnt);
         if (bad) atomicOr(&s_sum[2], 1u);
+        // e1 is a positive float: the order of its bits is its order
+        atomicMax(&s_sum[3], __hip_atomic_load(&p.dev_flags[2 * kMaxBatch + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         p.host_flags[0] = s_sum[0];  // 0: nobody overflowed; 1: some need the retry pass; >= 2: some need EXACT
         p.host_flags[1] = s_sum[1];  // candidates rescored in f32, whole batch
         p.host_flags[2] = s_sum[2];  // a query held non-finite values
-        p.host_flags[3] = __hip_atomic_load(&p.dev_flags[2 * kMaxBatch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // e1 of query 0
+        p.host_flags[3] = s_sum[3];  // largest e1 of the batch (the bound the profiling maximum is checked against)
         *p.done_ctr = 0;
         __hip_atomic_store(&p.host_flags[4], p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -165,10 +165,20 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
 #if MX_SCAN16_ABLATE == 1 || MX_SCAN16_ABLATE == 2
                 asm volatile("" ::"v"(a[ks % R]));
 #else
+#ifdef MX_SCAN16_I8_PROBE  /* scripts/scan16_ubench.hip: timing / power of the i8 instruction on the same stream (values meaningless) */
+                {
+                    typedef __attribute__((ext_vector_type(4))) int i32x4_;
+                    typedef __attribute__((ext_vector_type(16))) int i32x16_;
+                    f32x16 &dst = (DUAL && (ks & 1)) ? acc1 : acc;
+                    dst = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_, a[ks % R]), __builtin_bit_cast(i32x4_, qf[kc * 8 + ks]),
+                                                                                       __builtin_bit_cast(i32x16_, dst), 0, 0, 0));
+                }
+#else
                 if (DUAL && (ks & 1))
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % R], qf[kc * 8 + ks], acc1, 0, 0, 0);
                 else
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % R], qf[kc * 8 + ks], acc, 0, 0, 0);
+#endif
 #endif
                 // refill the register just consumed with the fragment R k-steps ahead (this slot or
                 // the next one): the read issues while the MFMA pipe works on the instruction above

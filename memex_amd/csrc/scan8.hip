@@ -1,0 +1,340 @@
+// scan8.hip -- the streaming cosine scan over an 8-bit filter copy of the corpus (SURVEY.md section 8 f-4:
+// "bf16 / 8-bit rows + fp32 rerank"), and the kernel that builds that copy.
+//
+// Same role and same pipeline as scan16.hip (exhaustive replacement of `self.hnsw.search(vec, limit, 32)`,
+// reference lib/libmemex/src/storage/local.rs:76): the scan only has to bring every row of the exact top-k
+// into finish_kernel, which rescores in f32 and decides in f64 on the f32 rows.  scan16_kernel is bound by
+// the package power cap, not by cycles, so what pays is joules per row -- and an
+// int8 row costs half the HBM bytes, half the LDS bytes and one v_mfma_i32_32x32x32_i8 where bf16 needs two
+// v_mfma_f32_32x32x16_bf16: the same 8-KiB slot stream at the same rate (scripts/r3_i8probe.sh) carries
+// twice the rows.
+//
+// Quantisation (shadow8_kernel).  Per 32-row half tile h:  s_h = max |c_i/|c|| / 127 over its rows,
+// c8 = rint((c/|c|) / s_h) in [-127, 127];  a query likewise with its own scale s_q.  The accumulator is
+// an exact integer, so
+//   approx = s_q * s_h * sum q8_i c8_i,   |approx - cos| <= Ec + Eq + Ec*Eq  (+ f32 normalisation slack)
+// with the MEASURED residual norms Ec = max_rows |c/|c| - s_h c8| (tracked while the copy is built) and
+// Eq = |q/|q| - s_q q8| (prep_queries_kernel): typically 0.016 at 384 dims, against 0.009 for bf16 -- a
+// few dozen more candidates per query for finish_kernel, no change to the answers.
+//
+// Layout.  A scan tile is 64 rows = two half tiles u = 0, 1; slot s of tile T (8 KiB, 128 dims) holds the
+// eight 1-KiB A operands f = 2j + u of k-step j (32 dims) and half u: lane l -> 16 int8 = row
+// 64T + 32u + (l & 31), dims 128s + 32j + 16(l >> 5) .. + 15 (A and B use the same k order, which is all
+// the dot product needs).  The kernel is scan16_kernel with two accumulators (one per half) fed alternately:
+// one persistent 512-thread workgroup per CU, one 1 KiB LDS-DMA per wave and slot, 15 slots in flight,
+// s_waitcnt vmcnt(13) + s_barrier per slot, 8 MFMAs per slot each followed by the ds_read_b128 that refills
+// the fragment register it consumed.  The query fragments take dim_pad/8 VGPRs (48 at 384 dims, 192 at
+// 1536), so one launch serves 256 queries at every supported width.
+// Tile epilogue, per half: integer max over the lane's 16 sums, one conversion, two multiplications
+// (s_h from the tile's 8 bytes of the DMA stream, s_q per lane), one compare with the query's threshold; a passing lane stores its
+// 16 scores as floats -- the record format of scan16_kernel with the 32-row tile index 2T + u, so theta_kernel
+// and finish_kernel do not know which scan ran.
+#include <type_traits>
+
+#include "index_kernels.h"
+
+namespace mx {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+#define MX_LDS_DMA16(rsrc, ldsptr, voff, soff, aux) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lds_void *)(ldsptr), 16, (voff), (soff), 0, (aux))
+
+static_assert(kRing16 == 16, "waits below assume a 16-slot ring with 15 slots in flight");
+
+namespace {
+template <int N>
+using ic = std::integral_constant<int, N>;
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(ic<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+// DMA operations a wave has issued after the one of slot j+1 when it waits for that slot at position kc of a
+// tile: the 13 slots j+2 .. j+14, plus one scale operation per tile that starts among them
+template <int KC>
+constexpr int ops_after(int lo, int hi) {  // slots lo .. hi relative to the tile start
+    int n = 0;
+    for (int i = lo; i <= hi; ++i) n += 1 + (i % KC == 0 ? 1 : 0);
+    return n;
+}
+}  // namespace
+
+template <int KC, int MODE>
+__global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams p) {
+    constexpr int R = KC <= 8 ? 8 : KC <= 10 ? 4 : 2;  // fragment ring: what the 256 VGPRs leave next to qf
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // slot ring | scale ring [kScaleRing8] x 256 B
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31;  // query column of B and D
+
+    // ---- register-resident query fragments (B operand): k-step ks = 32 dims, 16 int8 per lane
+    i32x4 qf[KC * 4];
+    {
+        const i32x4 *src = reinterpret_cast<const i32x4 *>(p.qfrag) + (size_t)wave * (KC * 4) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KC * 4; ++i) qf[i] = src[(size_t)i * 64];
+    }
+    const float theta = MODE == 1 ? p.theta[wave * 32 + m] : 0.0f;
+    const float sq = p.qscale[wave * 32 + m];  // 0 for an unusable (zero / padded) query
+
+    // ---- 64-row tiles of this workgroup: tile_begin + (blockIdx + i*grid) * tile_stride
+    const uint32_t grid = gridDim.x;
+    const uint32_t stride = p.tile_stride;
+    const uint32_t t0 = p.tile_begin + blockIdx.x * stride;
+    const uint32_t tstep = grid * stride;
+    const uint32_t nT = (t0 < p.tile_end) ? (p.tile_end - t0 + tstep - 1) / tstep : 0;
+    const uint32_t tilebytes = p.ds * (uint32_t)kTile8Rows;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+
+    // ---- DMA stream: as scan16_kernel (always issued; past the last tile num_records = 0 -> no memory touched).
+    // The two quantisation steps of a tile travel in the same stream: one 8-byte operation, issued right before
+    // the tile's first slot, so they have landed when that slot has (a scalar load per tile would expose an
+    // HBM latency per tile; a vector load would put its own wait on the ring's vmcnt).  Every wave issues it
+    // (same 8 bytes, same LDS address: the waits below stay wave-uniform arithmetic).
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t is_ti = 0;
+    auto open_tile = [&]() {
+        const uint32_t tile = t0 + is_ti * tstep;
+        const bool live = is_ti < nT;
+        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.tscale + 2 * (size_t)tile), 0, live ? 8u : 0u, 0x00020000);
+        char *sdst = smem + __builtin_amdgcn_readfirstlane(kRing16 * kSlot16Bytes + (is_ti & (kScaleRing8 - 1)) * 256);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void *)sdst, 4, lane4, 0, 0, 0);
+        const char *base = reinterpret_cast<const char *>(p.xh) + (size_t)tile * tilebytes;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? tilebytes : 0u, 0x00020000);
+        ++is_ti;
+    };
+    auto issue = [&](int kci, uint32_t ring_pos) {  // kci is a compile-time constant at every call site
+        if (kci == 0) open_tile();
+        char *dst = smem + __builtin_amdgcn_readfirstlane(ring_pos * kSlot16Bytes + wave * 1024);
+        MX_LDS_DMA16(rsrc, dst, lane16, kci * kSlot16Bytes + wave * 1024, 2 /* nt */);
+    };
+
+    auto mylane = [&]() { return (uint32_t)tid * gridDim.x + blockIdx.x; };
+    uint32_t cnt = 0;  // records written; bit 31: a record did not fit
+    float best = -INFINITY;
+
+#pragma unroll
+    for (int i = 0; i < kRing16 - 1; ++i) issue(i % KC, (uint32_t)i);
+
+    i32x4 a[R];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ops_after<KC>(1, kRing16 - 2)) : "memory");  // slot 0 (and its tile's scales) landed
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int f = 0; f < R; ++f) a[f] = *reinterpret_cast<const i32x4 *>(smem + lane16 + f * 1024);
+
+    uint32_t rp = 0;
+#pragma unroll 1
+    for (uint32_t ti = 0; ti < nT; ++ti) {
+        const uint32_t tile = t0 + ti * tstep;
+        i32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = 0, acc1[r] = 0;
+
+        static_for<0, KC>([&](auto kct) __attribute__((always_inline)) {
+            constexpr int kc = decltype(kct)::value;
+            const uint32_t rp1 = (rp + 1) & (kRing16 - 1);
+            const uint32_t rpi = (rp + kRing16 - 1) & (kRing16 - 1);
+            // slot j+1 landed (the ring reads ahead into it): everything issued after it may still be in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ops_after<KC>(kc + 2, kc + kRing16 - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();  // ... for every wave; slot j-1 is free for slot j+15
+            const uint32_t fb0 = rp * kSlot16Bytes + lane16, fb1 = rp1 * kSlot16Bytes + lane16;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                if (f & 1)
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[kc * 4 + (f >> 1)], acc1, 0, 0, 0);
+                else
+                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[kc * 4 + (f >> 1)], acc0, 0, 0, 0);
+                a[f % R] = *reinterpret_cast<const i32x4 *>(smem + (f + R < 8 ? fb0 : fb1) + ((f + R) & 7) * 1024);
+                if (f == 1) issue((kc + kRing16 - 1) % KC, rpi);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rp = rp1;
+        });
+
+        // ---- tile epilogue, per half: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*(lane>>5) of the half
+        // (read with inline asm: hipcc puts s_waitcnt vmcnt(0) in front of a plain LDS load that it thinks an LDS-DMA
+        // may have written, which would drain the ring once per tile; the scales landed with the tile's first slot)
+        float2 shs;
+        {
+            const uint32_t sa = kRing16 * kSlot16Bytes + (ti & (kScaleRing8 - 1)) * 256;
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(shs) : "v"(sa) : "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const i32x16 &acc = u ? acc1 : acc0;
+            const float sh = u ? shs.y : shs.x;
+            int mxi = max(max(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mxi = max(max(mxi, acc[r]), acc[r + 1]);
+            mxi = max(mxi, acc[15]);
+            // score of a sum: ((float)sum * s_h) * s_q -- monotone in the sum, so the test on the maximum is the
+            // test on "any of the 16 scores" as finish_kernel will see them
+            const float mx = ((float)mxi * sh) * sq;
+            if (MODE == 0) {
+                best = fmaxf(best, mx);  // only full tiles are sampled (index.hip): every row is a real row
+            } else if (__builtin_amdgcn_ballot_w64(mx >= theta) != 0) {
+                if (mx >= theta) {
+                    if ((cnt & 0x7fffffffu) < (uint32_t)kRecCap) {
+                        const size_t at = (size_t)mylane() * kRecCap + (cnt & 0x7fffffffu);
+                        f32x4 *dst = reinterpret_cast<f32x4 *>(p.lane_rec + at * 16);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            dst[i] = f32x4{((float)acc[4 * i] * sh) * sq, ((float)acc[4 * i + 1] * sh) * sq,
+                                           ((float)acc[4 * i + 2] * sh) * sq, ((float)acc[4 * i + 3] * sh) * sq};
+                        p.lane_tile[at] = 2 * tile + u;  // 32-row tile index, as finish_kernel counts them
+                        ++cnt;
+                    } else {
+                        cnt |= 0x80000000u;
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // dead DMA ops must not outlive the workgroup's LDS
+
+    if (MODE == 0) {
+        p.lane_max[mylane()] = best;
+    } else {
+        p.lane_cnt[mylane()] = cnt & 0x7fffffffu;
+        if (cnt >> 31) p.overflow[wave * 32 + m] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter-copy construction: one workgroup per 32-row half tile
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shadow8_kernel(const float *__restrict__ x, const float *__restrict__ scale, int ds,
+                                                      uint32_t half0, uint32_t half1, uint64_t row_hi,
+                                                      i32x4 *__restrict__ x8, float *__restrict__ tscale,
+                                                      uint32_t *__restrict__ ec_max) {
+    __shared__ float s_r2[kTileRows];
+    __shared__ float s_red[4];
+    __shared__ float s_rs[kTileRows];  // 1/|c| of the half tile's rows; 0 for a zero-norm row and for rows >= row_hi
+    const int tid = threadIdx.x;
+    const int kc = ds >> 7;
+    const uint32_t frags = (uint32_t)(ds >> 5) * 64u;  // 16-byte fragments per half tile
+    float worst = 0.0f;
+    for (uint32_t h = half0 + blockIdx.x; h < half1; h += gridDim.x) {
+        const float *xt = x + (size_t)h * kTileRows * ds;
+        if (tid < kTileRows) {
+            const uint64_t grow = (uint64_t)h * kTileRows + tid;
+            s_rs[tid] = grow < row_hi ? scale[grow] : 0.0f;
+            s_r2[tid] = 0.0f;
+        }
+        __syncthreads();
+        // ---- pass 1: largest |c_i / |c|| of the half tile
+        float mx = 0.0f;
+        for (uint32_t i = tid; i < (uint32_t)(kTileRows * ds) / 4; i += 256) {
+            const uint32_t row = i / (uint32_t)(ds >> 2);
+            const float sc = s_rs[row];
+            if (sc != 0.0f) {
+                const f32x4 v = reinterpret_cast<const f32x4 *>(xt)[i] * sc;
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        const float sh = mx / 127.0f, inv = mx > 0.0f ? 127.0f / mx : 0.0f;
+        // ---- pass 2: quantise, store in fragment order, residual per row
+        const uint32_t T = h >> 1, u = h & 1;
+        for (uint32_t f = tid; f < frags; f += 256) {
+            const uint32_t ks = f >> 6, l = f & 63, mm = l & 31, hh = l >> 5;  // k-step of 32 dims
+            const uint32_t s = ks >> 2, j = ks & 3;
+            const float sc = s_rs[mm];
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(xt + (size_t)mm * ds + ks * 32 + hh * 16);
+            int w[4];
+            float r2 = 0.0f;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = sc != 0.0f ? src[q4] * sc : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                uint32_t pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float qv = fminf(fmaxf(rintf(v[e] * inv), -127.0f), 127.0f);
+                    const float d = v[e] - qv * sh;
+                    r2 += d * d;
+                    pk |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
+                }
+                w[q4] = (int)pk;
+            }
+            x8[(((size_t)T * kc + s) * 8 + (j * 2 + u)) * 64 + l] = i32x4{w[0], w[1], w[2], w[3]};
+            atomicAdd(&s_r2[mm], r2);
+        }
+        __syncthreads();
+        if (tid == 0) tscale[h] = sh;
+        if (tid < kTileRows) worst = fmaxf(worst, sqrtf(s_r2[tid]));
+        __syncthreads();
+    }
+    if (tid < kTileRows) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
+        if (tid == 0 && worst > 0.0f) atomicMax(ec_max, __float_as_uint(worst));
+    }
+}
+
+hipError_t launch_shadow8(hipStream_t s, const float *x, const float *scale, int ds, uint32_t half0, uint32_t half1,
+                          uint64_t row_hi, void *x8, float *tscale, uint32_t *ec_max) {
+    if (half1 <= half0) return hipSuccess;
+    const uint32_t blocks = half1 - half0 < 16384u ? half1 - half0 : 16384u;
+    hipLaunchKernelGGL(shadow8_kernel, dim3(blocks), dim3(256), 0, s, x, scale, ds, half0, half1, row_hi,
+                       reinterpret_cast<i32x4 *>(x8), tscale, ec_max);
+    return hipGetLastError();
+}
+
+template <int KC, int MODE>
+static hipError_t setup8_one() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&scan8_kernel<KC, MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kScan8LdsBytes);
+}
+
+hipError_t scan8_setup() {
+    hipError_t e;
+#define MX_SETUP(KC)                                          \
+    if ((e = setup8_one<KC, 0>()) != hipSuccess) return e;    \
+    if ((e = setup8_one<KC, 1>()) != hipSuccess) return e;
+    MX_SETUP(1) MX_SETUP(2) MX_SETUP(3) MX_SETUP(4) MX_SETUP(5) MX_SETUP(6)
+    MX_SETUP(7) MX_SETUP(8) MX_SETUP(9) MX_SETUP(10) MX_SETUP(11) MX_SETUP(12)
+#undef MX_SETUP
+    return hipSuccess;
+}
+
+template <int KC>
+static hipError_t launch8_kc(hipStream_t s, bool collect, int nwg, const ScanParams &p) {
+    if (collect)
+        hipLaunchKernelGGL((scan8_kernel<KC, 1>), dim3(nwg), dim3(kScanThreads), kScan8LdsBytes, s, p);
+    else
+        hipLaunchKernelGGL((scan8_kernel<KC, 0>), dim3(nwg), dim3(kScanThreads), kScan8LdsBytes, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan8(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p) {
+    switch (kc) {
+        case 1: return launch8_kc<1>(s, collect, nwg, p);
+        case 2: return launch8_kc<2>(s, collect, nwg, p);
+        case 3: return launch8_kc<3>(s, collect, nwg, p);
+        case 4: return launch8_kc<4>(s, collect, nwg, p);
+        case 5: return launch8_kc<5>(s, collect, nwg, p);
+        case 6: return launch8_kc<6>(s, collect, nwg, p);
+        case 7: return launch8_kc<7>(s, collect, nwg, p);
+        case 8: return launch8_kc<8>(s, collect, nwg, p);
+        case 9: return launch8_kc<9>(s, collect, nwg, p);
+        case 10: return launch8_kc<10>(s, collect, nwg, p);
+        case 11: return launch8_kc<11>(s, collect, nwg, p);
+        case 12: return launch8_kc<12>(s, collect, nwg, p);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mx

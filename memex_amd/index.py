@@ -100,9 +100,16 @@ class FlatIndex:
     def set_search_mode(self, mode: int) -> None:
         check(lib().mx_index_set_search_mode(self._h, int(mode)))
 
-    def set_filter_copy(self, on: bool) -> None:
-        """Keep (default) or drop the bf16 filter copy the scan streams; results do not change."""
-        check(lib().mx_index_set_filter_copy(self._h, 1 if on else 0))
+    def set_filter_copy(self, on) -> None:
+        """Keep or drop the filter copy the scan streams; results do not change.  ``False`` / ``"none"``: none (the
+        scan reads the f32 rows); ``True`` / ``"auto"``: the library chooses (int8 up to 512 dims, bf16 above, and an
+        int8 copy is rebuilt as bf16 if a batch overflows it); ``"i8"``: int8 rows with one quantisation step per 32
+        rows; ``"bf16"``: bf16 rows."""
+        if isinstance(on, str):
+            kind = {"none": 0, "auto": 1, "i8": 2, "int8": 2, "bf16": 3}[on]
+        else:
+            kind = 1 if on else 0
+        check(lib().mx_index_set_filter_copy(self._h, int(kind)))
 
     def set_corpus_mode(self, mode: str) -> None:
         """``"f32"`` (default) or ``"bf16"``: keep only the bf16 rows (a third of the HBM); searches are

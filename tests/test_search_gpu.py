@@ -72,10 +72,10 @@ def test_get_vector_storage_roundtrip(tmp_path, lib_built):
 
 
 def _check(idx, X, Q, k, oracle, id_offset=0):
-    """Bit-exact against the oracle on both scan kernels: over the bf16 filter copy (default), over
-    the f32 rows (copy dropped), and over a copy rebuilt from the resident rows."""
+    """Bit-exact against the oracle on every scan kernel: over the bf16 filter copy, over the f32 rows (copy
+    dropped), over copies rebuilt from the resident rows, and over the int8 filter copy."""
     oi, od, os_, onf = oracle.search(X, Q, k, id_offset=id_offset)
-    for keep_copy in (None, False, True):
+    for keep_copy in (None, False, True, "i8", "bf16"):   # default copy, none, rebuilt bf16, int8 (scan8_kernel), bf16 again
         if keep_copy is not None:
             idx.set_filter_copy(keep_copy)
         ids, sc, di, nf = idx.search(Q, k)
@@ -314,19 +314,24 @@ def test_registry_shares_one_resident_index(lib_built):
 
 
 def test_approximation_error_bound_holds(lib_built):
-    """The exactness argument needs |bf16 score - cosine| <= e1, the per-query bound built from the
-    measured rounding residuals (itself capped by the a-priori kApproxErr = 0.0081)."""
+    """The exactness argument needs |filter score - cosine| <= e1, the per-query bound built from the measured
+    residuals of the filter copy and of the query: bf16 copy (two roundings, itself capped by the a-priori
+    kApproxErr = 0.0081) and int8 copy (one quantisation step per 32 rows / per query; no a-priori cap, the bound
+    is the measured one: ~0.02 on dense rows)."""
     from memex_amd.index import FlatIndex
     rng = np.random.default_rng(26)
-    for d, scale in ((3, 1.0), (16, 1.0), (384, 1.0), (384, 50.0), (768, 1e-3)):
+    for d, scale in ((3, 1.0), (16, 1.0), (384, 1.0), (384, 50.0), (768, 1e-3), (1536, 1.0)):
         X = (rng.standard_normal((20000, d)) * scale).astype(np.float32)
         Q = rng.standard_normal((32, d), dtype=np.float32)
-        with FlatIndex(d) as idx:
-            idx.set_profiling(True)
-            idx.add(X)
-            idx.search(Q, 10)
-            st = idx.stats()
-            assert 0.0 < st.max_abs_err <= st.approx_err_bound <= 0.0081
+        for kind, cap in (("bf16", 0.0081), ("i8", 0.03)):
+            with FlatIndex(d) as idx:
+                idx.set_filter_copy(kind)
+                idx.set_profiling(True)
+                idx.add(X)
+                idx.search(Q, 10)
+                st = idx.stats()
+                assert st.fallback_queries == 0
+                assert 0.0 < st.max_abs_err <= st.approx_err_bound <= cap, (d, scale, kind, st.max_abs_err, st.approx_err_bound)
 
 
 def test_multi_shard_merge_equals_unsharded(oracle, lib_built):
@@ -449,7 +454,7 @@ def test_filter_copy_follows_incremental_inserts(oracle, lib_built):
             np.testing.assert_array_equal(ids, want[0])
             np.testing.assert_array_equal(bits(di), bits(want[1]))
         st = idx.stats()
-        assert st.filter_copy_bytes >= 30000 * 256 * 2 and st.fallback_queries == 0
+        assert st.filter_copy_bytes >= 30000 * 256 and st.fallback_queries == 0   # int8 copy: one byte per element
         idx.clear()
         idx.add(X[5000:5100])
         np.testing.assert_array_equal(idx.search(Q, 10)[0], oracle.search(X[5000:5100], Q, 10)[0])
@@ -537,4 +542,88 @@ def test_wide_rows_use_the_split_scan(n, d, B, k, seed, oracle, lib_built):
         ids3, sc3, _, _ = idx.search(Q, k)
         np.testing.assert_array_equal(ids3, oi)
         np.testing.assert_array_equal(bits(sc3), bits(os_))
+        idx.set_filter_copy("i8")                       # int8 copy: one pass serves all 256 queries at any width
+        idx.reset_stats()
+        ids4, sc4, di4, _ = idx.search(Q, k)
+        np.testing.assert_array_equal(ids4, oi)
+        np.testing.assert_array_equal(bits(sc4), bits(os_))
+        np.testing.assert_array_equal(bits(di4), bits(od))
+        st = idx.stats()
+        assert st.fallback_queries == 0 and st.scan_launches == 1
 
+
+
+def test_int8_filter_copy_appends_rejects_and_certificate(oracle, lib_built):
+    """The int8 filter copy (scan8.hip) under the things that change it: appends that start and end inside a
+    32-row half tile (the half tile is requantised as a whole), a rejected batch (NaN row) in between, rows with very
+    different element ranges inside one half tile (a one-hot row next to dense rows: the shared step gets coarse,
+    the measured residual grows, answers stay exact), and the sample + threshold pipeline at 200k rows."""
+    from memex_amd import _lib
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(41)
+    n, d = 200_000, 384
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    X[1000] = 0
+    X[1000, 5] = 7.0                                       # one-hot row: element range 1.0 inside a dense half tile
+    X[70_000:70_020] = X[33]                               # duplicates
+    Q = rng.standard_normal((256, d), dtype=np.float32)
+    Q[0] = X[33] * 0.5
+    Q[1] = X[1000]
+    oi, od, os_, onf = oracle.search(X, Q, 10)
+    with FlatIndex(d) as idx:
+        idx.set_filter_copy("i8")
+        cuts = [0, 1, 33, 95, 4133, 100_001, n]
+        for a, b in zip(cuts, cuts[1:]):
+            if a == 4133:
+                bad = X[a:a + 100].copy()
+                bad[40, 3] = np.nan
+                with pytest.raises(_lib.MemexHipError):
+                    idx.add(bad)                           # nothing inserted; the tile of row 4133 is rebuilt
+                assert len(idx) == a
+            assert idx.add(X[a:b]) == a + 1
+        ids, sc, di, nf = idx.search(Q, 10)
+        np.testing.assert_array_equal(ids, oi)
+        np.testing.assert_array_equal(bits(di), bits(od))
+        np.testing.assert_array_equal(bits(sc), bits(os_))
+        st = idx.stats()
+        assert st.fallback_queries == 0
+        assert st.filter_copy_bytes % (384 * 64) == 0 and st.filter_copy_bytes < n * 384 * 2   # one byte per element
+        # a one-shot build of the same rows gives the same answers and (nearly) the same candidate counts
+        with FlatIndex(d) as one:
+            one.set_filter_copy("i8")
+            one.add(X)
+            ids1, sc1, _, _ = one.search(Q, 10)
+            np.testing.assert_array_equal(ids1, oi)
+            np.testing.assert_array_equal(bits(sc1), bits(os_))
+            assert one.stats().fallback_queries == 0
+
+
+def test_int8_copy_is_demoted_on_a_dense_corpus(oracle, lib_built):
+    """Automatic filter choice: a 384-d index starts on the int8 copy; when the rows sit in a cone narrower than the
+    int8 certificate (~0.05 in cosine -- here 60k rows whose cosines to a query spread by 0.014) a batch overflows it, the copy is
+    rebuilt as bf16 once, the batch is answered on it (no EXACT fallback), and the index stays on bf16.  A pinned
+    int8 copy is left alone and still answers exactly (through the retry / EXACT path)."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(43)
+    n, d = 60_000, 384
+    centre = rng.standard_normal(d).astype(np.float32)
+    X = (centre[None, :] + 0.6 * rng.standard_normal((n, d))).astype(np.float32) * rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+    Q = (centre[None, :] + 0.6 * rng.standard_normal((64, d))).astype(np.float32)
+    oi, od, os_, _ = oracle.search(X, Q, 10)
+    with FlatIndex(d) as idx:
+        idx.add(X)
+        assert idx.stats().filter_kind == 2                       # int8 by default at 384 dims
+        ids, sc, di, _ = idx.search(Q, 10)
+        np.testing.assert_array_equal(ids, oi)
+        np.testing.assert_array_equal(bits(di), bits(od))
+        st = idx.stats()
+        assert st.filter_kind == 3 and st.filter_demotions == 1 and st.fallback_queries == 0
+        ids, sc, _, _ = idx.search(Q, 10)                          # stays there
+        np.testing.assert_array_equal(ids, oi)
+        assert idx.stats().filter_demotions == 1
+        idx.set_filter_copy("i8")                                  # pinned: no demotion, same answers
+        ids, sc, _, _ = idx.search(Q, 10)
+        np.testing.assert_array_equal(ids, oi)
+        np.testing.assert_array_equal(bits(sc), bits(os_))
+        st = idx.stats()
+        assert st.filter_kind == 2 and st.filter_demotions == 1
