@@ -600,15 +600,15 @@ def test_int8_filter_copy_appends_rejects_and_certificate(oracle, lib_built):
 
 def test_int8_copy_is_demoted_on_a_dense_corpus(oracle, lib_built):
     """Automatic filter choice: a 384-d index starts on the int8 copy; when the rows sit in a cone narrower than the
-    int8 certificate (~0.05 in cosine -- here 60k rows whose cosines to a query spread by 0.014) a batch overflows it, the copy is
+    int8 certificate (~0.05 in cosine -- here 60k rows whose cosines to a query spread by 0.012: the int8 band holds 46k of them per query, the bf16 band 250) a batch overflows it, the copy is
     rebuilt as bf16 once, the batch is answered on it (no EXACT fallback), and the index stays on bf16.  A pinned
     int8 copy is left alone and still answers exactly (through the retry / EXACT path)."""
     from memex_amd.index import FlatIndex
     rng = np.random.default_rng(43)
     n, d = 60_000, 384
     centre = rng.standard_normal(d).astype(np.float32)
-    X = (centre[None, :] + 0.6 * rng.standard_normal((n, d))).astype(np.float32) * rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
-    Q = (centre[None, :] + 0.6 * rng.standard_normal((64, d))).astype(np.float32)
+    X = (centre[None, :] + 0.45 * rng.standard_normal((n, d))).astype(np.float32) * rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+    Q = (centre[None, :] + 0.45 * rng.standard_normal((64, d))).astype(np.float32)
     oi, od, os_, _ = oracle.search(X, Q, 10)
     with FlatIndex(d) as idx:
         idx.add(X)
