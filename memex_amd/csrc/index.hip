@@ -51,12 +51,13 @@ namespace {
 // the host a 4-word summary + its sequence number (host_sum); the block itself is only copied when the
 // summary reports an overflow, and on the EXACT path
 constexpr int kFlagWords = 4 * kMaxBatch;
-// Filter copy an f32 corpus keeps unless told otherwise: int8 up to 512 dims, bf16 above.  The int8 certificate is
-// ~0.02-0.026 wide whatever the width (quantisation noise of a unit vector does not depend on its length) while the
-// spread of cosines shrinks like 1/sqrt(dim): measured on Gaussian rows, B = 256, k = 10 (scripts/r3_dims.sh):
-// int8 / bf16 = 444k / 320k QPS at 128 dims, 270k / 181k at 256, 172k / 112k at 384, 134k / 96k at 512,
-// 54k / 68k at 768, 78k / 88k at 1024, 38k / 57k at 1536.
-constexpr int kAutoI8MaxDim = 512;  // filter copy of an f32 corpus: int8 (scan8.hip) or bf16 (scan16.hip)
+// Filter copy an f32 corpus keeps unless told otherwise: int8 up to 1024 dims, bf16 above.  The int8 certificate is
+// ~0.016-0.026 wide whatever the width (quantisation noise of a unit vector does not depend on its length) while the
+// spread of cosines shrinks like 1/sqrt(dim), so the int8 pass hands more rows to finish_kernel the wider the rows are.
+// Measured on Gaussian rows, B = 256, k = 10, one box (scripts/r3_dims.sh; int8 at its best sample size / bf16, kQPS):
+// 463 / 312 at 128 dims, 290 / 188 at 256, 188 / 117 at 384, 160 / 100 at 512, 102 / 70 at 768, 146 / 90 at 1024
+// (4M rows), 51 / 61 at 1536 (4M rows).
+constexpr int kAutoI8MaxDim = 1024;  // filter copy of an f32 corpus: int8 (scan8.hip) or bf16 (scan16.hip)
 constexpr int kSumWords = 5;  // max overflow code, candidates, any bad query, e1 of query 0, seq
 
 struct Scratch {
@@ -78,6 +79,7 @@ struct Scratch {
     float *lane_max = nullptr;
     float *qstage = nullptr;       // [256, dim] host->device query staging
     float *qscale = nullptr;       // [256] quantisation step of each query (8-bit filter copy)
+    float *qa = nullptr, *qb = nullptr;  // [256] a row's filter-score bound is qa + qb * residual (launch_prep_queries)
     uint64_t *out_ids = nullptr;   // [256, kcap] device outputs for the host API
     float *out_scores = nullptr;
     float *out_dists = nullptr;
@@ -145,6 +147,7 @@ struct mx_index {
     // half tile.  An f32 corpus only; the compressed corpus keeps its bf16 rows.
     bool filter_i8 = false;
     bool filter_auto = true;     // the library picks the kind (by row width) and may demote int8 to bf16 when a batch overflows
+    uint32_t i8_batches = 0, i8_retry_batches = 0;  // since the int8 copy was built: batches served, batches that needed the retry pass
     float *tsc = nullptr;
     // compressed corpus (mx_index_set_corpus_mode): xh is the ONLY copy of the rows; x / scale are not
     // allocated, appends pass through the small f32 staging window xs / ss
@@ -252,7 +255,7 @@ int free_index(mx_index *idx) {
     if (s.host_sum) (void)hipHostFree(s.host_sum);
     for (void *hp : {(void *)s.h_q, (void *)s.h_ids, (void *)s.h_scores, (void *)s.h_dists, (void *)s.h_nf})
         if (hp) (void)hipHostFree(hp);
-    F(s.lane_rec); F(s.lane_tile); F(s.lane_cnt); F(s.lane_max); F(s.qstage); F(s.qscale); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
+    F(s.lane_rec); F(s.lane_tile); F(s.lane_cnt); F(s.lane_max); F(s.qstage); F(s.qscale); F(s.qa); F(s.qb); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
     F(s.exact_keys); F(s.sel_state); F(s.max_err);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
@@ -289,6 +292,8 @@ int ensure_scratch(mx_index *idx) {
     MX_HIP(hipMalloc(&s.lane_max, (size_t)idx->nwg * kScanThreads * sizeof(float)));
     MX_HIP(hipMalloc(&s.qstage, (size_t)kMaxBatch * idx->dim * sizeof(float)));
     MX_HIP(hipMalloc(&s.qscale, kMaxBatch * sizeof(float)));
+    MX_HIP(hipMalloc(&s.qa, kMaxBatch * sizeof(float)));
+    MX_HIP(hipMalloc(&s.qb, kMaxBatch * sizeof(float)));
     MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_q), (size_t)kMaxBatch * idx->dim * sizeof(float), hipHostMallocDefault));
     MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_nf), kMaxBatch * sizeof(int32_t), hipHostMallocDefault));
     MX_HIP(hipMalloc(&s.max_err, sizeof(float)));
@@ -387,7 +392,7 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
         // the filter copy is an accelerator, not a requirement: without HBM for it the index
         // keeps working on the f32 scan
         const size_t eb = idx->filter_i8 ? 1 : 2;  // bytes per stored element
-        const size_t hb = (size_t)want * idx->ds * eb, tb = (size_t)(want / kTileRows) * sizeof(float);
+        const size_t hb = (size_t)want * idx->ds * eb, tb = (size_t)(want / kTile8Rows) * 4 * sizeof(float);
         if (hipMalloc(&nh.p, hb) != hipSuccess || (idx->filter_i8 && hipMalloc(&nts.p, tb) != hipSuccess)) {
             (void)hipGetLastError();
             if (nh.p) (void)hipFree(nh.release());
@@ -398,7 +403,7 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
             if (used) MX_HIP(hipMemcpyAsync(nh.p, idx->xh, used, hipMemcpyDeviceToDevice, idx->stream));
             MX_HIP(hipMemsetAsync(static_cast<char *>(nh.p) + used, 0, hb - used, idx->stream));
             if (idx->filter_i8) {
-                const size_t tused = (size_t)(used_rows / kTileRows) * sizeof(float);
+                const size_t tused = (size_t)(used_rows / kTile8Rows) * 4 * sizeof(float);
                 if (tused) MX_HIP(hipMemcpyAsync(nts.p, idx->tsc, tused, hipMemcpyDeviceToDevice, idx->stream));
                 MX_HIP(hipMemsetAsync(static_cast<char *>(nts.p) + tused, 0, tb - tused, idx->stream));
             }
@@ -518,17 +523,16 @@ uint32_t sample_stride(uint64_t full_tiles, int nwg, int k, bool filt8, int ds) 
     // 17 us at 1/32, 1/64, 1/128, 1/256; a weaker threshold means more records for finish_kernel to sift
     // (62 / 63 / 72 us, and at 1/256 lanes start to overflow their 32 records), while the collect launch
     // hardly notices since appends became whole-record stores (1.76 / 1.77 / 1.79 ms).  1/64 is the
-    // fastest end to end.  The int8 copy's certificate is five times wider (e1 0.022 against 0.004), so a weak
-    // threshold costs it far more rows: 1/8 of the tiles (1/64: 78 % of the queries overflow their lane buffers and
-    // take the retry pass; 1/16: 3 %; 1/8: none, 1.35 ms per step; 1/4: 1.42 ms -- scripts/r3_i8_sample.sh; at 512
-    // dims 1/8 still overflows and 1/4 does not -- scripts/r3_dims.sh).
+    // fastest end to end.  The int8 copy's certificate is four to five times wider, so a weak threshold costs it far
+    // more rows: 1/16 of the tiles up to 512 dims, 1/8 at 768, 1/4 at 1024 (a smaller sample makes lanes overflow
+    // their 64 records and the retry pass costs a whole scan: scripts/r3_i8_sample.sh, r3_dims.sh).
     // MEMEX_HIP_SAMPLE_DIV overrides both (a tuning knob: results do not depend on it).
     static const double env_div = [] {
         const char *e = getenv("MEMEX_HIP_SAMPLE_DIV");
         const double v = e ? atof(e) : 0.0;
         return v >= 2.0 && v <= 4096.0 ? v : 0.0;
     }();
-    const double div = env_div > 0.0 ? env_div : filt8 ? (ds <= 384 ? 8.0 : 4.0) : 64.0;
+    const double div = env_div > 0.0 ? env_div : !filt8 ? 64.0 : ds <= 512 ? 16.0 : ds <= 768 ? 8.0 : 4.0;
     const double f = std::min(0.5, std::max(1.0 / div, (double)k / (10.0 * div)));
     const uint64_t target = std::max<uint64_t>((uint64_t)nwg, (uint64_t)((double)full_tiles * f));
     return (uint32_t)std::max<uint64_t>(1, full_tiles / std::max<uint64_t>(target, 1));
@@ -561,6 +565,7 @@ int demote_filter(mx_index *idx) {
     idx->xh = nullptr;
     idx->tsc = nullptr;
     idx->filter_i8 = false;
+    idx->i8_batches = idx->i8_retry_batches = 0;
     MX_HIP(hipMemsetAsync(nh.p, 0, hb, idx->stream));
     MX_HIP(hipMemsetAsync(idx->flags + 2, 0, sizeof(uint32_t), idx->stream));
     MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh.p,
@@ -593,7 +598,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                             d_dists ? d_dists + o : nullptr, d_nfound + kWideBatch);
     }
     MX_HIP(launch_prep_queries(st, d_q, B, idx->dim, idx->ds, s.qfrag, s.qpad, s.qnorm2, s.theta, s.e1,
-                               idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags, filt8, s.qscale));
+                               idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags, s.qa, s.qb, filt8, s.qscale));
     const uint32_t *h_ovf = s.host_flags, *h_qfl = s.host_flags + 3 * kMaxBatch;
     auto any_bad_query = [&] {
         uint32_t bad = 0;
@@ -614,6 +619,9 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     fp.qpad = s.qpad;
     fp.qnorm2 = s.qnorm2;
     fp.e1 = s.e1;
+    fp.qa = s.qa;
+    fp.qb = s.qb;
+    fp.terr = filt8 ? idx->tsc : nullptr;
     fp.e2 = (float)(idx->ds + 8) * 5.9604645e-8f + 1e-6f;  // f32 fma dot of <= ds terms of unit vectors, any order
     fp.lane_rec = s.lane_rec;
     fp.lane_tile = s.lane_tile;
@@ -693,6 +701,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         p.overflow = s.overflow;
         p.tscale = idx->tsc;
         p.qscale = s.qscale;
+        p.qa = s.qa;
+        p.qb = s.qb;
         auto scan = [&](bool collect) {
             if (filt8) return launch_scan8(st, idx->kc, collect, idx->nwg, p);
             if (wide) return launch_scan16w(st, idx->kc, collect, idx->nwg, p);
@@ -722,7 +732,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
             p.tile_end = (uint32_t)full;
             p.tile_stride = sample_stride(full, idx->nwg, k, filt8, idx->ds);
             MX_HIP(scan(false));
-            MX_HIP(launch_theta(st, B, k, idx->nwg, s.lane_max, s.e1, s.theta));
+            MX_HIP(launch_theta(st, B, k, idx->nwg, s.lane_max, s.qa, !filt8, s.theta));
         }
         if ((rc = collect(true)) != MX_OK) return rc;
         if ((rc = finish_and_wait()) != MX_OK) return rc;
@@ -741,8 +751,11 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                 if (h_ovf[b] == 1) ++retry;
                 else if (h_ovf[b] >= 2) exact.push_back(b);
             }
-            if (filt8 && idx->filter_auto && (size_t)(retry + (int)exact.size()) * 16 > (size_t)B) {
-                // More than 1/16 of the batch did not fit the int8 pass: this corpus is too dense for the int8
+            if (filt8) idx->i8_retry_batches += 1;
+            // ... or the retry pass (a second whole scan) has become the rule: more than a quarter of the batches
+            const bool habitual = filt8 && idx->i8_batches >= 8 && idx->i8_retry_batches * 4 > idx->i8_batches;
+            if (filt8 && idx->filter_auto && ((size_t)(retry + (int)exact.size()) * 16 > (size_t)std::max(B, 16) || habitual)) {
+                // More than 1/16 of the batch (and more than one query) did not fit the int8 pass: this corpus is too dense for the int8
                 // certificate (neighbourhoods narrower than ~0.05 in cosine).  Rebuild the copy as bf16 (one pass
                 // over the f32 rows) and answer the batch on it; the index stays on bf16.
                 if (demote_filter(idx) == MX_OK) {
@@ -781,6 +794,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     // the batch had been fenced to device scope -- the results are in HBM, nothing else is queued)
     idx->stats.searches += 1;
     idx->stats.queries += (uint64_t)B;
+    if (filt8 && fast) idx->i8_batches += 1;
     return MX_OK;
 }
 
@@ -1548,9 +1562,10 @@ int mx_index_set_filter_copy(mx_index *idx, int on) {
     }
     idx->filter_i8 = i8;
     idx->filter_auto = on == 1;
+    idx->i8_batches = idx->i8_retry_batches = 0;
     if (idx->xh || idx->cap == 0 || idx->kc > kMaxKC16) return MX_OK;  // present, or built with the first rows
     DevBuf nh, nts;
-    const size_t hb = (size_t)idx->cap * idx->ds * (i8 ? 1 : 2), tb = (size_t)(idx->cap / kTileRows) * sizeof(float);
+    const size_t hb = (size_t)idx->cap * idx->ds * (i8 ? 1 : 2), tb = (size_t)(idx->cap / kTile8Rows) * 4 * sizeof(float);
     hipError_t e = hipMalloc(&nh.p, hb);
     if (e == hipSuccess && i8) e = hipMalloc(&nts.p, tb);
     if (e != hipSuccess) return fail(MX_ENOMEM, "hipMalloc(filter copy, %zu bytes): %s", hb, hipGetErrorString(e));

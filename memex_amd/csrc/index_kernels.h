@@ -33,7 +33,7 @@ constexpr int kWideBatch = 128;
 constexpr int kScan16WideLdsBytes = kRing16 * kSlot16Bytes + 4 * 64 * 16 * 4;
 
 constexpr int kMaxBatch = 256;     // queries per scan pass (8 waves x 32 MFMA columns)
-constexpr int kRecCap = 32;        // lane-private records per collect launch: one record = the lane's 16 scores of a tile
+constexpr int kRecCap = 64;        // lane-private records per collect launch: one record = the lane's 16 scores of a tile
 constexpr int kMaxScanWGs = 256;   // persistent workgroups (<= CUs)
 constexpr int kCandCap = 16384;    // candidates finish_kernel holds per query (LDS); more = rescan with a tight threshold
 constexpr int kZeroCap = 1024;     // zero-norm rows an index tracks in its list (more: EXACT path)
@@ -84,8 +84,9 @@ struct ScanParams {
     float *lane_max;         // [512][nwg] sample mode: running maximum of each lane
     uint32_t *overflow;      // [256]
     // 8-bit filter copy (scan8_kernel): xh holds int8 fragments, tiles are 64 rows
-    const float *tscale = nullptr;  // [cap_rows / 32] quantisation step of each 32-row half tile
+    const float *tscale = nullptr;  // [cap_rows / 64][4]: quantisation steps of a tile's two halves, then their residual bounds
     const float *qscale = nullptr;  // [256] quantisation step of each query
+    const float *qa = nullptr, *qb = nullptr;  // [256] a row's bound is qa + qb * residual (launch_prep_queries)
 };
 
 // launches ---------------------------------------------------------------------------------
@@ -101,8 +102,9 @@ constexpr int kScan8LdsBytes = kRing16 * kSlot16Bytes + kScaleRing8 * 256;
 hipError_t scan8_setup();
 hipError_t launch_scan8(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
 // (re)build half tiles [half0, half1) (32 rows each) of the 8-bit filter copy from the padded f32 store: per half
-// tile one quantisation step tscale[h] = max |c_i/|c|| / 127 over its rows below row_hi (rows at or above row_hi,
-// and zero-norm rows, are stored as zeros); ec_max as launch_shadow
+// tile one quantisation step = max |c_i/|c|| / 127 over its rows below row_hi (rows at or above row_hi, and zero-norm
+// rows, are stored as zeros) and one residual bound = 1.01 * max_rows |c/|c| - step * c8| + 1e-6; both go to
+// tscale[4 * (h / 2) + (h & 1)] and [.. + 2]: the 16 bytes of a 64-row scan tile; ec_max as launch_shadow
 hipError_t launch_shadow8(hipStream_t s, const float *x, const float *scale, int ds, uint32_t half0, uint32_t half1,
                           uint64_t row_hi, void *x8, float *tscale, uint32_t *ec_max);
 hipError_t scan16w_setup();
@@ -134,12 +136,17 @@ hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, flo
 // residual as float bits, or null = a-priori bound); flags[0] |= 1 when a query is not finite
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag,
                                float *qpad, double *qnorm2, float *theta, float *e1, const uint32_t *ec_max,
-                               uint32_t *overflow, uint32_t *flags, bool filt8 = false, float *qscale = nullptr);
+                               uint32_t *overflow, uint32_t *flags, float *qa, float *qb, bool filt8 = false,
+                               float *qscale = nullptr);
+// qa / qb [256]: the bound of one row's filter score is qa + qb * (residual of the row's half tile); scans that know
+// one residual for all rows get qa = e1, qb = 0
 // filt8: fragments for the 8-bit filter copy (scan8.hip: int8 [8 waves][ds/32][64 lanes][16]) and qscale[256] = the
 // query's quantisation step (0 for an unusable query); ec_max then is that copy's residual word (required)
 
 // theta[q] = (k-th largest of query q's lane maxima) - 2*e1[q]
-hipError_t launch_theta(hipStream_t s, int B, int k, int nwg, const float *lane_max, const float *e1, float *theta);
+// raw: the lane maxima are plain scores (theta = k-th - 2 * qa); otherwise they are lower bounds of cosines already
+// (scan8_kernel: theta = k-th - qa)
+hipError_t launch_theta(hipStream_t s, int B, int k, int nwg, const float *lane_max, const float *qa, bool raw, float *theta);
 
 // per query: gather the collect launch's lane buffers -> keep [kth approx - 2*e1, inf) -> f32
 // rescoring (error e2) -> keep [kth - 2*e2, inf) -> exact DistCosine -> order by (dist, id) -> emit.
@@ -155,6 +162,8 @@ struct FinishParams {
     const float *qpad;          // [256, ds]
     const double *qnorm2;       // [256]
     const float *e1;            // [256]
+    const float *qa, *qb;       // [256] bound of a row's filter score: qa + qb * residual(row)
+    const float *terr;          // the 8-bit copy's tscale array (residual of row r: [4 * (r / 64) + 2 + (r / 32 & 1)]); null: 0
     float e2;                   // bound on |f32 rescoring - cosine|
     const float *lane_rec;      // records of the collect launch (ScanParams)
     const uint32_t *lane_tile;

@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
                                                            double *__restrict__ qnorm2, float *__restrict__ theta,
                                                            float *__restrict__ e1, const uint32_t *__restrict__ ec_max,
                                                            uint32_t *__restrict__ overflow, uint32_t *__restrict__ flags,
-                                                           int filt8, float *__restrict__ qscale) {
+                                                           int filt8, float *__restrict__ qscale,
+                                                           float *__restrict__ qa, float *__restrict__ qb) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
     float *s_row = reinterpret_cast<float *>(psm);  // [d] this query (coalesced load; the chain reads LDS)
     __shared__ float s_inv;
@@ -292,14 +293,19 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
             if (!filt8) e = fminf(kApproxErr + ec * ec, e);  // two bf16 roundings have an a-priori bound as well
         }
         e1[b] = e;
+        // the bound of ONE row is a + b * (its residual): with a residual per half tile (8-bit copy, scan8.hip) the
+        // rows of a well-conditioned half tile get a tighter bound than e1, which is the bound of the worst one;
+        // the other scans know one residual for all rows: a = e1, b = 0
+        qa[b] = filt8 ? eq + kAccSlack : e;
+        qb[b] = filt8 ? 1.0f + eq : 0.0f;
     }
 }
 
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag, float *qpad,
                                double *qnorm2, float *theta, float *e1, const uint32_t *ec_max, uint32_t *overflow,
-                               uint32_t *flags, bool filt8, float *qscale) {
+                               uint32_t *flags, float *qa, float *qb, bool filt8, float *qscale) {
     hipLaunchKernelGGL(prep_queries_kernel, dim3(kMaxBatch), dim3(256), sizeof(float) * (size_t)d, s, q, B, d, ds,
-                       (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags, filt8 ? 1 : 0, qscale);
+                       (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags, filt8 ? 1 : 0, qscale, qa, qb);
     return hipGetLastError();
 }
 
@@ -309,8 +315,12 @@ hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int 
 // A query's 2*nwg lane maxima are approximate scores of 2*nwg DISTINCT rows, so the k-th largest of
 // them, a_k, is a lower bound of the k-th best approximate score, the exact k-th best cosine is
 // >= a_k - e1, and every row of the exact top-k has an approximate score >= a_k - 2*e1.
+// Per-row bounds (scan8_kernel): the lane maxima already are lower bounds of cosines, L_k is a lower bound of the
+// k-th best cosine, a row of the top-k has score + (qa + qb * residual) >= L_k, and the scan tests
+// score >= theta - qb * residual with theta = L_k - qa.  `raw` = 1: lane maxima are plain scores, theta = a_k - 2*qa
+// (qa = e1 there).
 __global__ __launch_bounds__(256) void theta_kernel(int k, int nwg, const float *__restrict__ lane_max,
-                                                    const float *__restrict__ e1, float *__restrict__ theta) {
+                                                    const float *__restrict__ qa, int raw, float *__restrict__ theta) {
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_pick[2];
     __shared__ uint32_t s_nvalid[4];
@@ -337,12 +347,12 @@ __global__ __launch_bounds__(256) void theta_kernel(int k, int nwg, const float 
     nv = s_nvalid[0] + s_nvalid[1] + s_nvalid[2] + s_nvalid[3];
     float kth = -INFINITY;  // fewer than k lanes saw a row: no threshold
     if (nv >= (uint32_t)k && k > 0) kth = key_f32(block_kth_largest<2>(key, valid, (uint32_t)k, s_hist, s_pick));
-    if (tid == 0 && theta[q] != INFINITY) theta[q] = kth - 2.0f * e1[q];
+    if (tid == 0 && theta[q] != INFINITY) theta[q] = kth - (raw ? 2.0f : 1.0f) * qa[q];
 }
 
-hipError_t launch_theta(hipStream_t s, int B, int k, int nwg, const float *lane_max, const float *e1, float *theta) {
+hipError_t launch_theta(hipStream_t s, int B, int k, int nwg, const float *lane_max, const float *qa, bool raw, float *theta) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(theta_kernel, dim3(B), dim3(256), 0, s, k, nwg, lane_max, e1, theta);
+    hipLaunchKernelGGL(theta_kernel, dim3(B), dim3(256), 0, s, k, nwg, lane_max, qa, raw ? 1 : 0, theta);
     return hipGetLastError();
 }
 
@@ -494,7 +504,9 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
         return;
     }
     const uint32_t lane_ovf = p.overflow[q];
-    const float e1 = p.e1[q];
+    // bound of a row's filter score: qa + qb * (residual of its half tile); one residual for all rows: qb = 0, qa = e1
+    const float qa = p.qa[q], qb = p.qb[q];
+    auto resid = [&](uint32_t row) { return p.terr ? p.terr[4 * (size_t)(row >> 6) + 2 + ((row >> 5) & 1u)] : 0.0f; };
     for (int i = tid; i < ds; i += kFinThreads) qv[i] = p.qpad[(size_t)q * ds + i];
 
     // ---- gather.  Scan workgroup w kept this query's records in lanes L0 and L0+32 of wave q/32
@@ -559,11 +571,14 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
             const f32x4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = a[r], v[4 + r] = b[r], v[8 + r] = c[r], v[12 + r] = d[r];
+            const float er = resid(rowb);                  // one half tile per record
+            const float thr = fmaf(-qb, er, th), eb = fmaf(qb, er, qa);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
-                const bool pass = v[r] >= th && (uint64_t)row < p.n_rows && !(v[r] == 0.0f && nz && is_zero_row(row));
+                const bool pass = v[r] >= thr && (uint64_t)row < p.n_rows && !(v[r] == 0.0f && nz && is_zero_row(row));
                 mask |= pass ? (1u << r) : 0u;
+                v[r] -= eb;                                // candidates carry the LOWER bound of their cosine
             }
         }
         // one LDS atomic per WAVE (a per-thread atomicAdd on the one counter serialises: ~1800 of them
@@ -600,7 +615,8 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
         return;
     }
 
-    // ---- stage 1: k-th best approximate score; keep [kth - 2*e1, +inf)
+    // ---- stage 1: L = k-th best lower bound; keep the rows whose upper bound (lower + 2 * own bound) reaches L;
+    // the survivors carry their filter score again (lower + own bound)
     uint32_t key[kFinPer], row[kFinPer];
     bool valid[kFinPer];
 #pragma unroll
@@ -619,18 +635,23 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     {
         const uint32_t kth = block_kth_largest<kFinPer>(key, valid, (uint32_t)want, s_hist, s_pick);
         if (p.debug_stop == 7) return;
-        const uint32_t keep = f32_key(key_f32(kth) - 2.0f * e1);
+        const float L1 = key_f32(kth);
         if (tid == 0) s_cnt = 0;
         __syncthreads();  // also: every thread has its entries in registers, ent[] may be overwritten
         uint32_t mine = 0;
+        float eb[kFinPer];
 #pragma unroll
-        for (int e = 0; e < kFinPer; ++e) mine += (valid[e] && key[e] >= keep) ? 1u : 0u;
+        for (int e = 0; e < kFinPer; ++e) {
+            eb[e] = valid[e] ? fmaf(qb, resid(row[e]), qa) : 0.0f;
+            valid[e] = valid[e] && key_f32(key[e]) + 2.0f * eb[e] >= L1;
+            mine += valid[e] ? 1u : 0u;
+        }
         uint32_t at = mine ? atomicAdd(&s_cnt, mine) : 0;
 #pragma unroll
         for (int e = 0; e < kFinPer; ++e)
-            if (valid[e] && key[e] >= keep) {
+            if (valid[e]) {
                 Cand cd;
-                cd.score = key_f32(key[e]);
+                cd.score = key_f32(key[e]) + eb[e];
                 cd.row = row[e];
                 ent[at++] = cd;
             }
@@ -747,7 +768,7 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
         }
         const float L = key_f32(kth);
         if (tid == 0) {
-            p.theta_retry[q] = L - p.e2 - e1 - 1e-6f;
+            p.theta_retry[q] = L - p.e2 - qa - 1e-6f;  // a row of the top-k: score + qa + qb * residual >= L - e2
             s_cnt = 0;
         }
         if (lane_ovf || too_many) {  // incomplete candidate set: the host rescans this query with theta_retry

@@ -26,7 +26,7 @@
 // the fragment register it consumed.  The query fragments take dim_pad/8 VGPRs (48 at 384 dims, 192 at
 // 1536), so one launch serves 256 queries at every supported width.
 // Tile epilogue, per half: integer max over the lane's 16 sums, one conversion, two multiplications
-// (s_h from the tile's 8 bytes of the DMA stream, s_q per lane), one compare with the query's threshold; a passing lane stores its
+// (s_h from the tile's 16 bytes of the DMA stream, s_q per lane), one compare with the query's threshold; a passing lane stores its
 // 16 scores as floats -- the record format of scan16_kernel with the 32-row tile index 2T + u, so theta_kernel
 // and finish_kernel do not know which scan ran.
 #include <type_traits>
@@ -44,6 +44,11 @@ typedef __attribute__((address_space(3))) void lds_void;
     __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lds_void *)(ldsptr), 16, (voff), (soff), 0, (aux))
 
 static_assert(kRing16 == 16, "waits below assume a 16-slot ring with 15 slots in flight");
+
+// Ablation switch for scripts/scan8_ubench.hip only (0 = production kernel): 1 = tile scales are constants (no LDS read)
+#ifndef MX_SCAN8_ABLATE
+#define MX_SCAN8_ABLATE 0
+#endif
 
 namespace {
 template <int N>
@@ -82,7 +87,11 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
 #pragma unroll
         for (int i = 0; i < KC * 4; ++i) qf[i] = src[(size_t)i * 64];
     }
+    // MODE 1: a half tile with residual bound e passes when a score reaches theta - qb * e (theta_kernel);
+    // MODE 0: the lane keeps the best LOWER bound of a cosine, score - (qa + qb * e)
     const float theta = MODE == 1 ? p.theta[wave * 32 + m] : 0.0f;
+    const float qa = MODE == 0 ? p.qa[wave * 32 + m] : 0.0f;
+    const float qb = p.qb[wave * 32 + m];
     const float sq = p.qscale[wave * 32 + m];  // 0 for an unusable (zero / padded) query
 
     // ---- 64-row tiles of this workgroup: tile_begin + (blockIdx + i*grid) * tile_stride
@@ -96,16 +105,16 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
     const uint32_t lane4 = (uint32_t)lane * 4u;
 
     // ---- DMA stream: as scan16_kernel (always issued; past the last tile num_records = 0 -> no memory touched).
-    // The two quantisation steps of a tile travel in the same stream: one 8-byte operation, issued right before
+    // The quantisation steps and residual bounds of a tile's halves travel in the same stream: one 16-byte operation, issued right before
     // the tile's first slot, so they have landed when that slot has (a scalar load per tile would expose an
     // HBM latency per tile; a vector load would put its own wait on the ring's vmcnt).  Every wave issues it
-    // (same 8 bytes, same LDS address: the waits below stay wave-uniform arithmetic).
+    // (same 16 bytes, same LDS address: the waits below stay wave-uniform arithmetic).
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t is_ti = 0;
     auto open_tile = [&]() {
         const uint32_t tile = t0 + is_ti * tstep;
         const bool live = is_ti < nT;
-        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.tscale + 2 * (size_t)tile), 0, live ? 8u : 0u, 0x00020000);
+        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.tscale + 4 * (size_t)tile), 0, live ? 16u : 0u, 0x00020000);
         char *sdst = smem + __builtin_amdgcn_readfirstlane(kRing16 * kSlot16Bytes + (is_ti & (kScaleRing8 - 1)) * 256);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void *)sdst, 4, lane4, 0, 0, 0);
         const char *base = reinterpret_cast<const char *>(p.xh) + (size_t)tile * tilebytes;
@@ -163,15 +172,19 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
         // ---- tile epilogue, per half: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*(lane>>5) of the half
         // (read with inline asm: hipcc puts s_waitcnt vmcnt(0) in front of a plain LDS load that it thinks an LDS-DMA
         // may have written, which would drain the ring once per tile; the scales landed with the tile's first slot)
-        float2 shs;
+        f32x4 shs;  // steps of the two halves, residual bounds of the two halves
+#if MX_SCAN8_ABLATE == 1  /* scripts/scan8_ubench.hip: no scale read */
+        shs = f32x4{1.0f, 1.0f, 0.0f, 0.0f};
+#else
         {
             const uint32_t sa = kRing16 * kSlot16Bytes + (ti & (kScaleRing8 - 1)) * 256;
-            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(shs) : "v"(sa) : "memory");
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(shs) : "v"(sa) : "memory");
         }
+#endif
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const i32x16 &acc = u ? acc1 : acc0;
-            const float sh = u ? shs.y : shs.x;
+            const float sh = u ? shs[1] : shs[0], er = u ? shs[3] : shs[2];
             int mxi = max(max(acc[0], acc[1]), acc[2]);
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mxi = max(max(mxi, acc[r]), acc[r + 1]);
@@ -179,10 +192,11 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
             // score of a sum: ((float)sum * s_h) * s_q -- monotone in the sum, so the test on the maximum is the
             // test on "any of the 16 scores" as finish_kernel will see them
             const float mx = ((float)mxi * sh) * sq;
+            const float thr = fmaf(-qb, er, theta);
             if (MODE == 0) {
-                best = fmaxf(best, mx);  // only full tiles are sampled (index.hip): every row is a real row
-            } else if (__builtin_amdgcn_ballot_w64(mx >= theta) != 0) {
-                if (mx >= theta) {
+                best = fmaxf(best, mx - fmaf(qb, er, qa));  // only full tiles are sampled (index.hip): every row is a real row
+            } else if (__builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
+                if (mx >= thr) {
                     if ((cnt & 0x7fffffffu) < (uint32_t)kRecCap) {
                         const size_t at = (size_t)mylane() * kRecCap + (cnt & 0x7fffffffu);
                         f32x4 *dst = reinterpret_cast<f32x4 *>(p.lane_rec + at * 16);
@@ -273,8 +287,14 @@ __global__ __launch_bounds__(256) void shadow8_kernel(const float *__restrict__ 
             atomicAdd(&s_r2[mm], r2);
         }
         __syncthreads();
-        if (tid == 0) tscale[h] = sh;
-        if (tid < kTileRows) worst = fmaxf(worst, sqrtf(s_r2[tid]));
+        float hw = tid < kTileRows ? sqrtf(s_r2[tid]) : 0.0f;  // worst residual of THIS half tile (waves 1-3 hold zeros)
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) hw = fmaxf(hw, __shfl_xor(hw, o));
+        if (tid == 0) {
+            tscale[4 * (size_t)T + u] = sh;
+            tscale[4 * (size_t)T + 2 + u] = hw * 1.01f + 1e-6f;
+        }
+        if (tid < kTileRows) worst = fmaxf(worst, hw);
         __syncthreads();
     }
     if (tid < kTileRows) {

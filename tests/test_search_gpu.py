@@ -180,23 +180,34 @@ def _rows_with_cosine(rng, q, cosines):
 
 def test_lane_overflow_is_rescanned_with_a_tight_threshold(oracle, lib_built):
     """A dense neighbourhood the sample cannot see: every tile of ONE scan workgroup is filled with
-    rows close to the query (cosines 0.99 .. 0.79, all distinct).  Only 2 of a query's 512 lanes see
-    them, so the sample threshold stays at background level, those lanes overflow (> 32 records: a
-    lane stores one record per tile with a passing row), and the query must be rescanned with the
-    threshold derived from what it did collect.  Still bit-exact, and no EXACT fallback."""
+    rows close to a query (cosines 0.99 .. 0.79, all distinct).  Only 2 of the query's 512 lanes see
+    them, so the sample threshold stays at background level, those lanes overflow (> 64 records: a
+    lane stores one record per 32 rows with a passing row), and the query must be rescanned with the
+    threshold derived from what it did collect.  Still bit-exact, and no EXACT fallback.  Query 2 does this
+    to the scans over 32-row tiles (bf16 copy, f32 rows), query 3 to the int8 scan (64-row tiles)."""
     from memex_amd.index import FlatIndex
     rng = np.random.default_rng(123)
-    n, d = 320000, 384
+    n, d = 640000, 384
     X = rng.standard_normal((n, d), dtype=np.float32)
     Q = rng.standard_normal((6, d), dtype=np.float32)
-    tiles = [t for t in range(n // 32) if t % 256 == 5]          # one workgroup's tiles (256 CUs)
+    tiles = [t for t in range(n // 32) if t % 256 == 5]          # one workgroup's 32-row tiles (256 CUs): 78 of them
     rows = np.concatenate([np.arange(32 * t, 32 * t + 32) for t in tiles])
     X[rows] = _rows_with_cosine(rng, Q[2], np.linspace(0.99, 0.79, len(rows)))
+    tiles = [t for t in range(n // 64) if t % 256 == 7]          # one workgroup's 64-row tiles: 39, two records each
+    rows = np.concatenate([np.arange(64 * t, 64 * t + 64) for t in tiles])
+    X[rows] = _rows_with_cosine(rng, Q[3], np.linspace(0.99, 0.79, len(rows)))
     with FlatIndex(d) as idx:
         idx.add(X)
-        _check(idx, X, Q, 10, oracle)
-        st = idx.stats()
-        assert st.retry_queries >= 1 and st.fallback_queries == 0
+        oi, od, os_, onf = oracle.search(X, Q, 10)
+        for kind in ("i8", "bf16", False):
+            idx.set_filter_copy(kind)
+            idx.reset_stats()
+            ids, sc, di, nf = idx.search(Q, 10)
+            np.testing.assert_array_equal(ids, oi)
+            np.testing.assert_array_equal(bits(di), bits(od))
+            np.testing.assert_array_equal(bits(sc), bits(os_))
+            st = idx.stats()
+            assert st.retry_queries >= 1 and st.fallback_queries == 0, kind
 
 
 def test_rescan_overflow_falls_back_to_exact_and_stays_bit_exact(oracle, lib_built):
@@ -525,6 +536,7 @@ def test_wide_rows_use_the_split_scan(n, d, B, k, seed, oracle, lib_built):
     X[100:125] = X[50]                                   # 26 exact ties: more survivors than finish_kernel can stage
     Q[B - 1] = X[50] * 3.0                               # in LDS at 1536 dims (21 rows) -> its chains read global memory
     with FlatIndex(d) as idx:
+        idx.set_filter_copy("bf16")                      # (the automatic choice is the int8 copy up to 1024 dims)
         assert idx.add(X) == 1 and len(idx) == n
         oi, od, os_, onf = oracle.search(X, Q, k)
         ids, sc, di, nf = idx.search(Q, k)
@@ -538,7 +550,7 @@ def test_wide_rows_use_the_split_scan(n, d, B, k, seed, oracle, lib_built):
         ids2, sc2, _, _ = idx.search(Q[:3], k)
         np.testing.assert_array_equal(ids2, oi[:3])
         np.testing.assert_array_equal(bits(sc2), bits(os_[:3]))
-        idx.set_filter_copy(True)                       # rebuilt from the resident rows
+        idx.set_filter_copy("bf16")                     # rebuilt from the resident rows
         ids3, sc3, _, _ = idx.search(Q, k)
         np.testing.assert_array_equal(ids3, oi)
         np.testing.assert_array_equal(bits(sc3), bits(os_))
