@@ -433,7 +433,7 @@ def roofline_of(st, scan: str, dim: int, batch: int, rows_total: int, world: int
         "traffic": traffic_from_profile(rows_total, dim, world, scan),
         "mfma_tflops": tflops,
         "mfma_frac": tflops / mfma_peak,
-        "power_note": "package power sits at its 1400 W cap during this kernel (profiles/r2_power_*.log)",
+        "power_note": "package power sits at its 1400 W cap during this kernel (profiles/r3_power_*.log)",
     }
 
 
@@ -459,11 +459,17 @@ def timed_steps(idx, step, fence, warmup: int, steps: int, world: int):
     return dt, st
 
 
+def scan_of(st) -> str:
+    """What the index's scan streams now (mx_index_stats.filter_kind): the library chooses unless told."""
+    return {0: "f32", 2: "i8", 3: "bf16"}[int(st.filter_kind)]
+
+
 def leg_report(st, dt: float, steps: int, workload: str, dim: int, batch: int, rows: int):
     return {"workload": workload, "value": batch * steps / dt, "unit": "queries/s", "steps": steps,
             "ms_per_step": dt / steps * 1e3, "candidates_per_query": st.candidates / max(1, st.queries),
             "retry_queries": int(st.retry_queries), "fallback_queries": int(st.fallback_queries),
-            "approx_err_bound": st.approx_err_bound, "roofline": roofline_of(st, "bf16", dim, batch, rows, 1)}
+            "approx_err_bound": st.approx_err_bound, "scan": scan_of(st), "filter_demotions": int(st.filter_demotions),
+            "roofline": roofline_of(st, scan_of(st), dim, batch, rows, 1)}
 
 
 def side_leg(rows: int, dim: int, batch: int, k: int, steps: int, data: str):
@@ -642,7 +648,9 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 corpus; bf16 MFMA filter -> f32 rescoring -> f64 DistCosine on the survivors (results bit-identical to all-f64)",
+            "dtype": {"i8": "f32 corpus; int8 MFMA filter (exact integer sums, measured-residual certificate)",
+                      "bf16": "f32 corpus; bf16 MFMA filter", "f32": "f32 corpus; bf16 MFMA filter on rows rounded in flight"}[a.scan]
+                     + " -> f32 rescoring -> f64 DistCosine on the survivors (results bit-identical to all-f64)",
             "scan": a.scan,
             "filter_copy_bytes": int(st.filter_copy_bytes),
             "data": "synthetic" if a.data == "gaussian" else "synthetic (clustered)",

@@ -1,6 +1,7 @@
 """Reduce the rocprofv3 output of scripts/profile_search.sh to the small summaries kept under profiles/.
 
   <tag>_bench_kernel_stats.csv   per-kernel totals/averages from --kernel-trace --stats
+  <tag>_scan8_traffic.json       HBM bytes per launch of the int8-copy scan kernel (+ SQ counters)
   <tag>_scan16_traffic.json      HBM bytes per launch of the bf16-copy scan kernel (+ SQ counters)
   <tag>_scan_traffic.json        same for the f32 scan kernel
 FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE under-counts 16-B/lane streaming reads by
@@ -82,7 +83,9 @@ def main():
         bench = json.loads(open(os.path.join(prof, f"{tag}_bench.json")).read())
     except Exception:
         pass
-    for label, want, fname, pat in (("bf16", "scan16_kernel<3, 1>", f"{tag}_scan16_traffic.json", "pmc_*"),
+    for label, want, fname, pat in (("i8", "scan8_kernel<3, 1>", f"{tag}_scan8_traffic.json", "pmc_*"),
+                                    ("768", "scan8_kernel<6, 1>", f"{tag}_scan8_768_traffic.json", "pmc768_*"),
+                                    ("bf16", "scan16_kernel<3, 1>", f"{tag}_scan16_traffic.json", "pmc_*"),
                                     ("f32", "scan_kernel<3, 1>", f"{tag}_scan_traffic.json", "pmc_*"),
                                     ("768", "scan16_kernel<6, 1>", f"{tag}_scan16_768_traffic.json", "pmc768_*")):
         c = {}
@@ -95,6 +98,8 @@ def main():
         write = c.get("WRITE_SIZE", (0.0, 0, 0.0))[0] * 1024.0
         if label == "768":
             rf = bench.get("cfg4_shard_10Mx768", {}).get("roofline", {})
+            if ("scan8" in want) != ("scan8" in str(rf.get("kernel", ""))):
+                rf = {}
         else:
             rf = bench.get("roofline", {}) if bench.get("scan") == label else bench.get("other_scan", {}).get("roofline", {})
         algo = rf.get("bytes_per_launch")

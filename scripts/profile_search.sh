@@ -23,6 +23,10 @@ done
 $BENCH > "$OUT/bench.json" 2> "$OUT/bench.log"
 # package power and shader clock while the scan kernel (and its ablations: 1 = DMA stream only,
 # 4 = fragment reads + MFMA without the DMA) runs back to back for >= 5 s
+if [ -x $ROOT/build_ub/scan8_ub_0 ]; then   # the int8-copy scan on signed Gaussian-like bytes, no records
+  python $ROOT/scripts/power_sampler.py "$OUT/power_scan8.log" -- $ROOT/build_ub/scan8_ub_0 10000000 384 6000 > /dev/null 2>&1
+  python $ROOT/scripts/power_sampler.py "$OUT/power_scan8_768.log" -- $ROOT/build_ub/scan8_ub_0 10000000 768 3000 > /dev/null 2>&1
+fi
 if [ -x $ROOT/build_ub/scan16_ub_0 ]; then
   for V in 0 1 4; do
     python $ROOT/scripts/power_sampler.py "$OUT/power_scan16_ablate$V.log" -- $ROOT/build_ub/scan16_ub_$V 10000000 384 3000 > /dev/null 2>&1
