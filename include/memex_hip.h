@@ -135,18 +135,27 @@ int mx_index_search(mx_index *idx, const float *queries, int B, int k, uint64_t 
 int mx_index_search_device(mx_index *idx, const float *d_queries, int B, int k, uint64_t *d_ids,
                            float *d_scores, float *d_dists, int32_t *d_n_found);
 
-/* Search strategy (testing / diagnostics).  AUTO = bf16-MFMA streaming scan that certifies a
- * candidate superset, exact f64 rescoring of the candidates, per-query fallback to EXACT when a
- * candidate buffer overflows.  EXACT = f64 arithmetic on every row (slow, always available). */
+/* Search strategy (testing / diagnostics).  AUTO = low-precision MFMA streaming scan (int8 or bf16
+ * filter copy, or the f32 rows) that certifies a candidate superset, f32 then exact f64 rescoring of the
+ * candidates, per-query fallback to EXACT when a candidate buffer overflows twice.  EXACT = f64 arithmetic on every row (slow, always available). */
 enum { MX_SEARCH_AUTO = 0, MX_SEARCH_EXACT = 1 };
 int mx_index_set_search_mode(mx_index *idx, int mode);
 
-/* Filter copy.  By default the index keeps, next to the f32 rows, a bf16 copy of them laid out for
- * the MFMA scan (+50 % HBM: rows*dim_pad*2 bytes).  The AUTO scan then streams 2 bytes per element
- * instead of 4; candidates are rescored from the f32 rows exactly as before, so results are
- * bit-identical with and without it.  on = 0 frees the copy (the scan reads the f32 rows), on = 1
- * (re)builds it.  If HBM for the copy cannot be allocated while the index grows, it is dropped
- * silently and the index continues on the f32 scan. */
+/* Filter copy.  By default the index keeps, next to the f32 rows, a low-precision copy of them laid out
+ * for the MFMA scan; the AUTO scan streams that copy instead of the f32 rows and candidates are rescored
+ * from the f32 rows, so results are bit-identical with every kind and without one.
+ *   on = 0  no copy (the scan reads the f32 rows: 4 bytes per element streamed)
+ *   on = 1  a copy whose kind the library chooses (the default): int8 up to 1024 dims, bf16 above; an int8
+ *           copy is rebuilt as bf16 -- once, from the f32 rows -- when the corpus proves too dense for its
+ *           certificate (more than 1/16 of a batch overflows the int8 pass, or the retry pass has become
+ *           habitual); mx_index_stats.filter_kind / filter_demotions tell
+ *   on = 2  int8 copy (+25 % HBM: rows*dim_pad bytes + 16 bytes per 64 rows): one quantisation step and one
+ *           measured residual bound per 32 rows, exact integer sums; the certificate is 4-5x wider than
+ *           bf16's, so finish_kernel sifts a few hundred candidates per query instead of a few dozen
+ *   on = 3  bf16 copy (+50 % HBM: rows*dim_pad*2 bytes)
+ * (Re)builds from the resident rows when the kind changes.  If HBM for the copy cannot be allocated while
+ * the index grows, it is dropped silently and the index continues on the f32 scan.  Environment:
+ * MEMEX_HIP_FILTER=i8|bf16 pins the kind for every index opened afterwards. */
 int mx_index_set_filter_copy(mx_index *idx, int on);
 
 /*
@@ -158,7 +167,7 @@ int mx_index_set_filter_copy(mx_index *idx, int on);
  * stored rows, and the answer is bit-identical to the reference's arithmetic applied to
  * mx_index_get_rows() -- each cosine is within ~2e-3 of the f32 one, so recall@10 against the f32
  * corpus stays ~0.99 while the scan is unchanged.  Choose the mode while the index is empty.
- * dim <= 768.  mx_index_save marks such a store in the file header; loading it into an index of
+ * dim <= 1536.  mx_index_save marks such a store in the file header; loading it into an index of
  * either mode reproduces the stored rows exactly.
  */
 enum { MX_CORPUS_F32 = 0, MX_CORPUS_BF16 = 1 };
@@ -185,11 +194,11 @@ typedef struct mx_index_stats {
     uint64_t queries;           /* queries served                                          */
     uint64_t fallback_queries;  /* queries answered by the EXACT path (rescan overflowed too) */
     uint64_t scan_launches;     /* launches of the main streaming-scan kernel              */
-    uint64_t scan_bytes;        /* bytes those launches streamed: rows*dim_pad*(2 with a filter copy, else 4) */
+    uint64_t scan_bytes;        /* bytes those launches streamed: rows*dim_pad*(1 int8 copy, 2 bf16 copy, 4 f32 rows) */
     double scan_ms;             /* HIP-event time of those launches (profiling on)         */
-    uint64_t candidates;        /* candidates that passed the bf16 filter and were rescored in f32 */
+    uint64_t candidates;        /* candidates that passed the filter and were rescored in f32 */
     double max_abs_err;         /* profiling only: max |approx - exact| cosine on candidates */
-    uint64_t filter_copy_bytes; /* HBM held by the bf16 filter copy (0 = scanning the f32 rows) */
+    uint64_t filter_copy_bytes; /* HBM held by the filter copy (0 = scanning the f32 rows) */
     uint64_t retry_queries;     /* queries rescanned once with a tightened threshold (lane buffer overflow) */
     double approx_err_bound;    /* largest per-query bound e1 on |filter score - cosine| of the last batch */
     uint64_t filter_kind;       /* what the scan streams now: 0 = the f32 rows, 2 = int8 filter copy, 3 = bf16 filter copy */

@@ -12,7 +12,7 @@ for STOP in ${STOPS:-0 1 2 3 4}; do
 import csv, glob, sys, os
 f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_stats.csv"), recursive=True)
 for r in csv.DictReader(open(f[0])):
-    if any(t in r["Name"] for t in ("finish_kernel", "theta_kernel", "scan16_kernel", "prep_queries")):
+    if any(t in r["Name"] for t in ("finish_kernel", "theta_kernel", "scan16_kernel", "scan8_kernel", "prep_queries")):
         print(f"stop={sys.argv[2]} {r['Name'][:50]:50s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:8.1f} us")
 PY
 done
