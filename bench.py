@@ -594,6 +594,22 @@ def main():
         host_api = leg_report(st3, dt3, a.side_steps, f"{rows_total}x{a.dim} f32 corpus ({a.data}), query batch {a.batch}, "
                               f"top-{k}, mx_index_search (host pointers)", a.dim, a.batch, rows_total)
 
+    small = None
+    if single and a.side_steps > 0:
+        # small batches through the same entry point: a lone query (what the reference's trait issues) and 32 of them.
+        # Waves of the scan without live queries skip their MFMAs, so these run at the stream's rate, not at the
+        # power-capped rate of a full batch.
+        small = {}
+        for nb in (1, 32):
+            qs = q[:nb].contiguous()
+            sb = SearchBuffers(nb, k)
+            dts, sts = timed_steps(idx, lambda: idx.search_device(qs, k, sb.ids, sb.scores, sb.dists, sb.nf), fence, 3, a.side_steps, world)
+            rf = roofline_of(sts, a.scan, a.dim, nb, rows_total, 1)
+            small[f"batch_{nb}"] = {"ms_per_call": dts / a.side_steps * 1e3, "queries_per_s": nb * a.side_steps / dts,
+                                    "collect_ms": rf["ms_per_launch"], "collect_GBps": rf["achieved"], "collect_hbm_frac": rf["frac"],
+                                    "ids_equal_full_batch": bool(torch.equal(sb.ids, ids_main[:nb]))}
+        step()
+
     # ---- recall@10 against the all-f64 EXACT path on a few queries (oracle-level parity at smaller
     # sizes and the oracle-based 10M check live in tests/; the EXACT path is itself oracle-checked there)
     recall = recall_exact_order = merged_ok = None
@@ -623,6 +639,7 @@ def main():
     sides = {}
     if single and a.side_steps > 0:
         sides["host_api"] = host_api
+        sides["small_batches"] = small
         other_data = "clustered" if a.data == "gaussian" else "gaussian"
         sides[other_data] = side_leg(rows_total, a.dim, a.batch, k, a.side_steps, other_data)
         sides["cfg4_shard_10Mx768"] = side_leg(10_000_000, 768, a.batch, k, a.side_steps, "gaussian")

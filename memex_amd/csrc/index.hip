@@ -694,6 +694,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         p.theta = s.theta;
         p.n_rows = idx->n;
         p.ds = (uint32_t)idx->ds;
+        p.n_queries = (uint32_t)B;
         p.lane_rec = s.lane_rec;
         p.lane_tile = s.lane_tile;
         p.lane_cnt = s.lane_cnt;

@@ -83,6 +83,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31;  // query column of B and D (lane >> 5 selects which 16 of the tile's 32 rows the lane scores)
+    // a wave whose 32 query columns are all padding only keeps the DMA stream and the barriers going
+    // (not at 768 dims: the query fragments take 192 of the 256 VGPRs there and the branch costs the rest)
+    const bool live = KC == 6 || (uint32_t)(wave * 32) < p.n_queries;
 
     // ---- register-resident query fragments (B operand), loaded once per launch
     bf16x8 qf[KC * 8];
@@ -160,6 +163,11 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
             // consumed (MFMA issued) its fragments of slot j-1, whose ring position is refilled below.
             __builtin_amdgcn_s_barrier();
             const uint32_t fb0 = rp * kSlot16Bytes + lane16, fb1 = rp1 * kSlot16Bytes + lane16;
+            if (!live) {
+                issue((kc + kRing16 - 1) % KC, rpi);
+                rp = rp1;
+                continue;
+            }
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
 #if MX_SCAN16_ABLATE == 1 || MX_SCAN16_ABLATE == 2
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
             rp = rp1;
         }
 
+        if (!live) continue;
         // ---- tile epilogue: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*h.
         // The copy holds c/|c|, so the accumulator already is the approximate cosine (a zero-norm row is
         // stored as zeros and scores 0: such rows reach finish_kernel through the index's zero-row list).

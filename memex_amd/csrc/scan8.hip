@@ -79,6 +79,10 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31;  // query column of B and D
+    // A wave whose 32 query columns are all padding (batch of fewer than 32 * (wave + 1) queries) only keeps the DMA
+    // stream and the barriers going: a single query costs the stream, not 256 queries' worth of MFMA energy
+    // (not at 1536 dims: the query fragments take 192 of the 256 VGPRs there and the branch costs the rest)
+    const bool live = KC == 12 || (uint32_t)(wave * 32) < p.n_queries;
 
     // ---- register-resident query fragments (B operand): k-step ks = 32 dims, 16 int8 per lane
     i32x4 qf[KC * 4];
@@ -156,19 +160,24 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ops_after<KC>(kc + 2, kc + kRing16 - 2)) : "memory");
             __builtin_amdgcn_s_barrier();  // ... for every wave; slot j-1 is free for slot j+15
             const uint32_t fb0 = rp * kSlot16Bytes + lane16, fb1 = rp1 * kSlot16Bytes + lane16;
+            if (live) {
 #pragma unroll
-            for (int f = 0; f < 8; ++f) {
-                if (f & 1)
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[kc * 4 + (f >> 1)], acc1, 0, 0, 0);
-                else
-                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[kc * 4 + (f >> 1)], acc0, 0, 0, 0);
-                a[f % R] = *reinterpret_cast<const i32x4 *>(smem + (f + R < 8 ? fb0 : fb1) + ((f + R) & 7) * 1024);
-                if (f == 1) issue((kc + kRing16 - 1) % KC, rpi);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int f = 0; f < 8; ++f) {
+                    if (f & 1)
+                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[kc * 4 + (f >> 1)], acc1, 0, 0, 0);
+                    else
+                        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[kc * 4 + (f >> 1)], acc0, 0, 0, 0);
+                    a[f % R] = *reinterpret_cast<const i32x4 *>(smem + (f + R < 8 ? fb0 : fb1) + ((f + R) & 7) * 1024);
+                    if (f == 1) issue((kc + kRing16 - 1) % KC, rpi);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                issue((kc + kRing16 - 1) % KC, rpi);
             }
             rp = rp1;
         });
 
+        if (!live) continue;
         // ---- tile epilogue, per half: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*(lane>>5) of the half
         // (read with inline asm: hipcc puts s_waitcnt vmcnt(0) in front of a plain LDS load that it thinks an LDS-DMA
         // may have written, which would drain the ring once per tile; the scales landed with the tile's first slot)

@@ -21,6 +21,11 @@ def run(n, d, B, k, steps=10):
     st = idx.stats()
     print(f"n={n} d={d} B={B} k={k}: {dt*1e3:.3f} ms/step {B/dt:.0f} QPS scan {st.scan_bytes/max(st.scan_ms,1e-9)/1e6:.0f} GB/s ({st.scan_ms/max(1,st.scan_launches):.3f} ms x {st.scan_launches}) fallback={st.fallback_queries} retry={st.retry_queries} cand/q={st.candidates/max(1,st.queries):.0f} e1={st.approx_err_bound:.4f} filter={st.filter_copy_bytes/max(1,n)/d:.1f} B/elem")
     idx.close()
+if len(sys.argv) > 1 and sys.argv[1] == "small":     # small batches: waves without live queries skip their MFMAs
+    for B in (1, 8, 32, 33, 64, 128, 256):
+        run(10_000_000, 384, B, 10, 10)
+    run(10_000_000, 768, 1, 10, 10)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "dims":      # MEMEX_HIP_FILTER=i8|bf16: which filter copy pays at which width
     for n, d in ((10_000_000, 384), (10_000_000, 512), (10_000_000, 768), (4_000_000, 1024), (4_000_000, 1536), (10_000_000, 256), (10_000_000, 128)):
         run(n, d, 256, 10, 6)
