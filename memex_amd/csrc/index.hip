@@ -3,18 +3,22 @@
 // lib/libmemex/src/storage/local.rs:21-166) reached through the VectorStore trait
 // (lib/libmemex/src/storage/mod.rs:55-66).
 //
-// Search pipeline per batch of <= 256 queries (kernels: scan16.hip / scan.hip, index_kernels.hip):
-//   prep      normalise queries -> bf16 MFMA fragments; f64 query norms (DistCosine order);
-//             per-query error bound e1 of the bf16 scan from measured rounding residuals
-//   sample    scan an evenly spread ~1/32 of the tiles keeping only each lane's maximum
-//   theta     k-th largest lane maximum - 2*e1 = pass threshold (certified: keeps the exact top-k)
-//   collect   scan every tile, appending rows with score >= theta to lane-private buffers
-//   finish    gather -> k-th best approximate score, keep [kth - 2*e1, inf) -> f32 rescoring (error
-//             e2 ~ 5e-5) -> keep [kth - 2*e2, inf) -> exact f64 DistCosine -> order by (dist, id)
+// Search pipeline per batch of <= 256 queries (kernels: scan8.hip / scan16.hip / scan16w.hip / scan.hip,
+// index_kernels.hip):
+//   prep      normalise queries -> MFMA fragments (int8 with the query's own step, or bf16); f64 query norms
+//             (DistCosine order); the bound of a row's filter score, qa + qb * (residual of the row's half
+//             tile), from measured residuals (one residual for all rows with the bf16 / f32 scans: qb = 0)
+//   sample    scan an evenly spread 1/4 .. 1/64 of the tiles keeping only each lane's best lower bound
+//   theta     k-th largest of those - qa = pass threshold (certified: keeps the exact top-k)
+//   collect   scan every tile; a lane with a passing row stores its 16 scores as one record
+//   finish    gather -> k-th best lower bound, keep the rows whose upper bound reaches it -> f32 rescoring
+//             (error e2 ~ 5e-5) -> keep [kth - 2*e2, inf) -> exact f64 DistCosine -> order by (dist, id)
 // Five launches; corpora of <= 2 tiles per workgroup skip sample/theta (theta = -inf).
+// What the scan streams: an int8 or a bf16 filter copy kept next to the f32 rows (the library chooses by row
+// width and demotes int8 to bf16 on a corpus too dense for its certificate), or the f32 rows themselves.
 // A query whose lane buffers overflowed (dense neighbourhoods, weak sample threshold) is rescanned
 // ONCE with the tight threshold finish derived from what it did collect (all such queries of the
-// batch share that one extra pass); only if that overflows too -- more than ~16k rows within e1 of
+// batch share that one extra pass); only if that overflows too -- more than ~16k rows within the bound of
 // the k-th neighbour -- is it answered on the EXACT path (f64 on every row).
 #include <dlfcn.h>
 #include <sys/stat.h>

@@ -68,6 +68,10 @@ constexpr int ops_after(int lo, int hi) {  // slots lo .. hi relative to the til
     for (int i = lo; i <= hi; ++i) n += 1 + (i % KC == 0 ? 1 : 0);
     return n;
 }
+// 384 dims (3 slots per tile): after slot j+1 come 13 slots and the scale operations of the tiles that start at
+// relative slots 3, 6, 9, 12 (position 0 and 2) or 3 .. 15 (position 1); before the loop, after slot 0: 14 + 4.
+static_assert(ops_after<3>(2, 14) == 17 && ops_after<3>(3, 15) == 18 && ops_after<3>(4, 16) == 17 && ops_after<3>(1, 14) == 18, "");
+static_assert(ops_after<1>(2, 14) == 26 && ops_after<12>(2, 14) == 14 && ops_after<12>(13, 25) == 14 && ops_after<6>(5, 17) == 15, "");
 }  // namespace
 
 template <int KC, int MODE>
