@@ -698,7 +698,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         p.theta = s.theta;
         p.n_rows = idx->n;
         p.ds = (uint32_t)idx->ds;
-        p.n_queries = (uint32_t)B;
+        p.wave_mask = (1u << ((B + 31) / 32)) - 1u;  // waves whose 32 columns are all padding skip their MFMAs
         p.lane_rec = s.lane_rec;
         p.lane_tile = s.lane_tile;
         p.lane_cnt = s.lane_cnt;
@@ -772,6 +772,9 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                 // ONE more pass for all overflowed queries of the batch, with the threshold finish derived
                 // from what they did collect (everyone else is parked at theta = +inf)
                 idx->stats.retry_queries += (uint64_t)retry;
+                p.wave_mask = 0;  // only the waves that hold a rescanned query multiply: the pass runs at the stream's rate
+                for (int b = 0; b < B; ++b)
+                    if (h_ovf[b] == 1) p.wave_mask |= 1u << (b >> 5);
                 MX_HIP(launch_retry_setup(st, s.theta, s.theta_retry, s.overflow, s.todo));
                 if ((rc = collect(false)) != MX_OK) return rc;
                 fp.todo = s.todo;

@@ -76,7 +76,7 @@ struct ScanParams {
     uint32_t tile_end;
     uint32_t tile_stride;    // 1 = every tile; > 1 = the evenly spread sample
     uint32_t ds;             // floats per stored row
-    uint32_t n_queries = 256;  // live queries of the batch: waves whose 32 query columns are all padding skip their MFMAs
+    uint32_t wave_mask = 0xff;  // bit w: wave w (queries 32w .. 32w+31) has a query that is wanted; the others skip their MFMAs
     // collect launch: a lane whose 16 scores of a tile contain one >= theta stores ALL 16 (one record =
     // 64 bytes + the tile index); finish_kernel picks the passing rows.  No per-row code on the stream.
     float *lane_rec;         // [512][nwg][kRecCap][16]  (thread-in-workgroup major)

@@ -83,9 +83,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31;  // query column of B and D (lane >> 5 selects which 16 of the tile's 32 rows the lane scores)
-    // a wave whose 32 query columns are all padding only keeps the DMA stream and the barriers going
+    // a wave none of whose 32 query columns is wanted only keeps the DMA stream and the barriers going (ScanParams::wave_mask)
     // (not at 768 dims: the query fragments take 192 of the 256 VGPRs there and the branch costs the rest)
-    const bool live = KC == 6 || (uint32_t)(wave * 32) < p.n_queries;
+    const bool live = KC == 6 || ((p.wave_mask >> wave) & 1u) != 0;
 
     // ---- register-resident query fragments (B operand), loaded once per launch
     bf16x8 qf[KC * 8];

@@ -83,10 +83,10 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31;  // query column of B and D
-    // A wave whose 32 query columns are all padding (batch of fewer than 32 * (wave + 1) queries) only keeps the DMA
+    // A wave none of whose 32 query columns is wanted (padding of a small batch; queries parked during a retry pass) only keeps the DMA
     // stream and the barriers going: a single query costs the stream, not 256 queries' worth of MFMA energy
     // (not at 1536 dims: the query fragments take 192 of the 256 VGPRs there and the branch costs the rest)
-    const bool live = KC == 12 || (uint32_t)(wave * 32) < p.n_queries;
+    const bool live = KC == 12 || ((p.wave_mask >> wave) & 1u) != 0;
 
     // ---- register-resident query fragments (B operand): k-step ks = 32 dims, 16 int8 per lane
     i32x4 qf[KC * 4];
