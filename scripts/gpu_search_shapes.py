@@ -26,6 +26,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "small":     # small batches: waves with
         run(10_000_000, 384, B, 10, 10)
     run(10_000_000, 768, 1, 10, 10)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "topk":      # larger k: the sample grows with k
+    for kk in (10, 30, 100, 256):
+        run(10_000_000, 384, 256, kk, 6)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "dims":      # MEMEX_HIP_FILTER=i8|bf16: which filter copy pays at which width
     for n, d in ((10_000_000, 384), (10_000_000, 512), (10_000_000, 768), (4_000_000, 1024), (4_000_000, 1536), (10_000_000, 256), (10_000_000, 128)):
         run(n, d, 256, 10, 6)
