@@ -62,6 +62,9 @@ def parse():
                     help="N=1 only: extra steps on the OTHER scan kernel, reported beside the main one (0 = skip)")
     ap.add_argument("--side-steps", type=int, default=20,
                     help="N=1 only: steps of each side leg (clustered data, host API, 10M x 768 shard); 0 = skip them")
+    ap.add_argument("--small-steps", type=int, default=None,
+                    help="N=1 only: steps of the 1-query and 32-query legs (default: --side-steps; 0 = skip, e.g. under a "
+                         "profiler, where their much shorter launches of the same kernel would blur its average)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the brute-force baseline sample")
     ap.add_argument("--hnsw-rows", type=int, default=100_000, help="corpus size of the HNSW CPU baseline (0 = skip)")
@@ -595,7 +598,8 @@ def main():
                               f"top-{k}, mx_index_search (host pointers)", a.dim, a.batch, rows_total)
 
     small = None
-    if single and a.side_steps > 0:
+    small_steps = a.side_steps if a.small_steps is None else a.small_steps
+    if single and small_steps > 0:
         # small batches through the same entry point: a lone query (what the reference's trait issues) and 32 of them.
         # Waves of the scan without live queries skip their MFMAs, so these run at the stream's rate, not at the
         # power-capped rate of a full batch.
@@ -603,9 +607,9 @@ def main():
         for nb in (1, 32):
             qs = q[:nb].contiguous()
             sb = SearchBuffers(nb, k)
-            dts, sts = timed_steps(idx, lambda: idx.search_device(qs, k, sb.ids, sb.scores, sb.dists, sb.nf), fence, 3, a.side_steps, world)
+            dts, sts = timed_steps(idx, lambda: idx.search_device(qs, k, sb.ids, sb.scores, sb.dists, sb.nf), fence, 3, small_steps, world)
             rf = roofline_of(sts, a.scan, a.dim, nb, rows_total, 1)
-            small[f"batch_{nb}"] = {"ms_per_call": dts / a.side_steps * 1e3, "queries_per_s": nb * a.side_steps / dts,
+            small[f"batch_{nb}"] = {"ms_per_call": dts / small_steps * 1e3, "queries_per_s": nb * small_steps / dts,
                                     "collect_ms": rf["ms_per_launch"], "collect_GBps": rf["achieved"], "collect_hbm_frac": rf["frac"],
                                     "ids_equal_full_batch": bool(torch.equal(sb.ids, ids_main[:nb]))}
         step()
