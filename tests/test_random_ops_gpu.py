@@ -1,0 +1,68 @@
+"""Random sequences of the operations that touch the filter copies -- appends of odd sizes (inside and across 32-row
+half tiles and 64-row scan tiles), rejected appends, clears, switches between the int8 / bf16 / no copy, save + load,
+capacity growth -- each followed by a search that must be bit-identical to the oracle on the rows inserted so far.
+Seeded, not hypothesis-driven: the GPU box runs it once."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("d,seed", [(384, 1), (100, 2), (1024, 3), (3, 4), (640, 5), (1536, 6)])
+def test_random_operation_sequences(d, seed, oracle, lib_built, tmp_path):
+    from memex_amd import _lib
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(seed)
+    rows = np.zeros((0, d), dtype=np.float32)
+    kinds = ["i8", "bf16", False, True]
+    idx = FlatIndex(d)
+    try:
+        for step in range(36):
+            op = rng.choice(["add", "add", "add", "kind", "bad", "clear", "saveload", "grow"], p=[.3, .2, .1, .15, .08, .04, .08, .05])
+            if op == "add" or rows.shape[0] == 0:
+                n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 200, 1000, 4097]))
+                X = (rng.standard_normal((n, d)) * rng.uniform(0.1, 10.0, (n, 1))).astype(np.float32)
+                if n > 2 and rng.random() < 0.3:
+                    X[rng.integers(0, n)] = 0                      # a zero-norm row
+                if n > 40 and rng.random() < 0.3:
+                    X[1:8] = X[0]                                  # duplicates
+                assert idx.add(X) == rows.shape[0] + 1
+                rows = np.concatenate([rows, X])
+            elif op == "grow":
+                idx.reserve(rows.shape[0] + int(rng.integers(1, 50000)))
+            elif op == "kind":
+                idx.set_filter_copy(kinds[int(rng.integers(0, len(kinds)))])
+            elif op == "bad":
+                bad = rng.standard_normal((int(rng.integers(1, 100)), d)).astype(np.float32)
+                bad[int(rng.integers(0, bad.shape[0])), int(rng.integers(0, d))] = np.inf
+                with pytest.raises(_lib.MemexHipError):
+                    idx.add(bad)
+            elif op == "clear" and rows.shape[0] > 3000:
+                idx.clear()
+                rows = np.zeros((0, d), dtype=np.float32)
+                continue
+            elif op == "saveload":
+                idx.save(str(tmp_path))
+                idx.close()
+                idx = FlatIndex(d)
+                if rng.random() < 0.5:
+                    idx.set_filter_copy(kinds[int(rng.integers(0, len(kinds)))])
+                idx.load(str(tmp_path))
+            assert len(idx) == rows.shape[0]
+            if rows.shape[0] == 0:
+                continue
+            B = int(rng.choice([1, 5, 33, 130]))
+            k = int(rng.choice([1, 10, 40]))
+            Q = rng.standard_normal((B, d)).astype(np.float32)
+            Q[0] = rows[int(rng.integers(0, rows.shape[0]))] * 2.0   # a query that is a row (or a zero row: dist 0 to all)
+            ids, sc, di, nf = idx.search(Q, k)
+            oi, od, os_, onf = oracle.search(rows, Q, k)
+            np.testing.assert_array_equal(ids, oi, err_msg=f"step {step} op {op} n {rows.shape[0]}")
+            np.testing.assert_array_equal(bits(di), bits(od))
+            np.testing.assert_array_equal(bits(sc), bits(os_))
+            np.testing.assert_array_equal(nf, onf)
+        assert idx.stats().fallback_queries == 0 or d == 3     # (3 dims: many exact ties -> the EXACT path is legitimate)
+    finally:
+        idx.close()
