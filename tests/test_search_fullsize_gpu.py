@@ -1,5 +1,6 @@
 """BASELINE.json full sizes on the GPU: cfg 3 (10M x 384 f32 in HBM, batch 256, top-10) and cfg 4's
-per-GPU shard (10M x 768), plus a clustered 1M corpus checked against the oracle row for row.
+per-GPU shard (10M x 768), wide rows (10M x 1024) on both filter copies, plus a clustered 1M corpus checked
+against the oracle row for row.
 
 The oracle cannot answer 10M x 256 in seconds, so the full-size checks are
  (a) size-independent properties (ordering, ranges, uniqueness, self-queries, idempotence),
@@ -161,6 +162,30 @@ def test_cfg4_shard_10m_x_768(oracle, lib_built):
     try:
         ids, sc, di = _properties(idx, q, n)
         _oracle_on_subset(oracle, ids, di, q, n, d, nq=4, every=20)
+    finally:
+        idx.close()
+        torch.cuda.empty_cache()
+
+
+def test_wide_rows_10m_x_1024(oracle, lib_built):
+    """Wide rows at full size (bge-large / e5-large width; 41 GB of f32 rows): the int8 scan (the library's choice at
+    1024 dims: 256 queries per pass, KC = 8) and, on the same index, the bf16 copy through scan16w_kernel (the k-steps
+    of a row dealt to two waves, 128 queries per pass) -- same properties, same oracle check, same answers."""
+    import torch
+    n, d = 10_000_000, 1024
+    idx, q = _build(n, d)
+    try:
+        assert idx.stats().filter_kind == 2
+        ids, sc, di = _properties(idx, q, n)
+        _oracle_on_subset(oracle, ids, di, q, n, d, nq=4, every=40)
+        idx.set_filter_copy("bf16")
+        idx.reset_stats()
+        ids2, sc2, di2 = _properties(idx, q, n)
+        st = idx.stats()
+        assert st.filter_kind == 3 and st.scan_launches >= 4          # two passes per 256-query batch
+        np.testing.assert_array_equal(ids2, ids)
+        np.testing.assert_array_equal(bits(di2), bits(di))
+        np.testing.assert_array_equal(bits(sc2), bits(sc))
     finally:
         idx.close()
         torch.cuda.empty_cache()
