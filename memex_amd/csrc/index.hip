@@ -102,6 +102,33 @@ struct Scratch {
     bool ready = false;
 };
 
+// The lane buffers of the scan (records of the collect launch: 64 per lane, 0.57 GB per set at 256 workgroups) are
+// only live inside one search_batch call, which returns host-synchronised.  They are therefore leased from a pool per
+// device instead of owned by every index: a process with many resident collections holds as many sets as it has
+// searches in flight on a device at the same time, not one per collection.  The pool is freed when the last index
+// on the device closes.
+struct LaneBufs {
+    float *rec = nullptr;
+    uint32_t *tile = nullptr, *cnt = nullptr;
+    float *max = nullptr;
+    int nwg = 0;
+};
+constexpr int kMaxDevices = 64;
+struct LanePool {
+    std::mutex mu;
+    std::vector<LaneBufs> idle;
+    int open_indexes = 0;
+};
+LanePool g_lanes[kMaxDevices];
+
+void lane_free(LaneBufs &b) {
+    if (b.rec) (void)hipFree(b.rec);
+    if (b.tile) (void)hipFree(b.tile);
+    if (b.cnt) (void)hipFree(b.cnt);
+    if (b.max) (void)hipFree(b.max);
+    b = LaneBufs{};
+}
+
 // RCCL entry points, resolved with dlopen the first time a sharded index spans more than one device
 // (libmemex_hip.so itself links only the HIP runtime; a single-GPU host never loads RCCL)
 struct Rccl {
@@ -151,6 +178,7 @@ struct mx_index {
     // half tile.  An f32 corpus only; the compressed corpus keeps its bf16 rows.
     bool filter_i8 = false;
     bool filter_auto = true;     // the library picks the kind (by row width) and may demote int8 to bf16 when a batch overflows
+    bool pooled = false;         // counted in its device's lane-buffer pool (open_plain)
     uint32_t i8_batches = 0, i8_retry_batches = 0;  // since the int8 copy was built: batches served, batches that needed the retry pass
     float *tsc = nullptr;
     // compressed corpus (mx_index_set_corpus_mode): xh is the ONLY copy of the rows; x / scale are not
@@ -259,15 +287,78 @@ int free_index(mx_index *idx) {
     if (s.host_sum) (void)hipHostFree(s.host_sum);
     for (void *hp : {(void *)s.h_q, (void *)s.h_ids, (void *)s.h_scores, (void *)s.h_dists, (void *)s.h_nf})
         if (hp) (void)hipHostFree(hp);
-    F(s.lane_rec); F(s.lane_tile); F(s.lane_cnt); F(s.lane_max); F(s.qstage); F(s.qscale); F(s.qa); F(s.qb); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
+    F(s.qstage); F(s.qscale); F(s.qa); F(s.qb); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
     F(s.exact_keys); F(s.sel_state); F(s.max_err);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
     if (idx->ev_wait) (void)hipEventDestroy(idx->ev_wait);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    if (idx->pooled && idx->device >= 0 && idx->device < kMaxDevices) {  // the last index on the device takes the lane-buffer pool with it
+        LanePool &lp = g_lanes[idx->device];
+        std::lock_guard<std::mutex> lk(lp.mu);
+        if (--lp.open_indexes <= 0) {
+            lp.open_indexes = 0;
+            for (LaneBufs &b : lp.idle) lane_free(b);
+            lp.idle.clear();
+        }
+    }
     delete idx;
     return MX_OK;
 }
+
+// One set of lane buffers for the duration of a search_batch call (see LanePool).
+struct LaneLease {
+    mx_index *idx = nullptr;
+    LaneBufs b;
+    int take(mx_index *i) {
+        idx = i;
+        if (i->device < 0 || i->device >= kMaxDevices) return fail(MX_EDEVICE, "device %d out of range", i->device);
+        LanePool &lp = g_lanes[i->device];
+        {
+            std::lock_guard<std::mutex> lk(lp.mu);
+            for (size_t j = 0; j < lp.idle.size(); ++j)
+                if (lp.idle[j].nwg == i->nwg) {
+                    b = lp.idle[j];
+                    lp.idle.erase(lp.idle.begin() + (long)j);
+                    break;
+                }
+        }
+        if (!b.rec) {
+            b.nwg = i->nwg;
+            const size_t lanes = (size_t)i->nwg * kScanThreads;
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&b.rec), lanes * kRecCap * 16 * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b.tile), lanes * kRecCap * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b.cnt), lanes * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b.max), lanes * sizeof(float));
+            if (e != hipSuccess) {
+                lane_free(b);
+                idx = nullptr;
+                return fail(MX_ENOMEM, "hipMalloc(lane buffers): %s", hipGetErrorString(e));
+            }
+        }
+        Scratch &s = i->s;
+        s.lane_rec = b.rec;
+        s.lane_tile = b.tile;
+        s.lane_cnt = b.cnt;
+        s.lane_max = b.max;
+        return MX_OK;
+    }
+    void drop() {  // the caller is host-synchronised with everything that used the buffers
+        if (!idx) return;
+        Scratch &s = idx->s;
+        s.lane_rec = nullptr;
+        s.lane_tile = nullptr;
+        s.lane_cnt = nullptr;
+        s.lane_max = nullptr;
+        LanePool &lp = g_lanes[idx->device];
+        std::lock_guard<std::mutex> lk(lp.mu);
+        if (lp.open_indexes > 0) lp.idle.push_back(b);
+        else lane_free(b);
+        idx = nullptr;
+        b = LaneBufs{};
+    }
+    ~LaneLease() { drop(); }
+};
 
 int ensure_scratch(mx_index *idx) {
     Scratch &s = idx->s;
@@ -290,10 +381,6 @@ int ensure_scratch(mx_index *idx) {
     memset(s.host_sum, 0, kSumWords * sizeof(uint32_t));
     MX_HIP(hipMalloc(&s.done_ctr, sizeof(uint32_t)));
     MX_HIP(hipMemsetAsync(s.done_ctr, 0, sizeof(uint32_t), idx->stream));
-    MX_HIP(hipMalloc(&s.lane_rec, (size_t)idx->nwg * kScanThreads * kRecCap * 16 * sizeof(float)));
-    MX_HIP(hipMalloc(&s.lane_tile, (size_t)idx->nwg * kScanThreads * kRecCap * sizeof(uint32_t)));
-    MX_HIP(hipMalloc(&s.lane_cnt, (size_t)idx->nwg * kScanThreads * sizeof(uint32_t)));
-    MX_HIP(hipMalloc(&s.lane_max, (size_t)idx->nwg * kScanThreads * sizeof(float)));
     MX_HIP(hipMalloc(&s.qstage, (size_t)kMaxBatch * idx->dim * sizeof(float)));
     MX_HIP(hipMalloc(&s.qscale, kMaxBatch * sizeof(float)));
     MX_HIP(hipMalloc(&s.qa, kMaxBatch * sizeof(float)));
@@ -603,6 +690,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         return search_batch(idx, d_q + (size_t)kWideBatch * idx->dim, B - kWideBatch, k, d_ids + o, d_scores + o,
                             d_dists ? d_dists + o : nullptr, d_nfound + kWideBatch);
     }
+    LaneLease lease;  // every return below is host-synchronised with the kernels that used the lane buffers
+    if ((rc = lease.take(idx)) != MX_OK) return rc;
     MX_HIP(launch_prep_queries(st, d_q, B, idx->dim, idx->ds, s.qfrag, s.qpad, s.qnorm2, s.theta, s.e1,
                                idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags, s.qa, s.qb, filt8, s.qscale));
     const uint32_t *h_ovf = s.host_flags, *h_qfl = s.host_flags + 3 * kMaxBatch;
@@ -767,6 +856,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                 // over the f32 rows) and answer the batch on it; the index stays on bf16.
                 if (demote_filter(idx) == MX_OK) {
                     idx->stats.filter_demotions += 1;
+                    lease.drop();
                     return search_batch(idx, d_q, B, k, d_ids, d_scores, d_dists, d_nfound);
                 }
             }
@@ -1157,6 +1247,11 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
     MX_HIP(hipMalloc(&idx->flags, 4 * sizeof(uint32_t)));
     MX_HIP(hipMemset(idx->flags, 0, 4 * sizeof(uint32_t)));
     MX_HIP(hipMalloc(&idx->zero_rows, kZeroCap * sizeof(uint32_t)));
+    if (device < kMaxDevices) {
+        std::lock_guard<std::mutex> lk(g_lanes[device].mu);
+        g_lanes[device].open_indexes += 1;
+        idx->pooled = true;
+    }
     *out = idx.release();
     return MX_OK;
 }

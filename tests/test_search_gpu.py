@@ -639,3 +639,33 @@ def test_int8_copy_is_demoted_on_a_dense_corpus(oracle, lib_built):
         np.testing.assert_array_equal(bits(sc), bits(os_))
         st = idx.stats()
         assert st.filter_kind == 2 and st.filter_demotions == 1
+
+
+def test_lane_buffers_are_leased_from_a_pool_per_device(oracle, lib_built):
+    """The scan's lane buffers (0.57 GB per set) are leased for the duration of a search, not owned by every index: a
+    process with many resident collections (memex keeps one index per collection) holds one set per concurrent
+    search.  12 indexes searched one after the other must not take 12 sets."""
+    import torch
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(51)
+    X = rng.standard_normal((3000, 384), dtype=np.float32)
+    Q = rng.standard_normal((4, 384), dtype=np.float32)
+    oi = oracle.search(X, Q, 5)[0]
+    torch.cuda.synchronize()
+    held = []
+    try:
+        first = FlatIndex(384)
+        held.append(first)
+        first.add(X)
+        np.testing.assert_array_equal(first.search(Q, 5)[0], oi)          # the pool now holds one idle set
+        free0 = torch.cuda.mem_get_info()[0]
+        for _ in range(11):
+            idx = FlatIndex(384)
+            held.append(idx)
+            idx.add(X)
+            np.testing.assert_array_equal(idx.search(Q, 5)[0], oi)
+        used = free0 - torch.cuda.mem_get_info()[0]
+        assert used < 0.5 * 2 ** 30, f"{used / 2 ** 30:.2f} GiB for 11 more small indexes"
+    finally:
+        for idx in held:
+            idx.close()
