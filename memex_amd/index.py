@@ -102,7 +102,7 @@ class FlatIndex:
 
     def set_filter_copy(self, on) -> None:
         """Keep or drop the filter copy the scan streams; results do not change.  ``False`` / ``"none"``: none (the
-        scan reads the f32 rows); ``True`` / ``"auto"``: the library chooses (int8 up to 512 dims, bf16 above, and an
+        scan reads the f32 rows); ``True`` / ``"auto"``: the library chooses (int8 up to 1024 dims, bf16 above, and an
         int8 copy is rebuilt as bf16 if a batch overflows it); ``"i8"``: int8 rows with one quantisation step per 32
         rows; ``"bf16"``: bf16 rows."""
         if isinstance(on, str):
