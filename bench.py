@@ -132,11 +132,11 @@ def fill_index(idx, rows_total: int, dim: int, lo: int, hi: int, data: str):
     torch.cuda.empty_cache()
 
 
-def make_queries(batch: int, dim: int, data: str):
+def make_queries(batch: int, dim: int, data: str, seed: int = 4321):
     import torch
     if data == "clustered":  # queries live in clusters too: each has a dense neighbourhood
-        return clustered_rows(batch, dim, 4321, clustered_centres(dim))
-    return gaussian_rows(batch, dim, 4321)
+        return clustered_rows(batch, dim, seed, clustered_centres(dim))
+    return gaussian_rows(batch, dim, seed)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -613,6 +613,16 @@ def main():
                                     "collect_ms": rf["ms_per_launch"], "collect_GBps": rf["achieved"], "collect_hbm_frac": rf["frac"],
                                     "ids_equal_full_batch": bool(torch.equal(sb.ids, ids_main[:nb]))}
         step()
+        # more than 256 queries in one call: the int8 scan serves 512 per pass (two query groups per wave) up to 512 dims
+        if a.batch == 256:
+            qb_ = torch.cat([q, make_queries(256, a.dim, a.data, seed=9876)]).contiguous()
+            bb = SearchBuffers(512, k)
+            dtb, stb = timed_steps(idx, lambda: idx.search_device(qb_, k, bb.ids, bb.scores, bb.dists, bb.nf), fence, 3, small_steps, world)
+            rfb = roofline_of(stb, a.scan, a.dim, 512, rows_total, 1)
+            small["batch_512"] = {"ms_per_call": dtb / small_steps * 1e3, "queries_per_s": 512 * small_steps / dtb,
+                                  "collect_ms": rfb["ms_per_launch"], "passes_per_call": stb.scan_launches / max(1, small_steps),
+                                  "ids_equal_full_batch": bool(torch.equal(bb.ids[:256], ids_main))}
+            del qb_, bb
 
     # ---- recall@10 against the all-f64 EXACT path on a few queries (oracle-level parity at smaller
     # sizes and the oracle-based 10M check live in tests/; the EXACT path is itself oracle-checked there)

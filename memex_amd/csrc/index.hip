@@ -325,7 +325,7 @@ struct LaneLease {
         }
         if (!b.rec) {
             b.nwg = i->nwg;
-            const size_t lanes = (size_t)i->nwg * kScanThreads;
+            const size_t lanes = (size_t)i->nwg * kScanThreads * 2;  // x 2: a 512-query pass numbers 16 waves
             hipError_t e = hipMalloc(reinterpret_cast<void **>(&b.rec), lanes * kRecCap * 16 * sizeof(float));
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b.tile), lanes * kRecCap * sizeof(uint32_t));
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b.cnt), lanes * sizeof(uint32_t));
@@ -683,6 +683,16 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     const bool wide = idx->kc > kMaxKC && !filt8;
     const bool fast = !trivial && idx->mode == MX_SEARCH_AUTO && (idx->kc > kMaxKC ? idx->xh != nullptr && idx->kc <= kMaxKC16 : true) &&
                       idx->wild_rows == 0 && k <= 256 && idx->n_zero <= (uint64_t)kZeroCap;
+    // a batch of more than 256 queries is one pass of the int8 scan with two query groups per wave (up to 512 dims),
+    // otherwise two passes
+    const bool x2 = fast && filt8 && idx->kc <= kMaxKC8x2 && B > kPassBatch;
+    if (B > kPassBatch && !x2 && !(fast && wide)) {
+        rc = search_batch(idx, d_q, kPassBatch, k, d_ids, d_scores, d_dists, d_nfound);
+        if (rc != MX_OK) return rc;
+        const size_t o = (size_t)kPassBatch * k;
+        return search_batch(idx, d_q + (size_t)kPassBatch * idx->dim, B - kPassBatch, k, d_ids + o, d_scores + o,
+                            d_dists ? d_dists + o : nullptr, d_nfound + kPassBatch);
+    }
     if (fast && wide && B > kWideBatch) {
         rc = search_batch(idx, d_q, kWideBatch, k, d_ids, d_scores, d_dists, d_nfound);
         if (rc != MX_OK) return rc;
@@ -800,7 +810,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         p.qa = s.qa;
         p.qb = s.qb;
         auto scan = [&](bool collect) {
-            if (filt8) return launch_scan8(st, idx->kc, collect, idx->nwg, p);
+            if (filt8) return launch_scan8(st, idx->kc, collect, idx->nwg, p, x2);
             if (wide) return launch_scan16w(st, idx->kc, collect, idx->nwg, p);
             return idx->xh ? launch_scan16(st, idx->kc, collect, idx->nwg, p) : launch_scan(st, idx->kc, collect, idx->nwg, p);
         };

@@ -32,7 +32,10 @@ constexpr int kMaxKC16 = 12;
 constexpr int kWideBatch = 128;
 constexpr int kScan16WideLdsBytes = kRing16 * kSlot16Bytes + 4 * 64 * 16 * 4;
 
-constexpr int kMaxBatch = 256;     // queries per scan pass (8 waves x 32 MFMA columns)
+constexpr int kPassBatch = 256;    // queries per scan pass (8 waves x 32 MFMA columns)
+constexpr int kMaxBatch = 512;     // queries per pipeline batch: a pass of the int8 scan with two query groups per wave (up to
+                                   // 512 dims) serves 512; everything else splits a batch into passes of 256 (128: scan16w)
+constexpr int kMaxKC8x2 = 4;       // ... up to this many 128-dim slots per row
 constexpr int kRecCap = 64;        // lane-private records per collect launch: one record = the lane's 16 scores of a tile
 constexpr int kMaxScanWGs = 256;   // persistent workgroups (<= CUs)
 constexpr int kCandCap = 16384;    // candidates finish_kernel holds per query (LDS); more = rescan with a tight threshold
@@ -77,9 +80,10 @@ struct ScanParams {
     uint32_t tile_stride;    // 1 = every tile; > 1 = the evenly spread sample
     uint32_t ds;             // floats per stored row
     uint32_t wave_mask = 0xff;  // bit w: wave w (queries 32w .. 32w+31) has a query that is wanted; the others skip their MFMAs
+                                // (two query groups per wave: one bit per group of 32, 16 bits)
     // collect launch: a lane whose 16 scores of a tile contain one >= theta stores ALL 16 (one record =
     // 64 bytes + the tile index); finish_kernel picks the passing rows.  No per-row code on the stream.
-    float *lane_rec;         // [512][nwg][kRecCap][16]  (thread-in-workgroup major)
+    float *lane_rec;         // [512][nwg][kRecCap][16]  (thread-in-workgroup major; [1024] with two query groups per wave)
     uint32_t *lane_tile;     // [512][nwg][kRecCap] tile index of each record
     uint32_t *lane_cnt;      // [512][nwg] records written
     float *lane_max;         // [512][nwg] sample mode: running maximum of each lane
@@ -101,7 +105,7 @@ constexpr int kTile8Rows = 64;
 constexpr int kScaleRing8 = 32;  // tiles whose scales can be in flight (15 slots ahead at one slot per tile, + the tile being multiplied)
 constexpr int kScan8LdsBytes = kRing16 * kSlot16Bytes + kScaleRing8 * 256;
 hipError_t scan8_setup();
-hipError_t launch_scan8(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
+hipError_t launch_scan8(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p, bool two_groups = false);
 // (re)build half tiles [half0, half1) (32 rows each) of the 8-bit filter copy from the padded f32 store: per half
 // tile one quantisation step = max |c_i/|c|| / 127 over its rows below row_hi (rows at or above row_hi, and zero-norm
 // rows, are stored as zeros) and one residual bound = 1.01 * max_rows |c/|c| - step * c8| + 1e-6; both go to

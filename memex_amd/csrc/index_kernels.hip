@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag, float *qpad,
                                double *qnorm2, float *theta, float *e1, const uint32_t *ec_max, uint32_t *overflow,
                                uint32_t *flags, float *qa, float *qb, bool filt8, float *qscale) {
-    hipLaunchKernelGGL(prep_queries_kernel, dim3(kMaxBatch), dim3(256), sizeof(float) * (size_t)d, s, q, B, d, ds,
+    // one block per query slot: 256 slots (a pass computes all of them), 512 for a batch of more than 256
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(B > kPassBatch ? kMaxBatch : kPassBatch), dim3(256), sizeof(float) * (size_t)d, s, q, B, d, ds,
                        (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags, filt8 ? 1 : 0, qscale, qa, qb);
     return hipGetLastError();
 }

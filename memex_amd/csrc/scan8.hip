@@ -74,33 +74,39 @@ static_assert(ops_after<3>(2, 14) == 17 && ops_after<3>(3, 15) == 18 && ops_afte
 static_assert(ops_after<1>(2, 14) == 26 && ops_after<12>(2, 14) == 14 && ops_after<12>(13, 25) == 14 && ops_after<6>(5, 17) == 15, "");
 }  // namespace
 
-template <int KC, int MODE>
+// QG = query groups (of 32) per wave: 1 = a pass of 256 queries (the kernel every batch size up to 256 runs);
+// 2 = a pass of 512 (each fragment read feeds two MFMAs; wave w holds the "virtual waves" 2w and 2w+1 of
+// theta_kernel's / finish_kernel's lane numbering; up to 512 dims)
+template <int KC, int MODE, int QG>
 __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams p) {
-    constexpr int R = KC <= 8 ? 8 : KC <= 10 ? 4 : 2;  // fragment ring: what the 256 VGPRs leave next to qf
+    constexpr int R = QG == 2 ? (KC <= 3 ? 8 : 4) : KC <= 8 ? 8 : KC <= 10 ? 4 : 2;  // fragment ring: what the 256 VGPRs leave next to qf
     extern __shared__ __attribute__((aligned(16))) char smem[];  // slot ring | scale ring [kScaleRing8] x 256 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31;  // query column of B and D
-    // A wave none of whose 32 query columns is wanted (padding of a small batch; queries parked during a retry pass) only keeps the DMA
-    // stream and the barriers going: a single query costs the stream, not 256 queries' worth of MFMA energy
-    // (not at 1536 dims: the query fragments take 192 of the 256 VGPRs there and the branch costs the rest)
-    const bool live = KC == 12 || ((p.wave_mask >> wave) & 1u) != 0;
+    // A wave none of whose query columns is wanted (padding of a small batch; queries parked during a retry pass) only
+    // keeps the DMA stream and the barriers going: a single query costs the stream, not 256 queries' worth of MFMA energy
+    // (not at 1536 dims, and not with two query groups per wave: the registers the branch costs are not there)
+    const bool live = KC == 12 || QG == 2 || ((p.wave_mask >> wave) & 1u) != 0;
 
     // ---- register-resident query fragments (B operand): k-step ks = 32 dims, 16 int8 per lane
-    i32x4 qf[KC * 4];
-    {
-        const i32x4 *src = reinterpret_cast<const i32x4 *>(p.qfrag) + (size_t)wave * (KC * 4) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < KC * 4; ++i) qf[i] = src[(size_t)i * 64];
-    }
+    i32x4 qf[QG * KC * 4];
     // MODE 1: a half tile with residual bound e passes when a score reaches theta - qb * e (theta_kernel);
     // MODE 0: the lane keeps the best LOWER bound of a cosine, score - (qa + qb * e)
-    const float theta = MODE == 1 ? p.theta[wave * 32 + m] : 0.0f;
-    const float qa = MODE == 0 ? p.qa[wave * 32 + m] : 0.0f;
-    const float qb = p.qb[wave * 32 + m];
-    const float sq = p.qscale[wave * 32 + m];  // 0 for an unusable (zero / padded) query
+    float theta[QG], qa[QG], qb[QG], sq[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int vw = wave * QG + g;  // wave index in the lane numbering of theta_kernel / finish_kernel
+        const i32x4 *src = reinterpret_cast<const i32x4 *>(p.qfrag) + (size_t)vw * (KC * 4) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KC * 4; ++i) qf[g * KC * 4 + i] = src[(size_t)i * 64];
+        theta[g] = MODE == 1 ? p.theta[vw * 32 + m] : 0.0f;
+        qa[g] = MODE == 0 ? p.qa[vw * 32 + m] : 0.0f;
+        qb[g] = p.qb[vw * 32 + m];
+        sq[g] = p.qscale[vw * 32 + m];  // 0 for an unusable (zero / padded) query
+    }
 
     // ---- 64-row tiles of this workgroup: tile_begin + (blockIdx + i*grid) * tile_stride
     const uint32_t grid = gridDim.x;
@@ -121,12 +127,12 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
     uint32_t is_ti = 0;
     auto open_tile = [&]() {
         const uint32_t tile = t0 + is_ti * tstep;
-        const bool live = is_ti < nT;
-        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.tscale + 4 * (size_t)tile), 0, live ? 16u : 0u, 0x00020000);
+        const bool live_tile = is_ti < nT;
+        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.tscale + 4 * (size_t)tile), 0, live_tile ? 16u : 0u, 0x00020000);
         char *sdst = smem + __builtin_amdgcn_readfirstlane(kRing16 * kSlot16Bytes + (is_ti & (kScaleRing8 - 1)) * 256);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void *)sdst, 4, lane4, 0, 0, 0);
         const char *base = reinterpret_cast<const char *>(p.xh) + (size_t)tile * tilebytes;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? tilebytes : 0u, 0x00020000);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live_tile ? tilebytes : 0u, 0x00020000);
         ++is_ti;
     };
     auto issue = [&](int kci, uint32_t ring_pos) {  // kci is a compile-time constant at every call site
@@ -135,9 +141,11 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
         MX_LDS_DMA16(rsrc, dst, lane16, kci * kSlot16Bytes + wave * 1024, 2 /* nt */);
     };
 
-    auto mylane = [&]() { return (uint32_t)tid * gridDim.x + blockIdx.x; };
-    uint32_t cnt = 0;  // records written; bit 31: a record did not fit
-    float best = -INFINITY;
+    auto mylane = [&](int g) { return (uint32_t)((wave * QG + g) * 64 + lane) * gridDim.x + blockIdx.x; };
+    uint32_t cnt[QG];  // records written; bit 31: a record did not fit
+    float best[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) cnt[g] = 0, best[g] = -INFINITY;
 
 #pragma unroll
     for (int i = 0; i < kRing16 - 1; ++i) issue(i % KC, (uint32_t)i);
@@ -152,9 +160,11 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
 #pragma unroll 1
     for (uint32_t ti = 0; ti < nT; ++ti) {
         const uint32_t tile = t0 + ti * tstep;
-        i32x16 acc0, acc1;
+        i32x16 acc[QG * 2];  // [query group][half tile]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = 0, acc1[r] = 0;
+        for (int g = 0; g < QG * 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0;
 
         static_for<0, KC>([&](auto kct) __attribute__((always_inline)) {
             constexpr int kc = decltype(kct)::value;
@@ -167,10 +177,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
             if (live) {
 #pragma unroll
                 for (int f = 0; f < 8; ++f) {
-                    if (f & 1)
-                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[kc * 4 + (f >> 1)], acc1, 0, 0, 0);
-                    else
-                        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[kc * 4 + (f >> 1)], acc0, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < QG; ++g)
+                        acc[g * 2 + (f & 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[g * KC * 4 + kc * 4 + (f >> 1)], acc[g * 2 + (f & 1)], 0, 0, 0);
                     a[f % R] = *reinterpret_cast<const i32x4 *>(smem + (f + R < 8 ? fb0 : fb1) + ((f + R) & 7) * 1024);
                     if (f == 1) issue((kc + kRing16 - 1) % KC, rpi);
                     __builtin_amdgcn_sched_barrier(0);
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
         });
 
         if (!live) continue;
-        // ---- tile epilogue, per half: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*(lane>>5) of the half
+        // ---- tile epilogue, per half: lane holds query (vw*32 + m), rows (r&3) + 8*(r>>2) + 4*(lane>>5) of the half
         // (read with inline asm: hipcc puts s_waitcnt vmcnt(0) in front of a plain LDS load that it thinks an LDS-DMA
         // may have written, which would drain the ring once per tile; the scales landed with the tile's first slot)
         f32x4 shs;  // steps of the two halves, residual bounds of the two halves
@@ -195,32 +204,35 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
         }
 #endif
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const i32x16 &acc = u ? acc1 : acc0;
-            const float sh = u ? shs[1] : shs[0], er = u ? shs[3] : shs[2];
-            int mxi = max(max(acc[0], acc[1]), acc[2]);
+        for (int g = 0; g < QG; ++g) {
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) mxi = max(max(mxi, acc[r]), acc[r + 1]);
-            mxi = max(mxi, acc[15]);
-            // score of a sum: ((float)sum * s_h) * s_q -- monotone in the sum, so the test on the maximum is the
-            // test on "any of the 16 scores" as finish_kernel will see them
-            const float mx = ((float)mxi * sh) * sq;
-            const float thr = fmaf(-qb, er, theta);
-            if (MODE == 0) {
-                best = fmaxf(best, mx - fmaf(qb, er, qa));  // only full tiles are sampled (index.hip): every row is a real row
-            } else if (__builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
-                if (mx >= thr) {
-                    if ((cnt & 0x7fffffffu) < (uint32_t)kRecCap) {
-                        const size_t at = (size_t)mylane() * kRecCap + (cnt & 0x7fffffffu);
-                        f32x4 *dst = reinterpret_cast<f32x4 *>(p.lane_rec + at * 16);
+            for (int u = 0; u < 2; ++u) {
+                const i32x16 &ac = acc[g * 2 + u];
+                const float sh = u ? shs[1] : shs[0], er = u ? shs[3] : shs[2];
+                int mxi = max(max(ac[0], ac[1]), ac[2]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            dst[i] = f32x4{((float)acc[4 * i] * sh) * sq, ((float)acc[4 * i + 1] * sh) * sq,
-                                           ((float)acc[4 * i + 2] * sh) * sq, ((float)acc[4 * i + 3] * sh) * sq};
-                        p.lane_tile[at] = 2 * tile + u;  // 32-row tile index, as finish_kernel counts them
-                        ++cnt;
-                    } else {
-                        cnt |= 0x80000000u;
+                for (int r = 3; r < 15; r += 2) mxi = max(max(mxi, ac[r]), ac[r + 1]);
+                mxi = max(mxi, ac[15]);
+                // score of a sum: ((float)sum * s_h) * s_q -- monotone in the sum, so the test on the maximum is the
+                // test on "any of the 16 scores" as finish_kernel will see them
+                const float mx = ((float)mxi * sh) * sq[g];
+                const float thr = fmaf(-qb[g], er, theta[g]);
+                if (MODE == 0) {
+                    best[g] = fmaxf(best[g], mx - fmaf(qb[g], er, qa[g]));  // only full tiles are sampled (index.hip): every row is a real row
+                } else if (__builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
+                    if (mx >= thr) {
+                        if ((cnt[g] & 0x7fffffffu) < (uint32_t)kRecCap) {
+                            const size_t at = (size_t)mylane(g) * kRecCap + (cnt[g] & 0x7fffffffu);
+                            f32x4 *dst = reinterpret_cast<f32x4 *>(p.lane_rec + at * 16);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                dst[i] = f32x4{((float)ac[4 * i] * sh) * sq[g], ((float)ac[4 * i + 1] * sh) * sq[g],
+                                               ((float)ac[4 * i + 2] * sh) * sq[g], ((float)ac[4 * i + 3] * sh) * sq[g]};
+                            p.lane_tile[at] = 2 * tile + u;  // 32-row tile index, as finish_kernel counts them
+                            ++cnt[g];
+                        } else {
+                            cnt[g] |= 0x80000000u;
+                        }
                     }
                 }
             }
@@ -228,11 +240,14 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // dead DMA ops must not outlive the workgroup's LDS
 
-    if (MODE == 0) {
-        p.lane_max[mylane()] = best;
-    } else {
-        p.lane_cnt[mylane()] = cnt & 0x7fffffffu;
-        if (cnt >> 31) p.overflow[wave * 32 + m] = 1;
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        if (MODE == 0) {
+            p.lane_max[mylane(g)] = best[g];
+        } else {
+            p.lane_cnt[mylane(g)] = cnt[g] & 0x7fffffffu;
+            if (cnt[g] >> 31) p.overflow[(wave * QG + g) * 32 + m] = 1;
+        }
     }
 }
 
@@ -326,46 +341,60 @@ hipError_t launch_shadow8(hipStream_t s, const float *x, const float *scale, int
     return hipGetLastError();
 }
 
-template <int KC, int MODE>
+template <int KC, int MODE, int QG>
 static hipError_t setup8_one() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&scan8_kernel<KC, MODE>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&scan8_kernel<KC, MODE, QG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kScan8LdsBytes);
 }
 
 hipError_t scan8_setup() {
     hipError_t e;
-#define MX_SETUP(KC)                                          \
-    if ((e = setup8_one<KC, 0>()) != hipSuccess) return e;    \
-    if ((e = setup8_one<KC, 1>()) != hipSuccess) return e;
+#define MX_SETUP(KC)                                             \
+    if ((e = setup8_one<KC, 0, 1>()) != hipSuccess) return e;    \
+    if ((e = setup8_one<KC, 1, 1>()) != hipSuccess) return e;
     MX_SETUP(1) MX_SETUP(2) MX_SETUP(3) MX_SETUP(4) MX_SETUP(5) MX_SETUP(6)
     MX_SETUP(7) MX_SETUP(8) MX_SETUP(9) MX_SETUP(10) MX_SETUP(11) MX_SETUP(12)
+#undef MX_SETUP
+#define MX_SETUP(KC)                                             \
+    if ((e = setup8_one<KC, 0, 2>()) != hipSuccess) return e;    \
+    if ((e = setup8_one<KC, 1, 2>()) != hipSuccess) return e;
+    MX_SETUP(1) MX_SETUP(2) MX_SETUP(3) MX_SETUP(4)
 #undef MX_SETUP
     return hipSuccess;
 }
 
-template <int KC>
+template <int KC, int QG>
 static hipError_t launch8_kc(hipStream_t s, bool collect, int nwg, const ScanParams &p) {
     if (collect)
-        hipLaunchKernelGGL((scan8_kernel<KC, 1>), dim3(nwg), dim3(kScanThreads), kScan8LdsBytes, s, p);
+        hipLaunchKernelGGL((scan8_kernel<KC, 1, QG>), dim3(nwg), dim3(kScanThreads), kScan8LdsBytes, s, p);
     else
-        hipLaunchKernelGGL((scan8_kernel<KC, 0>), dim3(nwg), dim3(kScanThreads), kScan8LdsBytes, s, p);
+        hipLaunchKernelGGL((scan8_kernel<KC, 0, QG>), dim3(nwg), dim3(kScanThreads), kScan8LdsBytes, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_scan8(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p) {
+hipError_t launch_scan8(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p, bool two_groups) {
+    if (two_groups) {  // 512 queries per pass: up to 512 dims (kMaxKC8x2)
+        switch (kc) {
+            case 1: return launch8_kc<1, 2>(s, collect, nwg, p);
+            case 2: return launch8_kc<2, 2>(s, collect, nwg, p);
+            case 3: return launch8_kc<3, 2>(s, collect, nwg, p);
+            case 4: return launch8_kc<4, 2>(s, collect, nwg, p);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (kc) {
-        case 1: return launch8_kc<1>(s, collect, nwg, p);
-        case 2: return launch8_kc<2>(s, collect, nwg, p);
-        case 3: return launch8_kc<3>(s, collect, nwg, p);
-        case 4: return launch8_kc<4>(s, collect, nwg, p);
-        case 5: return launch8_kc<5>(s, collect, nwg, p);
-        case 6: return launch8_kc<6>(s, collect, nwg, p);
-        case 7: return launch8_kc<7>(s, collect, nwg, p);
-        case 8: return launch8_kc<8>(s, collect, nwg, p);
-        case 9: return launch8_kc<9>(s, collect, nwg, p);
-        case 10: return launch8_kc<10>(s, collect, nwg, p);
-        case 11: return launch8_kc<11>(s, collect, nwg, p);
-        case 12: return launch8_kc<12>(s, collect, nwg, p);
+        case 1: return launch8_kc<1, 1>(s, collect, nwg, p);
+        case 2: return launch8_kc<2, 1>(s, collect, nwg, p);
+        case 3: return launch8_kc<3, 1>(s, collect, nwg, p);
+        case 4: return launch8_kc<4, 1>(s, collect, nwg, p);
+        case 5: return launch8_kc<5, 1>(s, collect, nwg, p);
+        case 6: return launch8_kc<6, 1>(s, collect, nwg, p);
+        case 7: return launch8_kc<7, 1>(s, collect, nwg, p);
+        case 8: return launch8_kc<8, 1>(s, collect, nwg, p);
+        case 9: return launch8_kc<9, 1>(s, collect, nwg, p);
+        case 10: return launch8_kc<10, 1>(s, collect, nwg, p);
+        case 11: return launch8_kc<11, 1>(s, collect, nwg, p);
+        case 12: return launch8_kc<12, 1>(s, collect, nwg, p);
         default: return hipErrorInvalidValue;
     }
 }

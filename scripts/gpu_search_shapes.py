@@ -26,6 +26,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "small":     # small batches: waves with
         run(10_000_000, 384, B, 10, 10)
     run(10_000_000, 768, 1, 10, 10)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "bulk":      # more than 256 queries per call: 512 per pass (int8 copy, <= 512 dims)
+    for B in (256, 512, 1024, 2048):
+        run(10_000_000, 384, B, 10, 6)
+    run(10_000_000, 256, 1024, 10, 6)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "topk":      # larger k: the sample grows with k
     for kk in (10, 30, 100, 256):
         run(10_000_000, 384, 256, kk, 6)

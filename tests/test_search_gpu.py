@@ -87,7 +87,8 @@ def _check(idx, X, Q, k, oracle, id_offset=0):
 
 @pytest.mark.parametrize("n,d,B,k,seed", [
     (3, 3, 1, 3, 0), (100, 3, 4, 10, 1), (1000, 384, 16, 10, 2), (5000, 100, 33, 7, 3),
-    (20000, 768, 256, 10, 4), (100000, 384, 256, 10, 5), (100000, 384, 300, 10, 6),
+    (20000, 768, 256, 10, 4), (100000, 384, 256, 10, 5), (100000, 384, 300, 10, 6), (100000, 384, 512, 10, 17),
+    (60000, 512, 700, 10, 18), (30000, 128, 257, 40, 19), (30000, 640, 400, 10, 20),
     (300000, 384, 64, 100, 7), (9000, 384, 5, 1, 8), (40000, 640, 20, 10, 9), (12345, 1, 4, 5, 10),
     (2000, 1000, 3, 10, 11), (7000, 500, 17, 9, 12), (31, 384, 5, 10, 13), (33, 384, 5, 40, 14),
     (65, 130, 2, 3, 15), (70000, 257, 40, 20, 16),
