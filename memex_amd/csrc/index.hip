@@ -3,7 +3,8 @@
 // lib/libmemex/src/storage/local.rs:21-166) reached through the VectorStore trait
 // (lib/libmemex/src/storage/mod.rs:55-66).
 //
-// Search pipeline per batch of <= 256 queries (kernels: scan8.hip / scan16.hip / scan16w.hip / scan.hip,
+// Search pipeline per batch of <= 512 queries (one scan pass serves 256 of them -- 512 on the int8 copy up to 512
+// dims, 128 on scan16w; kernels: scan8.hip / scan16.hip / scan16w.hip / scan.hip,
 // index_kernels.hip):
 //   prep      normalise queries -> MFMA fragments (int8 with the query's own step, or bf16); f64 query norms
 //             (DistCosine order); the bound of a row's filter score, qa + qb * (residual of the row's half
