@@ -125,7 +125,7 @@ int mx_index_clear(mx_index *idx);
  * is 1 by construction.  Outputs are row-major [B, k]; n_found[b] = min(k, size); unused slots
  * hold id 0 / score 0 / dist +inf.  `dists` may be NULL.  B > 1 is an extension (the trait is
  * single-query); B is processed in batches of 256.  Thread-safe, and concurrent calls are COMBINED:
- * requests that arrive while a pass is on the GPU are served together (up to 256 queries with the
+ * requests that arrive while a pass is on the GPU are served together (up to 512 queries with the
  * same k per pass, FIFO), which is what turns the reference's one-query-per-HTTP-request pattern
  * (api/handlers.rs:55-109) into full batches without touching the trait.  k <= 4096 (MX_EUNSUPPORTED above; the
  * reference's callers pass limit = 10, api/handlers.rs search default).
