@@ -124,7 +124,7 @@ int mx_index_clear(mx_index *idx);
  * Results per query are ordered by (dist ascending, id ascending) -- exact brute force, so recall
  * is 1 by construction.  Outputs are row-major [B, k]; n_found[b] = min(k, size); unused slots
  * hold id 0 / score 0 / dist +inf.  `dists` may be NULL.  B > 1 is an extension (the trait is
- * single-query); B is processed in batches of 256.  Thread-safe, and concurrent calls are COMBINED:
+ * single-query); B is processed in batches of up to 512.  Thread-safe, and concurrent calls are COMBINED:
  * requests that arrive while a pass is on the GPU are served together (up to 512 queries with the
  * same k per pass, FIFO), which is what turns the reference's one-query-per-HTTP-request pattern
  * (api/handlers.rs:55-109) into full batches without touching the trait.  k <= 4096 (MX_EUNSUPPORTED above; the
