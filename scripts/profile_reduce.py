@@ -83,8 +83,8 @@ def main():
         bench = json.loads(open(os.path.join(prof, f"{tag}_bench.json")).read())
     except Exception:
         pass
-    for label, want, fname, pat in (("i8", "scan8_kernel<3, 1>", f"{tag}_scan8_traffic.json", "pmc_*"),
-                                    ("768", "scan8_kernel<6, 1>", f"{tag}_scan8_768_traffic.json", "pmc768_*"),
+    for label, want, fname, pat in (("i8", "scan8_kernel<3, 1, 1>", f"{tag}_scan8_traffic.json", "pmc_*"),
+                                    ("768", "scan8_kernel<6, 1, 1>", f"{tag}_scan8_768_traffic.json", "pmc768_*"),
                                     ("bf16", "scan16_kernel<3, 1>", f"{tag}_scan16_traffic.json", "pmc_*"),
                                     ("f32", "scan_kernel<3, 1>", f"{tag}_scan_traffic.json", "pmc_*"),
                                     ("768", "scan16_kernel<6, 1>", f"{tag}_scan16_768_traffic.json", "pmc768_*")):
