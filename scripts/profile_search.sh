@@ -46,3 +46,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/enc_stats" -- pyth
 timeout 300 bash $ROOT/scripts/profile_encoder_clock.sh > "$OUT/encoder_clock_mfma.txt" 2>&1
 python $ROOT/bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.log"
 python "$ROOT/scripts/profile_reduce.py" "$OUT" "$TAG"
+# the raw rocprofv3 directories are large (gpurun brings back at most 64 MiB): keep the summaries and the logs
+rm -rf "$OUT"/stats "$OUT"/stats768 "$OUT"/enc_stats "$OUT"/pmc_*/ "$OUT"/pmc768_*/

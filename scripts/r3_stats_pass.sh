@@ -17,3 +17,4 @@ for r in csv.DictReader(open(os.path.join(o, "r3_bench_kernel_stats.csv"))):
     if any(k in r["Name"] for k in ("scan8_kernel<3", "scan16_kernel<3", "finish", "scan8_kernel<6")):
         print(f"{r['Name'][:60]:60s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:8.1f} us min {float(r['MinNs'])/1e3:8.1f} max {float(r['MaxNs'])/1e3:8.1f}")
 PY
+rm -rf "$OUT/stats"
