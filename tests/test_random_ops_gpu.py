@@ -10,7 +10,14 @@ from conftest import bits
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("d,seed", [(384, 1), (100, 2), (1024, 3), (3, 4), (640, 5), (1536, 6)])
+import os
+
+_CASES = [(384, 1), (100, 2), (1024, 3), (3, 4), (640, 5), (1536, 6)]
+# MEMEX_TEST_SOAK=n: n more seeded sequences per width (a one-off soak run, not part of the default suite)
+_CASES += [(d, 100 + 10 * i + j) for i in range(int(os.environ.get("MEMEX_TEST_SOAK", "0"))) for j, d in enumerate((384, 256, 512, 768, 1024, 130))]
+
+
+@pytest.mark.parametrize("d,seed", _CASES)
 def test_random_operation_sequences(d, seed, oracle, lib_built, tmp_path):
     from memex_amd import _lib
     from memex_amd.index import FlatIndex
@@ -53,7 +60,7 @@ def test_random_operation_sequences(d, seed, oracle, lib_built, tmp_path):
             assert len(idx) == rows.shape[0]
             if rows.shape[0] == 0:
                 continue
-            B = int(rng.choice([1, 5, 33, 130]))
+            B = int(rng.choice([1, 5, 33, 130, 300, 512]))
             k = int(rng.choice([1, 10, 40]))
             Q = rng.standard_normal((B, d)).astype(np.float32)
             Q[0] = rows[int(rng.integers(0, rows.shape[0]))] * 2.0   # a query that is a row (or a zero row: dist 0 to all)
