@@ -10,25 +10,29 @@
 // twice the rows.
 //
 // Quantisation (shadow8_kernel).  Per 32-row half tile h:  s_h = max |c_i/|c|| / 127 over its rows,
-// c8 = rint((c/|c|) / s_h) in [-127, 127];  a query likewise with its own scale s_q.  The accumulator is
-// an exact integer, so
-//   approx = s_q * s_h * sum q8_i c8_i,   |approx - cos| <= Ec + Eq + Ec*Eq  (+ f32 normalisation slack)
-// with the MEASURED residual norms Ec = max_rows |c/|c| - s_h c8| (tracked while the copy is built) and
-// Eq = |q/|q| - s_q q8| (prep_queries_kernel): typically 0.016 at 384 dims, against 0.009 for bf16 -- a
-// few dozen more candidates per query for finish_kernel, no change to the answers.
+// c8 = rint((c/|c|) / s_h) in [-127, 127];  a query likewise with its own step s_q.  The accumulator is
+// an exact integer, so for a row of half tile h
+//   score = s_q * s_h * sum q8_i c8_i,   |score - cos| <= qa + qb * e_h,   qa = Eq + slack, qb = 1 + Eq
+// with the MEASURED residual norms e_h = 1.01 max_rows-of-h |c/|c| - s_h c8| + 1e-6 (kept per half tile next to
+// s_h) and Eq = |q/|q| - s_q q8| (prep_queries_kernel): 0.016 for a typical half tile at 384 dims, 0.022-0.027 for
+// the worst one of a 10M-row corpus, against 0.004 for bf16 -- a few hundred candidates per query for
+// finish_kernel instead of a few dozen, no change to the answers.
 //
 // Layout.  A scan tile is 64 rows = two half tiles u = 0, 1; slot s of tile T (8 KiB, 128 dims) holds the
 // eight 1-KiB A operands f = 2j + u of k-step j (32 dims) and half u: lane l -> 16 int8 = row
 // 64T + 32u + (l & 31), dims 128s + 32j + 16(l >> 5) .. + 15 (A and B use the same k order, which is all
-// the dot product needs).  The kernel is scan16_kernel with two accumulators (one per half) fed alternately:
-// one persistent 512-thread workgroup per CU, one 1 KiB LDS-DMA per wave and slot, 15 slots in flight,
-// s_waitcnt vmcnt(13) + s_barrier per slot, 8 MFMAs per slot each followed by the ds_read_b128 that refills
-// the fragment register it consumed.  The query fragments take dim_pad/8 VGPRs (48 at 384 dims, 192 at
-// 1536), so one launch serves 256 queries at every supported width.
-// Tile epilogue, per half: integer max over the lane's 16 sums, one conversion, two multiplications
-// (s_h from the tile's 16 bytes of the DMA stream, s_q per lane), one compare with the query's threshold; a passing lane stores its
-// 16 scores as floats -- the record format of scan16_kernel with the 32-row tile index 2T + u, so theta_kernel
-// and finish_kernel do not know which scan ran.
+// the dot product needs).  tscale[T] = (s_h0, s_h1, e_h0, e_h1): 16 bytes per tile, fetched by one more DMA
+// operation right before the tile's first slot.  The kernel is scan16_kernel with two accumulators (one per
+// half) fed alternately: one persistent 512-thread workgroup per CU, one 1 KiB LDS-DMA per wave and slot, 15
+// slots in flight, one s_waitcnt vmcnt(N) + s_barrier per slot (N counts the operations issued after the slot
+// being waited for: 13 slots plus the scale operations among them, a compile-time constant per position in the
+// tile), 8 MFMAs per slot each followed by the ds_read_b128 that refills the fragment register it consumed.
+// The query fragments take dim_pad/8 VGPRs (48 at 384 dims, 192 at 1536), so one launch serves 256 queries at
+// every supported width -- 512 up to 512 dims, with two query groups per wave (QG = 2).  A wave none of whose
+// queries is wanted (small batches, retry passes: ScanParams::wave_mask) skips its MFMAs.
+// Tile epilogue, per half: integer max over the lane's 16 sums, one conversion, two multiplications (s_h, s_q),
+// one FMA (theta - qb * e_h), one compare; a passing lane stores its 16 scores as floats -- the record format of
+// scan16_kernel with the 32-row tile index 2T + u, so theta_kernel and finish_kernel do not know which scan ran.
 #include <type_traits>
 
 #include "index_kernels.h"
