@@ -72,7 +72,7 @@ struct mx_encoder {
     bool profiling = false;
     bool fused_tail = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_UNFUSED_TAIL=1 keeps the three GEMMs
     bool tail2 = false;       // MEMEX_HIP_TAIL=2|3: the layer tail runs on tail2_kernel (encoder_tail2.hip)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr, ev_done = nullptr;
     mx_encoder_stats stats{};
     int tail2_min_rows = 0;
     std::string key;  // registry key (mx_encoder_open); empty = private
@@ -282,7 +282,7 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
         if (rc != MX_OK) return rc;
     }
     if (e->profiling) MX_HIP(hipEventRecord(e->ev1, e->stream));
-    MX_HIP(hipStreamSynchronize(e->stream));  // results complete in d_out when the call returns
+    MX_HIP(napping_sync(e->stream, e->ev_done));  // results complete in d_out when the call returns (the thread naps meanwhile)
     if (e->profiling) {
         float ms = 0.f;
         MX_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
@@ -368,6 +368,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_wait, hipEventDisableTiming) != hipSuccess)
         return bail(fail(MX_EDEVICE, "stream/event creation failed"));
 
@@ -436,6 +437,7 @@ static void destroy_impl(mx_encoder *e) {
         if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->ev_wait) (void)hipEventDestroy(e->ev_wait);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;

@@ -30,6 +30,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <chrono>
+#include <ctime>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -200,6 +201,7 @@ struct mx_index {
     Scratch s;
     mx_index_stats stats{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
+    double wait_ema_us = 0.0;  // how long recent batches took from the finish launch to completion (sleeping wait)
     // persistence bookkeeping: what vectors.mxflat in `disk_dir` holds, as far as this handle knows
     std::string disk_dir;
     uint64_t disk_rows = 0;
@@ -761,21 +763,43 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     auto finish_and_wait = [&]() -> int {
         fp.seq = ++s.flag_seq;
         MX_HIP(launch_finish(st, B, fp));
-        // Default: wait in hipStreamSynchronize -- a server thread must not burn a core for the ~2 ms of a batch
-        // (measured: 1.902 vs 1.898 ms per step, scripts/r2_spin_vs_sleep.sh).  MEMEX_HIP_SPIN=1 (bench.py sets
-        // it) polls the completion word instead; MEMEX_HIP_NO_SPIN=1 is the older spelling of the default.
+        // Default: a SLEEPING wait -- a server thread must not burn a core for the ~1 ms of a batch.  The HIP runtime's
+        // own waits do not help: hipStreamSynchronize and hipEventSynchronize (also on a hipEventBlockingSync event)
+        // poll with the default scheduling policy -- 100 % of a core in all three forms (scripts/gpu_wait_modes.py) --
+        // and hipSetDeviceFlags(BlockingSync) is not this library's to set in a host process.  So: sleep for most of
+        // what the last batches took (clock_nanosleep), then poll the completion word; the estimate follows the
+        // workload (an EMA of the wait just observed).  MEMEX_HIP_SPIN=1 (bench.py sets it) polls from the start;
+        // MEMEX_HIP_NO_SPIN=1 is the older spelling of the default.
         static const bool no_spin = [] {
             const char *sp = getenv("MEMEX_HIP_SPIN"), *ns = getenv("MEMEX_HIP_NO_SPIN");
             if (ns && ns[0] == '1') return true;
             return !(sp && sp[0] == '1');
         }();
         const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 1; !no_spin; ++spins) {
-            if (__atomic_load_n(&s.host_sum[4], __ATOMIC_ACQUIRE) == fp.seq) return MX_OK;
+        if (no_spin && idx->wait_ema_us > 150.0) {
+            const double nap_us = 0.8 * idx->wait_ema_us - 60.0;  // timer slack and wake-up latency stay inside the estimate
+            if (nap_us > 50.0) {
+                struct timespec ts;
+                ts.tv_sec = (time_t)(nap_us / 1e6);
+                ts.tv_nsec = (long)((nap_us - (double)ts.tv_sec * 1e6) * 1e3);
+                (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
+            }
+        }
+        bool done = false;
+        for (unsigned spins = 1;; ++spins) {
+            if (__atomic_load_n(&s.host_sum[4], __ATOMIC_ACQUIRE) == fp.seq) {
+                done = true;
+                break;
+            }
             if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
             __builtin_ia32_pause();
         }
-        MX_HIP(hipStreamSynchronize(st));
+        if (done) {
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            idx->wait_ema_us = idx->wait_ema_us > 0.0 ? 0.75 * idx->wait_ema_us + 0.25 * us : us;
+            return MX_OK;
+        }
+        MX_HIP(hipStreamSynchronize(st));  // a kernel that never signals (fault): the synchronize reports it
         if (__atomic_load_n(&s.host_sum[4], __ATOMIC_ACQUIRE) == fp.seq) return MX_OK;
         return fail(MX_EDEVICE, "finish_kernel did not signal completion");
     };

@@ -2,9 +2,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <string>
 
 #include "../../include/memex_hip.h"
@@ -46,5 +49,27 @@ struct DeviceGuard {
 };
 
 inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
+
+// Host wait for everything queued on `st` that does not burn a core: hipStreamSynchronize / hipEventSynchronize poll
+// with the runtime's default scheduling policy (100 % of a core, scripts/gpu_wait_modes.py).  Record `ev`, poll it
+// for ~100 us (short work returns at once), then nap 50 us between polls.  MEMEX_HIP_SPIN=1: plain synchronize.
+inline hipError_t napping_sync(hipStream_t st, hipEvent_t ev) {
+    static const bool spin = [] {
+        const char *sp = getenv("MEMEX_HIP_SPIN");
+        return sp && sp[0] == '1';
+    }();
+    if (spin || !ev) return hipStreamSynchronize(st);
+    hipError_t e = hipEventRecord(ev, st);
+    if (e != hipSuccess) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) {
+            struct timespec ts = {0, 50 * 1000};
+            (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
+        }
+    }
+}
 
 }  // namespace mx
