@@ -201,7 +201,8 @@ struct mx_index {
     Scratch s;
     mx_index_stats stats{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr;
-    double wait_ema_us = 0.0;  // how long recent batches took from the finish launch to completion (sleeping wait)
+    double wait_ema_us[4] = {0.0, 0.0, 0.0, 0.0};  // how long recent batches of <= 32 / 128 / 256 / more queries took from the
+                                                   // finish launch to completion (sleeping wait)
     // persistence bookkeeping: what vectors.mxflat in `disk_dir` holds, as far as this handle knows
     std::string disk_dir;
     uint64_t disk_rows = 0;
@@ -776,8 +777,9 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
             return !(sp && sp[0] == '1');
         }();
         const auto t0 = std::chrono::steady_clock::now();
-        if (no_spin && idx->wait_ema_us > 150.0) {
-            const double nap_us = 0.8 * idx->wait_ema_us - 60.0;  // timer slack and wake-up latency stay inside the estimate
+        double &ema = idx->wait_ema_us[B <= 32 ? 0 : B <= 128 ? 1 : B <= 256 ? 2 : 3];
+        if (no_spin && ema > 150.0) {
+            const double nap_us = 0.8 * ema - 60.0;  // timer slack and wake-up latency stay inside the estimate
             if (nap_us > 50.0) {
                 struct timespec ts;
                 ts.tv_sec = (time_t)(nap_us / 1e6);
@@ -796,7 +798,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         }
         if (done) {
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-            idx->wait_ema_us = idx->wait_ema_us > 0.0 ? 0.75 * idx->wait_ema_us + 0.25 * us : us;
+            ema = ema > 0.0 ? 0.75 * ema + 0.25 * us : us;
             return MX_OK;
         }
         MX_HIP(hipStreamSynchronize(st));  // a kernel that never signals (fault): the synchronize reports it
