@@ -10,6 +10,7 @@
 #include <cmath>
 
 #include "index_kernels.h"
+#include "mx_rotate.h"
 
 namespace mx {
 
@@ -229,9 +230,16 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
     const int w = b >> 5, col = b & 31;
     float r2 = 0.0f;  // |stored(q/|q|) - q/|q||^2: this query's share of the scan's error bound
     if (filt8) {
-        // 8-bit filter copy (scan8.hip): q8 = rint((q/|q|) / s_q), s_q = max |q_i/|q|| / 127
+        // 8-bit filter copy (scan8.hip): the normalised query goes through the same rotation as the rows
+        // (mx_rotate.h), then q8 = rint(rotated / s_q), s_q = max |rotated_i| / 127
+        float *rin = s_row + d, *rot = rin + ds, *mixq = rot + ds;  // behind the query: [ds] | [ds] | [144]
+        for (int dim = tid; dim < ds; dim += 256) rin[dim] = dim < d ? s_row[dim] * inv : 0.0f;
+        rot_fill_mix(mixq, ds >> 7, tid, 256);
+        __syncthreads();
+        if (tid < 64) rot_wave(rin, rot, ds >> 7, tid, mixq);
+        __syncthreads();
         float mx = 0.0f;
-        for (int dim = tid; dim < d; dim += 256) mx = fmaxf(mx, fabsf(s_row[dim] * inv));
+        for (int dim = tid; dim < ds; dim += 256) mx = fmaxf(mx, fabsf(rot[dim]));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         if ((tid & 63) == 0) s_red[tid >> 6] = __float_as_uint(mx);
@@ -244,11 +252,11 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
         int8_t *q8 = reinterpret_cast<int8_t *>(qfrag);
         for (int dim = tid; dim < ds; dim += 256) {
             const float v = dim < d ? s_row[dim] : 0.0f;
-            qpad[(size_t)b * ds + dim] = v;
+            qpad[(size_t)b * ds + dim] = v;  // the rescoring stages read the query as it came
             // v_mfma_i32_32x32x32_i8 B-operand: lane l holds B[k = 16*(l>>5)+i][n = l&31], 16 int8
             const int ks = dim >> 5, hh = (dim >> 4) & 1, i = dim & 15;
             const int lane = hh * 32 + col;
-            const float vn = v * inv;
+            const float vn = rot[dim];
             const float qv = fminf(fmaxf(rintf(vn * qinv), -127.0f), 127.0f);
             q8[(((size_t)w * ksteps + ks) * 64 + lane) * 16 + i] = (int8_t)(int)qv;
             const float r = qv * sq - vn;
@@ -305,7 +313,8 @@ hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int 
                                double *qnorm2, float *theta, float *e1, const uint32_t *ec_max, uint32_t *overflow,
                                uint32_t *flags, float *qa, float *qb, bool filt8, float *qscale) {
     // one block per query slot: 256 slots (a pass computes all of them), 512 for a batch of more than 256
-    hipLaunchKernelGGL(prep_queries_kernel, dim3(B > kPassBatch ? kMaxBatch : kPassBatch), dim3(256), sizeof(float) * (size_t)d, s, q, B, d, ds,
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(B > kPassBatch ? kMaxBatch : kPassBatch), dim3(256),
+                       sizeof(float) * ((size_t)d + (filt8 ? 2 * (size_t)ds + kRotMaxBlocks * kRotMaxBlocks : 0)), s, q, B, d, ds,
                        (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags, filt8 ? 1 : 0, qscale, qa, qb);
     return hipGetLastError();
 }

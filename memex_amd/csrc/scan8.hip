@@ -9,8 +9,10 @@
 // v_mfma_f32_32x32x16_bf16: the same 8-KiB slot stream at the same rate (scripts/r3_i8probe.sh) carries
 // twice the rows.
 //
-// Quantisation (shadow8_kernel).  Per 32-row half tile h:  s_h = max |c_i/|c|| / 127 over its rows,
-// c8 = rint((c/|c|) / s_h) in [-127, 127];  a query likewise with its own step s_q.  The accumulator is
+// Quantisation (shadow8_kernel).  Rows are normalised and rotated (mx_rotate.h: a fixed orthonormal map, so dot
+// products are unchanged and the elements look Gaussian whatever the embedding model's spectrum is).  Per 32-row
+// half tile h:  s_h = max |rotated element| / 127 over its rows,  c8 = rint(rotated / s_h) in [-127, 127];  a query
+// likewise (same rotation) with its own step s_q.  The accumulator is
 // an exact integer, so for a row of half tile h
 //   score = s_q * s_h * sum q8_i c8_i,   |score - cos| <= qa + qb * e_h,   qa = Eq + slack, qb = 1 + Eq
 // with the MEASURED residual norms e_h = 1.01 max_rows-of-h |c/|c| - s_h c8| + 1e-6 (kept per half tile next to
@@ -36,6 +38,7 @@
 #include <type_traits>
 
 #include "index_kernels.h"
+#include "mx_rotate.h"
 
 namespace mx {
 
@@ -258,67 +261,78 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
 // ---------------------------------------------------------------------------------------------
 // filter-copy construction: one workgroup per 32-row half tile
 // ---------------------------------------------------------------------------------------------
+// Every row is normalised, ROTATED (mx_rotate.h: the quantiser then sees Gaussian-looking elements whatever the
+// embedding model's spectrum is) and quantised.  A wave handles a row at a time (8 of the half tile's 32); the step
+// needs the largest rotated element of all 32 rows, so the rows are rotated twice: once for the maximum, once to
+// quantise (the arithmetic is nothing next to the row reads).  The int8 rows are staged in LDS row-major and copied
+// out in fragment order by the whole workgroup.
 __global__ __launch_bounds__(256) void shadow8_kernel(const float *__restrict__ x, const float *__restrict__ scale, int ds,
                                                       uint32_t half0, uint32_t half1, uint64_t row_hi,
                                                       i32x4 *__restrict__ x8, float *__restrict__ tscale,
                                                       uint32_t *__restrict__ ec_max) {
-    __shared__ float s_r2[kTileRows];
-    __shared__ float s_red[4];
-    __shared__ float s_rs[kTileRows];  // 1/|c| of the half tile's rows; 0 for a zero-norm row and for rows >= row_hi
-    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char s8[];
+    // [4 waves][2][ds] f32 rotation buffers | [32][ds] int8 staged rows | mix [144] | per-row residuals, reductions
+    float *rbuf = reinterpret_cast<float *>(s8);
+    int8_t *stage = reinterpret_cast<int8_t *>(s8 + (size_t)8 * ds * sizeof(float));
+    float *mix = reinterpret_cast<float *>(s8 + (size_t)8 * ds * sizeof(float) + (size_t)kTileRows * ds);
+    float *s_r2 = mix + kRotMaxBlocks * kRotMaxBlocks;  // [32]
+    float *s_red = s_r2 + kTileRows;                    // [4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kc = ds >> 7;
     const uint32_t frags = (uint32_t)(ds >> 5) * 64u;  // 16-byte fragments per half tile
+    float *in = rbuf + (size_t)wave * 2 * ds, *out = in + ds;
+    rot_fill_mix(mix, kc, tid, 256);
+    __syncthreads();
     float worst = 0.0f;
     for (uint32_t h = half0 + blockIdx.x; h < half1; h += gridDim.x) {
         const float *xt = x + (size_t)h * kTileRows * ds;
-        if (tid < kTileRows) {
-            const uint64_t grow = (uint64_t)h * kTileRows + tid;
-            s_rs[tid] = grow < row_hi ? scale[grow] : 0.0f;
-            s_r2[tid] = 0.0f;
-        }
-        __syncthreads();
-        // ---- pass 1: largest |c_i / |c|| of the half tile
+        // a row of the half tile, normalised and rotated, in `out` (zeros for a zero-norm row and for rows >= row_hi)
+        auto rotated_row = [&](int r) -> bool {
+            const uint64_t grow = (uint64_t)h * kTileRows + (uint64_t)r;
+            const float sc = grow < row_hi ? scale[grow] : 0.0f;
+            if (sc == 0.0f) return false;
+            for (int i = lane; i < ds; i += 64) in[i] = xt[(size_t)r * ds + i] * sc;
+            rot_wave(in, out, kc, lane, mix);
+            return true;
+        };
+        // ---- pass 1: largest |element| of the rotated rows
         float mx = 0.0f;
-        for (uint32_t i = tid; i < (uint32_t)(kTileRows * ds) / 4; i += 256) {
-            const uint32_t row = i / (uint32_t)(ds >> 2);
-            const float sc = s_rs[row];
-            if (sc != 0.0f) {
-                const f32x4 v = reinterpret_cast<const f32x4 *>(xt)[i] * sc;
-                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-            }
-        }
+        for (int r = wave; r < kTileRows; r += 4)
+            if (rotated_row(r))
+                for (int i = lane; i < ds; i += 64) mx = fmaxf(mx, fabsf(out[i]));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+        if (lane == 0) s_red[wave] = mx;
         __syncthreads();
         mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
         const float sh = mx / 127.0f, inv = mx > 0.0f ? 127.0f / mx : 0.0f;
-        // ---- pass 2: quantise, store in fragment order, residual per row
+        // ---- pass 2: quantise, residual per row, int8 rows staged in LDS
+        for (int r = wave; r < kTileRows; r += 4) {
+            float r2 = 0.0f;
+            if (rotated_row(r)) {
+                for (int i = lane; i < ds; i += 64) {
+                    const float v = out[i];
+                    const float qv = fminf(fmaxf(rintf(v * inv), -127.0f), 127.0f);
+                    const float dlt = v - qv * sh;
+                    r2 += dlt * dlt;
+                    stage[(size_t)r * ds + i] = (int8_t)(int)qv;
+                }
+            } else {
+                for (int i = lane; i < ds; i += 64) stage[(size_t)r * ds + i] = 0;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
+            if (lane == 0) s_r2[r] = r2;
+        }
+        __syncthreads();
+        // ---- copy-out in fragment order
         const uint32_t T = h >> 1, u = h & 1;
         for (uint32_t f = tid; f < frags; f += 256) {
             const uint32_t ks = f >> 6, l = f & 63, mm = l & 31, hh = l >> 5;  // k-step of 32 dims
-            const uint32_t s = ks >> 2, j = ks & 3;
-            const float sc = s_rs[mm];
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(xt + (size_t)mm * ds + ks * 32 + hh * 16);
-            int w[4];
-            float r2 = 0.0f;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 v = sc != 0.0f ? src[q4] * sc : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                uint32_t pk = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float qv = fminf(fmaxf(rintf(v[e] * inv), -127.0f), 127.0f);
-                    const float d = v[e] - qv * sh;
-                    r2 += d * d;
-                    pk |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
-                }
-                w[q4] = (int)pk;
-            }
-            x8[(((size_t)T * kc + s) * 8 + (j * 2 + u)) * 64 + l] = i32x4{w[0], w[1], w[2], w[3]};
-            atomicAdd(&s_r2[mm], r2);
+            const uint32_t sl = ks >> 2, j = ks & 3;
+            x8[(((size_t)T * kc + sl) * 8 + (j * 2 + u)) * 64 + l] =
+                *reinterpret_cast<const i32x4 *>(stage + (size_t)mm * ds + ks * 32 + hh * 16);
         }
-        __syncthreads();
         float hw = tid < kTileRows ? sqrtf(s_r2[tid]) : 0.0f;  // worst residual of THIS half tile (waves 1-3 hold zeros)
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) hw = fmaxf(hw, __shfl_xor(hw, o));
@@ -336,11 +350,15 @@ __global__ __launch_bounds__(256) void shadow8_kernel(const float *__restrict__ 
     }
 }
 
+static size_t shadow8_lds(int ds) {
+    return (size_t)8 * ds * sizeof(float) + (size_t)kTileRows * ds + (kRotMaxBlocks * kRotMaxBlocks + kTileRows + 4) * sizeof(float);
+}
+
 hipError_t launch_shadow8(hipStream_t s, const float *x, const float *scale, int ds, uint32_t half0, uint32_t half1,
                           uint64_t row_hi, void *x8, float *tscale, uint32_t *ec_max) {
     if (half1 <= half0) return hipSuccess;
     const uint32_t blocks = half1 - half0 < 16384u ? half1 - half0 : 16384u;
-    hipLaunchKernelGGL(shadow8_kernel, dim3(blocks), dim3(256), 0, s, x, scale, ds, half0, half1, row_hi,
+    hipLaunchKernelGGL(shadow8_kernel, dim3(blocks), dim3(256), shadow8_lds(ds), s, x, scale, ds, half0, half1, row_hi,
                        reinterpret_cast<i32x4 *>(x8), tscale, ec_max);
     return hipGetLastError();
 }
@@ -353,6 +371,9 @@ static hipError_t setup8_one() {
 
 hipError_t scan8_setup() {
     hipError_t e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&shadow8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)shadow8_lds(kMaxKC16 * kChunkFloats))) != hipSuccess)
+        return e;
 #define MX_SETUP(KC)                                             \
     if ((e = setup8_one<KC, 0, 1>()) != hipSuccess) return e;    \
     if ((e = setup8_one<KC, 1, 1>()) != hipSuccess) return e;
