@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--data", choices=["gaussian", "clustered"], default="gaussian",
+    ap.add_argument("--data", choices=["gaussian", "clustered", "anisotropic"], default="gaussian",
                     help="rows of the headline corpus: i.i.d. N(0,1) (BASELINE's synthetic corpus) or clustered")
     ap.add_argument("--scan", choices=["i8", "bf16", "f32"], default="i8",
                     help="what the scan kernel streams: the int8 filter copy, the bf16 filter copy or the f32 rows")
@@ -110,6 +110,19 @@ def clustered_rows(n: int, dim: int, seed: int, centres, dev="cuda"):
     return x
 
 
+def anisotropic_rows(n: int, dim: int, seed: int, dev="cuda"):
+    """Rows that look more like sentence embeddings than i.i.d. Gaussians do: a decaying spectrum (dimension i scaled by
+    (i+1)^-0.5) and a common mean direction (random pairs have cosine ~0.45): most of a unit vector's energy sits in a few
+    dimensions -- what an 8-bit quantiser with one step per block dislikes (the rotation)."""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    spec = torch.arange(1, dim + 1, device=dev, dtype=torch.float32) ** -0.5
+    x = torch.randn((n, dim), device=dev, dtype=torch.float32, generator=g) * spec
+    x[:, 0] += 0.6 * spec.norm()
+    return x
+
+
 def gaussian_rows(n: int, dim: int, seed: int, dev="cuda"):
     import torch
     g = torch.Generator(device=dev)
@@ -124,7 +137,8 @@ def fill_index(idx, rows_total: int, dim: int, lo: int, hi: int, data: str):
     for gb in range(lo // BLOCK, (hi + BLOCK - 1) // BLOCK):
         g0 = gb * BLOCK
         nb = min(BLOCK, rows_total - g0)
-        xb = clustered_rows(nb, dim, 5000 + gb, centres) if data == "clustered" else gaussian_rows(nb, dim, 1234 + gb)
+        xb = (clustered_rows(nb, dim, 5000 + gb, centres) if data == "clustered" else
+              anisotropic_rows(nb, dim, 9000 + gb) if data == "anisotropic" else gaussian_rows(nb, dim, 1234 + gb))
         s0, s1 = max(lo, g0) - g0, min(hi, g0 + nb) - g0
         part = xb[s0:s1].contiguous()
         idx.add_device(part)
@@ -136,6 +150,8 @@ def make_queries(batch: int, dim: int, data: str, seed: int = 4321):
     import torch
     if data == "clustered":  # queries live in clusters too: each has a dense neighbourhood
         return clustered_rows(batch, dim, seed, clustered_centres(dim))
+    if data == "anisotropic":
+        return anisotropic_rows(batch, dim, seed)
     return gaussian_rows(batch, dim, seed)
 
 
@@ -656,6 +672,8 @@ def main():
         sides["small_batches"] = small
         other_data = "clustered" if a.data == "gaussian" else "gaussian"
         sides[other_data] = side_leg(rows_total, a.dim, a.batch, k, a.side_steps, other_data)
+        if a.data == "gaussian":  # embedding-like rows (decaying spectrum + common mean direction), the library's own choice of copy
+            sides["anisotropic"] = side_leg(rows_total, a.dim, a.batch, k, a.side_steps, "anisotropic")
         sides["cfg4_shard_10Mx768"] = side_leg(10_000_000, 768, a.batch, k, a.side_steps, "gaussian")
         if a.cfg2_segments > 0:
             sides["cfg2"] = cfg2_leg(a.cfg2_segments, a.batch, k, a.side_steps)
@@ -684,7 +702,7 @@ def main():
                      + " -> f32 rescoring -> f64 DistCosine on the survivors (results bit-identical to all-f64)",
             "scan": a.scan,
             "filter_copy_bytes": int(st.filter_copy_bytes),
-            "data": "synthetic" if a.data == "gaussian" else "synthetic (clustered)",
+            "data": "synthetic" if a.data == "gaussian" else f"synthetic ({a.data})",
             "config": {"workload": f"{rows_total}x{a.dim} f32 corpus in HBM ({a.data}), query batch {a.batch}, top-{k}",
                        "rows_per_gpu": n_local,
                        "wait": "poll" if os.environ.get("MEMEX_HIP_SPIN") == "1" else "sleep",
