@@ -682,3 +682,42 @@ def test_lane_buffers_are_leased_from_a_pool_per_device(oracle, lib_built):
     finally:
         for idx in held:
             idx.close()
+
+
+def test_concurrent_searches_on_several_indexes(oracle, lib_built):
+    """Four indexes (different widths and filter copies), four threads searching them at the same time: each search
+    leases its own lane buffers from the device's pool and returns its own answers."""
+    import threading
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(61)
+    specs = [(30000, 384, "i8"), (20000, 768, "bf16"), (25000, 128, True), (8000, 1024, False)]
+    held, want, errs = [], [], []
+    try:
+        for n, d, kind in specs:
+            X = rng.standard_normal((n, d), dtype=np.float32)
+            Q = rng.standard_normal((40, d), dtype=np.float32)
+            idx = FlatIndex(d)
+            idx.set_filter_copy(kind)
+            idx.add(X)
+            held.append((idx, Q))
+            want.append(oracle.search(X, Q, 10))
+
+        def worker(i):
+            try:
+                idx, Q = held[i]
+                for _ in range(25):
+                    ids, sc, di, nf = idx.search(Q, 10)
+                    np.testing.assert_array_equal(ids, want[i][0])
+                    np.testing.assert_array_equal(bits(di), bits(want[i][1]))
+            except Exception as e:  # noqa: BLE001
+                errs.append((i, repr(e)))
+
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(len(held))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+    finally:
+        for idx, _ in held:
+            idx.close()
