@@ -71,6 +71,7 @@ struct mx_encoder {
     float *out_dev = nullptr;
     bool profiling = false;
     bool fused_tail = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_UNFUSED_TAIL=1 keeps the three GEMMs
+    bool pgemm = true;        // large passes run their GEMMs on pgemm_kernel (encoder_pgemm.hip); MEMEX_HIP_PGEMM=0: gemm_kernel
     bool tail2 = false;       // MEMEX_HIP_TAIL=2|3: the layer tail runs on tail2_kernel (encoder_tail2.hip)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr, ev_done = nullptr;
     mx_encoder_stats stats{};
@@ -180,6 +181,9 @@ constexpr int kMaxSeqsPerPass = 1024;
 // packed rows per pass (131072): bounds the workspace; measured: larger passes are faster (fixed
 // per-pass costs), smaller ones do not help (the GEMMs are not bandwidth-bound)
 constexpr int kMaxRowsPerPass = 1 << 17;
+// passes of at least this many packed rows use pgemm_kernel: 128 row tiles of 256 = 16 per XCD, every CU busy for
+// the 768-wide outputs (3 column tiles); below, gemm_kernel's small tiles fill the chip better
+constexpr int kPgemmRows = 32768;
 
 // one pass: sequences [0, B) with device ids [B,S] (row pitch S) and HOST lens; output d_out [B,H]
 int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const int32_t *d_lens, int B, int S,
@@ -205,15 +209,30 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
     MX_HIP(launch_embed_ln(st, d_ids, S, e->tok_seq, e->tok_pos, t_pad, H, e->word, e->pos, e->type0, e->eg, e->eb,
                            c.ln_eps, c.vocab, e->x));
     const float qscale = (float)(1.4426950408889634 / std::sqrt((double)dh));
+    // Large passes (>= kPgemmRows packed rows) run every GEMM whose shape it takes on pgemm_kernel; the Add & LayerNorm
+    // GEMMs then leave y = product + bias + residual and ln_rows_kernel normalises it in place.
+    const bool big = e->pgemm && t_pad >= kPgemmRows;
+    auto gemm = [&](int epi, const GemmParams &gp) -> hipError_t {
+        if (big && pgemm_supported(epi, gp)) return launch_pgemm(st, epi, gp);
+        return launch_gemm(st, epi, gp);
+    };
+    auto gemm_res_ln = [&](GemmParams gp) -> hipError_t {  // out = LayerNorm(a W^T + bias + res)
+        if (big && pgemm_supported(EPI_BIAS_RES, gp)) {
+            hipError_t he = launch_pgemm(st, EPI_BIAS_RES, gp);
+            if (he != hipSuccess) return he;
+            return launch_ln_rows(st, gp.out, gp.ldo, gp.m, gp.n, gp.gamma, gp.beta, gp.eps);
+        }
+        return launch_gemm(st, EPI_BIAS_RES_LN, gp);
+    };
     for (const Layer &L : e->layers) {
         GemmParams g{};
         g.a = e->x; g.lda = H; g.w = L.wqkv; g.w_rows = 3 * H; g.w_row0 = 0; g.bias = L.bqkv; g.m = t_pad; g.n = 2 * H; g.k = H;
         g.out = e->q; g.out_k = e->k; g.ldo = H; g.hidden = H; g.qscale = qscale;
-        MX_HIP(launch_gemm(st, EPI_QKV, g));
+        MX_HIP(gemm(EPI_QKV, g));
         GemmParams gv{};  // V third of the concatenated projection, written feature-major
         gv.a = e->x; gv.lda = H; gv.w = L.wqkv; gv.w_rows = 3 * H; gv.w_row0 = 2 * H; gv.bias = L.bqkv + 2 * H; gv.m = t_pad; gv.n = H;
         gv.k = H; gv.out_vt = e->vt; gv.ldvt = t_pad; gv.hidden = H;
-        MX_HIP(launch_gemm(st, EPI_VT, gv));
+        MX_HIP(gemm(EPI_VT, gv));
         MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->cu, d_lens, B, max_len, heads, dh, H, e->ctx));
         if (e->fused_tail) {
             // out-projection + Add&Norm + MLP + Add&Norm in one kernel, in place on e->x
@@ -229,15 +248,15 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         GemmParams o{};
         o.a = e->ctx; o.lda = H; o.w = L.wo; o.w_rows = H; o.w_row0 = 0; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = H;
         o.out = e->x1; o.ldo = H; o.res = e->x; o.ldres = H; o.gamma = L.ln1g; o.beta = L.ln1b; o.eps = c.ln_eps;
-        MX_HIP(launch_gemm(st, EPI_BIAS_RES_LN, o));
+        MX_HIP(gemm_res_ln(o));
         GemmParams f1{};
         f1.a = e->x1; f1.lda = H; f1.w = L.wi; f1.w_rows = F; f1.w_row0 = 0; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = H;
         f1.out = e->hbuf; f1.ldo = F;
-        MX_HIP(launch_gemm(st, EPI_BIAS_GELU, f1));
+        MX_HIP(gemm(EPI_BIAS_GELU, f1));
         GemmParams f2{};
         f2.a = e->hbuf; f2.lda = F; f2.w = L.wo2; f2.w_rows = H; f2.w_row0 = 0; f2.bias = L.bo2; f2.m = t_pad; f2.n = H; f2.k = F;
         f2.out = e->x; f2.ldo = H; f2.res = e->x1; f2.ldres = H; f2.gamma = L.ln2g; f2.beta = L.ln2b; f2.eps = c.ln_eps;
-        MX_HIP(launch_gemm(st, EPI_BIAS_RES_LN, f2));
+        MX_HIP(gemm_res_ln(f2));
     }
     MX_HIP(launch_pool(st, e->x, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
     // no synchronisation here: the passes of one call queue up on the stream (same workspace, stream order)
@@ -340,6 +359,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
     std::call_once(g_enc_once, [] {
         g_enc_setup = encoder_kernels_setup();
+        if (g_enc_setup == hipSuccess) g_enc_setup = pgemm_setup();
         if (g_enc_setup == hipSuccess) g_enc_setup = tail_setup();
         if (g_enc_setup == hipSuccess) g_enc_setup = tail2_setup();
     });
@@ -352,6 +372,8 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     {
         const char *ev = getenv("MEMEX_HIP_UNFUSED_TAIL");
         e->fused_tail = tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
+        const char *pv = getenv("MEMEX_HIP_PGEMM");
+        e->pgemm = !(pv && pv[0] == '0');
         // tail2_kernel (encoder_tail2.hip) is the experimental activation-stationary form of the tail: correct and a
         // little more accurate, 3-5 % faster than tail_kernel alone on the chip, 1-2 % SLOWER inside the encoder
         // (scripts/r3_enc_ab.sh).  MEMEX_HIP_TAIL=2 selects it at every pass size, =3 from 128 rows

@@ -23,6 +23,7 @@ enum GemmEpilogue {
     EPI_QKV = 2,          // N = 2H: q (pre-scaled) and k, token-major into out / out_k
     EPI_VT = 4,           // N = H: v, feature-major (transposed) into out_vt
     EPI_BIAS_RES_LN = 3,  // out = bf16(LayerNorm(acc + bias + residual))   (BN == N == hidden)
+    EPI_BIAS_RES = 5,     // out = bf16(bf16(acc + bias) + residual): pgemm_kernel only, launch_ln_rows applies the LayerNorm
 };
 
 struct GemmParams {
@@ -93,6 +94,13 @@ void tail2_param_layout(const float *bo, const float *g1, const float *be1, cons
 
 hipError_t encoder_kernels_setup();
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p);
+
+// the large-pass GEMM (encoder_pgemm.hip): persistent 256 x 256 tiles, two wave rows running half a phase apart
+hipError_t pgemm_setup();
+bool pgemm_supported(int epi, const GemmParams &p);
+hipError_t launch_pgemm(hipStream_t s, int epi, const GemmParams &p);
+// x[r] = LayerNorm(x[r]) * gamma + beta in place, rows of `hidden` (384 / 768) bf16, row pitch ld
+hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden, const float *gamma, const float *beta, float eps);
 
 // token maps from sequence lengths: cu[b] (aligned starts), tok_seq / tok_pos for every packed row
 hipError_t launch_token_map(hipStream_t s, const int32_t *lens, int B, int S, int32_t *cu, int32_t *tok_seq,

@@ -19,6 +19,12 @@
 
 #include <cmath>
 
+// Ablation switch for scripts/gemm_ubench.hip only (0 = production kernels); bits for gemm_kernel:
+//   1 = no DMA inside the k loop (the ring keeps the prologue's tiles), 2 = no epilogue (accumulators kept alive)
+#ifndef MX_GEMM_ABLATE
+#define MX_GEMM_ABLATE 0
+#endif
+
 namespace mx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -148,7 +154,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most the (S-2) newer tiles' pieces of this wave are in flight
-        if (kt + S - 2 < nk) {
+        if (MX_GEMM_ABLATE & 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (kt + S - 2 < nk) {
             constexpr int kInFlight = G::PPW * (S - 2);  // DMA ops of newer tiles that may stay outstanding
             if (kInFlight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (kInFlight == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt landed; stage (kt-1)%S is free
-        if (kt + S - 1 < nk) issue_tile(kt + S - 1);
+        if (!(MX_GEMM_ABLATE & 1) && kt + S - 1 < nk) issue_tile(kt + S - 1);
         const char *st = smem + (kt % S) * G::STAGE;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -186,6 +194,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if (MX_GEMM_ABLATE & 2) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+#endif
     __syncthreads();  // all waves are done with the ring: its space becomes the output tile
 
     // ---- epilogue, one 128-row group at a time (the bf16 output tile of a group fits the ring's
@@ -486,6 +501,55 @@ hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32
         hipLaunchKernelGGL(embed_ln_kernel<3>, g8, dim3(256), 0, s, ids, S, tok_seq, tok_pos, t_pad, word, pos, type0, gamma, beta, eps, vocab, x);
     else if (hidden == 768)
         hipLaunchKernelGGL(embed_ln_kernel<6>, g8, dim3(256), 0, s, ids, S, tok_seq, tok_pos, t_pad, word, pos, type0, gamma, beta, eps, vocab, x);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4b: row LayerNorm in place (large passes of hidden-768 models: pgemm_kernel's EPI_BIAS_RES leaves
+// y = attention / MLP output + bias + residual, this turns it into LayerNorm(y)).  TPR lanes per row, 3 x 16 bytes per
+// lane (hidden = 24 TPR), same statistics / affine helpers as the fused epilogues.  HBM-bound: 2 x 201 MB per call at
+// 131k tokens x 768.
+// ---------------------------------------------------------------------------------------------
+template <int TPR>
+__global__ __launch_bounds__(256) void ln_rows_kernel(bf16_t *__restrict__ x, int ld, int rows, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float eps) {
+    const int l = threadIdx.x % TPR;
+    const int row = blockIdx.x * (256 / TPR) + threadIdx.x / TPR;
+    if (row >= rows) return;
+    bf16_t *xr = x + (size_t)row * ld;
+    float y[24];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(xr + (c * TPR + l) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[c * 8 + e] = (float)v[e];
+    }
+    float mean, rstd;
+    ln_row_stats<TPR, 24>(y, eps, mean, rstd);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int col = (c * TPR + l) * 8;
+        const f32x4 g0v = *reinterpret_cast<const f32x4 *>(gamma + col);
+        const f32x4 g1v = *reinterpret_cast<const f32x4 *>(gamma + col + 4);
+        const f32x4 b0v = *reinterpret_cast<const f32x4 *>(beta + col);
+        const f32x4 b1v = *reinterpret_cast<const f32x4 *>(beta + col + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (__bf16)ln_affine(y[c * 8 + e], mean, rstd, g0v[e], b0v[e]);
+            o[4 + e] = (__bf16)ln_affine(y[c * 8 + 4 + e], mean, rstd, g1v[e], b1v[e]);
+        }
+        *reinterpret_cast<bf16x8 *>(xr + col) = o;
+    }
+}
+
+hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden, const float *gamma, const float *beta, float eps) {
+    if (hidden == 768)
+        hipLaunchKernelGGL(ln_rows_kernel<32>, dim3((rows + 7) / 8), dim3(256), 0, s, x, ld, rows, gamma, beta, eps);
+    else if (hidden == 384)
+        hipLaunchKernelGGL(ln_rows_kernel<16>, dim3((rows + 15) / 16), dim3(256), 0, s, x, ld, rows, gamma, beta, eps);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -156,6 +156,46 @@ def test_fused_layer_tail_equals_gemm_by_gemm_path(lib_built, monkeypatch):
         np.testing.assert_array_equal(outs[0], outs[1])
 
 
+def test_large_passes_run_their_gemms_on_pgemm_kernel(lib_built, monkeypatch):
+    """Passes of >= 32768 packed rows run the projections and MLP GEMMs on pgemm_kernel (encoder_pgemm.hip: persistent
+    256 x 256 tiles, two wave rows half a phase apart) instead of gemm_kernel (MEMEX_HIP_PGEMM=0).  Same k order and
+    epilogue arithmetic: where only the schedule changes (hidden 384, GEMM-by-GEMM tail) the embeddings are
+    bit-identical; the hidden-768 layer also moves its two LayerNorms behind the GEMM (y rounded to bf16 first,
+    ln_rows_kernel), which must stay far inside the 1e-3 bar -- against the other path and against the f64 oracle."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    from oracle import bert_oracle
+    cases = ((dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 96, 512, 41, False),   # bge-base layers, 43k rows
+             (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000), 300, 160, 42, False),                # ragged, mean pooling
+             (dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000), 96, 512, 43, True),                  # QK projection + MLP GEMMs
+             (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000), 40, 256, 44, None))                  # 10k rows: below the threshold
+    for kw, B, S, seed, identical in cases:
+        cfg = EncoderConfig(**kw)
+        w = synthetic_weights(cfg, seed)
+        rng = np.random.default_rng(seed)
+        ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
+        lens = rng.integers(S // 2 + S // 4, S + 1, B).astype(np.int32)
+        if cfg.hidden == 384:
+            monkeypatch.setenv("MEMEX_HIP_UNFUSED_TAIL", "1")
+        outs = []
+        for pg in ("0", "1"):
+            monkeypatch.setenv("MEMEX_HIP_PGEMM", pg)
+            with Encoder(cfg, w) as enc:
+                outs.append(enc.encode(ids, lens))
+                np.testing.assert_array_equal(outs[-1], enc.encode(ids, lens))        # deterministic
+        monkeypatch.delenv("MEMEX_HIP_UNFUSED_TAIL", raising=False)
+        monkeypatch.delenv("MEMEX_HIP_PGEMM", raising=False)
+        assert np.isfinite(outs[1]).all(), kw
+        if identical or identical is None:
+            np.testing.assert_array_equal(outs[0], outs[1])
+        else:
+            assert (outs[0] != outs[1]).any(), "the large-pass path did not run"
+            assert (1.0 - _cos(outs[0].astype(np.float64), outs[1].astype(np.float64))).max() <= 5e-5, kw
+        sub = slice(0, min(B, 16))
+        ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub])
+        assert (1.0 - _cos(outs[1][sub].astype(np.float64), ref)).max() <= TOL, kw
+
+
 def test_activation_stationary_tail_kernel(lib_built, monkeypatch):
     """tail2_kernel (encoder_tail2.hip: the experimental form of the layer tail -- 128-token workgroups, one
     512-register wave per SIMD, weights through an LDS ring, LayerNorm and GELU in registers) against tail_kernel
