@@ -148,7 +148,8 @@ int mx_index_set_search_mode(mx_index *idx, int mode);
  *   on = 1  a copy whose kind the library chooses (the default): int8 up to 1024 dims, bf16 above; an int8
  *           copy is rebuilt as bf16 -- once, from the f32 rows -- when the corpus proves too dense for its
  *           certificate (more than 1/16 of a batch overflows the int8 pass, or the retry pass has become
- *           habitual); mx_index_stats.filter_kind / filter_demotions tell
+ *           habitual) and built again as int8 once the collection has doubled since (or when this call is
+ *           repeated with on = 1); mx_index_stats.filter_kind / filter_demotions / filter_promotions tell
  *   on = 2  int8 copy (+25 % HBM: rows*dim_pad bytes + 16 bytes per 64 rows): one quantisation step and one
  *           measured residual bound per 32 rows, exact integer sums; the certificate is 4-5x wider than
  *           bf16's, so finish_kernel sifts a few hundred candidates per query instead of a few dozen
@@ -203,7 +204,13 @@ typedef struct mx_index_stats {
     double approx_err_bound;    /* largest per-query bound e1 on |filter score - cosine| of the last batch */
     uint64_t filter_kind;       /* what the scan streams now: 0 = the f32 rows, 2 = int8 filter copy, 3 = bf16 filter copy */
     uint64_t filter_demotions;  /* times an automatically chosen int8 copy was rebuilt as bf16 (dense corpus)   */
+    uint64_t filter_promotions; /* times a demoted index got its int8 copy back (the collection had doubled since)  */
+    uint64_t listed_rows;       /* rows on the side list finish_kernel adds to every query: zero norm, or a norm outside [1e-15, 1e15] */
+    uint64_t exchange_fallbacks;/* sharded index: times the RCCL exchange failed at run time and peer copies took over  */
 } mx_index_stats;
+/* sizeof(mx_index_stats) of the library that is loaded: a shim compares it with its own at start-up (the struct grows
+ * at the end from version to version; mx_version() names the release). */
+size_t mx_index_stats_size(void);
 int mx_index_set_profiling(mx_index *idx, int on); /* record HIP events around the scan kernel */
 int mx_index_get_stats(mx_index *idx, mx_index_stats *out);
 int mx_index_reset_stats(mx_index *idx);

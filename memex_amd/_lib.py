@@ -22,7 +22,7 @@ MX_POOL_MEAN, MX_POOL_CLS = 0, 1
 
 # every symbol include/memex_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "mx_last_error", "mx_version", "mx_device_count",
+    "mx_last_error", "mx_version", "mx_index_stats_size", "mx_device_count",
     "mx_index_open", "mx_index_open_sharded", "mx_index_n_shards", "mx_index_exchange", "mx_index_wait_stream", "mx_index_close", "mx_index_dim", "mx_index_size", "mx_index_reserve",
     "mx_index_set_id_offset", "mx_index_add", "mx_index_add_device", "mx_index_clear",
     "mx_index_search", "mx_index_search_device", "mx_index_set_search_mode", "mx_index_set_filter_copy", "mx_index_set_corpus_mode", "mx_index_get_rows",
@@ -52,7 +52,8 @@ class IndexStats(ctypes.Structure):
                 ("candidates", ctypes.c_uint64), ("max_abs_err", ctypes.c_double),
                 ("filter_copy_bytes", ctypes.c_uint64), ("retry_queries", ctypes.c_uint64),
                 ("approx_err_bound", ctypes.c_double), ("filter_kind", ctypes.c_uint64),
-                ("filter_demotions", ctypes.c_uint64)]
+                ("filter_demotions", ctypes.c_uint64), ("filter_promotions", ctypes.c_uint64),
+                ("listed_rows", ctypes.c_uint64), ("exchange_fallbacks", ctypes.c_uint64)]
 
 
 class EncoderCfg(ctypes.Structure):

@@ -44,8 +44,6 @@ struct Layer {
     float *bi = nullptr;
     bf16_t *wo2 = nullptr;   // [H, F]
     bf16_t *wf = nullptr;    // wo, wi and wo2 once more, as tail_kernel's per-wave fragment streams (fused tail only)
-    bf16_t *wf2 = nullptr;   // ... and as tail2_kernel's single fragment stream (large passes)
-    float *pf = nullptr;     // tail2_kernel's parameter block (biases + LayerNorm parameters of the tail)
     float *bo2 = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 
@@ -72,10 +70,8 @@ struct mx_encoder {
     bool profiling = false;
     bool fused_tail = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_UNFUSED_TAIL=1 keeps the three GEMMs
     bool pgemm = true;        // large passes run their GEMMs on pgemm_kernel (encoder_pgemm.hip); MEMEX_HIP_PGEMM=0: gemm_kernel
-    bool tail2 = false;       // MEMEX_HIP_TAIL=2|3: the layer tail runs on tail2_kernel (encoder_tail2.hip)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr, ev_done = nullptr;
     mx_encoder_stats stats{};
-    int tail2_min_rows = 0;
     std::string key;  // registry key (mx_encoder_open); empty = private
     int refs = 1;
 };
@@ -109,19 +105,6 @@ int upload_tail_stream(mx_encoder *e, const float *wo, const float *wi, const fl
     e->allocs.push_back(*dst);
     MX_HIP(hipMemcpy(*dst, st.data(), st.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return MX_OK;
-}
-
-// wo, wi, wo2 -> tail2_kernel's fragment stream; the tail's biases / LayerNorm parameters -> its parameter block
-int upload_tail2(mx_encoder *e, const float *wo, const float *wi, const float *wo2, size_t F, const float *bo, const float *g1,
-                 const float *be1, const float *b1, const float *b2, const float *g2, const float *be2, Layer &L) {
-    std::vector<uint16_t> st(tail2_stream_elems((int)F));
-    tail2_stream_layout(wo, wi, wo2, (int)F, st.data(), &f32_to_bf16);
-    MX_HIP(hipMalloc(&L.wf2, st.size() * sizeof(uint16_t)));
-    e->allocs.push_back(L.wf2);
-    MX_HIP(hipMemcpy(L.wf2, st.data(), st.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    std::vector<float> pf(tail2_param_floats());
-    tail2_param_layout(bo, g1, be1, b1, b2, g2, be2, (int)F, pf.data());
-    return upload_f32(e, pf.data(), pf.size(), &L.pf);
 }
 
 void free_ws(mx_encoder *e) {
@@ -240,9 +223,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             tp.ctx = e->ctx; tp.ldc = H; tp.x = e->x; tp.ldx = H; tp.wf = L.wf; tp.bo = L.bo; tp.ln1g = L.ln1g; tp.ln1b = L.ln1b;
             tp.b1 = L.bi; tp.b2 = L.bo2; tp.f = F; tp.m = t_pad; tp.out = e->x; tp.ldo = H; tp.gamma = L.ln2g; tp.beta = L.ln2b;
             tp.eps = c.ln_eps;
-            tp.wf2 = L.wf2; tp.pf = L.pf;
-            if (e->tail2 && t_pad >= e->tail2_min_rows) MX_HIP(launch_tail2(st, tp));
-            else MX_HIP(launch_tail(st, tp));
+            MX_HIP(launch_tail(st, tp));
             continue;
         }
         GemmParams o{};
@@ -361,7 +342,6 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         g_enc_setup = encoder_kernels_setup();
         if (g_enc_setup == hipSuccess) g_enc_setup = pgemm_setup();
         if (g_enc_setup == hipSuccess) g_enc_setup = tail_setup();
-        if (g_enc_setup == hipSuccess) g_enc_setup = tail2_setup();
     });
     if (g_enc_setup != hipSuccess)
         return fail(MX_EDEVICE, "encoder kernel setup failed: %s", hipGetErrorString(g_enc_setup));
@@ -374,15 +354,6 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         e->fused_tail = tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
         const char *pv = getenv("MEMEX_HIP_PGEMM");
         e->pgemm = !(pv && pv[0] == '0');
-        // tail2_kernel (encoder_tail2.hip) is the experimental activation-stationary form of the tail: correct and a
-        // little more accurate, 3-5 % faster than tail_kernel alone on the chip, 1-2 % SLOWER inside the encoder
-        // (scripts/r3_enc_ab.sh).  MEMEX_HIP_TAIL=2 selects it at every pass size, =3 from 128 rows
-        // per CU on; the default (and =1) is tail_kernel.
-        const char *tv = getenv("MEMEX_HIP_TAIL");
-        e->tail2 = e->fused_tail && tail2_supported(cfg->hidden, cfg->ffn) && tv && (tv[0] == '2' || tv[0] == '3');
-        hipDeviceProp_t prop;
-        e->tail2_min_rows = hipGetDeviceProperties(&prop, device) == hipSuccess ? 128 * prop.multiProcessorCount : 32768;
-        if (tv && tv[0] == '2') e->tail2_min_rows = 0;
     }
     auto bail = [&](int code) {
         destroy_impl(e);
@@ -441,7 +412,6 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         MX_TRY(upload_f32(e, b2_src, H, &L.bo2));
         MX_TRY(upload_f32(e, g2_src, H, &L.ln2g));
         MX_TRY(upload_f32(e, be2_src, H, &L.ln2b));
-        if (e->tail2) MX_TRY(upload_tail2(e, wo_src, wi_src, wo2_src, F, bo_src, g1_src, be1_src, b1_src, b2_src, g2_src, be2_src, L));
     }
 #undef MX_TRY
     *out = e;

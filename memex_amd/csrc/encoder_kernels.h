@@ -57,8 +57,6 @@ struct TailParams {
     const bf16_t *x;      // [M, 384] layer input = residual of LayerNorm1 (MLP only: x1), row pitch ldx
     int ldx;
     const bf16_t *wf;     // Wo, W1, W2 as one bf16 stream per wave in consumption order (tail_stream_layout)
-    const bf16_t *wf2;    // tail2_kernel: Wo, W1, W2 as ONE fragment stream (tail2_stream_layout)
-    const float *pf;      // tail2_kernel: bo g1 be1 b2 g2 be2 | b1 in one block (tail2_param_layout)
     const float *bo;      // [384] out-projection bias
     const float *ln1g, *ln1b;
     const float *b1;      // [f]
@@ -81,16 +79,6 @@ hipError_t launch_tail(hipStream_t s, const TailParams &p);
 // wo [384][384], w1 [f][384], w2 [384][f] (nn.Linear layouts, f32) -> out [tail_stream_elems(f)] bf16
 size_t tail_stream_elems(int F);
 void tail_stream_layout(const float *wo, const float *w1, const float *w2, int F, uint16_t *out, uint16_t (*to_bf16)(float));
-
-// the large-pass form of the same tail (encoder_tail2.hip): 128-token workgroups, weights through an LDS ring
-hipError_t tail2_setup();
-bool tail2_supported(int hidden, int ffn);
-hipError_t launch_tail2(hipStream_t s, const TailParams &p);
-size_t tail2_stream_elems(int F);
-void tail2_stream_layout(const float *wo, const float *w1, const float *w2, int F, uint16_t *out, uint16_t (*to_bf16)(float));
-size_t tail2_param_floats();
-void tail2_param_layout(const float *bo, const float *g1, const float *be1, const float *b1, const float *b2, const float *g2,
-                        const float *be2, int F, float *out);
 
 hipError_t encoder_kernels_setup();
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p);

@@ -91,10 +91,8 @@ struct Scratch {
     float *out_dists = nullptr;
     int32_t *out_nfound = nullptr;
     int kcap = 0;
-    uint64_t *exact_keys = nullptr;
-    uint64_t exact_cap = 0;
-    uint64_t *sel_state = nullptr;  // [4 + ksel]
-    int ksel = 0;
+    void *exact_scratch = nullptr;  // EXACT path: distances of a query group, selection state (exact_group_scratch_bytes)
+    size_t exact_bytes = 0;
     float *max_err = nullptr;
     // pinned staging of the host API: queries in, results out (one H2D / D2H per combined batch)
     float *h_q = nullptr;
@@ -104,7 +102,8 @@ struct Scratch {
     bool ready = false;
 };
 
-// The lane buffers of the scan (records of the collect launch: 64 per lane, 0.57 GB per set at 256 workgroups) are
+// The lane buffers of the scan (records of the collect launch: 64 per lane x 68 B, 0.57 GB per set at 256 workgroups x 512
+// lanes; twice that for a 512-query pass of the int8 scan, which numbers 1024 lanes per workgroup) are
 // only live inside one search_batch call, which returns host-synchronised.  They are therefore leased from a pool per
 // device instead of owned by every index: a process with many resident collections holds as many sets as it has
 // searches in flight on a device at the same time, not one per collection.  The pool is freed when the last index
@@ -114,6 +113,7 @@ struct LaneBufs {
     uint32_t *tile = nullptr, *cnt = nullptr;
     float *max = nullptr;
     int nwg = 0;
+    int groups = 1;  // query groups per wave the set is sized for (2: a 512-query pass)
 };
 constexpr int kMaxDevices = 64;
 struct LanePool {
@@ -182,6 +182,8 @@ struct mx_index {
     bool filter_auto = true;     // the library picks the kind (by row width) and may demote int8 to bf16 when a batch overflows
     bool pooled = false;         // counted in its device's lane-buffer pool (open_plain)
     uint32_t i8_batches = 0, i8_retry_batches = 0;  // since the int8 copy was built: batches served, batches that needed the retry pass
+    uint64_t demoted_at_rows = 0;  // rows the index held when an automatic int8 copy was demoted to bf16 (0: never); the
+                                   // int8 copy gets another try once the collection has doubled (add_device_locked)
     float *tsc = nullptr;
     // compressed corpus (mx_index_set_corpus_mode): xh is the ONLY copy of the rows; x / scale are not
     // allocated, appends pass through the small f32 staging window xs / ss
@@ -191,10 +193,12 @@ struct mx_index {
     uint64_t xs_rows = 0;
     uint64_t n = 0, cap = 0;
     IdMap idmap{0, 0, 1, 0};
-    uint32_t *flags = nullptr;  // device: [0] non-finite rows, [1] out-of-range-norm rows (last add), [2] ec_max (float bits), [3] zero-norm rows
-    uint64_t wild_rows = 0;
+    uint32_t *flags = nullptr;  // device: [0] non-finite rows, [1] out-of-range-norm rows (last add), [2] ec_max (float bits), [3] zero-norm rows, [4] listed out-of-range-norm rows
+    uint64_t wild_rows = 0;         // rows with a norm outside [1e-15, 1e15] (a compressed corpus answers on the EXACT path then)
     uint32_t *zero_rows = nullptr;  // device: [kZeroCap] local rows with zero norm, ascending (finish_kernel adds them to every query)
     uint64_t n_zero = 0;            // zero-norm rows in the index; more than kZeroCap -> EXACT path
+    uint32_t *wild_list = nullptr;  // device: [kWildCap] local rows with a norm outside [1e-15, 1e15] (f32 corpus), ascending
+    uint64_t n_wild = 0;            // ... how many; more than kWildCap -> EXACT path
     int mode = MX_SEARCH_AUTO;
     bool profiling = false;
     int n_cu = 0, nwg = 0;
@@ -231,6 +235,7 @@ std::once_flag g_scan_once;
 hipError_t g_scan_setup_err = hipSuccess;
 std::mutex g_rccl_mu;
 Rccl g_rccl;
+bool g_rccl_broken = false;  // an initialisation hung: no further attempts in this process
 
 bool load_rccl() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
@@ -273,6 +278,10 @@ int free_index(mx_index *idx) {
     }
     if (idx->composite()) {
         idx->pool.reset();  // joins the helper threads
+        for (mx_index *sh : idx->shards) {
+            DeviceGuard dg(sh->device);
+            if (sh->stream) (void)hipStreamSynchronize(sh->stream);
+        }
         free_composite_buffers(idx);
         for (void *c : idx->comms)
             if (c && g_rccl.ok) (void)g_rccl.CommDestroy(c);
@@ -284,7 +293,7 @@ int free_index(mx_index *idx) {
     auto F = [](void *p) {
         if (p) (void)hipFree(p);
     };
-    F(idx->x); F(idx->scale); F(idx->xh); F(idx->tsc); F(idx->flags); F(idx->xs); F(idx->ss); F(idx->zero_rows);
+    F(idx->x); F(idx->scale); F(idx->xh); F(idx->tsc); F(idx->flags); F(idx->xs); F(idx->ss); F(idx->zero_rows); F(idx->wild_list);
     Scratch &s = idx->s;
     F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.theta_retry); F(s.todo); F(s.dev_flags); F(s.done_ctr);
     if (s.host_flags) (void)hipHostFree(s.host_flags);
@@ -292,7 +301,7 @@ int free_index(mx_index *idx) {
     for (void *hp : {(void *)s.h_q, (void *)s.h_ids, (void *)s.h_scores, (void *)s.h_dists, (void *)s.h_nf})
         if (hp) (void)hipHostFree(hp);
     F(s.qstage); F(s.qscale); F(s.qa); F(s.qb); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
-    F(s.exact_keys); F(s.sel_state); F(s.max_err);
+    F(s.exact_scratch); F(s.max_err);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
     if (idx->ev_wait) (void)hipEventDestroy(idx->ev_wait);
@@ -314,14 +323,14 @@ int free_index(mx_index *idx) {
 struct LaneLease {
     mx_index *idx = nullptr;
     LaneBufs b;
-    int take(mx_index *i) {
-        idx = i;
+    int take(mx_index *i, int groups) {
         if (i->device < 0 || i->device >= kMaxDevices) return fail(MX_EDEVICE, "device %d out of range", i->device);
+        idx = i;
         LanePool &lp = g_lanes[i->device];
         {
             std::lock_guard<std::mutex> lk(lp.mu);
             for (size_t j = 0; j < lp.idle.size(); ++j)
-                if (lp.idle[j].nwg == i->nwg) {
+                if (lp.idle[j].nwg == i->nwg && lp.idle[j].groups == groups) {
                     b = lp.idle[j];
                     lp.idle.erase(lp.idle.begin() + (long)j);
                     break;
@@ -329,7 +338,8 @@ struct LaneLease {
         }
         if (!b.rec) {
             b.nwg = i->nwg;
-            const size_t lanes = (size_t)i->nwg * kScanThreads * 2;  // x 2: a 512-query pass numbers 16 waves
+            b.groups = groups;
+            const size_t lanes = (size_t)i->nwg * kScanThreads * (size_t)groups;  // a 512-query pass numbers 16 waves per workgroup
             hipError_t e = hipMalloc(reinterpret_cast<void **>(&b.rec), lanes * kRecCap * 16 * sizeof(float));
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b.tile), lanes * kRecCap * sizeof(uint32_t));
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b.cnt), lanes * sizeof(uint32_t));
@@ -423,21 +433,22 @@ int ensure_out(mx_index *idx, int k) {
 
 int ensure_exact(mx_index *idx, int k) {
     Scratch &s = idx->s;
-    if (s.exact_cap < idx->n) {
-        if (s.exact_keys) (void)hipFree(s.exact_keys);
-        s.exact_keys = nullptr;
-        s.exact_cap = 0;
-        const uint64_t cap = std::max<uint64_t>(idx->n, 1024);
-        MX_HIP(hipMalloc(&s.exact_keys, cap * sizeof(uint64_t)));
-        s.exact_cap = cap;
-    }
-    if (s.ksel < k) {
-        if (s.sel_state) (void)hipFree(s.sel_state);
-        s.sel_state = nullptr;
-        s.ksel = 0;
-        const int kk = std::max(k, 64);
-        MX_HIP(hipMalloc(&s.sel_state, (size_t)(4 + kk) * sizeof(uint64_t)));
-        s.ksel = kk;
+    const size_t need = exact_group_scratch_bytes(idx->n, k);
+    if (s.exact_bytes < need) {
+        if (s.exact_scratch) {
+            MX_HIP(hipStreamSynchronize(idx->stream));
+            (void)hipFree(s.exact_scratch);
+        }
+        s.exact_scratch = nullptr;
+        s.exact_bytes = 0;
+        const size_t want = need + need / 4;  // room for appends before the next reallocation
+        if (hipMalloc(&s.exact_scratch, want) == hipSuccess) {
+            s.exact_bytes = want;
+        } else {
+            (void)hipGetLastError();
+            MX_HIP(hipMalloc(&s.exact_scratch, need));
+            s.exact_bytes = need;
+        }
     }
     return MX_OK;
 }
@@ -524,16 +535,28 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
     return MX_OK;
 }
 
+int build_filter_copy(mx_index *idx, bool i8);
+
 // reads the ingest flags back; a batch with non-finite rows is rejected (zero-row list rolled back),
 // otherwise the zero-norm rows it brought are committed (list kept ascending for finish_kernel)
-int commit_ingest(mx_index *idx, uint32_t (&fl)[4]) {
+int commit_ingest(mx_index *idx, uint32_t (&fl)[5]) {
     MX_HIP(hipMemcpyAsync(fl, idx->flags, sizeof(fl), hipMemcpyDeviceToHost, idx->stream));
     MX_HIP(hipStreamSynchronize(idx->stream));
     if (fl[0] != 0) {
-        const uint32_t keep = (uint32_t)idx->n_zero;
-        MX_HIP(hipMemcpyAsync(idx->flags + 3, &keep, sizeof(keep), hipMemcpyHostToDevice, idx->stream));
+        const uint32_t keep[2] = {(uint32_t)idx->n_zero, (uint32_t)idx->n_wild};
+        MX_HIP(hipMemcpyAsync(idx->flags + 3, keep, sizeof(keep), hipMemcpyHostToDevice, idx->stream));
         MX_HIP(hipStreamSynchronize(idx->stream));
         return fail(MX_EINVAL, "%u row(s) contain non-finite values; nothing inserted", fl[0]);
+    }
+    if (fl[4] != idx->n_wild) {  // new listed rows arrive in atomic order: keep the list ascending
+        const size_t have = std::min<size_t>(fl[4], kWildCap);
+        if (have > std::min<uint64_t>(idx->n_wild, kWildCap)) {
+            std::vector<uint32_t> z(have);
+            MX_HIP(hipMemcpy(z.data(), idx->wild_list, have * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            std::sort(z.begin(), z.end());
+            MX_HIP(hipMemcpy(idx->wild_list, z.data(), have * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        idx->n_wild = fl[4];
     }
     if (fl[3] != idx->n_zero) {
         const size_t have = std::min<size_t>(fl[3], kZeroCap);
@@ -567,12 +590,12 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
             MX_HIP(hipMalloc(reinterpret_cast<void **>(&idx->ss), (size_t)(kWin + kTileRows) * sizeof(float)));
             idx->xs_rows = kWin + kTileRows;
         }
-        uint32_t fl[4] = {0, 0, 0, 0};
+        uint32_t fl[5] = {0, 0, 0, 0, 0};
         for (uint64_t done = 0; done < n; done += kWin) {
             const uint64_t m = std::min(kWin, n - done), g0 = idx->n + done;     // global rows [g0, g0 + m)
             const uint64_t t0 = g0 / kTileRows, off = g0 % kTileRows;
             MX_HIP(launch_ingest(idx->stream, d_rows + (size_t)done * idx->dim, m, idx->dim, idx->xs, idx->ss, off, idx->ds, idx->flags,
-                                 idx->raw_ingest ? 1 : 0, idx->zero_rows, g0));
+                                 idx->raw_ingest ? 1 : 0, idx->zero_rows, idx->wild_list, g0));
             MX_HIP(launch_shadow(idx->stream, idx->xs, idx->ss, idx->ds, (uint32_t)t0, (uint32_t)((g0 + m + kTileRows - 1) / kTileRows),
                                  idx->xh, idx->flags + 2, (uint32_t)t0, g0, g0 + m));
         }
@@ -583,7 +606,7 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
         idx->n += n;
         return MX_OK;
     }
-    MX_HIP(launch_ingest(idx->stream, d_rows, n, idx->dim, idx->x, idx->scale, idx->n, idx->ds, idx->flags, 0, idx->zero_rows, idx->n));
+    MX_HIP(launch_ingest(idx->stream, d_rows, n, idx->dim, idx->x, idx->scale, idx->n, idx->ds, idx->flags, 2, idx->zero_rows, idx->wild_list, idx->n));
     // tiles touched by this append (the first one may already be partly filled; an 8-bit half tile is requantised
     // as a whole: its step depends on all of its rows)
     auto refilter = [&](uint64_t row_lo, uint64_t row_hi) -> hipError_t {
@@ -593,7 +616,7 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
         return launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, h0, std::max(h1, h0 + 1), idx->xh, idx->flags + 2);
     };
     if (idx->xh) MX_HIP(refilter(idx->n, idx->n + n));
-    uint32_t fl[4] = {0, 0, 0, 0};
+    uint32_t fl[5] = {0, 0, 0, 0, 0};
     rc = commit_ingest(idx, fl);
     if (rc != MX_OK) {
         // rows past idx->n are never read, but the filter copy's tile of row n may now hold garbage: rebuild it
@@ -607,6 +630,20 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
     idx->wild_rows += fl[1];
     if (first_id) *first_id = idx->idmap.id_of((uint32_t)idx->n);  // local.rs:63: next_id = len + 1
     idx->n += n;
+    // A demotion is not for life: it was decided on the rows and the queries of its day.  Once the collection has doubled
+    // since, the automatic choice gets its int8 copy back (one pass over the rows, as when it was first built) and the
+    // demotion rule judges it afresh; mx_index_set_filter_copy(idx, 1) does the same at once.
+    if (idx->filter_auto && idx->xh && !idx->filter_i8 && idx->demoted_at_rows && idx->n >= 2 * idx->demoted_at_rows &&
+        idx->ds <= kAutoI8MaxDim) {
+        const std::string keep = last_error_slot();
+        if (build_filter_copy(idx, true) == MX_OK) {
+            idx->demoted_at_rows = 0;
+            idx->stats.filter_promotions += 1;
+        } else {
+            idx->demoted_at_rows = idx->n;  // no room now: ask again after the next doubling
+            last_error_slot() = keep;
+        }
+    }
     return MX_OK;
 }
 
@@ -641,35 +678,59 @@ int run_exact(mx_index *idx, const std::vector<int> &qs, int k, uint64_t *d_ids,
     int rc = ensure_exact(idx, k);
     if (rc != MX_OK) return rc;
     Scratch &s = idx->s;
-    for (int b : qs)
-        MX_HIP(launch_exact_query(idx->stream, k, idx->dim, idx->ds, idx->compressed ? nullptr : idx->x, idx->xh, idx->n, idx->idmap,
-                                  s.qpad + (size_t)b * idx->ds, s.exact_keys, s.sel_state, d_ids + (size_t)b * k,
-                                  d_scores + (size_t)b * k, d_dists ? d_dists + (size_t)b * k : nullptr, d_nfound + b));
+    // groups of up to 32 queries share one pass over the rows (launch_exact_group); the groups of a batch reuse the scratch
+    // in stream order
+    for (size_t g0 = 0; g0 < qs.size(); g0 += kExactGroup) {
+        ExactGroup grp{};
+        grp.n = (int)std::min<size_t>(kExactGroup, qs.size() - g0);
+        for (int j = 0; j < grp.n; ++j) grp.q[j] = qs[g0 + j];
+        MX_HIP(launch_exact_group(idx->stream, k, idx->ds, idx->compressed ? nullptr : idx->x, idx->xh, idx->n, idx->idmap, s.qpad,
+                                  s.qnorm2, grp, s.exact_scratch, d_ids, d_scores, d_dists, d_nfound));
+    }
     return MX_OK;
 }
 
-// int8 filter copy -> bf16 filter copy, rebuilt from the f32 rows (an automatic choice that did not suit the data)
-int demote_filter(mx_index *idx) {
-    DevBuf nh;
-    const size_t hb = (size_t)idx->cap * idx->ds * 2;
-    if (hipMalloc(&nh.p, hb) != hipSuccess) {
+// builds the filter copy of kind (i8 ? int8 : bf16) from the f32 rows, complete before it replaces whatever copy is resident
+int build_filter_copy(mx_index *idx, bool i8) {
+    DevBuf nh, nts, nec;
+    const size_t hb = (size_t)idx->cap * idx->ds * (i8 ? 1 : 2), tb = (size_t)(idx->cap / kTile8Rows) * 4 * sizeof(float);
+    hipError_t e = hipMalloc(&nh.p, hb);
+    if (e == hipSuccess && i8) e = hipMalloc(&nts.p, tb);
+    if (e == hipSuccess) e = hipMalloc(&nec.p, sizeof(uint32_t));
+    if (e != hipSuccess) {
         (void)hipGetLastError();
-        return MX_ENOMEM;  // no room for the wider copy: stay on int8
+        return fail(MX_ENOMEM, "hipMalloc(filter copy, %zu bytes): %s", hb, hipGetErrorString(e));
     }
+    uint32_t *ec = static_cast<uint32_t *>(nec.p);
+    MX_HIP(hipMemsetAsync(nh.p, 0, hb, idx->stream));
+    if (i8) MX_HIP(hipMemsetAsync(nts.p, 0, tb, idx->stream));
+    MX_HIP(hipMemsetAsync(ec, 0, sizeof(uint32_t), idx->stream));
+    const uint32_t t1 = (uint32_t)((idx->n + kTileRows - 1) / kTileRows);
+    if (i8)
+        MX_HIP(launch_shadow8(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)round_up(t1, 2), idx->n, nh.p, static_cast<float *>(nts.p), ec));
+    else
+        MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, t1, nh.p, ec));
+    MX_HIP(hipMemcpyAsync(idx->flags + 2, ec, sizeof(uint32_t), hipMemcpyDeviceToDevice, idx->stream));
     MX_HIP(hipStreamSynchronize(idx->stream));
     if (idx->xh) (void)hipFree(idx->xh);
     if (idx->tsc) (void)hipFree(idx->tsc);
-    idx->xh = nullptr;
-    idx->tsc = nullptr;
-    idx->filter_i8 = false;
-    idx->i8_batches = idx->i8_retry_batches = 0;
-    MX_HIP(hipMemsetAsync(nh.p, 0, hb, idx->stream));
-    MX_HIP(hipMemsetAsync(idx->flags + 2, 0, sizeof(uint32_t), idx->stream));
-    MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)((idx->n + kTileRows - 1) / kTileRows), nh.p,
-                         idx->flags + 2));
-    MX_HIP(hipStreamSynchronize(idx->stream));
     idx->xh = nh.release();
+    idx->tsc = static_cast<float *>(nts.release());
+    idx->filter_i8 = i8;
+    idx->i8_batches = idx->i8_retry_batches = 0;
+    for (double &w : idx->wait_ema_us) w = 0.0;
     return MX_OK;
+}
+
+// int8 filter copy -> bf16 filter copy, rebuilt from the f32 rows (an automatic choice that did not suit the data).
+// The bf16 copy is complete (and its residual word known) before the int8 copy is released: any failure leaves the
+// index exactly as it was.  MX_ENOMEM: no room for the wider copy, the caller stays on int8.
+int demote_filter(mx_index *idx) {
+    const std::string keep = last_error_slot();
+    const int rc = build_filter_copy(idx, false);
+    if (rc == MX_ENOMEM) last_error_slot() = keep;
+    if (rc == MX_OK) idx->demoted_at_rows = std::max<uint64_t>(idx->n, 1);
+    return rc;
 }
 
 // one batch (B <= 256) with queries and outputs on the device
@@ -686,7 +747,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     const bool filt8 = idx->xh != nullptr && idx->filter_i8 && !idx->compressed;  // 8-bit copy: 256 queries per pass at every width
     const bool wide = idx->kc > kMaxKC && !filt8;
     const bool fast = !trivial && idx->mode == MX_SEARCH_AUTO && (idx->kc > kMaxKC ? idx->xh != nullptr && idx->kc <= kMaxKC16 : true) &&
-                      idx->wild_rows == 0 && k <= 256 && idx->n_zero <= (uint64_t)kZeroCap;
+                      (!idx->compressed || idx->wild_rows == 0) && k <= 256 && idx->n_zero <= (uint64_t)kZeroCap &&
+                      idx->n_wild <= (uint64_t)kWildCap;
     // a batch of more than 256 queries is one pass of the int8 scan with two query groups per wave (up to 512 dims),
     // otherwise two passes
     const bool x2 = fast && filt8 && idx->kc <= kMaxKC8x2 && B > kPassBatch;
@@ -705,7 +767,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                             d_dists ? d_dists + o : nullptr, d_nfound + kWideBatch);
     }
     LaneLease lease;  // every return below is host-synchronised with the kernels that used the lane buffers
-    if ((rc = lease.take(idx)) != MX_OK) return rc;
+    if ((rc = lease.take(idx, x2 ? 2 : 1)) != MX_OK) return rc;
     MX_HIP(launch_prep_queries(st, d_q, B, idx->dim, idx->ds, s.qfrag, s.qpad, s.qnorm2, s.theta, s.e1,
                                idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags, s.qa, s.qb, filt8, s.qscale));
     const uint32_t *h_ovf = s.host_flags, *h_qfl = s.host_flags + 3 * kMaxBatch;
@@ -738,6 +800,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     fp.theta = s.theta;
     fp.zero_rows = idx->zero_rows;
     fp.n_zero = (uint32_t)std::min<uint64_t>(idx->n_zero, kZeroCap);
+    fp.wild_rows = idx->wild_list;
+    fp.n_wild = (uint32_t)std::min<uint64_t>(idx->n_wild, kWildCap);
     fp.overflow = s.overflow;
     fp.todo = nullptr;
     fp.theta_retry = s.theta_retry;
@@ -778,6 +842,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         }();
         const auto t0 = std::chrono::steady_clock::now();
         double &ema = idx->wait_ema_us[B <= 32 ? 0 : B <= 128 ? 1 : B <= 256 ? 2 : 3];
+        bool overslept = false;  // the batch was already complete when the nap ended: the estimate is too long
         if (no_spin && ema > 150.0) {
             const double nap_us = 0.8 * ema - 60.0;  // timer slack and wake-up latency stay inside the estimate
             if (nap_us > 50.0) {
@@ -785,6 +850,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                 ts.tv_sec = (time_t)(nap_us / 1e6);
                 ts.tv_nsec = (long)((nap_us - (double)ts.tv_sec * 1e6) * 1e3);
                 (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
+                overslept = __atomic_load_n(&s.host_sum[4], __ATOMIC_ACQUIRE) == fp.seq;
             }
         }
         bool done = false;
@@ -797,8 +863,11 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
             __builtin_ia32_pause();
         }
         if (done) {
+            // what was observed includes the nap: when the batch had finished before the nap did (batches got faster: a
+            // cleared or smaller index, another k) only an upper bound is known, so the estimate is halved instead of
+            // creeping down 5 % per batch
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-            ema = ema > 0.0 ? 0.75 * ema + 0.25 * us : us;
+            ema = overslept ? 0.5 * ema : ema > 0.0 ? 0.75 * ema + 0.25 * us : us;
             return MX_OK;
         }
         MX_HIP(hipStreamSynchronize(st));  // a kernel that never signals (fault): the synchronize reports it
@@ -891,11 +960,13 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                 // More than 1/16 of the batch (and more than one query) did not fit the int8 pass: this corpus is too dense for the int8
                 // certificate (neighbourhoods narrower than ~0.05 in cosine).  Rebuild the copy as bf16 (one pass
                 // over the f32 rows) and answer the batch on it; the index stays on bf16.
-                if (demote_filter(idx) == MX_OK) {
+                const int drc = demote_filter(idx);
+                if (drc == MX_OK) {
                     idx->stats.filter_demotions += 1;
                     lease.drop();
                     return search_batch(idx, d_q, B, k, d_ids, d_scores, d_dists, d_nfound);
                 }
+                if (drc != MX_ENOMEM) return drc;  // (no room for the wider copy: the batch finishes on int8 below)
             }
             if (retry) {
                 // ONE more pass for all overflowed queries of the batch, with the threshold finish derived
@@ -939,8 +1010,16 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
 // composite: rows dealt block-cyclically to shard indexes (one per device), local top-k per shard,
 // exchange of the packed [ids | dists] blocks (RCCL all-gather over xGMI, or peer copies), merge
 // ---------------------------------------------------------------------------------------------
+void sync_shard_streams(mx_index *idx) {
+    for (mx_index *sh : idx->shards) {
+        DeviceGuard dg(sh->device);
+        if (sh->stream) (void)hipStreamSynchronize(sh->stream);
+    }
+}
+
 int ensure_composite_buffers(mx_index *idx, int k) {
     if (k <= idx->sh_kcap) return MX_OK;
+    sync_shard_streams(idx);  // the last batch's all-gather may still be running on shards >= 1
     free_composite_buffers(idx);
     const int kc = std::max(k, 16);
     const size_t G = idx->shards.size();
@@ -965,6 +1044,83 @@ uint64_t shard_rows(uint64_t total, uint64_t R, uint64_t G, uint64_t g) {
     uint64_t rows = (full_blocks / G) * R + (g < full_blocks % G ? R : 0);
     if (full_blocks % G == g) rows += tail;
     return rows;
+}
+
+// peer copies between the shards' devices and shards[0]'s
+void enable_peer_access(mx_index *idx) {
+    for (size_t g = 1; g < idx->shards.size(); ++g) {
+        if (idx->shards[g]->device == idx->shards[0]->device) continue;
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, idx->shards[0]->device, idx->shards[g]->device);
+        if (can) {
+            DeviceGuard dg(idx->shards[0]->device);
+            (void)hipDeviceEnablePeerAccess(idx->shards[g]->device, 0);
+            (void)hipGetLastError();
+            DeviceGuard d2(idx->shards[g]->device);
+            (void)hipDeviceEnablePeerAccess(idx->shards[0]->device, 0);
+            (void)hipGetLastError();
+        }
+    }
+}
+
+// One tiny all-gather on throw-away streams, bounded by a deadline: a communicator that initialises but whose first
+// collective fails or never completes (a first run on a new node) must cost a sharded index its RCCL exchange, not its
+// searches.  false: do not use the communicators (a hung collective's streams and buffers are abandoned, not destroyed).
+bool rccl_selftest(mx_index *idx, double seconds) {
+    const int G = (int)idx->shards.size();
+    std::vector<hipStream_t> st(G, nullptr);
+    std::vector<unsigned char *> snd(G, nullptr), rcv(G, nullptr);
+    bool ok = true;
+    for (int g = 0; g < G && ok; ++g) {
+        DeviceGuard dg(idx->shards[g]->device);
+        ok = hipStreamCreateWithFlags(&st[g], hipStreamNonBlocking) == hipSuccess && hipMalloc(&snd[g], 64) == hipSuccess &&
+             hipMalloc(&rcv[g], 64 * (size_t)G) == hipSuccess && hipMemsetAsync(snd[g], g + 1, 64, st[g]) == hipSuccess &&
+             hipMemsetAsync(rcv[g], 0, 64 * (size_t)G, st[g]) == hipSuccess;
+    }
+    bool hung = false;
+    if (ok) {
+        int e = g_rccl.GroupStart();
+        for (int g = 0; g < G && e == 0; ++g) e = g_rccl.AllGather(snd[g], rcv[g], 64, 1 /*ncclUint8*/, idx->comms[g], st[g]);
+        const int e2 = g_rccl.GroupEnd();
+        ok = e == 0 && e2 == 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int g = 0; g < G && ok && !hung; ++g) {
+            DeviceGuard dg(idx->shards[g]->device);
+            for (;;) {
+                const hipError_t q = hipStreamQuery(st[g]);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) {
+                    ok = false;
+                    break;
+                }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
+                    hung = true;
+                    break;
+                }
+                struct timespec ts = {0, 200 * 1000};
+                (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
+            }
+        }
+        if (ok && !hung) {
+            std::vector<unsigned char> h(64 * (size_t)G);
+            DeviceGuard dg(idx->shards[0]->device);
+            ok = hipMemcpy(h.data(), rcv[0], h.size(), hipMemcpyDeviceToHost) == hipSuccess;
+            for (int g = 0; g < G && ok; ++g) ok = h[64 * (size_t)g] == (unsigned char)(g + 1) && h[64 * (size_t)g + 63] == (unsigned char)(g + 1);
+        }
+    }
+    if (hung) {
+        fprintf(stderr, "memex-hip: the RCCL self-test did not complete within %.0f s; exchanging by peer copies\n", seconds);
+        return false;  // the collective may still own the streams and buffers: leave them
+    }
+    for (int g = 0; g < G; ++g) {
+        DeviceGuard dg(idx->shards[g]->device);
+        if (snd[g]) (void)hipFree(snd[g]);
+        if (rcv[g]) (void)hipFree(rcv[g]);
+        if (st[g]) (void)hipStreamDestroy(st[g]);
+    }
+    (void)hipGetLastError();
+    if (!ok) fprintf(stderr, "memex-hip: the RCCL self-test failed; exchanging by peer copies\n");
+    return ok;
 }
 
 // one batch on a composite: d_q and the outputs live on shards[0]'s device
@@ -1012,18 +1168,43 @@ int composite_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_i
         }
     mx_index *s0 = idx->shards[0];
     DeviceGuard dg(s0->device);
+    const bool copies_pending = idx->use_rccl;  // the shards left their blocks in place for the all-gather
     if (k > 0) {
         if (idx->use_rccl) {
             // ONE all-gather of B*k*12 bytes per shard over xGMI; every device receives all
             // blocks, device 0 merges
-            int e = g_rccl.GroupStart();
-            for (int g = 0; g < G && e == 0; ++g)
-                e = g_rccl.AllGather(idx->sh_block[g], idx->sh_gather[g], blk, 1 /*ncclUint8*/, idx->comms[g], idx->shards[g]->stream);
-            const int e2 = g_rccl.GroupEnd();
-            if (e != 0 || e2 != 0)
-                return fail(MX_EDEVICE, "RCCL all-gather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e ? e : e2) : "?");
+            static const bool inject = [] {  // tests: the first all-gather of the process reports an error
+                const char *e = getenv("MEMEX_HIP_TEST_RCCL_FAIL");
+                return e && e[0] == '1';
+            }();
+            static bool injected = false;
+            int e = 0, e2 = 0;
+            if (inject && !injected) {
+                injected = true;
+                e = 1;
+            } else {
+                e = g_rccl.GroupStart();
+                for (int g = 0; g < G && e == 0; ++g)
+                    e = g_rccl.AllGather(idx->sh_block[g], idx->sh_gather[g], blk, 1 /*ncclUint8*/, idx->comms[g], idx->shards[g]->stream);
+                e2 = g_rccl.GroupEnd();
+            }
+            if (e != 0 || e2 != 0) {
+                // The collective could not be queued: this batch and every later one exchange by copies into the slots
+                // of the gather area on shards[0]'s device (what an index without RCCL does from the start).  Every shard
+                // is host-synchronised at this point (search_batch returned), so the blocks are complete.
+                fprintf(stderr, "memex-hip: RCCL all-gather failed (%s); the sharded index continues on peer copies\n",
+                        g_rccl.GetErrorString && (e > 1 || e2) ? g_rccl.GetErrorString(e ? e : e2) : "error");
+                sync_shard_streams(idx);
+                idx->use_rccl = false;
+                idx->stats.exchange_fallbacks += 1;
+                enable_peer_access(idx);
+            }
             // no host wait on shards >= 1: their part of the collective is ordered on their own streams (the
             // next batch's kernels queue behind it), and the merge below follows shard 0's part in stream order
+        }
+        if (!idx->use_rccl && copies_pending) {  // (only right after a fallback: the shards did not copy their blocks themselves)
+            for (int g = 0; g < G; ++g)
+                MX_HIP(hipMemcpyAsync(static_cast<char *>(idx->sh_gather[0]) + (size_t)g * blk, idx->sh_block[g], blk, hipMemcpyDefault, s0->stream));
         }
         MX_HIP(launch_merge(s0->stream, idx->sh_gather[0], blk, static_cast<const char *>(idx->sh_gather[0]) + ids_bytes, blk, G, B,
                             k, d_ids, d_dists ? d_dists : reinterpret_cast<float *>(static_cast<char *>(idx->sh_block[0]) + ids_bytes),
@@ -1045,9 +1226,9 @@ int any_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids, fl
 // what an append can change in a plain index, and how to undo it: an insert is all-or-nothing, also when it
 // spans several shards or several staging chunks and a later part fails (non-finite device rows, HBM)
 struct RowMark {
-    uint64_t n, n_zero, wild_rows;
+    uint64_t n, n_zero, wild_rows, n_wild;
 };
-RowMark mark_rows(const mx_index *idx) { return RowMark{idx->n, idx->n_zero, idx->wild_rows}; }
+RowMark mark_rows(const mx_index *idx) { return RowMark{idx->n, idx->n_zero, idx->wild_rows, idx->n_wild}; }
 void rollback_rows(mx_index *idx, const RowMark &m) {
     if (idx->n == m.n) return;
     const std::string keep = last_error_slot();
@@ -1055,8 +1236,9 @@ void rollback_rows(mx_index *idx, const RowMark &m) {
     idx->n = m.n;  // rows past n are never read by a search (finish_kernel drops them); the next append overwrites them
     idx->n_zero = m.n_zero;
     idx->wild_rows = m.wild_rows;
-    const uint32_t zc = (uint32_t)m.n_zero;  // the device-side zero-row count: entries past it are dead
-    (void)hipMemcpyAsync(idx->flags + 3, &zc, sizeof(zc), hipMemcpyHostToDevice, idx->stream);
+    idx->n_wild = m.n_wild;
+    const uint32_t zc[2] = {(uint32_t)m.n_zero, (uint32_t)m.n_wild};  // the device-side list counts: entries past them are dead
+    (void)hipMemcpyAsync(idx->flags + 3, zc, sizeof(zc), hipMemcpyHostToDevice, idx->stream);
     (void)hipStreamSynchronize(idx->stream);
     idx->disk_dir.clear();
     last_error_slot() = keep;
@@ -1202,9 +1384,11 @@ int clear_locked(mx_index *idx) {
         idx->n = 0;  // ids restart at 1 (local.rs:50,63); HBM is kept for reuse
         idx->wild_rows = 0;
         idx->n_zero = 0;
+        idx->n_wild = 0;
+        for (double &w : idx->wait_ema_us) w = 0.0;
         if (idx->flags) {
             DeviceGuard dg(idx->device);
-            (void)hipMemsetAsync(idx->flags + 2, 0, 2 * sizeof(uint32_t), idx->stream);  // ec_max, zero-row count
+            (void)hipMemsetAsync(idx->flags + 2, 0, 3 * sizeof(uint32_t), idx->stream);  // ec_max, zero-row count, listed-row count
         }
     }
     idx->disk_dir.clear();
@@ -1249,6 +1433,7 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
     if (e != hipSuccess || ndev <= 0)
         return fail(MX_EDEVICE, "no HIP device available (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
     if (device < 0 || device >= ndev) return fail(MX_EDEVICE, "device %d out of range (have %d)", device, ndev);
+    if (device >= kMaxDevices) return fail(MX_EUNSUPPORTED, "device %d: at most %d devices per process", device, kMaxDevices);
     DeviceGuard g(device);
     if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
     std::call_once(g_scan_once, [] {
@@ -1281,9 +1466,10 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
     MX_HIP(hipEventCreate(&idx->ev0));
     MX_HIP(hipEventCreate(&idx->ev1));
     MX_HIP(hipEventCreateWithFlags(&idx->ev_wait, hipEventDisableTiming));
-    MX_HIP(hipMalloc(&idx->flags, 4 * sizeof(uint32_t)));
-    MX_HIP(hipMemset(idx->flags, 0, 4 * sizeof(uint32_t)));
+    MX_HIP(hipMalloc(&idx->flags, 5 * sizeof(uint32_t)));
+    MX_HIP(hipMemset(idx->flags, 0, 5 * sizeof(uint32_t)));
     MX_HIP(hipMalloc(&idx->zero_rows, kZeroCap * sizeof(uint32_t)));
+    MX_HIP(hipMalloc(&idx->wild_list, kWildCap * sizeof(uint32_t)));
     if (device < kMaxDevices) {
         std::lock_guard<std::mutex> lk(g_lanes[device].mu);
         g_lanes[device].open_indexes += 1;
@@ -1301,7 +1487,8 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
 extern "C" {
 
 const char *mx_last_error(void) { return last_error_slot().c_str(); }
-const char *mx_version(void) { return "memex-hip 0.2.0 (gfx950)"; }
+const char *mx_version(void) { return "memex-hip 0.4.0 (gfx950)"; }
+size_t mx_index_stats_size(void) { return sizeof(mx_index_stats); }
 
 int mx_device_count(int *n) {
     if (!n) return fail(MX_EINVAL, "null argument");
@@ -1383,40 +1570,59 @@ int mx_index_open_sharded(const char *key, int dim, int n_dev, const int *device
     const bool want_rccl = ex ? strcmp(ex, "rccl") == 0 : distinct;
     const bool forbid_rccl = ex && strcmp(ex, "p2p") == 0;
     if (want_rccl && !forbid_rccl && (distinct || n_dev == 1)) {
-        if (load_rccl()) {
-            std::vector<int> devs;
-            for (mx_index *sh : idx->shards) devs.push_back(sh->device);
-            idx->comms.assign(n_dev, nullptr);
-            const int e = g_rccl.CommInitAll(idx->comms.data(), n_dev, devs.data());
-            if (e == 0) {
-                idx->use_rccl = true;
+        std::string why;
+        if (g_rccl_broken) {
+            why = "an earlier RCCL initialisation of this process hung";
+        } else if (!load_rccl()) {
+            why = "librccl.so.1 cannot be loaded";
+        } else {
+            // ncclCommInitAll under a watchdog (MEMEX_HIP_RCCL_TIMEOUT seconds, default 30): on a node where it never
+            // returns, the thread is abandoned and this process exchanges by peer copies from here on
+            struct Init {
+                std::mutex mu;
+                std::condition_variable cv;
+                bool done = false;
+                int rc = -1;
+                std::vector<void *> comms;
+                std::vector<int> devs;
+            };
+            auto init = std::make_shared<Init>();
+            for (mx_index *sh : idx->shards) init->devs.push_back(sh->device);
+            init->comms.assign(n_dev, nullptr);
+            std::thread([init, n_dev] {
+                const int rc = g_rccl.CommInitAll(init->comms.data(), n_dev, init->devs.data());
+                std::lock_guard<std::mutex> l2(init->mu);
+                init->rc = rc;
+                init->done = true;
+                init->cv.notify_all();
+            }).detach();
+            const char *tv = getenv("MEMEX_HIP_RCCL_TIMEOUT");
+            const double secs = tv && atof(tv) > 0.0 ? atof(tv) : 30.0;
+            std::unique_lock<std::mutex> l2(init->mu);
+            if (!init->cv.wait_for(l2, std::chrono::duration<double>(secs), [&] { return init->done; })) {
+                g_rccl_broken = true;
+                why = "ncclCommInitAll did not return in time";
+            } else if (init->rc != 0) {
+                why = std::string("ncclCommInitAll failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(init->rc) : "?");
             } else {
-                idx->comms.clear();
-                if (ex) {
-                    for (mx_index *s2 : idx->shards) free_index(s2);
-                    return fail(MX_EDEVICE, "ncclCommInitAll failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+                idx->comms = init->comms;
+                if (rccl_selftest(idx.get(), secs)) {
+                    idx->use_rccl = true;
+                } else {
+                    why = "the first all-gather failed or did not complete";
+                    idx->comms.clear();  // (not destroyed: a communicator with a collective in an unknown state)
                 }
             }
-        } else if (ex) {
-            for (mx_index *s2 : idx->shards) free_index(s2);
-            return fail(MX_EDEVICE, "MEMEX_HIP_EXCHANGE=rccl but librccl.so.1 cannot be loaded");
         }
-    }
-    if (!idx->use_rccl && distinct) {
-        // peer copies between the shards' devices and shards[0]'s
-        for (int g = 1; g < n_dev; ++g) {
-            int can = 0;
-            (void)hipDeviceCanAccessPeer(&can, idx->shards[0]->device, idx->shards[g]->device);
-            if (can) {
-                DeviceGuard dg(idx->shards[0]->device);
-                (void)hipDeviceEnablePeerAccess(idx->shards[g]->device, 0);
-                (void)hipGetLastError();
-                DeviceGuard d2(idx->shards[g]->device);
-                (void)hipDeviceEnablePeerAccess(idx->shards[0]->device, 0);
-                (void)hipGetLastError();
+        if (!idx->use_rccl) {
+            if (ex) {  // MEMEX_HIP_EXCHANGE=rccl insists
+                for (mx_index *s2 : idx->shards) free_index(s2);
+                return fail(MX_EDEVICE, "MEMEX_HIP_EXCHANGE=rccl: %s", why.c_str());
             }
+            fprintf(stderr, "memex-hip: sharded index '%s' exchanges by peer copies (%s)\n", k.c_str(), why.c_str());
         }
     }
+    if (!idx->use_rccl && distinct) enable_peer_access(idx.get());
     {   // helper threads: one per shard >= 1 when every shard has its own device.  MEMEX_HIP_SHARD_THREADS=1
         // forces them for logical shards on one device too (how the hand-off is tested on a 1-GPU box), =0 never
         const char *tv = getenv("MEMEX_HIP_SHARD_THREADS");
@@ -1705,24 +1911,10 @@ int mx_index_set_filter_copy(mx_index *idx, int on) {
     idx->filter_i8 = i8;
     idx->filter_auto = on == 1;
     idx->i8_batches = idx->i8_retry_batches = 0;
+    idx->demoted_at_rows = 0;
+    for (double &w : idx->wait_ema_us) w = 0.0;
     if (idx->xh || idx->cap == 0 || idx->kc > kMaxKC16) return MX_OK;  // present, or built with the first rows
-    DevBuf nh, nts;
-    const size_t hb = (size_t)idx->cap * idx->ds * (i8 ? 1 : 2), tb = (size_t)(idx->cap / kTile8Rows) * 4 * sizeof(float);
-    hipError_t e = hipMalloc(&nh.p, hb);
-    if (e == hipSuccess && i8) e = hipMalloc(&nts.p, tb);
-    if (e != hipSuccess) return fail(MX_ENOMEM, "hipMalloc(filter copy, %zu bytes): %s", hb, hipGetErrorString(e));
-    MX_HIP(hipMemsetAsync(nh.p, 0, hb, idx->stream));
-    if (i8) MX_HIP(hipMemsetAsync(nts.p, 0, tb, idx->stream));
-    MX_HIP(hipMemsetAsync(idx->flags + 2, 0, sizeof(uint32_t), idx->stream));
-    const uint32_t t1 = (uint32_t)((idx->n + kTileRows - 1) / kTileRows);
-    if (i8)
-        MX_HIP(launch_shadow8(idx->stream, idx->x, idx->scale, idx->ds, 0, t1, idx->n, nh.p, static_cast<float *>(nts.p), idx->flags + 2));
-    else
-        MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, t1, nh.p, idx->flags + 2));
-    MX_HIP(hipStreamSynchronize(idx->stream));
-    idx->xh = nh.release();
-    idx->tsc = static_cast<float *>(nts.release());
-    return MX_OK;
+    return build_filter_copy(idx, i8);
 }
 
 int mx_index_set_corpus_mode(mx_index *idx, int mode) {
@@ -1790,6 +1982,8 @@ int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
             acc.filter_copy_bytes += s1.filter_copy_bytes;
             acc.filter_kind = std::max(acc.filter_kind, s1.filter_kind);  // shards choose alike; a demoted one shows as bf16
             acc.filter_demotions += s1.filter_demotions;
+            acc.filter_promotions += s1.filter_promotions;
+            acc.listed_rows += s1.listed_rows;
         }
         *out = acc;
         return MX_OK;
@@ -1807,6 +2001,7 @@ int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
     }
     idx->stats.filter_kind = !idx->xh ? 0u : (idx->filter_i8 && !idx->compressed ? 2u : 3u);
     idx->stats.filter_copy_bytes = idx->xh ? (uint64_t)idx->cap * idx->ds * (idx->filter_i8 && !idx->compressed ? 1ull : 2ull) : 0;
+    idx->stats.listed_rows = idx->n_zero + idx->n_wild;
     *out = idx->stats;
     return MX_OK;
 }

@@ -40,6 +40,7 @@ constexpr int kRecCap = 64;        // lane-private records per collect launch: o
 constexpr int kMaxScanWGs = 256;   // persistent workgroups (<= CUs)
 constexpr int kCandCap = 16384;    // candidates finish_kernel holds per query (LDS); more = rescan with a tight threshold
 constexpr int kZeroCap = 1024;     // zero-norm rows an index tracks in its list (more: EXACT path)
+constexpr int kWildCap = 64;       // rows with a norm outside [1e-15, 1e15] an f32 index lists (more: EXACT path)
 
 // cosine-unit bounds on |approx - exact| of the bf16 scan.
 //   a priori:  two bf16 roundings (unit roundoff 2^-8 each) of unit vectors, Cauchy-Schwarz:
@@ -131,9 +132,10 @@ hipError_t launch_unshadow(hipStream_t s, const void *xh, int ds, int d, uint64_
 
 // rows [n, d] (device) -> x[first.., ds] zero-padded + scale (0 for a zero-norm row); flags[0] += non-finite
 // rows, flags[1] += rows whose norm is outside the range the bf16 scan is certified for, flags[3] +=
-// zero-norm rows, whose local row numbers (row_base + r) go to zero_rows[] (first kZeroCap)
+// zero-norm rows, whose local row numbers (row_base + r) go to zero_rows[] (first kZeroCap); raw & 2: flags[4] += rows
+// with such a norm, stored as zeros and listed in wild_rows[] (first kWildCap)
 hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, float *x, float *scale,
-                         uint64_t first, int ds, uint32_t *flags, int raw, uint32_t *zero_rows, uint64_t row_base);
+                         uint64_t first, int ds, uint32_t *flags, int raw, uint32_t *zero_rows, uint32_t *wild_rows, uint64_t row_base);
 
 // queries [B, d] (device) -> qfrag (normalised bf16 fragments), qpad [256, ds] f32 original
 // values zero padded, qnorm2 [256] f64 (sequential DistCosine accumulation), theta init, e1 [256]
@@ -176,6 +178,8 @@ struct FinishParams {
     const float *theta;         // [256] the collect launch's pass threshold
     const uint32_t *zero_rows;  // [kZeroCap] zero-norm rows of the index (their stored scores are 0: they enter here)
     uint32_t n_zero;
+    const uint32_t *wild_rows;  // [kWildCap] rows with a norm outside the f32 stages' range, ascending: stage 3 takes them all
+    uint32_t n_wild;
     uint32_t *overflow;         // [256]
     const uint32_t *todo;       // null = every query; else only queries with todo[q] != 0
     float *theta_retry;         // [256]
@@ -199,11 +203,19 @@ hipError_t finish_setup();
 hipError_t launch_finish(hipStream_t s, int B, const FinishParams &p);
 hipError_t launch_retry_setup(hipStream_t s, float *theta, const float *theta_retry, uint32_t *overflow, uint32_t *todo);
 
-// EXACT path: one query against every row in f64, then a 64-step radix select on (dist,row) keys
-hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *x, const void *xh, uint64_t n_rows,
-                              const IdMap &idmap, const float *qpad_row, uint64_t *keys,
-                              uint64_t *sel_state, uint64_t *ids, float *scores, float *dists,
-                              int32_t *n_found);
+// EXACT path, batched: a group of up to kExactGroup queries against every row in one pass (f32 products, sequential f64
+// sums per pair: DistCosine), then a 3-pass radix select per query with ties ordered by row.  Queries are named by
+// their slot in qpad / qnorm2 / the output arrays; scratch holds exact_group_scratch_bytes(n_rows, k).
+constexpr int kExactGroup = 32;
+constexpr int kExactSlices = 256;  // row slices per query in the selection passes
+struct ExactGroup {
+    int n;
+    int q[kExactGroup];
+};
+size_t exact_group_scratch_bytes(uint64_t n_rows, int k);
+hipError_t launch_exact_group(hipStream_t s, int k, int ds, const float *x, const void *xh, uint64_t n_rows, const IdMap &idmap,
+                              const float *qpad, const double *qnorm2, const ExactGroup &grp, void *scratch, uint64_t *ids,
+                              float *scores, float *dists, int32_t *n_found);
 
 hipError_t launch_fill_nfound(hipStream_t s, int32_t *nf, int B, int32_t v);
 hipError_t launch_merge(hipStream_t s, const void *ids, size_t ids_stride, const void *dists, size_t dists_stride,

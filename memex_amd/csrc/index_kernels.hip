@@ -135,12 +135,14 @@ __device__ __forceinline__ uint32_t block_kth_largest(const uint32_t (&key)[PER]
 // ---------------------------------------------------------------------------------------------
 // ingest: copy rows into the padded store and compute 1/|c|   (replaces hnsw.insert, local.rs:65)
 // ---------------------------------------------------------------------------------------------
-// raw != 0: the rows are stored values of a compressed corpus coming back from disk (unit length up to
-// bf16 rounding): they must be stored as they are, so 1/|c| is replaced by 1.
+// raw & 1: the rows are stored values of a compressed corpus coming back from disk (unit length up to
+// bf16 rounding): they must be stored as they are, so 1/|c| is replaced by 1.  raw & 2 (f32 corpus): rows whose norm is
+// outside [1e-15, 1e15] are stored as zeros and listed in wild_rows (below).
 __global__ __launch_bounds__(256) void ingest_kernel(const float *__restrict__ src, uint64_t n, int d,
                                                      float *__restrict__ x, float *__restrict__ scale,
                                                      uint64_t first, int ds, uint32_t *flags, int raw,
-                                                     uint32_t *__restrict__ zero_rows, uint64_t row_base) {
+                                                     uint32_t *__restrict__ zero_rows, uint32_t *__restrict__ wild_rows,
+                                                     uint64_t row_base) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
@@ -160,9 +162,18 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float *__restrict__ s
         const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0;
         if (lane == 0) {
             float sc;
-            if (acc > 0.0) {
-                sc = raw ? 1.0f : (float)(1.0 / sqrt(acc));
-                if (acc < 1e-30 || acc > 1e30) atomicAdd(&flags[1], 1u);
+            const bool wild = acc > 0.0 && (acc < 1e-30 || acc > 1e30) && isfinite(acc);
+            if (wild) atomicAdd(&flags[1], 1u);
+            if (wild && (raw & 2) && !anybad) {
+                // a norm outside [1e-15, 1e15]: the f32 stages are not certified for it (1/|c| and c/|c| leave the
+                // f32 range).  The row is stored as zeros in every filter copy (1/|c| kept as 0) and listed: the scan
+                // and the f32 stages never see it, finish_kernel hands it to its f64 stage for EVERY query, beside
+                // the survivors.  One such row costs one more f64 chain per query, not the whole collection its fast path.
+                sc = 0.0f;
+                const uint32_t at = atomicAdd(&flags[4], 1u);
+                if (at < (uint32_t)kWildCap) wild_rows[at] = (uint32_t)(row_base + r);
+            } else if (acc > 0.0) {
+                sc = (raw & 1) ? 1.0f : (float)(1.0 / sqrt(acc));
             } else {
                 // zero-norm row: exact dist is 0 for every query (DistCosine else-branch).  It is stored as
                 // zeros (scan score 0) and remembered in the index's zero-row list, from which
@@ -180,11 +191,11 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float *__restrict__ s
 }
 
 hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, float *x, float *scale,
-                         uint64_t first, int ds, uint32_t *flags, int raw, uint32_t *zero_rows, uint64_t row_base) {
+                         uint64_t first, int ds, uint32_t *flags, int raw, uint32_t *zero_rows, uint32_t *wild_rows, uint64_t row_base) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(ingest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, n, d, x, scale, first, ds, flags, raw, zero_rows, row_base);
+    hipLaunchKernelGGL(ingest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, n, d, x, scale, first, ds, flags, raw, zero_rows, wild_rows, row_base);
     return hipGetLastError();
 }
 
@@ -529,15 +540,19 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     const int nwg = p.nwg;
     const float th = p.theta[q];
     const uint32_t nz = p.n_zero;
-    auto is_zero_row = [&](uint32_t row) {  // the list is ascending (rows are appended in insertion order)
-        uint32_t lo = 0, hi = nz;
+    // rows with a norm outside the f32 stages' range (stored as zeros, like the zero-norm rows, but their cosine is
+    // not known): they never become candidates; stage 3 evaluates them in f64 for every query, beside the survivors
+    const uint32_t nw = p.n_wild;
+    auto in_list = [&](const uint32_t *list, uint32_t n, uint32_t row) {  // ascending lists
+        uint32_t lo = 0, hi = n;
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (p.zero_rows[mid] < row) lo = mid + 1;
+            if (list[mid] < row) lo = mid + 1;
             else hi = mid;
         }
-        return lo < nz && p.zero_rows[lo] == row;
+        return lo < n && list[lo] == row;
     };
+    auto is_zero_row = [&](uint32_t row) { return (nz && in_list(p.zero_rows, nz, row)) || (nw && in_list(p.wild_rows, nw, row)); };
     // (a) record counts of this query's 2*nwg lane buffers -> exclusive scan in LDS
     uint32_t *s_off = reinterpret_cast<uint32_t *>(qv + ds) + 32;  // [2*kMaxScanWGs + 1], behind the staged-row ids
     uint32_t nrec = 0;
@@ -586,7 +601,7 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t row = rowb + (r & 3) + 8 * (r >> 2);
-                const bool pass = v[r] >= thr && (uint64_t)row < p.n_rows && !(v[r] == 0.0f && nz && is_zero_row(row));
+                const bool pass = v[r] >= thr && (uint64_t)row < p.n_rows && !(v[r] == 0.0f && (nz | nw) && is_zero_row(row));
                 mask |= pass ? (1u << r) : 0u;
                 v[r] -= eb;                                // candidates carry the LOWER bound of their cosine
             }
@@ -814,22 +829,28 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     const int pitch = ds + 4;                                                   // +16 B: conflict-free ds_read_b128 across rows
     // rows that fit behind the keys in ent[]'s storage: 32 up to 1020 dims, 21 at 1536
     const uint32_t stage_rows = min((uint32_t)kStageRows, (uint32_t)((sizeof(Cand) * kCandCap - 2 * kStageRows * sizeof(float)) / (pitch * sizeof(float))));
-    if (m2 <= stage_rows) {
+    // the listed wide-norm rows join here: mt keys in all
+    uint32_t nwv = 0;  // those of them below n_rows (a rolled-back append may have left later ones)
+    for (uint32_t i = 0; i < nw; ++i) nwv += (uint64_t)p.wild_rows[i] < p.n_rows ? 1u : 0u;  // ascending: a prefix
+    const uint32_t mt = m2 + nwv;
+    if (mt <= stage_rows) {
         if (tid < (int)m2) srow[tid] = ent[tid].row;
+        else if (tid < (int)mt) srow[tid] = p.wild_rows[tid - (int)m2];
         __syncthreads();  // row ids are out of ent[]: its storage becomes keys + staged rows
         const uint32_t nc4s = (uint32_t)ds >> 2;
-        for (uint32_t i = tid; i < m2 * nc4s; i += kFinThreads) {
+        for (uint32_t i = tid; i < mt * nc4s; i += kFinThreads) {
             const uint32_t r = i / nc4s, c4 = i - r * nc4s;
             *reinterpret_cast<float4 *>(stage + (size_t)r * pitch + 4 * c4) = row_load4<CMP>(p.x, p.xh, ds, srow[r], (int)c4);
         }
         __syncthreads();
-        if (tid < (int)m2) {
+        if (tid < (int)mt) {
             const float d = exact_dist_row(qv, stage + (size_t)tid * pitch, ds, na, nullptr);
             keys[tid] = ((uint64_t)__float_as_uint(d) << 32) | srow[tid];
         }
     } else {
-        for (uint32_t cI = tid; cI < m2; cI += kFinThreads) {
-            const uint32_t r = ent[cI].row;
+        // (keys[] shares ent[]'s storage, 8 bytes per entry both: thread cI reads ent[cI] and writes keys[cI] itself)
+        for (uint32_t cI = tid; cI < mt; cI += kFinThreads) {
+            const uint32_t r = cI < m2 ? ent[cI].row : p.wild_rows[cI - m2];
             const float d = exact_dist_stored<CMP>(qv, p.x, p.xh, ds, r, na);
             keys[cI] = ((uint64_t)__float_as_uint(d) << 32) | r;
         }
@@ -839,14 +860,14 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
 
     // ---- order by (dist, row) and emit the first `want`
     uint64_t lim = ~0ull;  // keys above the want-th smallest need no rank
-    if (m2 > 2048u) {
+    if (mt > 2048u) {
         // many exact ties (duplicated rows): select the want-th smallest key first (64-bit radix,
         // MSB first), so that the quadratic ranking below runs on `want` keys only
         uint64_t prefix = 0;
         for (int bit = 63; bit >= 0; --bit) {
             const uint64_t trial = prefix | (1ull << bit);
             uint32_t cc = 0;
-            for (uint32_t cI = tid; cI < m2; cI += kFinThreads) cc += keys[cI] < trial ? 1u : 0u;
+            for (uint32_t cI = tid; cI < mt; cI += kFinThreads) cc += keys[cI] < trial ? 1u : 0u;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) cc += __shfl_xor(cc, o);
             uint32_t *slot = s_sel[bit & 1];
@@ -859,11 +880,11 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
         }
         lim = prefix;
     }
-    for (uint32_t cI = tid; cI < m2; cI += kFinThreads) {
+    for (uint32_t cI = tid; cI < mt; cI += kFinThreads) {
         const uint64_t me = keys[cI];
         if (me > lim) continue;
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < m2; ++j) rank += keys[j] < me ? 1u : 0u;
+        for (uint32_t j = 0; j < mt; ++j) rank += keys[j] < me ? 1u : 0u;
         if (rank < (uint32_t)want) {
             const float d = __uint_as_float((uint32_t)(me >> 32));
             oid[rank] = p.idmap.id_of((uint32_t)me);
@@ -931,72 +952,218 @@ hipError_t launch_finish(hipStream_t s, int B, const FinishParams &p) {
 // ---------------------------------------------------------------------------------------------
 // EXACT path: f64 DistCosine on every row, then a 64-step MSB-first select on (dist,row) keys
 // ---------------------------------------------------------------------------------------------
-template <bool CMP>
-__global__ __launch_bounds__(256) void exact_keys_kernel(int ds, const float *__restrict__ x, const void *__restrict__ xh,
-                                                         uint64_t n_rows, const float *__restrict__ qrow,
-                                                         uint64_t *__restrict__ keys) {
-    // all LDS in the dynamic region (a static __shared__ in front would misalign the float4 reads)
-    extern __shared__ __attribute__((aligned(16))) char esm[];
-    float *qv = reinterpret_cast<float *>(esm);
-    double *s_na = reinterpret_cast<double *>(esm + sizeof(float) * (size_t)ds);
-    for (int i = threadIdx.x; i < ds; i += 256) qv[i] = qrow[i];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double na = 0.0;
-        for (int i = 0; i < ds; ++i) na += (double)__fmul_rn(qv[i], qv[i]);
-        *s_na = na;
-    }
-    __syncthreads();
-    const double na = *s_na;
-    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * 256) {
-        const float d = exact_dist_stored<CMP>(qv, x, xh, ds, (uint32_t)r, na);
-        keys[r] = ((uint64_t)__float_as_uint(d) << 32) | (uint32_t)r;
-    }
-}
+// ---------------------------------------------------------------------------------------------
+// EXACT path, batched: every row against a GROUP of up to 32 queries in one pass (k > 256, more listed rows than
+// finish_kernel takes, rows wider than the scans, MX_SEARCH_EXACT, and queries whose neighbourhood overflowed twice).
+// The reference answers any vector and any limit at one price (local.rs:71-91); so must this: a group costs about one
+// f32 scan of the corpus plus five light passes over its 4-byte distances, whatever k is.
+//   exact_dist_batch_kernel   dist[g][row] = DistCosine(query g, row): f32 products, sequential f64 sums in element
+//                             order (one chain per pair), as the oracle; a workgroup = 64 rows x 32 queries, the rows and
+//                             the queries of a 128-dim chunk in LDS (rows padded: conflict-free), thread = 1 row x 8 queries
+//   xsel_hist / xsel_pick     3-pass radix select (12 + 12 + 8 bits) of the kk-th smallest distance per query
+//   xsel_count / xsel_collect rows below it, plus the lowest-numbered rows equal to it (ties are ordered by row: slices
+//                             are contiguous and ascending, a tie's rank is a prefix count)
+//   xsel_emit_kernel          order the kk keys by (dist, row), emit ids / scores / dists
+// ---------------------------------------------------------------------------------------------
+constexpr int kXRows = 64;      // rows per workgroup pass
+constexpr int kXChunk = 128;    // dims per LDS chunk
+constexpr int kXPitch = kXChunk + 4;  // row pitch in floats: lanes (rows) hit distinct bank groups with 16-byte reads
 
-// sel_state: [0] prefix, [1] count, [2] output cursor
-__global__ __launch_bounds__(256) void exact_count_kernel(const uint64_t *__restrict__ keys, uint64_t n, int bit,
-                                                          uint64_t *state) {
-    const uint64_t trial = state[0] | (1ull << bit);
-    uint32_t c = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
-        c += keys[i] < trial ? 1u : 0u;
+template <bool CMP>
+__global__ __launch_bounds__(256) void exact_dist_batch_kernel(int ds, const float *__restrict__ x, const void *__restrict__ xh,
+                                                               uint64_t n_rows, const float *__restrict__ qpad,
+                                                               const double *__restrict__ qnorm2, ExactGroup grp,
+                                                               uint32_t *__restrict__ dist) {
+    __shared__ __attribute__((aligned(16))) float s_rows[kXRows * kXPitch];
+    __shared__ __attribute__((aligned(16))) float s_q[kExactGroup * kXChunk];
+    const int tid = threadIdx.x, lr = tid & 63, qg = tid >> 6;  // local row, query octet (wave-uniform)
+    const int nq = grp.n;
+    double na[8];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(reinterpret_cast<unsigned long long *>(&state[1]), (unsigned long long)c);
-}
-__global__ void exact_decide_kernel(int bit, uint64_t kk, uint64_t *state) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (state[1] < kk) state[0] |= (1ull << bit);  // fewer than k keys below trial: k-th smallest >= trial
-        state[1] = 0;
-    }
-}
-__global__ __launch_bounds__(256) void exact_collect_kernel(const uint64_t *__restrict__ keys, uint64_t n,
-                                                            uint64_t kk, uint64_t *state, uint64_t *sel) {
-    const uint64_t kth = state[0];
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const uint64_t key = keys[i];
-        if (key <= kth) {
-            const unsigned long long p = atomicAdd(reinterpret_cast<unsigned long long *>(&state[2]), 1ull);
-            if (p < kk) sel[p] = key;
+    for (int j = 0; j < 8; ++j) na[j] = qg * 8 + j < nq ? qnorm2[grp.q[qg * 8 + j]] : 0.0;
+    const uint64_t tiles = (n_rows + kXRows - 1) / kXRows;
+    for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const uint64_t r0 = t * kXRows;
+        double dot[8], nb = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dot[j] = 0.0;
+        for (int c0 = 0; c0 < ds; c0 += kXChunk) {
+            __syncthreads();  // the previous chunk has been consumed
+            for (int i = tid; i < kXRows * (kXChunk / 4); i += 256) {  // coalesced: 32 consecutive float4 per row
+                const int r = i / (kXChunk / 4), c4 = i % (kXChunk / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r0 + r < n_rows) v = row_load4<CMP>(x, xh, ds, (uint32_t)(r0 + r), c0 / 4 + c4);
+                *reinterpret_cast<float4 *>(s_rows + r * kXPitch + 4 * c4) = v;
+            }
+            for (int i = tid; i < kExactGroup * (kXChunk / 4); i += 256) {
+                const int g = i / (kXChunk / 4), c4 = i % (kXChunk / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g < nq) v = *reinterpret_cast<const float4 *>(qpad + (size_t)grp.q[g] * ds + c0 + 4 * c4);
+                *reinterpret_cast<float4 *>(s_q + g * kXChunk + 4 * c4) = v;
+            }
+            __syncthreads();
+            const float *rw = s_rows + lr * kXPitch;
+            const float *qw = s_q + qg * 8 * kXChunk;
+#pragma unroll 2
+            for (int i = 0; i < kXChunk / 4; ++i) {
+                const float4 c = *reinterpret_cast<const float4 *>(rw + 4 * i);
+                nb += (double)__fmul_rn(c.x, c.x);
+                nb += (double)__fmul_rn(c.y, c.y);
+                nb += (double)__fmul_rn(c.z, c.z);
+                nb += (double)__fmul_rn(c.w, c.w);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 a = *reinterpret_cast<const float4 *>(qw + j * kXChunk + 4 * i);  // same address in every lane
+                    dot[j] += (double)__fmul_rn(a.x, c.x);
+                    dot[j] += (double)__fmul_rn(a.y, c.y);
+                    dot[j] += (double)__fmul_rn(a.z, c.z);
+                    dot[j] += (double)__fmul_rn(a.w, c.w);
+                }
+            }
+        }
+        if (r0 + lr < n_rows) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (qg * 8 + j < nq) dist[(size_t)(qg * 8 + j) * n_rows + r0 + lr] = __float_as_uint(dist_from_sums(dot[j], na[j], nb));
         }
     }
 }
-__global__ __launch_bounds__(256) void exact_emit_kernel(int k, uint64_t kk, IdMap idmap,
-                                                         const uint64_t *__restrict__ sel, uint64_t *ids,
-                                                         float *scores, float *dists, int32_t *n_found) {
-    const int tid = threadIdx.x;
-    if (tid == 0) *n_found = (int32_t)kk;
+
+// per query g of the group: state[g] = {prefix, need, -, cursor}; hist[g][4096]
+constexpr int kXBins = 4096;
+__global__ void xsel_init_kernel(uint32_t kk, uint32_t *state) {
+    state[4 * threadIdx.x] = 0;
+    state[4 * threadIdx.x + 1] = kk;
+    state[4 * threadIdx.x + 2] = 0;
+    state[4 * threadIdx.x + 3] = 0;
+}
+__global__ __launch_bounds__(256) void xsel_hist_kernel(const uint32_t *__restrict__ dist, uint64_t n_rows, int pass,
+                                                        const uint32_t *__restrict__ state, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[kXBins];
+    const int g = blockIdx.y;
+    for (int i = threadIdx.x; i < kXBins; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint32_t prefix = state[4 * g];
+    const int shift = pass == 0 ? 20 : pass == 1 ? 8 : 0;
+    const uint32_t bmask = pass == 2 ? 0xffu : 0xfffu;
+    const uint32_t pmask = pass == 0 ? 0u : pass == 1 ? 0xfff00000u : 0xffffff00u;
+    const uint64_t per = (n_rows + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n_rows ? lo + per : n_rows;
+    const uint32_t *d = dist + (size_t)g * n_rows;
+    for (uint64_t r = lo + threadIdx.x; r < hi; r += 256) {
+        const uint32_t key = d[r];
+        if ((key & pmask) == prefix) atomicAdd(&h[(key >> shift) & bmask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kXBins; i += 256)
+        if (h[i]) atomicAdd(&hist[(size_t)g * kXBins + i], h[i]);
+}
+// one workgroup per query: the bin that holds the need-th smallest remaining key; clears the histogram for the next pass
+__global__ __launch_bounds__(256) void xsel_pick_kernel(int pass, uint32_t *__restrict__ state, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t s_part[256];
+    __shared__ uint32_t s_res[2];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    uint32_t *h = hist + (size_t)g * kXBins;
+    const int nb = pass == 2 ? 256 : kXBins, per = nb / 256;  // bins per thread, ascending
+    uint32_t mine = 0;
+    for (int i = 0; i < per; ++i) mine += h[tid * per + i];
+    s_part[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t need = state[4 * g + 1];
+        uint32_t below = 0;
+        int t = 0;
+        for (; t < 255 && below + s_part[t] < need; ++t) below += s_part[t];
+        int bin = t * per;
+        for (; bin < t * per + per - 1 && below + h[bin] < need; ++bin) below += h[bin];
+        const int shift = pass == 0 ? 20 : pass == 1 ? 8 : 0;
+        s_res[0] = state[4 * g] | ((uint32_t)bin << shift);
+        s_res[1] = need - below;
+    }
+    __syncthreads();
+    for (int i = tid; i < kXBins; i += 256) h[i] = 0;
+    if (tid == 0) {
+        state[4 * g] = s_res[0];           // pass 2: the kk-th smallest key T itself
+        state[4 * g + 1] = s_res[1];       // pass 2: how many rows equal to T are wanted
+    }
+}
+// rows equal to T per slice (slices = contiguous ascending row ranges)
+__global__ __launch_bounds__(256) void xsel_count_kernel(const uint32_t *__restrict__ dist, uint64_t n_rows,
+                                                         const uint32_t *__restrict__ state, uint32_t *__restrict__ eq_cnt) {
+    __shared__ uint32_t s4[4];
+    const int g = blockIdx.y;
+    const uint32_t T = state[4 * g];
+    const uint64_t per = (n_rows + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n_rows ? lo + per : n_rows;
+    const uint32_t *d = dist + (size_t)g * n_rows;
+    uint32_t c = 0;
+    for (uint64_t r = lo + threadIdx.x; r < hi; r += 256) c += d[r] == T ? 1u : 0u;
+    c = block_sum_256(c, s4);
+    if (threadIdx.x == 0) eq_cnt[(size_t)g * gridDim.x + blockIdx.x] = c;
+}
+// sel[g][kk]: keys (dist << 32 | row) of the rows below T (any order) and of the first `need` rows equal to T
+__global__ __launch_bounds__(256) void xsel_collect_kernel(const uint32_t *__restrict__ dist, uint64_t n_rows, uint32_t kk,
+                                                           uint32_t *__restrict__ state, const uint32_t *__restrict__ eq_cnt,
+                                                           uint64_t *__restrict__ sel) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_base;
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t T = state[4 * g], need = state[4 * g + 1], n_lt = kk - need;
+    const uint64_t per = (n_rows + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n_rows ? lo + per : n_rows;
+    const uint32_t *d = dist + (size_t)g * n_rows;
+    uint64_t *out = sel + (size_t)g * kk;
+    if (tid == 0) {
+        uint32_t b = 0;
+        for (unsigned i = 0; i < blockIdx.x; ++i) b += eq_cnt[(size_t)g * gridDim.x + i];
+        s_base = b;
+    }
+    __syncthreads();
+    uint32_t eq_base = s_base;  // ties in lower-numbered rows
+    for (uint64_t r0 = lo; r0 < hi; r0 += 256) {  // block-uniform trip count
+        const uint64_t r = r0 + tid;
+        const uint32_t key = r < hi ? d[r] : 0xffffffffu;
+        const bool lt = r < hi && key < T, eq = r < hi && key == T;
+        if (lt) {
+            const uint32_t at = atomicAdd(&state[4 * g + 3], 1u);
+            if (at < n_lt) out[at] = ((uint64_t)key << 32) | (uint32_t)r;
+        }
+        // rank of a tie among the ties of this slice, in row order
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(eq);
+        const uint32_t before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull)), wtot = (uint32_t)__popcll(bal);
+        __syncthreads();
+        if (lane == 0) s_w[wave] = wtot;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            wbase += w < wave ? s_w[w] : 0u;
+            tot += s_w[w];
+        }
+        if (eq) {
+            const uint32_t rank = eq_base + wbase + before;
+            if (rank < need) out[n_lt + rank] = ((uint64_t)key << 32) | (uint32_t)r;
+        }
+        eq_base += tot;
+    }
+}
+__global__ __launch_bounds__(256) void xsel_emit_kernel(int k, uint32_t kk, IdMap idmap, ExactGroup grp,
+                                                        const uint64_t *__restrict__ sel_all, uint64_t *ids_all,
+                                                        float *scores_all, float *dists_all, int32_t *n_found) {
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int q = grp.q[g];
+    const uint64_t *sel = sel_all + (size_t)g * kk;
+    uint64_t *ids = ids_all + (size_t)q * k;
+    float *scores = scores_all + (size_t)q * k;
+    float *dists = dists_all ? dists_all + (size_t)q * k : nullptr;
+    if (tid == 0) n_found[q] = (int32_t)kk;
     for (int j = tid; j < k; j += 256) {
         ids[j] = 0;
         scores[j] = 0.0f;
         if (dists) dists[j] = INFINITY;
     }
     __syncthreads();
-    for (uint64_t c = tid; c < kk; c += 256) {
+    for (uint32_t c = tid; c < kk; c += 256) {
         const uint64_t me = sel[c];
-        uint64_t rank = 0;
-        for (uint64_t j = 0; j < kk; ++j) rank += sel[j] < me ? 1u : 0u;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < kk; ++j) rank += sel[j] < me ? 1u : 0u;
         const float d = __uint_as_float((uint32_t)(me >> 32));
         ids[rank] = idmap.id_of((uint32_t)me);
         scores[rank] = score_from_dist(d);
@@ -1004,27 +1171,44 @@ __global__ __launch_bounds__(256) void exact_emit_kernel(int k, uint64_t kk, IdM
     }
 }
 
-hipError_t launch_exact_query(hipStream_t s, int k, int d, int ds, const float *x, const void *xh, uint64_t n_rows,
-                              const IdMap &idmap, const float *qpad_row, uint64_t *keys, uint64_t *sel_state,
-                              uint64_t *ids, float *scores, float *dists, int32_t *n_found) {
-    (void)d;
+size_t exact_group_scratch_bytes(uint64_t n_rows, int k) {
     const uint64_t kk = n_rows < (uint64_t)k ? n_rows : (uint64_t)k;
-    hipError_t e = hipMemsetAsync(sel_state, 0, 3 * sizeof(uint64_t), s);
-    if (e != hipSuccess) return e;
-    uint64_t *sel = sel_state + 4;  // [k] selected keys
+    return (size_t)kExactGroup * n_rows * sizeof(uint32_t)                 // dist
+           + (size_t)kExactGroup * kXBins * sizeof(uint32_t)               // hist
+           + (size_t)kExactGroup * 4 * sizeof(uint32_t)                    // state
+           + (size_t)kExactGroup * kExactSlices * sizeof(uint32_t)         // eq_cnt
+           + (size_t)kExactGroup * (kk ? kk : 1) * sizeof(uint64_t) + 64;  // sel
+}
+
+hipError_t launch_exact_group(hipStream_t s, int k, int ds, const float *x, const void *xh, uint64_t n_rows, const IdMap &idmap,
+                              const float *qpad, const double *qnorm2, const ExactGroup &grp, void *scratch, uint64_t *ids,
+                              float *scores, float *dists, int32_t *n_found) {
+    if (grp.n <= 0) return hipSuccess;
+    const uint32_t kk = (uint32_t)(n_rows < (uint64_t)k ? n_rows : (uint64_t)k);
+    char *base = static_cast<char *>(scratch);
+    uint32_t *dist = reinterpret_cast<uint32_t *>(base);
+    uint32_t *hist = dist + (size_t)kExactGroup * n_rows;
+    uint32_t *state = hist + (size_t)kExactGroup * kXBins;
+    uint32_t *eq_cnt = state + kExactGroup * 4;
+    uint64_t *sel = reinterpret_cast<uint64_t *>(((uintptr_t)(eq_cnt + (size_t)kExactGroup * kExactSlices) + 15) & ~(uintptr_t)15);
     if (kk > 0) {
-        unsigned blocks = (unsigned)((n_rows + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        if (x) hipLaunchKernelGGL(exact_keys_kernel<false>, dim3(blocks), dim3(256), sizeof(float) * (size_t)ds + 16, s, ds, x, xh, n_rows, qpad_row, keys);
-        else hipLaunchKernelGGL(exact_keys_kernel<true>, dim3(blocks), dim3(256), sizeof(float) * (size_t)ds + 16, s, ds, x, xh, n_rows, qpad_row, keys);
-        unsigned cblocks = blocks > 1024 ? 1024 : blocks;
-        for (int bit = 63; bit >= 0; --bit) {
-            hipLaunchKernelGGL(exact_count_kernel, dim3(cblocks), dim3(256), 0, s, keys, n_rows, bit, sel_state);
-            hipLaunchKernelGGL(exact_decide_kernel, dim3(1), dim3(64), 0, s, bit, kk, sel_state);
+        hipError_t e = hipMemsetAsync(hist, 0, ((size_t)kExactGroup * kXBins + kExactGroup * 4) * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(xsel_init_kernel, dim3(1), dim3(kExactGroup), 0, s, kk, state);
+        const uint64_t tiles = (n_rows + kXRows - 1) / kXRows;
+        const unsigned blocks = (unsigned)(tiles < 2048 ? tiles : 2048);
+        if (x) hipLaunchKernelGGL(exact_dist_batch_kernel<false>, dim3(blocks), dim3(256), 0, s, ds, x, xh, n_rows, qpad, qnorm2, grp, dist);
+        else hipLaunchKernelGGL(exact_dist_batch_kernel<true>, dim3(blocks), dim3(256), 0, s, ds, x, xh, n_rows, qpad, qnorm2, grp, dist);
+        const unsigned slices = (unsigned)((n_rows + 4095) / 4096 < (uint64_t)kExactSlices ? (n_rows + 4095) / 4096 : (uint64_t)kExactSlices);
+        const dim3 sg(slices ? slices : 1, grp.n);
+        for (int pass = 0; pass < 3; ++pass) {
+            hipLaunchKernelGGL(xsel_hist_kernel, sg, dim3(256), 0, s, dist, n_rows, pass, state, hist);
+            hipLaunchKernelGGL(xsel_pick_kernel, dim3(grp.n), dim3(256), 0, s, pass, state, hist);
         }
-        hipLaunchKernelGGL(exact_collect_kernel, dim3(cblocks), dim3(256), 0, s, keys, n_rows, kk, sel_state, sel);
+        hipLaunchKernelGGL(xsel_count_kernel, sg, dim3(256), 0, s, dist, n_rows, state, eq_cnt);
+        hipLaunchKernelGGL(xsel_collect_kernel, sg, dim3(256), 0, s, dist, n_rows, kk, state, eq_cnt, sel);
     }
-    hipLaunchKernelGGL(exact_emit_kernel, dim3(1), dim3(256), 0, s, k, kk, idmap, sel, ids, scores, dists, n_found);
+    hipLaunchKernelGGL(xsel_emit_kernel, dim3(grp.n), dim3(256), 0, s, k, kk, idmap, grp, sel, ids, scores, dists, n_found);
     return hipGetLastError();
 }
 

@@ -29,6 +29,9 @@ def _caller_stream(t) -> ctypes.c_void_p | None:
     return None
 
 
+SEARCH_AUTO, SEARCH_EXACT = 0, 1   # mx_index_set_search_mode
+
+
 class FlatIndex:
     """``devices=None``: one index on ``device``.  ``devices=[...]``: the in-library sharded index
     (``mx_index_open_sharded``): rows dealt to the listed devices in blocks of ``block_rows``, local

@@ -102,6 +102,26 @@ def synthetic_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray
     return out
 
 
+def checkpoint_like_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
+    """``synthetic_weights`` with the features of TRAINED BERT-family checkpoints that are the known hazards of a bf16
+    forward pass (real weights are unreachable offline: the reference downloads them, embedding.rs:99-100): a few
+    "outlier" hidden dimensions carried through every layer -- LayerNorm gains of ~20 and biases of +-30 on the same
+    handful of dimensions in every LayerNorm, as in BERT / RoBERTa checkpoints -- and query / key projections scaled so
+    that attention logits reach +-60.  Used by the stress parity tests."""
+    w = synthetic_weights(cfg, seed)
+    rng = np.random.default_rng(seed + 1000)
+    dims = rng.choice(cfg.hidden, size=5, replace=False)
+    for name in list(w):
+        if name.endswith("LayerNorm.weight"):
+            w[name][dims[:3]] *= np.float32(20.0)
+        elif name.endswith("LayerNorm.bias"):
+            w[name][dims[3]] = np.float32(30.0)
+            w[name][dims[4]] = np.float32(-30.0)
+        elif name.endswith("attention.self.query.weight") or name.endswith("attention.self.key.weight"):
+            w[name] = (w[name] * np.float32(4.0)).astype(np.float32)
+    return w
+
+
 def load_safetensors(path: str) -> Dict[str, np.ndarray]:
     from safetensors.numpy import load_file
     return load_file(path)

@@ -3,7 +3,7 @@
 # no spills / scratch, no compiler-generated AGPR or MFMA instruction, no compiler vmcnt(0) inside the loops.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I $ROOT/memex_amd/csrc -S --cuda-device-only $ROOT/memex_amd/csrc/encoder_tail2.hip -o $T/t2.s -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "VGPRs:|AGPRs:|Spill|ScratchSize" | sed 's/.*remark: *//'
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I $ROOT/memex_amd/csrc -I $ROOT/scripts -S --cuda-device-only $ROOT/scripts/encoder_tail2.hip -o $T/t2.s -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "VGPRs:|AGPRs:|Spill|ScratchSize" | sed 's/.*remark: *//'
 python3 - $T/t2.s <<'PY'
 import re, sys, statistics
 lines = open(sys.argv[1]).read().split('\n')

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "encoder_kernels.h"
+#include "encoder_tail2.h"
 
 namespace mx {
 
@@ -181,7 +182,7 @@ __device__ __forceinline__ void from_frag(bf16x8 f, float (&v)[8]) {
 #define MX_Z8(a, b, c, d, e, f, g, h) MX_Z1(a) MX_Z1(b) MX_Z1(c) MX_Z1(d) MX_Z1(e) MX_Z1(f) MX_Z1(g) MX_Z1(h)
 #define MX_C8(a, b, c, d, e, f, g, h) "a" #a, "a" #b, "a" #c, "a" #d, "a" #e, "a" #f, "a" #g, "a" #h
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tail2_kernel(const TailParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tail2_kernel(const Tail2Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -563,7 +564,7 @@ hipError_t tail2_setup() {
 
 bool tail2_supported(int hidden, int ffn) { return hidden == kHid && ffn >= 128 && ffn % 128 == 0 && ffn <= kMaxF; }
 
-hipError_t launch_tail2(hipStream_t s, const TailParams &p) {
+hipError_t launch_tail2(hipStream_t s, const Tail2Params &p) {
     if (p.m % kTok || p.f % 128 || p.f < 128 || p.f > kMaxF || !p.wf2 || !p.pf || !p.ctx) return hipErrorInvalidValue;
     hipLaunchKernelGGL(tail2_kernel, dim3(p.m / kTok), dim3(256), kLds2, s, p);
     return hipGetLastError();

@@ -5,8 +5,8 @@
 // the first milliseconds run at ramp-up clocks.  -DMX_TAIL_ABLATE=N selects the ablations of the kernel.
 // argv: rows ffn reps po skew_iters skew_shift skew_hi.  Then the same for tail2_kernel (encoder_tail2.hip) with the
 // largest difference between the two outputs (different rounding points: a few bf16 ulps).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I memex_amd/csrc scripts/tail_ubench.hip \
-//        memex_amd/csrc/encoder_tail.hip memex_amd/csrc/encoder_tail2.hip -o build_ub/tail_ub
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I memex_amd/csrc -I scripts scripts/tail_ubench.hip \
+//        memex_amd/csrc/encoder_tail.hip scripts/encoder_tail2.hip -o build_ub/tail_ub
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <utility>
 #include "encoder_kernels.h"
+#include "encoder_tail2.h"
 using namespace mx;
 #ifndef MX_TAIL_ABLATE
 #define MX_TAIL_ABLATE 0
@@ -123,7 +124,7 @@ int main(int argc, char** argv) {
       for (int n = 0; n < 384; ++n) { double a = hb2[n] + x1[n]; for (int j = 0; j < f; ++j) a += hh[j] * rl2[(size_t)n * f + j]; y[n] = a; }
       outv.resize(384); ln(y, outv); };
     CK(tail2_setup());
-    TailParams p3 = p2; p3.wf2 = wf2; p3.pf = pf; p3.out = out3; p3.trace = nullptr;
+    Tail2Params p3; static_cast<TailParams &>(p3) = p2; p3.wf2 = wf2; p3.pf = pf; p3.out = out3; p3.trace = nullptr;
     CK(hipMemset(out3, 0xff, (size_t)m * 384 * 2));
     CK(launch_tail2(0, p3)); CK(hipDeviceSynchronize());
     { std::vector<unsigned short> a((size_t)m * 384), c((size_t)m * 384);

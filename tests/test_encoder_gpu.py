@@ -196,40 +196,46 @@ def test_large_passes_run_their_gemms_on_pgemm_kernel(lib_built, monkeypatch):
         assert (1.0 - _cos(outs[1][sub].astype(np.float64), ref)).max() <= TOL, kw
 
 
-def test_activation_stationary_tail_kernel(lib_built, monkeypatch):
-    """tail2_kernel (encoder_tail2.hip: the experimental form of the layer tail -- 128-token workgroups, one
-    512-register wave per SIMD, weights through an LDS ring, LayerNorm and GELU in registers) against tail_kernel
-    and against the f64 oracle.  Its rounding points differ on purpose (f32 residuals, x1 unrounded into
-    LayerNorm2, the sigmoid-quintic GELU, |error| <= 2.6e-5): the embeddings must agree far inside the 1e-3 bar.
-    MEMEX_HIP_TAIL=2 selects it at every pass size, =3 from 128 rows per CU on; the default is tail_kernel."""
+@pytest.mark.parametrize("kw,B,S,seed", [
+    (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000), 12, 256, 51),                    # all-MiniLM-L6-v2 shape: fused tail
+    (dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 6, 200, 52),     # bge-base shape: gemm_kernel path
+    (dict(layers=4, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 80, 512, 53),     # bge-base layers, 41k rows: pgemm_kernel + ln_rows_kernel
+    (dict(layers=4, hidden=384, heads=12, ffn=1536, vocab=3000), 96, 512, 54),                    # MiniLM layers, large pass
+])
+def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, lib_built):
+    """Trained checkpoints carry what random weights do not: outlier hidden dimensions (LayerNorm gains ~20, biases
+    +-30 on a handful of dimensions in every layer) and attention logits of +-60.  Those are the bf16 hazards --
+    activation range through the residual stream, the pre-LayerNorm sums the large-pass path rounds to bf16, the
+    attention fast path's un-shifted exp2.  Real weights cannot be loaded offline (the reference downloads them,
+    embedding.rs:99-100), so `checkpoint_like_weights` injects those features: cosine against the f64 oracle must stay
+    within the same 1e-3."""
     from memex_amd.encoder import Encoder
-    from memex_amd.weights import EncoderConfig, synthetic_weights
+    from memex_amd.weights import EncoderConfig, checkpoint_like_weights
     from oracle import bert_oracle
-    for kw, B, S, seed in ((dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000), 96, 512, 31),    # 43k rows: a large pass
-                           (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000), 40, 256, 32),
-                           (dict(layers=2, hidden=384, heads=12, ffn=768, vocab=3000), 300, 160, 33),
-                           (dict(layers=3, hidden=384, heads=12, ffn=384, vocab=3000), 1, 9, 34)):
-        cfg = EncoderConfig(**kw)
-        w = synthetic_weights(cfg, seed)
-        rng = np.random.default_rng(seed)
-        ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
-        lens = rng.integers(S // 2 + S // 4, S + 1, B).astype(np.int32)
-        outs = {}
-        for mode in ("1", "2", "3", None):
-            if mode is None:
-                monkeypatch.delenv("MEMEX_HIP_TAIL", raising=False)
-            else:
-                monkeypatch.setenv("MEMEX_HIP_TAIL", mode)
-            with Encoder(cfg, w) as enc:
-                outs[mode] = enc.encode(ids, lens)
-                np.testing.assert_array_equal(outs[mode], enc.encode(ids, lens))      # deterministic
-        assert np.isfinite(outs["2"]).all()
-        assert (1.0 - _cos(outs["2"].astype(np.float64), outs["1"].astype(np.float64))).max() <= 5e-5, kw
-        np.testing.assert_array_equal(outs[None], outs["1"])             # the default is tail_kernel
-        np.testing.assert_array_equal(outs["3"], outs["2"] if B * S >= 128 * 256 else outs["1"])
-        sub = slice(0, min(B, 24))
-        ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub])
-        assert (1.0 - _cos(outs["2"][sub].astype(np.float64), ref)).max() <= TOL, kw
+    cfg = EncoderConfig(**kw)
+    w = checkpoint_like_weights(cfg, seed)
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
+    lens = rng.integers(S // 2, S + 1, B).astype(np.int32)
+    lens[0] = S
+    with Encoder(cfg, w) as enc:
+        out = enc.encode(ids, lens)
+    assert np.isfinite(out).all()
+    sub = slice(0, min(B, 8))
+    ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub])
+    cos = _cos(out[sub].astype(np.float64), ref)
+    assert (1.0 - cos).max() <= TOL, (kw, cos)
+    # what the search sees: the cosines BETWEEN embeddings.  These weights put a large common component into every
+    # embedding (pairwise cosines ~0.96), so the row-wise cosine above is the easy half; the pairwise ones move by up to
+    # 1.3e-3 (measured: MiniLM-L6 shape, round 4) -- the price of bf16 activations on dimensions of magnitude 20-60, where
+    # a bf16 step is 0.125-0.25.  Bounded here at 2.5e-3 so that a regression shows; DESIGN.md section 4 states it.
+    o = out[sub].astype(np.float64)
+    o /= np.linalg.norm(o, axis=1, keepdims=True)
+    r = ref / np.linalg.norm(ref, axis=1, keepdims=True)
+    pair = np.abs(o @ o.T - r @ r.T).max()
+    print(f"checkpoint-like weights {kw['layers']}x{kw['hidden']} B={B} S={S}: max(1 - cos) = {(1.0 - cos).max():.2e}, "
+          f"max |pairwise cosine error| = {pair:.2e}")
+    assert pair <= 2.5e-3, (kw, pair)
 
 
 def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
