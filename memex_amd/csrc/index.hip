@@ -1707,6 +1707,10 @@ int mx_index_wait_stream(mx_index *idx, void *stream) {
     std::lock_guard<std::mutex> lk(idx->mu);
     mx_index *t = idx->composite() ? idx->shards[0] : idx;
     DeviceGuard g(t->device);
+    // nothing pending on the caller's stream (the usual case between two searches): no event, no dependency to process --
+    // one query call instead of a record + wait pair in front of every batch
+    if (hipStreamQuery(static_cast<hipStream_t>(stream)) == hipSuccess) return MX_OK;
+    (void)hipGetLastError();
     MX_HIP(hipEventRecord(t->ev_wait, static_cast<hipStream_t>(stream)));
     MX_HIP(hipStreamWaitEvent(t->stream, t->ev_wait, 0));
     return MX_OK;

@@ -969,24 +969,26 @@ constexpr int kXRows = 64;      // rows per workgroup pass
 constexpr int kXChunk = 128;    // dims per LDS chunk
 constexpr int kXPitch = kXChunk + 4;  // row pitch in floats: lanes (rows) hit distinct bank groups with 16-byte reads
 
-template <bool CMP>
+// QPT = queries per thread: the workgroup's four waves take QPT queries each (4 QPT per pass over the rows); the host picks
+// the smallest QPT that holds the group, so that four queries do not pay for thirty-two
+template <bool CMP, int QPT>
 __global__ __launch_bounds__(256) void exact_dist_batch_kernel(int ds, const float *__restrict__ x, const void *__restrict__ xh,
                                                                uint64_t n_rows, const float *__restrict__ qpad,
                                                                const double *__restrict__ qnorm2, ExactGroup grp,
                                                                uint32_t *__restrict__ dist) {
     __shared__ __attribute__((aligned(16))) float s_rows[kXRows * kXPitch];
     __shared__ __attribute__((aligned(16))) float s_q[kExactGroup * kXChunk];
-    const int tid = threadIdx.x, lr = tid & 63, qg = tid >> 6;  // local row, query octet (wave-uniform)
+    const int tid = threadIdx.x, lr = tid & 63, qg = tid >> 6;  // local row, query group of the wave (QPT queries)
     const int nq = grp.n;
-    double na[8];
+    double na[QPT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) na[j] = qg * 8 + j < nq ? qnorm2[grp.q[qg * 8 + j]] : 0.0;
+    for (int j = 0; j < QPT; ++j) na[j] = qg * QPT + j < nq ? qnorm2[grp.q[qg * QPT + j]] : 0.0;
     const uint64_t tiles = (n_rows + kXRows - 1) / kXRows;
     for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         const uint64_t r0 = t * kXRows;
-        double dot[8], nb = 0.0;
+        double dot[QPT], nb = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dot[j] = 0.0;
+        for (int j = 0; j < QPT; ++j) dot[j] = 0.0;
         for (int c0 = 0; c0 < ds; c0 += kXChunk) {
             __syncthreads();  // the previous chunk has been consumed
             for (int i = tid; i < kXRows * (kXChunk / 4); i += 256) {  // coalesced: 32 consecutive float4 per row
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(256) void exact_dist_batch_kernel(int ds, const flo
                 if (r0 + r < n_rows) v = row_load4<CMP>(x, xh, ds, (uint32_t)(r0 + r), c0 / 4 + c4);
                 *reinterpret_cast<float4 *>(s_rows + r * kXPitch + 4 * c4) = v;
             }
-            for (int i = tid; i < kExactGroup * (kXChunk / 4); i += 256) {
+            for (int i = tid; i < 4 * QPT * (kXChunk / 4); i += 256) {
                 const int g = i / (kXChunk / 4), c4 = i % (kXChunk / 4);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (g < nq) v = *reinterpret_cast<const float4 *>(qpad + (size_t)grp.q[g] * ds + c0 + 4 * c4);
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(256) void exact_dist_batch_kernel(int ds, const flo
             }
             __syncthreads();
             const float *rw = s_rows + lr * kXPitch;
-            const float *qw = s_q + qg * 8 * kXChunk;
+            const float *qw = s_q + qg * QPT * kXChunk;
 #pragma unroll 2
             for (int i = 0; i < kXChunk / 4; ++i) {
                 const float4 c = *reinterpret_cast<const float4 *>(rw + 4 * i);
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(256) void exact_dist_batch_kernel(int ds, const flo
                 nb += (double)__fmul_rn(c.z, c.z);
                 nb += (double)__fmul_rn(c.w, c.w);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < QPT; ++j) {
                     const float4 a = *reinterpret_cast<const float4 *>(qw + j * kXChunk + 4 * i);  // same address in every lane
                     dot[j] += (double)__fmul_rn(a.x, c.x);
                     dot[j] += (double)__fmul_rn(a.y, c.y);
@@ -1023,8 +1025,8 @@ __global__ __launch_bounds__(256) void exact_dist_batch_kernel(int ds, const flo
         }
         if (r0 + lr < n_rows) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (qg * 8 + j < nq) dist[(size_t)(qg * 8 + j) * n_rows + r0 + lr] = __float_as_uint(dist_from_sums(dot[j], na[j], nb));
+            for (int j = 0; j < QPT; ++j)
+                if (qg * QPT + j < nq) dist[(size_t)(qg * QPT + j) * n_rows + r0 + lr] = __float_as_uint(dist_from_sums(dot[j], na[j], nb));
         }
     }
 }
@@ -1197,8 +1199,19 @@ hipError_t launch_exact_group(hipStream_t s, int k, int ds, const float *x, cons
         hipLaunchKernelGGL(xsel_init_kernel, dim3(1), dim3(kExactGroup), 0, s, kk, state);
         const uint64_t tiles = (n_rows + kXRows - 1) / kXRows;
         const unsigned blocks = (unsigned)(tiles < 2048 ? tiles : 2048);
-        if (x) hipLaunchKernelGGL(exact_dist_batch_kernel<false>, dim3(blocks), dim3(256), 0, s, ds, x, xh, n_rows, qpad, qnorm2, grp, dist);
-        else hipLaunchKernelGGL(exact_dist_batch_kernel<true>, dim3(blocks), dim3(256), 0, s, ds, x, xh, n_rows, qpad, qnorm2, grp, dist);
+#define MX_XDIST(CMP_, QPT_) hipLaunchKernelGGL((exact_dist_batch_kernel<CMP_, QPT_>), dim3(blocks), dim3(256), 0, s, ds, x, xh, n_rows, qpad, qnorm2, grp, dist)
+        if (x) {
+            if (grp.n <= 4) MX_XDIST(false, 1);
+            else if (grp.n <= 8) MX_XDIST(false, 2);
+            else if (grp.n <= 16) MX_XDIST(false, 4);
+            else MX_XDIST(false, 8);
+        } else {
+            if (grp.n <= 4) MX_XDIST(true, 1);
+            else if (grp.n <= 8) MX_XDIST(true, 2);
+            else if (grp.n <= 16) MX_XDIST(true, 4);
+            else MX_XDIST(true, 8);
+        }
+#undef MX_XDIST
         const unsigned slices = (unsigned)((n_rows + 4095) / 4096 < (uint64_t)kExactSlices ? (n_rows + 4095) / 4096 : (uint64_t)kExactSlices);
         const dim3 sg(slices ? slices : 1, grp.n);
         for (int pass = 0; pass < 3; ++pass) {
