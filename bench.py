@@ -476,7 +476,7 @@ def traffic_from_profile(rows_total: int, dim: int, world: int, scan: str):
            (768, "i8"): "scan8_768"}.get((dim, scan))
     if world != 1 or rows_total != 10_000_000 or tag is None:
         return None
-    for rnd in ("r3", "r2", "r1"):
+    for rnd in ("r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_traffic.json")
         if os.path.exists(path):
             try:
@@ -519,7 +519,7 @@ def roofline_of(st, scan: str, dim: int, batch: int, rows_total: int, world: int
         "traffic": traffic_from_profile(rows_total, dim, world, scan),
         "mfma_tflops": tflops,
         "mfma_frac": tflops / mfma_peak,
-        "power_note": "package power sits at its 1400 W cap during this kernel (profiles/r3_power_*.log)",
+        "power_note": "package power sits at its 1400 W cap during this kernel (profiles/r4_power_*.log)",
     }
 
 

@@ -86,9 +86,12 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
     if (my_tiles == 0) return;
     const int nk = p.k / kPK;
     const int total_kt = my_tiles * nk;
-    // Start-up skew (speed only): every workgroup has the same work, so without it all CUs write their 128 KiB output
-    // tiles at the same moments -- 32 MB bursts at HBM speed with every matrix pipe idle -- and stream nothing in
-    // between.  Workgroup (b >> 3) & 15 starts that many skew units (~0.5 us each) late.
+    // Start-up skew (a measurement knob, 0 in production): every workgroup has the same work, so all CUs write their
+    // 128 KiB output tiles at the same moments.  Spreading the starts (workgroup (b >> 3) & 15 starts that many units of
+    // ~0.5 us late) buys nothing, it only adds the idle time (profiles/r4_pgemm_skew.txt); neither does a blocked tile
+    // order (8 m-tiles x 4 n-tiles per window instead of row-major: the 1.67 GB the W1 launch fetches against 0.21 GB of
+    // operands come out of the Infinity Cache at no measurable cost) nor leaving the output stores in flight across the
+    // next k-tile's DMA wait (profiles/r4_pgemm_tile_order_and_wait.txt).
     for (int i = ((blockIdx.x >> 3) & 15) * skew; i > 0; --i) __builtin_amdgcn_s_sleep(16);
 
     // past the workgroup's last k-tile the descriptors get num_records = 0: the DMA operation still counts in vmcnt
@@ -429,7 +432,7 @@ hipError_t pgemm_attr() {
 }
 
 int g_pgemm_cus = 0;
-int g_pgemm_skew = 2;
+int g_pgemm_skew = 0;  // MEMEX_HIP_PGEMM_SKEW: measured 0 .. 8, 0 is the fastest (profiles/r4_pgemm_skew.txt)
 
 template <int EPI>
 hipError_t pgemm_go(hipStream_t s, const GemmParams &p) {

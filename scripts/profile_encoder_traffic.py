@@ -1,0 +1,42 @@
+"""HBM traffic per launch of the encoder's kernels (bge-base shape) from the FETCH_SIZE / WRITE_SIZE passes of
+scripts/profile_search.sh, next to what each launch has to move once (its operands and outputs at 131072 tokens).
+FETCH_SIZE KB x 1024 x 2 (gfx950 correction for 16-byte-per-lane streaming reads, MI355X_MICROARCH.md); WRITE_SIZE KB x 1024."""
+import collections, csv, glob, os, sys
+
+out = sys.argv[1]
+T, H, F = 131072, 768, 3072
+MB = 1e6
+algo = {  # bytes a launch must read + write once
+    "pgemm_kernel<2>": (T * H * 2 + 2 * H * H * 2, 2 * T * H * 2),          # QK projection: x, Wq|Wk -> q, k
+    "pgemm_kernel<4>": (T * H * 2 + H * H * 2, T * H * 2),                  # V projection
+    "pgemm_kernel<1>": (T * H * 2 + F * H * 2, T * F * 2),                  # W1 + GELU
+    "pgemm_kernel<5>": None,                                                # two shapes share the name: see the rows below
+    "ln_rows_kernel<32>": (T * H * 2, T * H * 2),
+    "attention_kernel<64>": (3 * T * H * 2, T * H * 2),
+}
+res = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    hits = glob.glob(os.path.join(out, "encpmc_" + c, "**", "*_counter_collection.csv"), recursive=True)
+    if not hits:
+        continue
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    durs = collections.defaultdict(dict)
+    for r in csv.DictReader(open(hits[0])):
+        name = r["Kernel_Name"].split("(")[0].replace("void mx::", "").replace("mx::", "").replace(" ", "")
+        per[name][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        durs[name][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    for name, d in per.items():
+        vals = sorted(d.values())
+        res[name][c] = (sum(vals) / len(vals), len(vals), vals[0], vals[-1], sum(durs[name].values()) / len(durs[name]))
+print(f"{'kernel':34s} {'n':>4s} {'fetch MB':>9s} {'write MB':>9s} {'total MB':>9s} {'must move MB':>13s} {'ratio':>6s} {'us (that pass)':>14s}")
+for name in sorted(res):
+    f = res[name].get("FETCH_SIZE"); w = res[name].get("WRITE_SIZE")
+    fb = f[0] * 1024 * 2 if f else 0.0
+    wb = w[0] * 1024 if w else 0.0
+    a = algo.get(name)
+    am = (a[0] + a[1]) if a else None
+    print(f"{name:34s} {f[1] if f else 0:4d} {fb / MB:9.1f} {wb / MB:9.1f} {(fb + wb) / MB:9.1f} {am / MB if am else float('nan'):13.1f} "
+          f"{(fb + wb) / am if am else float('nan'):6.2f} {f[4] if f else 0.0:14.1f}")
+    if name.startswith("pgemm_kernel<5>") and f:
+        print(f"{'':34s} (out-projection: must move {(2 * T * H * 2 + H * H * 2 + T * H * 2) / MB:.1f} MB; W2: {(T * F * 2 + T * H * 2 + H * F * 2 + T * H * 2) / MB:.1f} MB; "
+              f"fetch min / max over launches {f[2] * 2048 / MB:.1f} / {f[3] * 2048 / MB:.1f} MB)")

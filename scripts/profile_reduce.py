@@ -56,6 +56,14 @@ def main():
     if enc:
         with open(enc) as f, open(os.path.join(prof, f"{tag}_encoder_kernel_stats.csv"), "w") as g:
             g.write(f.read())
+    encb = find(os.path.join(out_dir, "enc_bge_stats"), "_kernel_stats.csv")
+    if encb:
+        with open(encb) as f, open(os.path.join(prof, f"{tag}_encoder_bge_kernel_stats.csv"), "w") as g:
+            g.write(f.read())
+    et = os.path.join(out_dir, "encoder_bge_traffic.txt")
+    if os.path.exists(et):
+        with open(et) as f, open(os.path.join(prof, f"{tag}_encoder_bge_traffic.txt"), "w") as g:
+            g.write(f.read())
     st768 = find(os.path.join(out_dir, "stats768"), "_kernel_stats.csv")
     if st768:
         with open(st768) as f, open(os.path.join(prof, f"{tag}_bench768_kernel_stats.csv"), "w") as g:
