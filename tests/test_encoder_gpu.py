@@ -226,16 +226,18 @@ def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, lib_built
     cos = _cos(out[sub].astype(np.float64), ref)
     assert (1.0 - cos).max() <= TOL, (kw, cos)
     # what the search sees: the cosines BETWEEN embeddings.  These weights put a large common component into every
-    # embedding (pairwise cosines ~0.96), so the row-wise cosine above is the easy half; the pairwise ones move by up to
-    # 1.3e-3 (measured: MiniLM-L6 shape, round 4) -- the price of bf16 activations on dimensions of magnitude 20-60, where
-    # a bf16 step is 0.125-0.25.  Bounded here at 2.5e-3 so that a regression shows; DESIGN.md section 4 states it.
+    # embedding (pairwise cosines ~0.96) and most of its energy into five dimensions of magnitude 20-60, where a bf16 step
+    # is 0.125-0.25: the row-wise cosine above is the easy half.  Measured (round 4): the pairwise cosines move by up to
+    # 1.3e-3 with mean pooling (256+ tokens average the rounding noise) and by ~1e-2 with CLS pooling (one token, twelve
+    # layers of bf16 hidden states; gemm_kernel and pgemm_kernel paths alike) -- the price of a bf16 residual stream under
+    # such outliers, stated in DESIGN.md section 4.  Bounded here so that a regression shows.
     o = out[sub].astype(np.float64)
     o /= np.linalg.norm(o, axis=1, keepdims=True)
     r = ref / np.linalg.norm(ref, axis=1, keepdims=True)
     pair = np.abs(o @ o.T - r @ r.T).max()
     print(f"checkpoint-like weights {kw['layers']}x{kw['hidden']} B={B} S={S}: max(1 - cos) = {(1.0 - cos).max():.2e}, "
           f"max |pairwise cosine error| = {pair:.2e}")
-    assert pair <= 2.5e-3, (kw, pair)
+    assert pair <= (2.5e-2 if cfg.pooling == "cls" else 2.5e-3), (kw, pair)
 
 
 def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
