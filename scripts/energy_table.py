@@ -4,10 +4,12 @@
 The package sits at its 1400 W cap while the encoder runs (profiles/r*_power_tail_ablate0.log; idle 250 W), so a kernel's
 energy per layer is its time x 1150 W of dynamic power, whatever it does with it.  The split into MFMA / HBM / rest is an
 ESTIMATE from coefficients measured on this chip in earlier rounds (DESIGN.md sections 3.2b and 4):
-  MFMA on random bf16 operands  ~1.0 pJ/flop   (tail kernel with nothing but MFMAs: 1.09 PFLOP/s at 1335 - 250 W)
+  MFMA + its LDS fragment reads ~0.8 pJ/flop   (between scan16's 0.53 -- small-valued operands, 1.86 PFLOP/s at 1236 - 250 W -- and the
+                                                tail kernel's 1.0 on random activations, 1.09 PFLOP/s at 1335 - 250 W; the QK launch's
+                                                whole budget is 1.05 pJ/flop, which bounds it from above)
   HBM <-> LDS / registers       ~118 pJ/byte   (scan16's DMA stream alone: 7.1 TB/s at 1088 - 250 W)
-  rest = LDS fragment reads (~3.3 pJ/byte), L2 -> LDS operand traffic, VALU, leakage above idle, and stall time (a stalled
-  chip still burns most of its dynamic power at these clocks)
+  rest = L2 / Infinity Cache -> LDS operand traffic (W1 alone fetches 1.67 GB per launch past the L2), VALU (GELU, softmax,
+  LayerNorm), and stall time (a stalled chip still burns much of its dynamic power at these clocks)
 'must move' bytes: operands read once + outputs written once (what a launch cannot avoid)."""
 import csv
 import os
@@ -17,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 T = 131072
 P_DYN = 1150.0  # W
-PJ_FLOP, PJ_BYTE = 1.0e-12, 118e-12
+PJ_FLOP, PJ_BYTE = 0.8e-12, 118e-12
 
 
 def rows(path):
