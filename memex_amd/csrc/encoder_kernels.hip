@@ -556,218 +556,330 @@ hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: attention.  grid = (query blocks of 256, heads, sequences); 8 waves x 32 queries.
-// The whole K ([keys][d]) and V^T ([d][keys]) of the (sequence, head) sit in LDS.  Scores are
-// computed TRANSPOSED (A = 32 keys, B = 32 queries) so that a lane owns one query: the running
-// max / sum and the rescale factor are lane-local, P converts to the PV B-operand without any
-// cross-lane movement, and O^T = V^T P^T accumulates with the query still in the lane.
-// At d = 32 the kernel is softmax(VALU)-bound by construction (128 MFMA flops per score), so the
-// VALU work per score is kept minimal: raw v_exp_f32, masking only in the tail key block, the
+// K3: attention.  grid = (1, heads / hpw, sequences); 16 waves x 32 queries (sequences of <= 512 tokens).
+// A workgroup walks hpw heads of its sequence.  K ([keys][d]) and V^T ([d][keys]) stream through LDS in STAGES of 256
+// keys, double-buffered, moved by LDS-DMA (global -> LDS, 1 KiB per wave-instruction, no registers): the DMA of stage
+// j+1 -- the other half of the keys, or the next head -- is issued when the barrier that ends stage j-1 has passed and
+// lands under the key loop of stage j; a counted s_waitcnt + ONE barrier per stage.  (Round 4: the form this replaces
+// loaded a head into registers, waited, wrote LDS, ran the loop; with the loop skipped a launch still took 209 of 341
+// us at d = 64 and 113 of 161 at d = 32 -- 805 / 403 MB at ~4 TB/s, none of it overlapped with the loop.  A register
+// prefetch of the next head under the loop needs 32 more VGPRs than the 128 a 16-wave workgroup has at d = 64.)
+// Scores are computed TRANSPOSED (A = 32 keys, B = 32 queries) so that a lane owns one query: the running max / sum and
+// the rescale factor are lane-local, P converts to the PV B-operand without any cross-lane movement, and O^T = V^T P^T
+// accumulates with the query still in the lane.  At d = 32 the kernel is softmax(VALU)-bound by construction (128 MFMA
+// flops per score), so the VALU work per score is kept minimal: raw v_exp_f32, masking only in the tail key block, the
 // O/l rescale only when some lane's running max actually grew.
-// V^T tile key order: inside every 16-key group the two middle 4-key groups are swapped
-// ([0-3, 8-11, 4-7, 12-15]) -- exactly the keys a lane's P registers hold for one k16 step -- so a
-// PV A-fragment is ONE ds_read_b128.
+// Key order: the lane that supplies A-row j of a score tile reads key row pi(j) (bits 2 and 3 of j swapped), so the 8
+// scores a lane holds for one k16 step of PV are 8 CONSECUTIVE keys and a PV A-fragment is ONE ds_read_b128 of the
+// V^T tile in natural key order (which is what a DMA can deliver).
+// LDS tiles are unpadded; the DMA's source side applies the swizzles that make the fragment reads conflict-free:
+//   K   row r (2D bytes):  16-byte chunk c at c ^ ((r / RW) & (CH - 1)), CH = D/8 chunks per row, RW = 128/D rows per 256 B
+//   V^T row f (512 bytes): 16-byte chunk c at c ^ (f & 15)
+// Rows >= len of q / k read as zero and the matching ctx stores are dropped by the buffer bounds check; V^T columns >=
+// len hold other tokens' (finite or not) values: the tail key block masks its V fragments along with its scores.
 // ---------------------------------------------------------------------------------------------
 constexpr int kAttnWaves = 16;
 constexpr int kAttnQ = kAttnWaves * 32;  // queries per workgroup
+constexpr int kAttnStage = 256;          // keys per stage
 
 template <int D>
-__global__ __launch_bounds__(kAttnWaves * 64, D == 32 ? 8 : 4) void attention_kernel(const bf16_t *__restrict__ q,
-                                                                    const bf16_t *__restrict__ k,
-                                                                    const bf16_t *__restrict__ vt, int ldvt,
-                                                                    const int32_t *__restrict__ cu,
-                                                                    const int32_t *__restrict__ lens, int hidden,
-                                                                    bf16_t *__restrict__ ctx, int safe_only) {
+__global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k,
+                                                                                     const bf16_t *__restrict__ vt, int ldvt,
+                                                                                     const int32_t *__restrict__ cu, const int32_t *__restrict__ lens,
+                                                                                     int hidden, bf16_t *__restrict__ ctx, int mode, int hpw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = kAttnWaves * 64;
-    constexpr int KP = D * 2 + 16;  // K row pitch (bytes)
-    const int b = blockIdx.z, hd = blockIdx.y, qb = blockIdx.x;
+    constexpr int RB = D * 2;                   // bytes of a K row
+    constexpr int CH = RB / 16;                 // 16-byte chunks per K row
+    constexpr int RW = 256 / RB;                // K rows per 256 bytes
+    constexpr int KBYTES = kAttnStage * RB;     // K tile of a stage; the V^T tile (D rows x 512 B) is as large
+    constexpr int SB = 2 * KBYTES;              // one stage buffer
+    constexpr int KI = D / 32;                  // DMA instructions per wave and tile
+    constexpr int NS = D / 32 * 4;              // ctx stores per head and lane
+    constexpr bool PFQ = true;                  // next head's q fragments loaded under the current head's last stage
+    const int b = blockIdx.z, hd0 = blockIdx.y * hpw;
     const int len = lens[b];
-    if (qb * kAttnQ >= len) return;
     const int tok0 = cu[b];
-    const int sb = (len + 31) / 32 * 32;  // keys rounded to MFMA blocks
-    const int VP = sb * 2 + 16;           // V^T row pitch (bytes)
-    char *ks = smem;
-    char *vs = smem + (size_t)sb * KP;
+    const int sb = (len + 31) / 32 * 32;        // keys rounded to MFMA blocks
+    const int nh = (sb + kAttnStage - 1) / kAttnStage;  // stages per head (1 or 2)
     const int tid = threadIdx.x;
-
-    // ---- stage K (rows >= len zero-filled) and V^T (keys >= len zero-filled, permuted key order)
-    constexpr int KC = D * 2 / 16;
-    for (int c = tid; c < sb * KC; c += NT) {
-        const int row = c / KC, cc = c % KC;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < len) v = *reinterpret_cast<const u32x4 *>(k + (size_t)(tok0 + row) * hidden + hd * D + cc * 8);
-        *reinterpret_cast<u32x4 *>(ks + row * KP + cc * 16) = v;
-    }
-    const int vc = sb / 8;
-    for (int c = tid; c < D * vc; c += NT) {
-        const int f = c / vc, kc = c % vc;  // 8 keys 8kc .. 8kc+7 of feature f
-        bf16x8 t = *reinterpret_cast<const bf16x8 *>(vt + (size_t)(hd * D + f) * ldvt + tok0 + kc * 8);
-        if (kc * 8 + 8 > len) {  // mask the tail so that 0 * garbage can never be NaN
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (kc * 8 + e >= len) t[e] = (__bf16)0.0f;
-        }
-        // 4-key groups g = 2*(kc&1), 2*(kc&1)+1 of the 16-key block kc>>1 -> physical (0,2) / (1,3)
-        char *dstrow = vs + f * VP + (kc >> 1) * 32;
-        bf16x4 lo = {t[0], t[1], t[2], t[3]}, hi = {t[4], t[5], t[6], t[7]};
-        *reinterpret_cast<bf16x4 *>(dstrow + (kc & 1) * 8) = lo;
-        *reinterpret_cast<bf16x4 *>(dstrow + 16 + (kc & 1) * 8) = hi;
-    }
-    __syncthreads();
-
-    const int lane = tid & 63, wave = tid >> 6;
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int q0 = qb * kAttnQ + wave * 32;
-    if (q0 >= len) return;
-    const int qi = q0 + l31;
+    const bool active = wave * 32 < len;  // wave-uniform; a wave without queries still stages
+    const int pitch = hidden * 2;
+    // MEMEX_HIP_ATTN_SAFE=2, 3, 4 (measurement only): no key loop; 3: no q loads and no ctx stores either; 4: no ctx stores
+    // 5: key loop only (no DMA traffic, no q loads, no ctx stores); 6: everything but the ctx stores
+    const int nkb_all = mode >= 2 && mode <= 4 ? 0 : sb / 32;
+    const bool q_live = mode != 3 && mode != 5, c_live = mode < 3, kv_live = mode != 5;
+    uint32_t *wg_redo = reinterpret_cast<uint32_t *>(smem + 2 * SB);
+    if (tid == 0) *wg_redo = 0u;
 
-    // Q^T B-fragments: lane (query l31, half h) holds q[query][ks*16 + 8h .. +8]
-    bf16x8 qf[D / 16];
+    // ---- one stage: K rows / V^T columns [256 half, 256 half + 256) of head hd -> buffer buf.  Every wave issues exactly
+    // 2 KI DMA operations per stage (rows >= len and key columns >= sb get an out-of-range offset: zeros, no traffic).
+    auto issue_stage = [&](int hd, int half, int buf) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(lane));  // per-lane offsets are derived here, per stage: ~10 VALU, no registers held
+        const __amdgpu_buffer_rsrc_t rs_k =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(k + (size_t)tok0 * hidden + hd * D), 0, kv_live ? (uint32_t)((len - 1) * pitch + RB) : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void *)(vt + (size_t)hd * D * ldvt + tok0), 0,
+                                                                               kv_live ? (uint32_t)(((size_t)D * ldvt - tok0) * 2) : 0u, 0x00020000);
+        const uint32_t dst = (uint32_t)(buf * SB + wave * KI * 1024);
 #pragma unroll
-    for (int s = 0; s < D / 16; ++s) {
-        if (qi < len)
-            qf[s] = *reinterpret_cast<const bf16x8 *>(q + (size_t)(tok0 + qi) * hidden + hd * D + s * 16 + h * 8);
-        else
+        for (int i = 0; i < KI; ++i) {
+            const int row = (wave * KI + i) * (1024 / RB) + lane / CH;
+            const int lc = (lane % CH) ^ ((row / RW) & (CH - 1));
+            const uint32_t vo = (uint32_t)((half * kAttnStage + row) * pitch + lc * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void_t *)(smem + dst + i * 1024), 16, vo, 0, 0, 0);
+        }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)0.0f;
-    }
-
-    f32x16 o[D / 32];
-#pragma unroll
-    for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
-    float m_run = -1e30f, l_run = 0.0f;
-    const int nkb = sb / 32;
-    const int full_blocks = len / 32;  // key blocks without padding keys
-
-    // SAFE: the textbook running maximum (max + cross-half exchange + compare per 32-key block, rescale when
-    // it grows).  !SAFE: NO shift at all, P = exp2(score) -- softmax is shift-invariant and P, l, O are floating
-    // point, so scores away from 0 only move the exponents; what can go wrong is exp2 overflowing (a score
-    // above 127; the pre-scaled logits of the models this runs stay within a few tens) or a whole row
-    // underflowing, and both leave the row sum outside (1e-30, 1e30), which sends the wave through the SAFE
-    // loop afterwards.  The max chain and the subtraction are 21 of ~105 VALU issue slots per block in a loop
-    // that is VALU-bound, and the max sits on the MFMA -> exp dependency chain.
-    auto key_loop = [&](auto safe_tag) __attribute__((always_inline)) {
-        constexpr bool SAFE = decltype(safe_tag)::value;
-        for (int kb = 0; kb < nkb; ++kb) {
-            // S^T tile: rows = keys kb*32 + (r&3) + 8*(r>>2) + 4h, col = query l31
-            f32x16 sc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < D / 16; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(ks + (kb * 32 + l31) * KP + s * 32 + h * 16);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
-            }
-            if (kb >= full_blocks) {  // wave-uniform: only the last block can hold padding keys
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    sc[r] = key < len ? sc[r] : -1e30f;  // reference: additive -10000 mask == exclusion in f32
-                }
-            }
-            // the softmax arithmetic is what bounds this kernel at d = 32 (VALU issue, not MFMA): keep it to
-            // v_max3 chains and packed f32 adds / subtracts (2 scores per instruction)
-            if (SAFE) {
-                float bm = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
-#pragma unroll
-                for (int r = 3; r < 15; r += 2) bm = fmaxf(fmaxf(bm, sc[r]), sc[r + 1]);
-                bm = fmaxf(bm, sc[15]);
-                bm = fmaxf(bm, __shfl_xor(bm, 32));
-                if (__builtin_amdgcn_ballot_w64(bm > m_run) != 0) {  // some query's max grew: rescale (rare later on)
-                    const float m_new = fmaxf(m_run, bm);
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    l_run *= alpha;
-                    m_run = m_new;
-#pragma unroll
-                    for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-                }
-            }
-            typedef __attribute__((ext_vector_type(2))) float f32x2;
-            const f32x2 mm = {m_run, m_run};
-            f32x2 ps2 = {0.0f, 0.0f};
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2 t = {sc[r], sc[r + 1]};
-                if (SAFE) t -= mm;
-                const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                sc[r] = e[0];
-                sc[r + 1] = e[1];
-                ps2 += e;
-            }
-            const float ps = ps2[0] + ps2[1];
-            l_run += ps;
-            // O^T += V^T P^T: k16 step s uses this lane's p[8s .. 8s+7] = keys 16s + 8(i>>2) + 4h + (i&3),
-            // stored contiguously in the permuted V^T tile at physical key offset 16s + 8h
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 pf;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s + e];
-#pragma unroll
-                for (int t = 0; t < D / 32; ++t) {
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(vs + (t * 32 + l31) * VP + (kb * 32 + 16 * s + 8 * h) * 2);
-                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
-                }
-            }
+        for (int i = 0; i < KI; ++i) {
+            const int f = (wave * KI + i) * 2 + (lane >> 5);
+            const int lc = (lane & 31) ^ (f & 15);
+            const int key = half * kAttnStage + lc * 8;
+            const uint32_t vo = key < sb ? (uint32_t)(f * ldvt * 2 + key * 2) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_t *)(smem + dst + KBYTES + i * 1024), 16, vo, 0, 0, 0);
         }
     };
-    if (!safe_only) key_loop(std::false_type{});
-    // a row sum outside (1e-30, 1e30): an exp2 (or P * v) may have overflowed, or the whole row underflowed
-    // -> redo with the running maximum (the comparison is false for NaN as well)
-    const float l_row = l_run + __shfl_xor(l_run, 32);
-    if (safe_only || __builtin_amdgcn_ballot_w64(!(l_row > 1.0e-30f && l_row < 1.0e30f)) != 0) {
+    // Q^T B-fragments: lane (query l31, half h) holds q[query][s*16 + 8h .. +8] (zero for queries >= len)
+    // (live = false: a descriptor of 0 bytes -- the operation counts in vmcnt and touches no memory; the control flow around
+    // the loads, the stores and their waits stays free of conditions, see the waits below)
+    auto load_q = [&](int hd, bool live, bf16x8 (&dst)[D / 16]) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(lane));
+        const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void *)(q + (size_t)tok0 * hidden + hd * D), 0,
+                                                                               live ? (uint32_t)((len - 1) * pitch + RB) : 0u, 0x00020000);
+        const int vo = (wave * 32 + (lane & 31)) * pitch + (lane >> 5) * 16;
 #pragma unroll
-        for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
-        m_run = -1e30f;
-        l_run = 0.0f;
-        key_loop(std::true_type{});
-    }
-    l_run += __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_run;
-    if (qi < len) {
-        // O^T layout: col = query l31, row = dv (r&3) + 8*(r>>2) + 4h (+32t): 4 consecutive dv per group
-        bf16_t *dst = ctx + (size_t)(tok0 + qi) * hidden + hd * D;
-#pragma unroll
-        for (int t = 0; t < D / 32; ++t)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                bf16x4 pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[t][rg * 4 + e] * inv);
-                *reinterpret_cast<bf16x4 *>(dst + t * 32 + 8 * rg + 4 * h) = pk;
+        for (int s = 0; s < D / 16; ++s) dst[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_q, vo + s * 32, 0, 0));
+    };
+
+    // fragment read offsets inside a stage buffer (see the swizzles above); k16 step s and key block kb are XORed / added in
+    const int pr = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);  // pi(l31)
+    const uint32_t k_frag = (uint32_t)(pr * RB + ((h ^ ((pr / RW) & (CH - 1))) << 4));
+    const uint32_t v_frag = (uint32_t)(KBYTES + l31 * 512 + ((h ^ (l31 & 15)) << 4));
+    const int full_blocks = len / 32;  // key blocks without padding keys
+
+    uint32_t my_redo = 0u;  // heads whose row sums left (1e-30, 1e30) in this wave: redone with the running maximum
+    // ---- one pass over the heads in `heads` (bit i = head hd0 + i); a wave computes the heads in `mine`.
+    // SAFE: the textbook running maximum (max + cross-half exchange + compare per 32-key block, rescale when it grows).
+    // !SAFE: NO shift at all, P = exp2(score) -- softmax is shift-invariant and P, l, O are floating point, so scores away
+    // from 0 only move the exponents; what can go wrong is exp2 overflowing (a score above 127; the pre-scaled logits of
+    // the models this runs stay within a few tens) or a whole row underflowing, and both leave the row sum outside
+    // (1e-30, 1e30), which puts the head on the wave's redo list.  The max chain and the subtraction are 21 of ~105 VALU
+    // issue slots per block, and the max sits on the MFMA -> exp dependency chain.
+    auto pass = [&](auto safe_tag, const uint32_t heads, const uint32_t mine) __attribute__((always_inline)) {
+        constexpr bool SAFE = decltype(safe_tag)::value;
+        if (heads == 0u) return;
+        uint32_t dm = heads;  // DMA cursor: heads not yet fully issued, half of the next stage, its buffer
+        int dhalf = 0, dbuf = 0;
+        auto issue_next = [&]() __attribute__((always_inline)) {
+            if (dm == 0u) return;
+            issue_stage(hd0 + __builtin_ctz(dm), dhalf, dbuf);
+            dbuf ^= 1;
+            if (++dhalf == nh) {
+                dhalf = 0;
+                dm &= dm - 1u;
             }
-    }
+        };
+        uint32_t cm = heads;  // compute cursor
+        int chalf = 0, cbuf = 0;
+        bf16x8 qf[D / 16], qn[D / 16];
+        f32x16 o[D / 32];
+        float m_run = -1e30f, l_run = 0.0f;
+        issue_next();
+        load_q(hd0 + __builtin_ctz(cm), q_live, qf);
+        // Waits for a stage's DMA are the builtin, not inline asm: the compiler's wait-count pass must know that the q
+        // fragments have landed as well, or it waits for them -- and with them for the DMA just issued -- at their first
+        // use in the key loop.  For the same reason the loads, the stores and the wait that leaves the stores in flight sit
+        // in one block under one condition (with more conditions hipcc's control flow grows paths on which its model
+        // sees a q load without a wait).
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        asm volatile("" ::: "memory");
+#pragma unroll 1
+        while (cm != 0u) {
+            const int hi = __builtin_ctz(cm);
+            const bool last_half = chalf == nh - 1;
+            const bool mine_now = (mine >> hi) & 1u;
+            // this wave's part of the stage's tiles has landed (the wait at the end of the previous trip) -> everybody's has,
+            // and every wave is done with the other buffer (a bare s_barrier: __syncthreads() would put s_waitcnt vmcnt(0)
+            // in front of it and wait for the ctx stores as well)
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_next();
+            const uint32_t rest = cm & (cm - 1u);
+            const int hd_next = hd0 + (rest != 0u ? __builtin_ctz(rest) : hi);
+            if (PFQ && chalf == 0) load_q(hd_next, rest != 0u && q_live, qn);  // (first stage: the ctx stores load the last one)
+            if (chalf == 0) {
+#pragma unroll
+                for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+                m_run = -1e30f;
+                l_run = 0.0f;
+            }
+            const int kb0 = chalf * (kAttnStage / 32);
+            const int nkb = mine_now && active ? min(nkb_all - kb0, kAttnStage / 32) : 0;
+            const char *kt = smem + cbuf * SB;
+            // one block of 32 keys; TAIL: the block holds padding keys (only a head's last block can), masked in the scores
+            // and in the V fragments -- a separate instance, so that the common one is one straight basic block
+            auto key_block = [&](const int kbl, auto tail_tag) __attribute__((always_inline)) {
+                constexpr bool TAIL = decltype(tail_tag)::value;
+                const int kb = kb0 + kbl;
+                // S^T tile: A-row j = (r&3) + 8*(r>>2) + 4h holds key kb*32 + pi(j) = kb*32 + 16*(r>>3) + 8h + (r&7); col = query l31
+                f32x16 sc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < D / 16; ++s) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kt + (k_frag ^ (uint32_t)(s * 32)) + kbl * 32 * RB);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
+                }
+                const int rem = len - kb * 32 - 8 * h;  // this lane's keys 16 (r>>3) + (r&7) < rem are real
+                if (TAIL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] = 16 * (r >> 3) + (r & 7) < rem ? sc[r] : -1e30f;  // reference: additive -10000 mask == exclusion in f32
+                }
+                if (SAFE) {
+                    float bm = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+                    for (int r = 3; r < 15; r += 2) bm = fmaxf(fmaxf(bm, sc[r]), sc[r + 1]);
+                    bm = fmaxf(bm, sc[15]);
+                    bm = fmaxf(bm, __shfl_xor(bm, 32));
+                    if (__builtin_amdgcn_ballot_w64(bm > m_run) != 0) {  // some query's max grew: rescale (rare later on)
+                        const float m_new = fmaxf(m_run, bm);
+                        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                        l_run *= alpha;
+                        m_run = m_new;
+#pragma unroll
+                        for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                    }
+                }
+                typedef __attribute__((ext_vector_type(2))) float f32x2;
+                const f32x2 mm = {m_run, m_run};
+                f32x2 ps2 = {0.0f, 0.0f};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 t = {sc[r], sc[r + 1]};
+                    if (SAFE) t -= mm;
+                    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    sc[r] = e[0];
+                    sc[r + 1] = e[1];
+                    ps2 += e;
+                }
+                l_run += ps2[0] + ps2[1];
+                // O^T += V^T P^T: k16 step s uses this lane's p[8s .. 8s+7] = keys kb*32 + 16s + 8h + (0..7)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s + e];
+#pragma unroll
+                    for (int t = 0; t < D / 32; ++t) {
+                        bf16x8 vf = *reinterpret_cast<const bf16x8 *>(kt + (v_frag ^ (uint32_t)((kbl & 3) * 64 + s * 32)) + (kbl >> 2) * 256 +
+                                                                      t * 32 * 512);
+                        if (TAIL) {  // 0 * (another token's value, possibly not finite) must stay 0
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (16 * s + e >= rem) vf[e] = (__bf16)0.0f;
+                        }
+                        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
+                    }
+                }
+            };
+            const int nfull = max(0, min(full_blocks - kb0, nkb));
+            for (int kbl = 0; kbl < nfull; ++kbl) key_block(kbl, std::false_type{});
+            for (int kbl = nfull; kbl < nkb; ++kbl) key_block(kbl, std::true_type{});
+            if (last_half) {
+                // a row sum outside (1e-30, 1e30): an exp2 (or P * v) may have overflowed, or the whole row underflowed
+                // -> redo with the running maximum (the comparison is false for NaN as well)
+                const float l_row = l_run + __shfl_xor(l_run, 32);
+                const bool bad = !SAFE && mode == 0 && active && __builtin_amdgcn_ballot_w64(!(l_row > 1.0e-30f && l_row < 1.0e30f)) != 0;
+                if (bad) my_redo |= 1u << hi;
+                const float inv = 1.0f / l_row;
+                // next head's q (before the ctx stores: the wait for qn must not cover them)
+                if (PFQ) {
+#pragma unroll
+                    for (int s = 0; s < D / 16; ++s) qf[s] = qn[s];
+                } else {
+                    load_q(hd_next, rest != 0u && q_live, qf);
+                }
+                // O^T layout: col = query l31, row = dv (r&3) + 8*(r>>2) + 4h (+32t): 4 consecutive dv per group
+                asm volatile("" : "+v"(lane));
+                const int vo = (wave * 32 + (lane & 31)) * pitch + (lane >> 5) * 8;
+                const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(ctx + (size_t)tok0 * hidden + (hd0 + hi) * D), 0, mine_now && !bad && c_live ? (uint32_t)((len - 1) * pitch + RB) : 0u, 0x00020000);
+#pragma unroll
+                for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[t][rg * 4 + e] * inv);
+                        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs_c, vo + (t * 32 + 8 * rg) * 2, 0, 0);
+                    }
+                // the next stage's tiles (issued before this stage's key loop) have landed; the stores stay in flight
+                __builtin_amdgcn_s_waitcnt(0x0F70 | NS);  // vmcnt(NS)
+                cm = rest;
+                chalf = 0;
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                chalf = 1;
+            }
+            asm volatile("" ::: "memory");
+            cbuf ^= 1;
+        }
+    };
+
+    const uint32_t all = hpw >= 32 ? 0xFFFFFFFFu : (1u << hpw) - 1u;
+    if (mode != 1) pass(std::false_type{}, all, all);
+    else my_redo = all;  // MEMEX_HIP_ATTN_SAFE=1: everything through the running-maximum loop
+    if (mode >= 2) return;
+    // heads some wave of this workgroup has to redo (rare): staged again by everybody, computed by the waves that asked
+    if (my_redo != 0u && (tid & 63) == 0) __hip_atomic_fetch_or(wg_redo, my_redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    const uint32_t redo = __builtin_amdgcn_readfirstlane(*wg_redo);
+    pass(std::true_type{}, redo, my_redo);
 }
 
-static size_t attn_lds(int max_len, int d) {
-    const int sb = (max_len + 31) / 32 * 32;
-    return (size_t)sb * (d * 2 + 16) + (size_t)d * (sb * 2 + 16);
-}
+static size_t attn_lds(int d) { return (size_t)2 * 2 * kAttnStage * d * 2 + 16; }
 
 hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt,
                             const int32_t *cu, const int32_t *lens, int B, int max_len, int heads, int d_head,
                             int hidden, bf16_t *ctx) {
-    if (max_len > 512 || max_len < 1) return hipErrorInvalidValue;
-    dim3 grid((max_len + kAttnQ - 1) / kAttnQ, heads, B);
-    const size_t lds = attn_lds(max_len, d_head);
-    // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path)
-    const int safe_only = [] {
+    if (max_len > kAttnQ || max_len < 1 || (d_head != 32 && d_head != 64)) return hipErrorInvalidValue;
+    if ((size_t)d_head * ldvt * 2 > 0xFFFFFFF0ull || (size_t)kAttnQ * hidden * 2 > 0x7FFFFFFFull) return hipErrorInvalidValue;  // 32-bit buffer offsets
+    // heads per workgroup: as many as keep every CU busy (d = 64: one 16-wave workgroup fills a CU's LDS, d = 32: two),
+    // a divisor of `heads`, at most 16 (the redo masks); MEMEX_HIP_ATTN_HPW overrides
+    static const int n_cu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }();
+    static const int hpw_env = [] {
+        const char *ev = getenv("MEMEX_HIP_ATTN_HPW");
+        return ev ? atoi(ev) : 0;
+    }();
+    const long want = (long)n_cu;
+    int hpw = 1;
+    for (int c = heads < 16 ? heads : 16; c >= 1; --c)
+        if (heads % c == 0 && (long)B * (heads / c) >= want) {
+            hpw = c;
+            break;
+        }
+    if (hpw_env > 0 && hpw_env <= 16 && heads % hpw_env == 0) hpw = hpw_env;
+    dim3 grid(1, heads / hpw, B);
+    const size_t lds = attn_lds(d_head);
+    // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path); =2: no key loop (measurement)
+    const int mode = [] {
         const char *ev = getenv("MEMEX_HIP_ATTN_SAFE");
-        return ev && ev[0] == '1' ? 1 : 0;
+        return ev ? atoi(ev) : 0;
     }();
     if (d_head == 32)
-        hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, safe_only);
-    else if (d_head == 64)
-        hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, safe_only);
+        hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
     else
-        return hipErrorInvalidValue;
+        hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
     return hipGetLastError();
 }
 
@@ -836,10 +948,10 @@ hipError_t encoder_kernels_setup() {
     if ((e = gemm_attr<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>()) != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<32>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(512, 32));
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(32));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<64>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(512, 64));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(64));
 }
 
 }  // namespace mx

@@ -1,0 +1,18 @@
+#!/bin/bash
+# attention kernels: staging cost by access pattern (MEMEX_HIP_ATTN_SAFE modes >= 2 skip the key loop; + 16 / 48 address
+# q, k / q, k, ctx head-major: timing only, results are garbage) and heads per workgroup
+mkdir -p gpurun_out; out=$GRAFT_REPO_ROOT/gpurun_out/r4_attn3.txt; : > $out
+cd /tmp && export TMPDIR=/tmp
+run() {  # model safe hpw
+rm -rf /tmp/st; MEMEX_HIP_ATTN_SAFE=$2 MEMEX_HIP_ATTN_HPW=$3 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -- python $GRAFT_REPO_ROOT/scripts/gpu_encoder_prof.py $1 > /dev/null 2>&1
+python - $1 $2 $3 >> $out <<'PY'
+import csv, glob, sys
+f = glob.glob("/tmp/st/**/*_kernel_stats.csv", recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if "attention" in r["Name"]: print("%s SAFE=%s HPW=%s" % tuple(sys.argv[1:4]), r["Name"].split("(")[0][:40], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
+PY
+}
+for safe in 0 2 3 18 19 50; do run bge $safe 0; done
+for hpw in 1 2 3 6; do run bge 0 $hpw; run l6 0 $hpw; done
+for safe in 2 3 18 50; do run l6 $safe 0; done
+cat $out
