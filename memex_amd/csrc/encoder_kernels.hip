@@ -582,19 +582,20 @@ constexpr int kAttnWaves = 16;
 constexpr int kAttnQ = kAttnWaves * 32;  // queries per workgroup
 constexpr int kAttnStage = 256;          // keys per stage
 
-template <int D>
+template <int DH, int HP>
 __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k,
                                                                                      const bf16_t *__restrict__ vt, int ldvt,
                                                                                      const int32_t *__restrict__ cu, const int32_t *__restrict__ lens,
                                                                                      int hidden, bf16_t *__restrict__ ctx, int mode, int hpw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = DH * HP;                  // features per stage: HP adjacent heads of DH (a "head group": rows of 2D bytes)
     constexpr int RB = D * 2;                   // bytes of a K row
     constexpr int CH = RB / 16;                 // 16-byte chunks per K row
     constexpr int RW = 256 / RB;                // K rows per 256 bytes
     constexpr int KBYTES = kAttnStage * RB;     // K tile of a stage; the V^T tile (D rows x 512 B) is as large
     constexpr int SB = 2 * KBYTES;              // one stage buffer
     constexpr int KI = D / 32;                  // DMA instructions per wave and tile
-    constexpr int NS = D / 32 * 4;              // ctx stores per head and lane
+    constexpr int NS = D / 32 * 2;              // ctx stores per head group and lane
     constexpr bool PFQ = true;                  // next head's q fragments loaded under the current head's last stage
     const int b = blockIdx.z, hd0 = blockIdx.y * hpw;
     const int len = lens[b];
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
     // !SAFE: NO shift at all, P = exp2(score) -- softmax is shift-invariant and P, l, O are floating point, so scores away
     // from 0 only move the exponents; what can go wrong is exp2 overflowing (a score above 127; the pre-scaled logits of
     // the models this runs stay within a few tens) or a whole row underflowing, and both leave the row sum outside
-    // (1e-30, 1e30), which puts the head on the wave's redo list.  The max chain and the subtraction are 21 of ~105 VALU
+    // (1e-30, 1e30), which puts the head (group) on the wave's redo list.  The max chain and the subtraction are 21 of ~105 VALU
     // issue slots per block, and the max sits on the MFMA -> exp dependency chain.
     auto pass = [&](auto safe_tag, const uint32_t heads, const uint32_t mine) __attribute__((always_inline)) {
         constexpr bool SAFE = decltype(safe_tag)::value;
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
         int chalf = 0, cbuf = 0;
         bf16x8 qf[D / 16], qn[D / 16];
         f32x16 o[D / 32];
-        float m_run = -1e30f, l_run = 0.0f;
+        float m_run[HP], l_run[HP];
         issue_next();
         load_q(hd0 + __builtin_ctz(cm), q_live, qf);
         // Waits for a stage's DMA are the builtin, not inline asm: the compiler's wait-count pass must know that the q
@@ -713,8 +714,11 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                 for (int t = 0; t < D / 32; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
-                m_run = -1e30f;
-                l_run = 0.0f;
+#pragma unroll
+                for (int hh = 0; hh < HP; ++hh) {
+                    m_run[hh] = -1e30f;
+                    l_run[hh] = 0.0f;
+                }
             }
             const int kb0 = chalf * (kAttnStage / 32);
             const int nkb = mine_now && active ? min(nkb_all - kb0, kAttnStage / 32) : 0;
@@ -724,16 +728,18 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
             auto key_block = [&](const int kbl, auto tail_tag) __attribute__((always_inline)) {
                 constexpr bool TAIL = decltype(tail_tag)::value;
                 const int kb = kb0 + kbl;
+                const int rem = len - kb * 32 - 8 * h;  // this lane's keys 16 (r>>3) + (r&7) < rem are real
+#pragma unroll
+                for (int hh = 0; hh < HP; ++hh) {
                 // S^T tile: A-row j = (r&3) + 8*(r>>2) + 4h holds key kb*32 + pi(j) = kb*32 + 16*(r>>3) + 8h + (r&7); col = query l31
                 f32x16 sc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
 #pragma unroll
-                for (int s = 0; s < D / 16; ++s) {
+                for (int s = hh * (DH / 16); s < (hh + 1) * (DH / 16); ++s) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kt + (k_frag ^ (uint32_t)(s * 32)) + kbl * 32 * RB);
                     sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
                 }
-                const int rem = len - kb * 32 - 8 * h;  // this lane's keys 16 (r>>3) + (r&7) < rem are real
                 if (TAIL) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sc[r] = 16 * (r >> 3) + (r & 7) < rem ? sc[r] : -1e30f;  // reference: additive -10000 mask == exclusion in f32
@@ -744,19 +750,19 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                     for (int r = 3; r < 15; r += 2) bm = fmaxf(fmaxf(bm, sc[r]), sc[r + 1]);
                     bm = fmaxf(bm, sc[15]);
                     bm = fmaxf(bm, __shfl_xor(bm, 32));
-                    if (__builtin_amdgcn_ballot_w64(bm > m_run) != 0) {  // some query's max grew: rescale (rare later on)
-                        const float m_new = fmaxf(m_run, bm);
-                        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                        l_run *= alpha;
-                        m_run = m_new;
+                    if (__builtin_amdgcn_ballot_w64(bm > m_run[hh]) != 0) {  // some query's max grew: rescale (rare later on)
+                        const float m_new = fmaxf(m_run[hh], bm);
+                        const float alpha = __builtin_amdgcn_exp2f(m_run[hh] - m_new);
+                        l_run[hh] *= alpha;
+                        m_run[hh] = m_new;
 #pragma unroll
-                        for (int t = 0; t < D / 32; ++t)
+                        for (int t = hh * (DH / 32); t < (hh + 1) * (DH / 32); ++t)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
                     }
                 }
                 typedef __attribute__((ext_vector_type(2))) float f32x2;
-                const f32x2 mm = {m_run, m_run};
+                const f32x2 mm = {m_run[hh], m_run[hh]};
                 f32x2 ps2 = {0.0f, 0.0f};
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                     sc[r + 1] = e[1];
                     ps2 += e;
                 }
-                l_run += ps2[0] + ps2[1];
+                l_run[hh] += ps2[0] + ps2[1];
                 // O^T += V^T P^T: k16 step s uses this lane's p[8s .. 8s+7] = keys kb*32 + 16s + 8h + (0..7)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -775,7 +781,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s + e];
 #pragma unroll
-                    for (int t = 0; t < D / 32; ++t) {
+                    for (int t = hh * (DH / 32); t < (hh + 1) * (DH / 32); ++t) {
                         bf16x8 vf = *reinterpret_cast<const bf16x8 *>(kt + (v_frag ^ (uint32_t)((kbl & 3) * 64 + s * 32)) + (kbl >> 2) * 256 +
                                                                       t * 32 * 512);
                         if (TAIL) {  // 0 * (another token's value, possibly not finite) must stay 0
@@ -786,6 +792,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                         o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
                     }
                 }
+                }
             };
             const int nfull = max(0, min(full_blocks - kb0, nkb));
             for (int kbl = 0; kbl < nfull; ++kbl) key_block(kbl, std::false_type{});
@@ -793,10 +800,16 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
             if (last_half) {
                 // a row sum outside (1e-30, 1e30): an exp2 (or P * v) may have overflowed, or the whole row underflowed
                 // -> redo with the running maximum (the comparison is false for NaN as well)
-                const float l_row = l_run + __shfl_xor(l_run, 32);
-                const bool bad = !SAFE && mode == 0 && active && __builtin_amdgcn_ballot_w64(!(l_row > 1.0e-30f && l_row < 1.0e30f)) != 0;
+                float inv[HP];
+                bool bad = false;
+#pragma unroll
+                for (int hh = 0; hh < HP; ++hh) {
+                    const float l_row = l_run[hh] + __shfl_xor(l_run[hh], 32);
+                    bad = bad || __builtin_amdgcn_ballot_w64(!(l_row > 1.0e-30f && l_row < 1.0e30f)) != 0;
+                    inv[hh] = 1.0f / l_row;
+                }
+                bad = bad && !SAFE && mode == 0 && active;
                 if (bad) my_redo |= 1u << hi;
-                const float inv = 1.0f / l_row;
                 // next head's q (before the ctx stores: the wait for qn must not cover them)
                 if (PFQ) {
 #pragma unroll
@@ -804,20 +817,33 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                 } else {
                     load_q(hd_next, rest != 0u && q_live, qf);
                 }
-                // O^T layout: col = query l31, row = dv (r&3) + 8*(r>>2) + 4h (+32t): 4 consecutive dv per group
+                // O^T layout: col = query l31, row = dv (r&3) + 8*(r>>2) + 4h (+32t): 4 consecutive dv per register group.  The two
+                // halves of the wave trade groups (v_permlane32_swap: lanes 32-63 of one register <-> lanes 0-31 of another), after
+                // which lane (l31, h) holds dv 16 rgp + 8h .. + 7 of its row: 16-byte stores, half as many (the issue of the
+                // 8-byte ones -- 32 lines touched per instruction -- cost 19 us of a 246 us launch at d = 64)
                 asm volatile("" : "+v"(lane));
-                const int vo = (wave * 32 + (lane & 31)) * pitch + (lane >> 5) * 8;
+                const int vo = (wave * 32 + (lane & 31)) * pitch + (lane >> 5) * 16;
                 const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
                     (void *)(ctx + (size_t)tok0 * hidden + (hd0 + hi) * D), 0, mine_now && !bad && c_live ? (uint32_t)((len - 1) * pitch + RB) : 0u, 0x00020000);
 #pragma unroll
                 for (int t = 0; t < D / 32; ++t)
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        bf16x4 pk;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(o[t][rg * 4 + e] * inv);
+                    for (int rgp = 0; rgp < 2; ++rgp) {
                         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs_c, vo + (t * 32 + 8 * rg) * 2, 0, 0);
+                        u32x2 pa, pb;  // groups 2 rgp, 2 rgp + 1
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                            const float sc_ = inv[t / (DH / 32)];
+                            const bf16x2 a2 = {(__bf16)(o[t][rgp * 8 + 2 * e] * sc_), (__bf16)(o[t][rgp * 8 + 2 * e + 1] * sc_)};
+                            const bf16x2 b2 = {(__bf16)(o[t][rgp * 8 + 4 + 2 * e] * sc_), (__bf16)(o[t][rgp * 8 + 4 + 2 * e + 1] * sc_)};
+                            pa[e] = __builtin_bit_cast(unsigned int, a2);
+                            pb[e] = __builtin_bit_cast(unsigned int, b2);
+                        }
+                        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(pa[0], pb[0], false, false);
+                        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pa[1], pb[1], false, false);
+                        const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, vo + (t * 32 + 16 * rgp) * 2, 0, 0);
                     }
                 // the next stage's tiles (issued before this stage's key loop) have landed; the stores stay in flight
                 __builtin_amdgcn_s_waitcnt(0x0F70 | NS);  // vmcnt(NS)
@@ -861,25 +887,36 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
         const char *ev = getenv("MEMEX_HIP_ATTN_HPW");
         return ev ? atoi(ev) : 0;
     }();
+    // d = 32: two adjacent heads per stage (q / k / ctx rows in 128-byte pieces instead of 64: 403 MB per pass of 131k tokens
+    // took 111-118 us alone in 64-byte pieces, 87-93 in 128-byte ones; the launch itself is bound by its exp2: 166 us either way;
+    // MEMEX_HIP_ATTN_PAIR=0: one head per stage)
+    const bool pair_env = [] {
+        const char *ev = getenv("MEMEX_HIP_ATTN_PAIR");
+        return !(ev && ev[0] == '0');
+    }();
+    const bool pair = d_head == 32 && heads % 2 == 0 && pair_env;
+    const int groups = pair ? heads / 2 : heads;  // head groups: what a stage holds
     const long want = (long)n_cu;
     int hpw = 1;
-    for (int c = heads < 16 ? heads : 16; c >= 1; --c)
-        if (heads % c == 0 && (long)B * (heads / c) >= want) {
+    for (int c = groups < 16 ? groups : 16; c >= 1; --c)
+        if (groups % c == 0 && (long)B * (groups / c) >= want) {
             hpw = c;
             break;
         }
-    if (hpw_env > 0 && hpw_env <= 16 && heads % hpw_env == 0) hpw = hpw_env;
-    dim3 grid(1, heads / hpw, B);
-    const size_t lds = attn_lds(d_head);
+    if (hpw_env > 0 && hpw_env <= 16 && groups % hpw_env == 0) hpw = hpw_env;
+    dim3 grid(1, groups / hpw, B);
+    const size_t lds = attn_lds(pair ? 64 : d_head);
     // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path); =2: no key loop (measurement)
     const int mode = [] {
         const char *ev = getenv("MEMEX_HIP_ATTN_SAFE");
         return ev ? atoi(ev) : 0;
     }();
-    if (d_head == 32)
-        hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
+    if (d_head == 32 && pair)
+        hipLaunchKernelGGL((attention_kernel<32, 2>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
+    else if (d_head == 32)
+        hipLaunchKernelGGL((attention_kernel<32, 1>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
     else
-        hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
+        hipLaunchKernelGGL((attention_kernel<64, 1>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
     return hipGetLastError();
 }
 
@@ -947,10 +984,13 @@ hipError_t encoder_kernels_setup() {
     if ((e = gemm_attr<EPI_VT, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>()) != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<32>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<32, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(32));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<64>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<32, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(64));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<64, 1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(64));
 }
 

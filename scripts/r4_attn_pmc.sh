@@ -1,12 +1,12 @@
 #!/bin/bash
 # SQ counters of the encoder kernels (attention in particular): where do the wave-cycles go?
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/attn_pmc_bge; rm -rf $OUT; mkdir -p $OUT
+OUT=$ROOT/gpurun_out/attn_pmc_${MODEL:-bge}${TAG}; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python $ROOT/scripts/gpu_encoder_prof.py bge > /dev/null 2> $OUT/p$i.log
+  timeout 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python $ROOT/scripts/gpu_encoder_prof.py ${MODEL:-bge} > /dev/null 2> $OUT/p$i.log
 done
 python - $OUT <<'PY'
 import csv, glob, os, sys

@@ -252,9 +252,9 @@ def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
     from oracle import bert_oracle
     cfg = EncoderConfig(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000)
     rng = np.random.default_rng(21)
-    B, S = 6, 256
+    B, S = 6, 512  # (keys stream through LDS in stages of 256: one-stage and two-stage sequences, ragged tails in either)
     ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
-    lens = np.array([256, 200, 97, 256, 33, 160], dtype=np.int32)
+    lens = np.array([512, 200, 97, 257, 33, 480], dtype=np.int32)
     for scale in (1.0, 4.0, 24.0):  # scores of a few units / of +-60 (fast path, some rows near its limits) / of several hundred
         w = synthetic_weights(cfg, 21)
         for name in list(w):
@@ -274,6 +274,19 @@ def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
                 assert (1.0 - cos).max() <= TOL, cos
         cos = (outs[0] * outs[1]).sum(1) / np.linalg.norm(outs[0], axis=1) / np.linalg.norm(outs[1], axis=1)
         assert (1.0 - cos).max() <= 1e-4, (scale, cos)
+        # d = 32 stages two adjacent heads together by default; one head per stage does the same arithmetic per head: the
+        # same bits -- except that a redo takes both heads of a pair through the running-maximum loop (scale 4)
+        monkeypatch.setenv("MEMEX_HIP_ATTN_PAIR", "0")
+        for i, safe in enumerate(("0", "1")):
+            monkeypatch.setenv("MEMEX_HIP_ATTN_SAFE", safe)
+            with Encoder(cfg, w) as enc:
+                o = enc.encode(ids, lens)
+            if scale == 4.0 and safe == "0":
+                cos = (o * outs[i]).sum(1) / np.linalg.norm(o, axis=1) / np.linalg.norm(outs[i], axis=1)
+                assert (1.0 - cos).max() <= 1e-4, (scale, cos)
+            else:
+                assert np.array_equal(o, outs[i]), (scale, safe)
+        monkeypatch.delenv("MEMEX_HIP_ATTN_PAIR")
 
 
 def test_embedder_batches_concurrent_requests(lib_built):
