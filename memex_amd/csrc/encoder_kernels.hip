@@ -615,24 +615,27 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
     uint32_t *wg_redo = reinterpret_cast<uint32_t *>(smem + 2 * SB);
     if (tid == 0) *wg_redo = 0u;
 
-    // ---- one stage: K rows / V^T columns [256 half, 256 half + 256) of head hd -> buffer buf.  Every wave issues exactly
-    // 2 KI DMA operations per stage (rows >= len and key columns >= sb get an out-of-range offset: zeros, no traffic).
-    auto issue_stage = [&](int hd, int half, int buf) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(lane));  // per-lane offsets are derived here, per stage: ~10 VALU, no registers held
-        const __amdgpu_buffer_rsrc_t rs_k =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(k + (size_t)tok0 * hidden + hd * D), 0, kv_live ? (uint32_t)((len - 1) * pitch + RB) : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void *)(vt + (size_t)hd * D * ldvt + tok0), 0,
-                                                                               kv_live ? (uint32_t)(((size_t)D * ldvt - tok0) * 2) : 0u, 0x00020000);
+    // ---- one stage: K rows / V^T columns [256 half, 256 half + 256) of head hd -> buffer buf, in NP pieces of one DMA
+    // instruction per wave (pieces < KI: K, the others: V^T; rows >= len and key columns >= sb get an out-of-range offset:
+    // zeros, no traffic; live = false: a descriptor of 0 bytes -- the operation counts in vmcnt and touches no memory).
+    // A wave issues ONE piece per key block: 16 waves x 4-8 vector-memory instructions in a burst behind the stage's
+    // barrier hold every wave at the issue until the address unit has taken them (~16-32 clocks each).
+    constexpr int NP = 2 * KI;
+    auto issue_piece = [&](int hd, int half, int buf, bool live, const int pc) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(lane));  // per-lane offsets are derived here: ~5 VALU, no registers held
         const uint32_t dst = (uint32_t)(buf * SB + wave * KI * 1024);
-#pragma unroll
-        for (int i = 0; i < KI; ++i) {
+        if (pc < KI) {
+            const int i = pc;
+            const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void *)(k + (size_t)tok0 * hidden + hd * D), 0,
+                                                                                   live && kv_live ? (uint32_t)((len - 1) * pitch + RB) : 0u, 0x00020000);
             const int row = (wave * KI + i) * (1024 / RB) + lane / CH;
             const int lc = (lane % CH) ^ ((row / RW) & (CH - 1));
             const uint32_t vo = (uint32_t)((half * kAttnStage + row) * pitch + lc * 16);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_void_t *)(smem + dst + i * 1024), 16, vo, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < KI; ++i) {
+        } else {
+            const int i = pc - KI;
+            const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(vt + (size_t)hd * D * ldvt + tok0), 0, live && kv_live ? (uint32_t)(((size_t)D * ldvt - tok0) * 2) : 0u, 0x00020000);
             const int f = (wave * KI + i) * 2 + (lane >> 5);
             const int lc = (lane & 31) ^ (f & 15);
             const int key = half * kAttnStage + lc * 8;
@@ -643,13 +646,16 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
     // Q^T B-fragments: lane (query l31, half h) holds q[query][s*16 + 8h .. +8] (zero for queries >= len)
     // (live = false: a descriptor of 0 bytes -- the operation counts in vmcnt and touches no memory; the control flow around
     // the loads, the stores and their waits stays free of conditions, see the waits below)
-    auto load_q = [&](int hd, bool live, bf16x8 (&dst)[D / 16]) __attribute__((always_inline)) {
+    auto load_q1 = [&](int hd, bool live, const int s) __attribute__((always_inline)) {
         asm volatile("" : "+v"(lane));
         const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void *)(q + (size_t)tok0 * hidden + hd * D), 0,
                                                                                live ? (uint32_t)((len - 1) * pitch + RB) : 0u, 0x00020000);
         const int vo = (wave * 32 + (lane & 31)) * pitch + (lane >> 5) * 16;
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_q, vo + s * 32, 0, 0));
+    };
+    auto load_q = [&](int hd, bool live, bf16x8 (&dst)[D / 16]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < D / 16; ++s) dst[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_q, vo + s * 32, 0, 0));
+        for (int s = 0; s < D / 16; ++s) dst[s] = load_q1(hd, live, s);
     };
 
     // fragment read offsets inside a stage buffer (see the swizzles above); k16 step s and key block kb are XORed / added in
@@ -671,9 +677,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
         if (heads == 0u) return;
         uint32_t dm = heads;  // DMA cursor: heads not yet fully issued, half of the next stage, its buffer
         int dhalf = 0, dbuf = 0;
-        auto issue_next = [&]() __attribute__((always_inline)) {
-            if (dm == 0u) return;
-            issue_stage(hd0 + __builtin_ctz(dm), dhalf, dbuf);
+        auto cursor_next = [&]() __attribute__((always_inline)) {
             dbuf ^= 1;
             if (++dhalf == nh) {
                 dhalf = 0;
@@ -685,7 +689,9 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
         bf16x8 qf[D / 16], qn[D / 16];
         f32x16 o[D / 32];
         float m_run[HP], l_run[HP];
-        issue_next();
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) issue_piece(hd0 + __builtin_ctz(dm), 0, 0, true, pc);
+        cursor_next();
         load_q(hd0 + __builtin_ctz(cm), q_live, qf);
         // Waits for a stage's DMA are the builtin, not inline asm: the compiler's wait-count pass must know that the q
         // fragments have landed as well, or it waits for them -- and with them for the DMA just issued -- at their first
@@ -705,10 +711,11 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            issue_next();
+            const bool d_live = dm != 0u;  // the stage to issue under this one (none behind the last: dead pieces)
+            const int d_hd = hd0 + (d_live ? __builtin_ctz(dm) : 0), d_half = dhalf, d_buf = dbuf;
+            if (d_live) cursor_next();
             const uint32_t rest = cm & (cm - 1u);
             const int hd_next = hd0 + (rest != 0u ? __builtin_ctz(rest) : hi);
-            if (PFQ && chalf == 0) load_q(hd_next, rest != 0u && q_live, qn);  // (first stage: the ctx stores load the last one)
             if (chalf == 0) {
 #pragma unroll
                 for (int t = 0; t < D / 32; ++t)
@@ -795,7 +802,16 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                 }
             };
             const int nfull = max(0, min(full_blocks - kb0, nkb));
-            for (int kbl = 0; kbl < nfull; ++kbl) key_block(kbl, std::false_type{});
+            static_assert(NP + D / 16 <= kAttnStage / 32, "one DMA piece / q load per key block");
+#pragma unroll
+            for (int kbl = 0; kbl < kAttnStage / 32; ++kbl) {
+                // the next stage's pieces, then (a head's first stage: the ctx stores load the last one) the next head's q
+                if (kbl < NP) issue_piece(d_hd, d_half, d_buf, d_live, kbl);
+                else if (PFQ && kbl - NP < D / 16) {
+                    if (chalf == 0) qn[kbl - NP < D / 16 ? kbl - NP : 0] = load_q1(hd_next, rest != 0u && q_live, kbl - NP);
+                }
+                if (kbl < nfull) key_block(kbl, std::false_type{});
+            }
             for (int kbl = nfull; kbl < nkb; ++kbl) key_block(kbl, std::true_type{});
             if (last_half) {
                 // a row sum outside (1e-30, 1e30): an exp2 (or P * v) may have overflowed, or the whole row underflowed
