@@ -34,7 +34,7 @@
 // Ablation switch for scripts/gemm_ubench.hip only (0 = production kernel); bits:
 //   1 = no DMA inside the loop (the ring keeps the prologue's tiles), 2 = no epilogue (accumulators kept alive),
 //   4 = no stagger between the wave rows, 8 = s_setprio 1 around the MFMA sections (measured slower: 306 against 281 us
-//   on the QK projection of a hidden-768 layer)
+//   on the QK projection of a hidden-768 layer), 16 = no bias loads in the epilogue (a constant)
 #ifndef MX_PGEMM_ABLATE
 #define MX_PGEMM_ABLATE 0
 #endif
@@ -189,7 +189,11 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ncol = n0 + wc * 64 + j * 32;
+#if MX_PGEMM_ABLATE & 16
+                const float b = 0.01f;
+#else
                 const float b = p.bias[ncol + l31];
+#endif
 #pragma unroll
                 for (int ip = 0; ip < 2; ++ip) {  // 64 m per pass: blocks 2ip, 2ip+1
 #pragma unroll
@@ -224,7 +228,11 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
+#if MX_PGEMM_ABLATE & 16
+                    b4[j][rg] = f32x4{0.01f, 0.01f, 0.01f, 0.01f};
+#else
                     b4[j][rg] = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wc * 64 + j * 32 + 8 * rg + 4 * h);
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // D^T[n][m]: lane owns row m = l31 of block i, 4 consecutive columns n per register group

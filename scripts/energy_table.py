@@ -61,7 +61,7 @@ if os.path.exists(bge):
     table(f"bge-base-en shape (hidden 768, ffn 3072), one layer at {T} tokens [{os.path.basename(bge)}]", rows(bge), 12, 12, H, F, [
         ("pgemm_kernel<2>", 1, g(2 * H, H), 3 * act, "QK projection"),
         ("pgemm_kernel<4>", 1, g(H, H), 2 * act, "V projection (feature-major)"),
-        ("attention_kernel<64>", 1, 4.0 * T * 512 * H / 1e9, 4 * act, "softmax(QK^T)V, 512-token sequences"),
+        ("attention_kernel<64,1>", 1, 4.0 * T * 512 * H / 1e9, 4 * act, "softmax(QK^T)V, 512-token sequences"),
         ("pgemm_kernel<5>", 2, g(H, H) + g(H, F), (3 * act) + (T * F * 2 / 1e6 + 2 * act), "out-projection + W2, each + bias + residual (two launches)"),
         ("ln_rows_kernel<32>", 2, 0.0, 4 * act, "the two LayerNorms, in place"),
         ("pgemm_kernel<1>", 1, g(F, H), act + T * F * 2 / 1e6, "W1 + GELU"),
@@ -73,10 +73,11 @@ if os.path.exists(l6):
     g = lambda n, k: 2.0 * T * n * k / 1e9
     st = rows(l6)
     qk = "pgemm_kernel<2>" if "pgemm_kernel<2>" in st else "gemm_kernel<2,2,2,2,32,4>"
+    att32 = "attention_kernel<32,2>" if "attention_kernel<32,2>" in st else "attention_kernel<32,1>"
     # scripts/gpu_encoder_prof.py l6: 2048 chunks = 8 passes, 3 encodes, 6 layers
     table(f"all-MiniLM-L6-v2 shape (hidden 384, ffn 1536), one layer at {T} tokens [{os.path.basename(l6)}]", st, 6, 24, H, F, [
         (qk, 1, g(2 * H, H), 3 * act, "QK projection"),
         ("gemm_kernel<4,2,2,2,32,4>", 1, g(H, H), 2 * act, "V projection (feature-major)"),
-        ("attention_kernel<32>", 1, 4.0 * T * 512 * H / 1e9, 4 * act, "softmax(QK^T)V, 512-token sequences"),
+        (att32, 1, 4.0 * T * 512 * H / 1e9, 4 * act, "softmax(QK^T)V, 512-token sequences"),
         ("tail_kernel<true>", 1, g(H, H) + 2 * g(F, H), 3 * act, "out-projection + LayerNorm + MLP + LayerNorm, fused"),
     ])

@@ -12,7 +12,7 @@ algo = {  # bytes a launch must read + write once
     "pgemm_kernel<1>": (T * H * 2 + F * H * 2, T * F * 2),                  # W1 + GELU
     "pgemm_kernel<5>": None,                                                # two shapes share the name: see the rows below
     "ln_rows_kernel<32>": (T * H * 2, T * H * 2),
-    "attention_kernel<64>": (3 * T * H * 2, T * H * 2),
+    "attention_kernel<64,1>": (3 * T * H * 2, T * H * 2),
 }
 res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):

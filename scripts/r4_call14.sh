@@ -10,5 +10,5 @@ for r in csv.DictReader(open(f)):
     if "attention" in r["Name"]: print("%s SAFE=%s HPW=%s" % tuple(sys.argv[1:4]), r["Name"].split("(")[0][:40], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
 PY
 }
-for m in bge l6; do for safe in 0 2; do run $m $safe 0; done; done
+for m in bge l6; do for safe in 0 2 3 4 5 6; do run $m $safe 0; done; done
 cat $out
