@@ -54,6 +54,29 @@ def test_encoder_vs_oracle(kw, B, S, seed, lib_built):
     np.testing.assert_array_equal(out, again)                      # deterministic
 
 
+@pytest.mark.parametrize("hidden,ffn", [(384, 1536), (768, 3072)])
+def test_attention_stage_and_block_boundaries(hidden, ffn, lib_built):
+    """attention_kernel streams keys in stages of 256 and blocks of 32, masks only the last block of a sequence, and
+    lets the buffer bounds drop the rows past a sequence's end: lengths on every one of those edges, both head widths
+    (d = 32 staged two heads at a time, d = 64), against the oracle; one sequence alone == the same sequence in the batch."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    from oracle import bert_oracle
+    cfg = EncoderConfig(layers=2, hidden=hidden, heads=12, ffn=ffn, vocab=3000)
+    w = synthetic_weights(cfg, 31)
+    rng = np.random.default_rng(31)
+    lens = np.array([1, 7, 8, 31, 32, 33, 63, 64, 255, 256, 257, 287, 288, 289, 480, 511, 512], dtype=np.int32)
+    ids = rng.integers(1000, cfg.vocab, size=(len(lens), 512)).astype(np.int32)
+    with Encoder(cfg, w) as enc:
+        out = enc.encode(ids, lens)
+        alone = [enc.encode(ids[i:i + 1, :lens[i]], lens[i:i + 1])[0] for i in (0, 5, 10, 16)]
+    ref = bert_oracle.encode(w, cfg.as_dict(), ids, lens)
+    assert np.isfinite(out).all()
+    assert (1.0 - _cos(out.astype(np.float64), ref)).max() <= TOL
+    for j, i in enumerate((0, 5, 10, 16)):
+        np.testing.assert_array_equal(out[i], alone[j])
+
+
 def test_batch_composition_does_not_change_a_row(lib_built):
     """Varlen packing: a sequence's embedding must not depend on its batch neighbours / padding ids."""
     from memex_amd.encoder import Encoder
