@@ -931,7 +931,8 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
     // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path); =2: no key loop (measurement)
     const int mode = [] {
         const char *ev = getenv("MEMEX_HIP_ATTN_SAFE");
-        return ev ? atoi(ev) : 0;
+        const int m = ev ? atoi(ev) : 0;
+        return m >= 0 && m <= 6 ? m : 0;  // 2 .. 6 are measurement modes (no key loop / no loads / no stores: wrong results)
     }();
     if (d_head == 32 && pair)
         hipLaunchKernelGGL((attention_kernel<32, 2>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
