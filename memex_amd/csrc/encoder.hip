@@ -66,6 +66,7 @@ struct mx_encoder {
     int ws_rows = 0, ws_seqs = 0, ws_ids = 0;
     bf16_t *x = nullptr, *x1 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *hbuf = nullptr;
     int32_t *cu = nullptr, *tok_seq = nullptr, *tok_pos = nullptr, *lens_dev = nullptr, *ids_dev = nullptr;
+    void *attn_plan = nullptr;  // attention work list of the pass in flight (kAttnPlanBytesPerSeq per sequence)
     float *out_dev = nullptr;
     bool profiling = false;
     bool fused_tail = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_UNFUSED_TAIL=1 keeps the three GEMMs
@@ -143,11 +144,13 @@ int ensure_ws(mx_encoder *e, int rows, int seqs, int n_ids) {
         if (e->cu) (void)hipFree(e->cu);
         if (e->lens_dev) (void)hipFree(e->lens_dev);
         if (e->out_dev) (void)hipFree(e->out_dev);
-        e->cu = nullptr; e->lens_dev = nullptr; e->out_dev = nullptr;
+        if (e->attn_plan) (void)hipFree(e->attn_plan);
+        e->cu = nullptr; e->lens_dev = nullptr; e->out_dev = nullptr; e->attn_plan = nullptr;
         e->ws_seqs = 0;
         MX_HIP(hipMalloc(&e->cu, ((size_t)seqs + 1) * sizeof(int32_t)));
         MX_HIP(hipMalloc(&e->lens_dev, (size_t)seqs * sizeof(int32_t)));
         MX_HIP(hipMalloc(&e->out_dev, (size_t)seqs * H * sizeof(float)));
+        MX_HIP(hipMalloc(&e->attn_plan, (size_t)seqs * kAttnPlanBytesPerSeq));
         e->ws_seqs = seqs;
     }
     if (n_ids > e->ws_ids) {
@@ -191,6 +194,8 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
     MX_HIP(launch_token_map(st, d_lens, B, S, e->cu, e->tok_seq, e->tok_pos, t_pad));
     MX_HIP(launch_embed_ln(st, d_ids, S, e->tok_seq, e->tok_pos, t_pad, H, e->word, e->pos, e->type0, e->eg, e->eb,
                            c.ln_eps, c.vocab, e->x));
+    if ((size_t)attention_groups(heads, dh) * 16 > kAttnPlanBytesPerSeq) return fail(MX_EINVAL, "more than 16 head groups per sequence");
+    MX_HIP(launch_attention_plan(st, d_lens, e->cu, B, max_len, heads, dh, e->attn_plan));
     const float qscale = (float)(1.4426950408889634 / std::sqrt((double)dh));
     // Large passes (>= kPgemmRows packed rows) run every GEMM whose shape it takes on pgemm_kernel; the Add & LayerNorm
     // GEMMs then leave y = product + bias + residual and ln_rows_kernel normalises it in place.
@@ -216,7 +221,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         gv.a = e->x; gv.lda = H; gv.w = L.wqkv; gv.w_rows = 3 * H; gv.w_row0 = 2 * H; gv.bias = L.bqkv + 2 * H; gv.m = t_pad; gv.n = H;
         gv.k = H; gv.out_vt = e->vt; gv.ldvt = t_pad; gv.hidden = H;
         MX_HIP(gemm(EPI_VT, gv));
-        MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->cu, d_lens, B, max_len, heads, dh, H, e->ctx));
+        MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->attn_plan, B, heads, dh, H, e->ctx));
         if (e->fused_tail) {
             // out-projection + Add&Norm + MLP + Add&Norm in one kernel, in place on e->x
             TailParams tp{};
@@ -424,7 +429,7 @@ static void destroy_impl(mx_encoder *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void *p : e->allocs) (void)hipFree(p);
     free_ws(e);
-    void *ptrs[] = {e->cu, e->lens_dev, e->ids_dev, e->out_dev};
+    void *ptrs[] = {e->cu, e->lens_dev, e->ids_dev, e->out_dev, e->attn_plan};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);

@@ -100,9 +100,14 @@ hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32
                            const float *gamma, const float *beta, float eps, int vocab, bf16_t *x);
 
 // softmax(q k^T + mask) v per (sequence, head); q is pre-scaled by 1/sqrt(d)*log2(e)
-hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt,
-                            const int32_t *cu, const int32_t *lens, int B, int max_len, int heads, int d_head,
-                            int hidden, bf16_t *ctx);
+// `plan`: kAttnPlanBytesPerSeq bytes per sequence, written by launch_attention_plan once per pass (the work list: one
+// item per (sequence, head group), longest sequences first) and read by every layer's launch_attention
+constexpr size_t kAttnPlanBytesPerSeq = 16 * 16;
+int attention_groups(int heads, int d_head);
+hipError_t launch_attention_plan(hipStream_t s, const int32_t *lens, const int32_t *cu, int B, int max_len, int heads, int d_head,
+                                 void *plan);
+hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt, const void *plan, int B,
+                            int heads, int d_head, int hidden, bf16_t *ctx);
 
 // masked mean (or CLS) over tokens + optional L2 normalise -> out [B, H] f32
 hipError_t launch_pool(hipStream_t s, const bf16_t *x, const int32_t *cu, const int32_t *lens, int B, int hidden,

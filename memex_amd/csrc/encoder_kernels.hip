@@ -562,8 +562,8 @@ hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3: attention.  grid = (1, heads / hpw, sequences); 16 waves x 32 queries (sequences of <= 512 tokens).
-// A workgroup walks hpw heads of its sequence.  K ([keys][d]) and V^T ([d][keys]) stream through LDS in STAGES of 256
+// K3: attention.  A persistent grid of one workgroup per CU, 16 waves x 32 queries (sequences of <= 512 tokens); a workgroup
+// walks its share of the pass's (sequence, head group) items, longest sequences first (attn_plan_kernel).  K ([keys][d]) and V^T ([d][keys]) stream through LDS in STAGES of 256
 // keys, double-buffered, moved by LDS-DMA (global -> LDS, 1 KiB per wave-instruction, no registers): the DMA of stage
 // j+1 -- the other half of the keys, or the next head -- is issued when the barrier that ends stage j-1 has passed and
 // lands under the key loop of stage j; a counted s_waitcnt + ONE barrier per stage.  (Round 4: the form this replaces
@@ -588,11 +588,39 @@ constexpr int kAttnWaves = 16;
 constexpr int kAttnQ = kAttnWaves * 32;  // queries per workgroup
 constexpr int kAttnStage = 256;          // keys per stage
 
+// The work list of a pass: one ITEM per (sequence, head group), sequences in order of decreasing length (all groups of a
+// sequence adjacent), built on the device by attn_plan_kernel.  Workgroup j of the persistent attention grid takes the
+// items j, j + G, j + 2G, ... -- one from every tier of the sorted list, so the loads differ by about one short item.
+struct AttnItem {
+    int32_t tok0, len, group, pad;
+};
+
+__global__ __launch_bounds__(1024) void attn_plan_kernel(const int32_t *__restrict__ lens, const int32_t *__restrict__ cu, int B,
+                                                         int S, int groups, AttnItem *__restrict__ plan) {
+    __shared__ int s_len[1024];
+    const int tid = threadIdx.x;
+    int l = 0;
+    if (tid < B) {
+        l = lens[tid];
+        l = l < 1 ? 1 : (l > S ? S : l);  // (what token_map_kernel packs)
+    }
+    s_len[tid] = tid < B ? l : -1;
+    __syncthreads();
+    if (tid >= B) return;
+    int rank = 0;  // sequences that come first: longer ones, and equally long ones with a smaller index
+    for (int j = 0; j < B; ++j) {
+        const int o = s_len[j];
+        rank += (o > l || (o == l && j < tid)) ? 1 : 0;
+    }
+    const int t0 = cu[tid];
+    for (int g = 0; g < groups; ++g) plan[(size_t)rank * groups + g] = AttnItem{t0, l, g, 0};
+}
+
 template <int DH, int HP>
 __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k,
-                                                                                     const bf16_t *__restrict__ vt, int ldvt,
-                                                                                     const int32_t *__restrict__ cu, const int32_t *__restrict__ lens,
-                                                                                     int hidden, bf16_t *__restrict__ ctx, int mode, int hpw) {
+                                                                       const bf16_t *__restrict__ vt, int ldvt,
+                                                                       const AttnItem *__restrict__ plan, int n_items, int hidden,
+                                                                       bf16_t *__restrict__ ctx, int mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = DH * HP;                  // features per stage: HP adjacent heads of DH (a "head group": rows of 2D bytes)
     constexpr int RB = D * 2;                   // bytes of a K row
@@ -601,39 +629,52 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
     constexpr int KBYTES = kAttnStage * RB;     // K tile of a stage; the V^T tile (D rows x 512 B) is as large
     constexpr int SB = 2 * KBYTES;              // one stage buffer
     constexpr int KI = D / 32;                  // DMA instructions per wave and tile
-    constexpr int NS = D / 32 * 2;              // ctx stores per head group and lane
-    constexpr bool PFQ = true;                  // next head's q fragments loaded under the current head's last stage
-    const int b = blockIdx.z, hd0 = blockIdx.y * hpw;
-    const int len = lens[b];
-    const int tok0 = cu[b];
-    const int sb = (len + 31) / 32 * 32;        // keys rounded to MFMA blocks
-    const int nh = (sb + kAttnStage - 1) / kAttnStage;  // stages per head (1 or 2)
+    constexpr int NS = D / 32 * 2;              // ctx stores per item and lane
+    const int G = gridDim.x;
+    const int n_my = (n_items - (int)blockIdx.x + G - 1) / G;  // this workgroup's items: ordinals 0 .. n_my - 1 (<= 64)
+    if (n_my <= 0) return;
     const int tid = threadIdx.x;
     int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const bool active = wave * 32 < len;  // wave-uniform; a wave without queries still stages
     const int pitch = hidden * 2;
-    // MEMEX_HIP_ATTN_SAFE=2, 3, 4 (measurement only): no key loop; 3: no q loads and no ctx stores either; 4: no ctx stores
-    // 5: key loop only (no DMA traffic, no q loads, no ctx stores); 6: everything but the ctx stores
-    const int nkb_all = mode >= 2 && mode <= 4 ? 0 : sb / 32;
+    // MEMEX_HIP_ATTN_SAFE=2 .. 6 (measurement only): 2, 3, 4 no key loop; 3: no q loads and no ctx stores either; 4: no ctx
+    // stores; 5: key loop only (no DMA traffic, no q loads, no ctx stores); 6: everything but the ctx stores
+    const bool no_keys = mode >= 2 && mode <= 4;
     const bool q_live = mode != 3 && mode != 5, c_live = mode < 3, kv_live = mode != 5;
-    uint32_t *wg_redo = reinterpret_cast<uint32_t *>(smem + 2 * SB);
-    if (tid == 0) *wg_redo = 0u;
+    uint64_t *wg_redo = reinterpret_cast<uint64_t *>(smem + 2 * SB);
+    if (tid == 0) *wg_redo = 0ull;
 
-    // ---- one stage: K rows / V^T columns [256 half, 256 half + 256) of head hd -> buffer buf, in NP pieces of one DMA
+    struct Item {  // wave-uniform
+        int tok0, len, grp, sb, nh;
+        bool live;
+    };
+    auto fetch = [&](int ord) __attribute__((always_inline)) {  // ordinal -> item (one 16-byte scalar load)
+        Item it;
+        it.live = ord >= 0 && ord < n_my;
+        const AttnItem r = plan[it.live ? (int)blockIdx.x + ord * G : (int)blockIdx.x];
+        it.tok0 = r.tok0;
+        it.len = r.len;
+        it.grp = r.group;
+        it.sb = (r.len + 31) / 32 * 32;                          // keys rounded to MFMA blocks
+        it.nh = (it.sb + kAttnStage - 1) / kAttnStage;           // stages of the item (1 or 2)
+        return it;
+    };
+
+    // ---- one stage: K rows / V^T columns [256 half, 256 half + 256) of item `it` -> buffer buf, in NP pieces of one DMA
     // instruction per wave (pieces < KI: K, the others: V^T; rows >= len and key columns >= sb get an out-of-range offset:
-    // zeros, no traffic; live = false: a descriptor of 0 bytes -- the operation counts in vmcnt and touches no memory).
+    // zeros, no traffic; a dead item: descriptors of 0 bytes -- the operation counts in vmcnt and touches no memory).
     // A wave issues ONE piece per key block: 16 waves x 4-8 vector-memory instructions in a burst behind the stage's
     // barrier hold every wave at the issue until the address unit has taken them (~16-32 clocks each).
     constexpr int NP = 2 * KI;
-    auto issue_piece = [&](int hd, int half, int buf, bool live, const int pc) __attribute__((always_inline)) {
+    auto issue_piece = [&](const Item &it, int half, int buf, const int pc) __attribute__((always_inline)) {
         asm volatile("" : "+v"(lane));  // per-lane offsets are derived here: ~5 VALU, no registers held
         const uint32_t dst = (uint32_t)(buf * SB + wave * KI * 1024);
+        const bool live = it.live && kv_live;
         if (pc < KI) {
             const int i = pc;
-            const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void *)(k + (size_t)tok0 * hidden + hd * D), 0,
-                                                                                   live && kv_live ? (uint32_t)((len - 1) * pitch + RB) : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void *)(k + (size_t)it.tok0 * hidden + it.grp * D), 0,
+                                                                                   live ? (uint32_t)((it.len - 1) * pitch + RB) : 0u, 0x00020000);
             const int row = (wave * KI + i) * (1024 / RB) + lane / CH;
             const int lc = (lane % CH) ^ ((row / RW) & (CH - 1));
             const uint32_t vo = (uint32_t)((half * kAttnStage + row) * pitch + lc * 16);
@@ -641,64 +682,57 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
         } else {
             const int i = pc - KI;
             const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(vt + (size_t)hd * D * ldvt + tok0), 0, live && kv_live ? (uint32_t)(((size_t)D * ldvt - tok0) * 2) : 0u, 0x00020000);
+                (void *)(vt + (size_t)it.grp * D * ldvt + it.tok0), 0, live ? (uint32_t)(((size_t)D * ldvt - it.tok0) * 2) : 0u, 0x00020000);
             const int f = (wave * KI + i) * 2 + (lane >> 5);
             const int lc = (lane & 31) ^ (f & 15);
             const int key = half * kAttnStage + lc * 8;
-            const uint32_t vo = key < sb ? (uint32_t)(f * ldvt * 2 + key * 2) : 0xFFFFFFF0u;
+            const uint32_t vo = key < it.sb ? (uint32_t)(f * ldvt * 2 + key * 2) : 0xFFFFFFF0u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_void_t *)(smem + dst + KBYTES + i * 1024), 16, vo, 0, 0, 0);
         }
     };
-    // Q^T B-fragments: lane (query l31, half h) holds q[query][s*16 + 8h .. +8] (zero for queries >= len)
-    // (live = false: a descriptor of 0 bytes -- the operation counts in vmcnt and touches no memory; the control flow around
-    // the loads, the stores and their waits stays free of conditions, see the waits below)
-    auto load_q1 = [&](int hd, bool live, const int s) __attribute__((always_inline)) {
+    // Q^T B-fragments: lane (query l31, half h) holds q[query][s*16 + 8h .. +8] (zero for queries >= len; dead item: zeros)
+    auto load_q1 = [&](const Item &it, const int s) __attribute__((always_inline)) {
         asm volatile("" : "+v"(lane));
-        const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void *)(q + (size_t)tok0 * hidden + hd * D), 0,
-                                                                               live ? (uint32_t)((len - 1) * pitch + RB) : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(q + (size_t)it.tok0 * hidden + it.grp * D), 0, it.live && q_live ? (uint32_t)((it.len - 1) * pitch + RB) : 0u, 0x00020000);
         const int vo = (wave * 32 + (lane & 31)) * pitch + (lane >> 5) * 16;
         return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_q, vo + s * 32, 0, 0));
-    };
-    auto load_q = [&](int hd, bool live, bf16x8 (&dst)[D / 16]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < D / 16; ++s) dst[s] = load_q1(hd, live, s);
     };
 
     // fragment read offsets inside a stage buffer (see the swizzles above); k16 step s and key block kb are XORed / added in
     const int pr = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);  // pi(l31)
     const uint32_t k_frag = (uint32_t)(pr * RB + ((h ^ ((pr / RW) & (CH - 1))) << 4));
     const uint32_t v_frag = (uint32_t)(KBYTES + l31 * 512 + ((h ^ (l31 & 15)) << 4));
-    const int full_blocks = len / 32;  // key blocks without padding keys
 
-    uint32_t my_redo = 0u;  // heads whose row sums left (1e-30, 1e30) in this wave: redone with the running maximum
-    // ---- one pass over the heads in `heads` (bit i = head hd0 + i); a wave computes the heads in `mine`.
+    uint64_t my_redo = 0ull;  // items (by ordinal) whose row sums left (1e-30, 1e30) in this wave: redone with the running maximum
+    // ---- one pass over the items in `todo` (bit i = ordinal i); a wave computes the items in `mine`.  The stage pipeline
+    // runs across items: the DMA of an item's first stage is issued under the previous item's last one.
     // SAFE: the textbook running maximum (max + cross-half exchange + compare per 32-key block, rescale when it grows).
     // !SAFE: NO shift at all, P = exp2(score) -- softmax is shift-invariant and P, l, O are floating point, so scores away
     // from 0 only move the exponents; what can go wrong is exp2 overflowing (a score above 127; the pre-scaled logits of
     // the models this runs stay within a few tens) or a whole row underflowing, and both leave the row sum outside
-    // (1e-30, 1e30), which puts the head (group) on the wave's redo list.  The max chain and the subtraction are 21 of ~105 VALU
+    // (1e-30, 1e30), which puts the item on the wave's redo list.  The max chain and the subtraction are 21 of ~105 VALU
     // issue slots per block, and the max sits on the MFMA -> exp dependency chain.
-    auto pass = [&](auto safe_tag, const uint32_t heads, const uint32_t mine) __attribute__((always_inline)) {
+    auto pass = [&](auto safe_tag, const uint64_t todo, const uint64_t mine) __attribute__((always_inline)) {
         constexpr bool SAFE = decltype(safe_tag)::value;
-        if (heads == 0u) return;
-        uint32_t dm = heads;  // DMA cursor: heads not yet fully issued, half of the next stage, its buffer
-        int dhalf = 0, dbuf = 0;
-        auto cursor_next = [&]() __attribute__((always_inline)) {
-            dbuf ^= 1;
-            if (++dhalf == nh) {
-                dhalf = 0;
-                dm &= dm - 1u;
-            }
+        if (todo == 0ull) return;
+        auto first_of = [](uint64_t m) { return m ? __builtin_ctzll(m) : -1; };
+        uint64_t rest = todo;  // ordinals not yet fetched
+        auto pop = [&]() __attribute__((always_inline)) {
+            const int o = first_of(rest);
+            rest &= rest - 1ull;
+            return o;
         };
-        uint32_t cm = heads;  // compute cursor
+        int c_ord = pop(), x_ord = pop(), nn_ord = pop();
+        Item cur = fetch(c_ord), nxt = fetch(x_ord), nn = fetch(nn_ord);  // nn: fetched an item early, becomes nxt at the next boundary
         int chalf = 0, cbuf = 0;
         bf16x8 qf[D / 16], qn[D / 16];
         f32x16 o[D / 32];
         float m_run[HP], l_run[HP];
 #pragma unroll
-        for (int pc = 0; pc < NP; ++pc) issue_piece(hd0 + __builtin_ctz(dm), 0, 0, true, pc);
-        cursor_next();
-        load_q(hd0 + __builtin_ctz(cm), q_live, qf);
+        for (int pc = 0; pc < NP; ++pc) issue_piece(cur, 0, 0, pc);
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s) qf[s] = load_q1(cur, s);
         // Waits for a stage's DMA are the builtin, not inline asm: the compiler's wait-count pass must know that the q
         // fragments have landed as well, or it waits for them -- and with them for the DMA just issued -- at their first
         // use in the key loop.  For the same reason the loads, the stores and the wait that leaves the stores in flight sit
@@ -706,22 +740,22 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
         // sees a q load without a wait).
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s) asm volatile("" : "+v"(qf[s]));  // (pins the loads above the wait: hipcc sank one below it)
 #pragma unroll 1
-        while (cm != 0u) {
-            const int hi = __builtin_ctz(cm);
-            const bool last_half = chalf == nh - 1;
-            const bool mine_now = (mine >> hi) & 1u;
+        while (cur.live) {
+            const bool last_half = chalf == cur.nh - 1;
+            const bool mine_now = (mine >> c_ord) & 1ull;
+            const bool active = wave * 32 < cur.len;  // wave-uniform; a wave without queries still stages
             // this wave's part of the stage's tiles has landed (the wait at the end of the previous trip) -> everybody's has,
             // and every wave is done with the other buffer (a bare s_barrier: __syncthreads() would put s_waitcnt vmcnt(0)
             // in front of it and wait for the ctx stores as well)
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const bool d_live = dm != 0u;  // the stage to issue under this one (none behind the last: dead pieces)
-            const int d_hd = hd0 + (d_live ? __builtin_ctz(dm) : 0), d_half = dhalf, d_buf = dbuf;
-            if (d_live) cursor_next();
-            const uint32_t rest = cm & (cm - 1u);
-            const int hd_next = hd0 + (rest != 0u ? __builtin_ctz(rest) : hi);
+            // the stage to issue under this one: this item's other half, or the next item's first
+            const Item &d_it = last_half ? nxt : cur;
+            const int d_half = last_half ? 0 : chalf + 1;
             if (chalf == 0) {
 #pragma unroll
                 for (int t = 0; t < D / 32; ++t)
@@ -733,10 +767,12 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                     l_run[hh] = 0.0f;
                 }
             }
+            const int len = cur.len;
+            const int full_blocks = len / 32;  // key blocks without padding keys
             const int kb0 = chalf * (kAttnStage / 32);
-            const int nkb = mine_now && active ? min(nkb_all - kb0, kAttnStage / 32) : 0;
+            const int nkb = mine_now && active && !no_keys ? min(cur.sb / 32 - kb0, kAttnStage / 32) : 0;
             const char *kt = smem + cbuf * SB;
-            // one block of 32 keys; TAIL: the block holds padding keys (only a head's last block can), masked in the scores
+            // one block of 32 keys; TAIL: the block holds padding keys (only an item's last block can), masked in the scores
             // and in the V fragments -- a separate instance, so that the common one is one straight basic block
             auto key_block = [&](const int kbl, auto tail_tag) __attribute__((always_inline)) {
                 constexpr bool TAIL = decltype(tail_tag)::value;
@@ -744,77 +780,77 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                 const int rem = len - kb * 32 - 8 * h;  // this lane's keys 16 (r>>3) + (r&7) < rem are real
 #pragma unroll
                 for (int hh = 0; hh < HP; ++hh) {
-                // S^T tile: A-row j = (r&3) + 8*(r>>2) + 4h holds key kb*32 + pi(j) = kb*32 + 16*(r>>3) + 8h + (r&7); col = query l31
-                f32x16 sc;
+                    // S^T tile: A-row j = (r&3) + 8*(r>>2) + 4h holds key kb*32 + pi(j) = kb*32 + 16*(r>>3) + 8h + (r&7); col = query l31
+                    f32x16 sc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
 #pragma unroll
-                for (int s = hh * (DH / 16); s < (hh + 1) * (DH / 16); ++s) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kt + (k_frag ^ (uint32_t)(s * 32)) + kbl * 32 * RB);
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
-                }
-                if (TAIL) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[r] = 16 * (r >> 3) + (r & 7) < rem ? sc[r] : -1e30f;  // reference: additive -10000 mask == exclusion in f32
-                }
-                if (SAFE) {
-                    float bm = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
-#pragma unroll
-                    for (int r = 3; r < 15; r += 2) bm = fmaxf(fmaxf(bm, sc[r]), sc[r + 1]);
-                    bm = fmaxf(bm, sc[15]);
-                    bm = fmaxf(bm, __shfl_xor(bm, 32));
-                    if (__builtin_amdgcn_ballot_w64(bm > m_run[hh]) != 0) {  // some query's max grew: rescale (rare later on)
-                        const float m_new = fmaxf(m_run[hh], bm);
-                        const float alpha = __builtin_amdgcn_exp2f(m_run[hh] - m_new);
-                        l_run[hh] *= alpha;
-                        m_run[hh] = m_new;
-#pragma unroll
-                        for (int t = hh * (DH / 32); t < (hh + 1) * (DH / 32); ++t)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                    for (int s = hh * (DH / 16); s < (hh + 1) * (DH / 16); ++s) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kt + (k_frag ^ (uint32_t)(s * 32)) + kbl * 32 * RB);
+                        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
                     }
-                }
-                typedef __attribute__((ext_vector_type(2))) float f32x2;
-                const f32x2 mm = {m_run[hh], m_run[hh]};
-                f32x2 ps2 = {0.0f, 0.0f};
+                    if (TAIL) {
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    f32x2 t = {sc[r], sc[r + 1]};
-                    if (SAFE) t -= mm;
-                    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                    sc[r] = e[0];
-                    sc[r + 1] = e[1];
-                    ps2 += e;
-                }
-                l_run[hh] += ps2[0] + ps2[1];
-                // O^T += V^T P^T: k16 step s uses this lane's p[8s .. 8s+7] = keys kb*32 + 16s + 8h + (0..7)
+                        for (int r = 0; r < 16; ++r) sc[r] = 16 * (r >> 3) + (r & 7) < rem ? sc[r] : -1e30f;  // reference: additive -10000 mask == exclusion in f32
+                    }
+                    if (SAFE) {
+                        float bm = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    bf16x8 pf;
+                        for (int r = 3; r < 15; r += 2) bm = fmaxf(fmaxf(bm, sc[r]), sc[r + 1]);
+                        bm = fmaxf(bm, sc[15]);
+                        bm = fmaxf(bm, __shfl_xor(bm, 32));
+                        if (__builtin_amdgcn_ballot_w64(bm > m_run[hh]) != 0) {  // some query's max grew: rescale (rare later on)
+                            const float m_new = fmaxf(m_run[hh], bm);
+                            const float alpha = __builtin_amdgcn_exp2f(m_run[hh] - m_new);
+                            l_run[hh] *= alpha;
+                            m_run[hh] = m_new;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s + e];
+                            for (int t = hh * (DH / 32); t < (hh + 1) * (DH / 32); ++t)
 #pragma unroll
-                    for (int t = hh * (DH / 32); t < (hh + 1) * (DH / 32); ++t) {
-                        bf16x8 vf = *reinterpret_cast<const bf16x8 *>(kt + (v_frag ^ (uint32_t)((kbl & 3) * 64 + s * 32)) + (kbl >> 2) * 256 +
-                                                                      t * 32 * 512);
-                        if (TAIL) {  // 0 * (another token's value, possibly not finite) must stay 0
-#pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                if (16 * s + e >= rem) vf[e] = (__bf16)0.0f;
+                                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
                         }
-                        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
                     }
-                }
+                    typedef __attribute__((ext_vector_type(2))) float f32x2;
+                    const f32x2 mm = {m_run[hh], m_run[hh]};
+                    f32x2 ps2 = {0.0f, 0.0f};
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2 t = {sc[r], sc[r + 1]};
+                        if (SAFE) t -= mm;
+                        const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                        sc[r] = e[0];
+                        sc[r + 1] = e[1];
+                        ps2 += e;
+                    }
+                    l_run[hh] += ps2[0] + ps2[1];
+                    // O^T += V^T P^T: k16 step s uses this lane's p[8s .. 8s+7] = keys kb*32 + 16s + 8h + (0..7)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        bf16x8 pf;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s + e];
+#pragma unroll
+                        for (int t = hh * (DH / 32); t < (hh + 1) * (DH / 32); ++t) {
+                            bf16x8 vf = *reinterpret_cast<const bf16x8 *>(kt + (v_frag ^ (uint32_t)((kbl & 3) * 64 + s * 32)) + (kbl >> 2) * 256 +
+                                                                          t * 32 * 512);
+                            if (TAIL) {  // 0 * (another token's value, possibly not finite) must stay 0
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    if (16 * s + e >= rem) vf[e] = (__bf16)0.0f;
+                            }
+                            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
+                        }
+                    }
                 }
             };
             const int nfull = max(0, min(full_blocks - kb0, nkb));
             static_assert(NP + D / 16 <= kAttnStage / 32, "one DMA piece / q load per key block");
 #pragma unroll
             for (int kbl = 0; kbl < kAttnStage / 32; ++kbl) {
-                // the next stage's pieces, then (a head's first stage: the ctx stores load the last one) the next head's q
-                if (kbl < NP) issue_piece(d_hd, d_half, d_buf, d_live, kbl);
-                else if (PFQ && kbl - NP < D / 16) {
-                    if (chalf == 0) qn[kbl - NP < D / 16 ? kbl - NP : 0] = load_q1(hd_next, rest != 0u && q_live, kbl - NP);
+                // the next stage's pieces, then (an item's first stage: the ctx stores load its last one) the next item's q
+                if (kbl < NP) issue_piece(d_it, d_half, cbuf ^ 1, kbl);
+                else if (kbl - NP < D / 16) {
+                    if (chalf == 0) qn[kbl - NP < D / 16 ? kbl - NP : 0] = load_q1(nxt, kbl - NP);
                 }
                 if (kbl < nfull) key_block(kbl, std::false_type{});
             }
@@ -831,14 +867,10 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                     inv[hh] = 1.0f / l_row;
                 }
                 bad = bad && !SAFE && mode == 0 && active;
-                if (bad) my_redo |= 1u << hi;
-                // next head's q (before the ctx stores: the wait for qn must not cover them)
-                if (PFQ) {
+                if (bad) my_redo |= 1ull << c_ord;
+                // next item's q (before the ctx stores: the wait for qn must not cover them)
 #pragma unroll
-                    for (int s = 0; s < D / 16; ++s) qf[s] = qn[s];
-                } else {
-                    load_q(hd_next, rest != 0u && q_live, qf);
-                }
+                for (int s = 0; s < D / 16; ++s) qf[s] = qn[s];
                 // O^T layout: col = query l31, row = dv (r&3) + 8*(r>>2) + 4h (+32t): 4 consecutive dv per register group.  The two
                 // halves of the wave trade groups (v_permlane32_swap: lanes 32-63 of one register <-> lanes 0-31 of another), after
                 // which lane (l31, h) holds dv 16 rgp + 8h .. + 7 of its row: 16-byte stores, half as many (the issue of the
@@ -846,7 +878,8 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                 asm volatile("" : "+v"(lane));
                 const int vo = (wave * 32 + (lane & 31)) * pitch + (lane >> 5) * 16;
                 const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
-                    (void *)(ctx + (size_t)tok0 * hidden + (hd0 + hi) * D), 0, mine_now && !bad && c_live ? (uint32_t)((len - 1) * pitch + RB) : 0u, 0x00020000);
+                    (void *)(ctx + (size_t)cur.tok0 * hidden + cur.grp * D), 0, mine_now && !bad && c_live ? (uint32_t)((len - 1) * pitch + RB) : 0u,
+                    0x00020000);
 #pragma unroll
                 for (int t = 0; t < D / 32; ++t)
 #pragma unroll
@@ -869,7 +902,13 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
                     }
                 // the next stage's tiles (issued before this stage's key loop) have landed; the stores stay in flight
                 __builtin_amdgcn_s_waitcnt(0x0F70 | NS);  // vmcnt(NS)
-                cm = rest;
+                // on to the next item; the one after it was fetched an item ago, the one after that is fetched now
+                cur = nxt;
+                c_ord = x_ord;
+                nxt = nn;
+                x_ord = nn_ord;
+                nn_ord = pop();
+                nn = fetch(nn_ord);
                 chalf = 0;
             } else {
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -880,66 +919,74 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
         }
     };
 
-    const uint32_t all = hpw >= 32 ? 0xFFFFFFFFu : (1u << hpw) - 1u;
+    const uint64_t all = n_my >= 64 ? ~0ull : (1ull << n_my) - 1ull;
     if (mode != 1) pass(std::false_type{}, all, all);
     else my_redo = all;  // MEMEX_HIP_ATTN_SAFE=1: everything through the running-maximum loop
     if (mode >= 2) return;
-    // heads some wave of this workgroup has to redo (rare): staged again by everybody, computed by the waves that asked
-    if (my_redo != 0u && (tid & 63) == 0) __hip_atomic_fetch_or(wg_redo, my_redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // items some wave of this workgroup has to redo (rare): staged again by everybody, computed by the waves that asked
+    if (my_redo != 0ull && (tid & 63) == 0) __hip_atomic_fetch_or(wg_redo, my_redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
-    const uint32_t redo = __builtin_amdgcn_readfirstlane(*wg_redo);
-    pass(std::true_type{}, redo, my_redo);
+    const uint64_t redo = *wg_redo;
+    const uint64_t redo_u = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(redo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)redo);
+    pass(std::true_type{}, redo_u, my_redo);
 }
 
 static size_t attn_lds(int d) { return (size_t)2 * 2 * kAttnStage * d * 2 + 16; }
 
-hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt,
-                            const int32_t *cu, const int32_t *lens, int B, int max_len, int heads, int d_head,
-                            int hidden, bf16_t *ctx) {
-    if (max_len > kAttnQ || max_len < 1 || (d_head != 32 && d_head != 64)) return hipErrorInvalidValue;
-    if ((size_t)d_head * ldvt * 2 > 0xFFFFFFF0ull || (size_t)kAttnQ * hidden * 2 > 0x7FFFFFFFull) return hipErrorInvalidValue;  // 32-bit buffer offsets
-    // heads per workgroup: as many as keep every CU busy (d = 64: one 16-wave workgroup fills a CU's LDS, d = 32: two),
-    // a divisor of `heads`, at most 16 (the redo masks); MEMEX_HIP_ATTN_HPW overrides
+// head groups of a stage: d = 32 stages two adjacent heads together (q / k / ctx rows in 128-byte pieces instead of 64:
+// 403 MB per pass of 131k tokens took 111-118 us alone in 64-byte pieces, 87-93 in 128-byte ones; the launch itself is bound
+// by its exp2 either way; MEMEX_HIP_ATTN_PAIR=0: one head per stage)
+static bool attn_pair(int heads, int d_head) {
+    const char *ev = getenv("MEMEX_HIP_ATTN_PAIR");
+    return d_head == 32 && heads % 2 == 0 && !(ev && ev[0] == '0');
+}
+int attention_groups(int heads, int d_head) { return attn_pair(heads, d_head) ? heads / 2 : heads; }
+
+hipError_t launch_attention_plan(hipStream_t s, const int32_t *lens, const int32_t *cu, int B, int max_len, int heads, int d_head,
+                                 void *plan) {
+    if (B < 1 || B > 1024 || max_len < 1 || max_len > kAttnQ) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_plan_kernel, dim3(1), dim3(1024), 0, s, lens, cu, B, max_len, attention_groups(heads, d_head),
+                       reinterpret_cast<AttnItem *>(plan));
+    return hipGetLastError();
+}
+
+hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt, const void *plan, int B,
+                            int heads, int d_head, int hidden, bf16_t *ctx) {
+    if (B < 1 || B > 1024 || (d_head != 32 && d_head != 64) || heads * d_head != hidden) return hipErrorInvalidValue;
+    if ((size_t)d_head * 2 * ldvt * 2 > 0xFFFFFFF0ull || (size_t)kAttnQ * hidden * 2 > 0x7FFFFFFFull) return hipErrorInvalidValue;  // 32-bit buffer offsets
     static const int n_cu = [] {
         int dev = 0;
         hipDeviceProp_t prop;
         return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
     }();
-    static const int hpw_env = [] {
-        const char *ev = getenv("MEMEX_HIP_ATTN_HPW");
-        return ev ? atoi(ev) : 0;
-    }();
-    // d = 32: two adjacent heads per stage (q / k / ctx rows in 128-byte pieces instead of 64: 403 MB per pass of 131k tokens
-    // took 111-118 us alone in 64-byte pieces, 87-93 in 128-byte ones; the launch itself is bound by its exp2: 166 us either way;
-    // MEMEX_HIP_ATTN_PAIR=0: one head per stage)
-    const bool pair_env = [] {
-        const char *ev = getenv("MEMEX_HIP_ATTN_PAIR");
-        return !(ev && ev[0] == '0');
-    }();
-    const bool pair = d_head == 32 && heads % 2 == 0 && pair_env;
-    const int groups = pair ? heads / 2 : heads;  // head groups: what a stage holds
-    const long want = (long)n_cu;
-    int hpw = 1;
-    for (int c = groups < 16 ? groups : 16; c >= 1; --c)
-        if (groups % c == 0 && (long)B * (groups / c) >= want) {
-            hpw = c;
-            break;
-        }
-    if (hpw_env > 0 && hpw_env <= 16 && groups % hpw_env == 0) hpw = hpw_env;
-    dim3 grid(1, groups / hpw, B);
+    const bool pair = attn_pair(heads, d_head);
+    const int n_items = B * attention_groups(heads, d_head);
     const size_t lds = attn_lds(pair ? 64 : d_head);
-    // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path); =2: no key loop (measurement)
+    // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path); 2 .. 6: measurement modes
+    // (no key loop / no loads / no stores: wrong results)
     const int mode = [] {
         const char *ev = getenv("MEMEX_HIP_ATTN_SAFE");
         const int m = ev ? atoi(ev) : 0;
-        return m >= 0 && m <= 6 ? m : 0;  // 2 .. 6 are measurement modes (no key loop / no loads / no stores: wrong results)
+        return m >= 0 && m <= 6 ? m : 0;
     }();
-    if (d_head == 32 && pair)
-        hipLaunchKernelGGL((attention_kernel<32, 2>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
-    else if (d_head == 32)
-        hipLaunchKernelGGL((attention_kernel<32, 1>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
-    else
-        hipLaunchKernelGGL((attention_kernel<64, 1>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, cu, lens, hidden, ctx, mode, hpw);
+    // a persistent grid: one 16-wave workgroup per CU (LDS: one at d = 64, register file: one at d = 32), each walks up to 64
+    // items (its redo masks are 64 bits); MEMEX_HIP_ATTN_CUS: fewer workgroups (measurement)
+    static const int cus_env = [] {
+        const char *ev = getenv("MEMEX_HIP_ATTN_CUS");
+        return ev ? atoi(ev) : 0;
+    }();
+    const int G = cus_env > 0 ? cus_env : n_cu;
+    const AttnItem *items = reinterpret_cast<const AttnItem *>(plan);
+    for (int off = 0; off < n_items; off += 64 * G) {
+        const int n = n_items - off < 64 * G ? n_items - off : 64 * G;
+        const dim3 grid(n < G ? n : G);
+        if (d_head == 32 && pair)
+            hipLaunchKernelGGL((attention_kernel<32, 2>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, items + off, n, hidden, ctx, mode);
+        else if (d_head == 32)
+            hipLaunchKernelGGL((attention_kernel<32, 1>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, items + off, n, hidden, ctx, mode);
+        else
+            hipLaunchKernelGGL((attention_kernel<64, 1>), grid, dim3(kAttnWaves * 64), lds, s, q, k, vt, ldvt, items + off, n, hidden, ctx, mode);
+    }
     return hipGetLastError();
 }
 
