@@ -191,11 +191,10 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
     int rc = ensure_ws(e, t_pad, B, 0);
     if (rc != MX_OK) return rc;
     hipStream_t st = e->stream;
-    MX_HIP(launch_token_map(st, d_lens, B, S, e->cu, e->tok_seq, e->tok_pos, t_pad));
+    if ((size_t)attention_groups(heads, dh) * 16 > kAttnPlanBytesPerSeq) return fail(MX_EINVAL, "more than 16 head groups per sequence");
+    MX_HIP(launch_token_map(st, d_lens, B, S, e->cu, e->tok_seq, e->tok_pos, t_pad, heads, dh, e->attn_plan));
     MX_HIP(launch_embed_ln(st, d_ids, S, e->tok_seq, e->tok_pos, t_pad, H, e->word, e->pos, e->type0, e->eg, e->eb,
                            c.ln_eps, c.vocab, e->x));
-    if ((size_t)attention_groups(heads, dh) * 16 > kAttnPlanBytesPerSeq) return fail(MX_EINVAL, "more than 16 head groups per sequence");
-    MX_HIP(launch_attention_plan(st, d_lens, e->cu, B, max_len, heads, dh, e->attn_plan));
     const float qscale = (float)(1.4426950408889634 / std::sqrt((double)dh));
     // Large passes (>= kPgemmRows packed rows) run every GEMM whose shape it takes on pgemm_kernel; the Add & LayerNorm
     // GEMMs then leave y = product + bias + residual and ln_rows_kernel normalises it in place.

@@ -91,8 +91,9 @@ hipError_t launch_pgemm(hipStream_t s, int epi, const GemmParams &p);
 hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden, const float *gamma, const float *beta, float eps);
 
 // token maps from sequence lengths: cu[b] (aligned starts), tok_seq / tok_pos for every packed row
+// (+ the attention work list of the pass, see launch_attention)
 hipError_t launch_token_map(hipStream_t s, const int32_t *lens, int B, int S, int32_t *cu, int32_t *tok_seq,
-                            int32_t *tok_pos, int t_pad);
+                            int32_t *tok_pos, int t_pad, int heads, int d_head, void *attn_plan);
 
 // x[t] = LayerNorm(word[id] + pos[p] + type[0])
 hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32_t *tok_seq, const int32_t *tok_pos,
@@ -100,12 +101,10 @@ hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32
                            const float *gamma, const float *beta, float eps, int vocab, bf16_t *x);
 
 // softmax(q k^T + mask) v per (sequence, head); q is pre-scaled by 1/sqrt(d)*log2(e)
-// `plan`: kAttnPlanBytesPerSeq bytes per sequence, written by launch_attention_plan once per pass (the work list: one
+// `plan`: kAttnPlanBytesPerSeq bytes per sequence, written by launch_token_map once per pass (the work list: one
 // item per (sequence, head group), longest sequences first) and read by every layer's launch_attention
 constexpr size_t kAttnPlanBytesPerSeq = 16 * 16;
 int attention_groups(int heads, int d_head);
-hipError_t launch_attention_plan(hipStream_t s, const int32_t *lens, const int32_t *cu, int B, int max_len, int heads, int d_head,
-                                 void *plan);
 hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt, const void *plan, int B,
                             int heads, int d_head, int hidden, bf16_t *ctx);
 

@@ -371,8 +371,17 @@ hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
 // ---------------------------------------------------------------------------------------------
 // token map
 // ---------------------------------------------------------------------------------------------
+// The attention work list of a pass (attention_kernel below): one ITEM per (sequence, head group), sequences in order of
+// decreasing length (all groups of a sequence adjacent), written by block 0 of token_map_kernel.  Workgroup j of the
+// persistent attention grid takes the items j, j + G, j + 2G, ... -- one from every tier of the sorted list, so the loads
+// differ by about one short item.
+struct AttnItem {
+    int32_t tok0, len, group, pad;
+};
+
 __global__ __launch_bounds__(1024) void token_map_kernel(const int32_t *__restrict__ lens, int B, int S, int32_t *cu,
-                                                         int32_t *tok_seq, int32_t *tok_pos, int t_pad) {
+                                                         int32_t *tok_seq, int32_t *tok_pos, int t_pad, int groups,
+                                                         AttnItem *__restrict__ plan) {
     // blocks of 1024 threads (B <= 1024): every block scans the aligned lengths itself (1024 elements: cheaper
     // than a second launch), then the packed rows, dealt over the grid, find their sequence by binary
     // search in the scanned starts
@@ -396,6 +405,14 @@ __global__ __launch_bounds__(1024) void token_map_kernel(const int32_t *__restri
         __syncthreads();
     }
     if (blockIdx.x == 0 && tid <= B) cu[tid] = s_cu[tid];
+    if (blockIdx.x == gridDim.x - 1 && tid < B && plan) {
+        int rank = 0;  // sequences that come first: longer ones, and equally long ones with a smaller index
+        for (int j = 0; j < B; ++j) {
+            const int o = s_len[j];
+            rank += (o > l || (o == l && j < tid)) ? 1 : 0;
+        }
+        for (int g = 0; g < groups; ++g) plan[(size_t)rank * groups + g] = AttnItem{s_cu[tid], l, g, 0};
+    }
     const int total = s_cu[B];
     for (int t = blockIdx.x * 1024 + tid; t < t_pad; t += gridDim.x * 1024) {
         int seq = -1, pos = 0;
@@ -417,11 +434,13 @@ __global__ __launch_bounds__(1024) void token_map_kernel(const int32_t *__restri
     }
 }
 
+static bool attn_pair(int heads, int d_head);
 hipError_t launch_token_map(hipStream_t s, const int32_t *lens, int B, int S, int32_t *cu, int32_t *tok_seq,
-                            int32_t *tok_pos, int t_pad) {
+                            int32_t *tok_pos, int t_pad, int heads, int d_head, void *attn_plan) {
     if (B > 1024) return hipErrorInvalidValue;
     const int blocks = t_pad / 1024 < 1 ? 1 : (t_pad / 1024 > 256 ? 256 : t_pad / 1024);
-    hipLaunchKernelGGL(token_map_kernel, dim3(blocks), dim3(1024), 0, s, lens, B, S, cu, tok_seq, tok_pos, t_pad);
+    hipLaunchKernelGGL(token_map_kernel, dim3(blocks), dim3(1024), 0, s, lens, B, S, cu, tok_seq, tok_pos, t_pad,
+                       attention_groups(heads, d_head), reinterpret_cast<AttnItem *>(attn_plan));
     return hipGetLastError();
 }
 
@@ -563,7 +582,7 @@ hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden
 
 // ---------------------------------------------------------------------------------------------
 // K3: attention.  A persistent grid of one workgroup per CU, 16 waves x 32 queries (sequences of <= 512 tokens); a workgroup
-// walks its share of the pass's (sequence, head group) items, longest sequences first (attn_plan_kernel).  K ([keys][d]) and V^T ([d][keys]) stream through LDS in STAGES of 256
+// walks its share of the pass's (sequence, head group) items, longest sequences first (the plan token_map_kernel writes).  K ([keys][d]) and V^T ([d][keys]) stream through LDS in STAGES of 256
 // keys, double-buffered, moved by LDS-DMA (global -> LDS, 1 KiB per wave-instruction, no registers): the DMA of stage
 // j+1 -- the other half of the keys, or the next head -- is issued when the barrier that ends stage j-1 has passed and
 // lands under the key loop of stage j; a counted s_waitcnt + ONE barrier per stage.  (Round 4: the form this replaces
@@ -587,34 +606,6 @@ hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden
 constexpr int kAttnWaves = 16;
 constexpr int kAttnQ = kAttnWaves * 32;  // queries per workgroup
 constexpr int kAttnStage = 256;          // keys per stage
-
-// The work list of a pass: one ITEM per (sequence, head group), sequences in order of decreasing length (all groups of a
-// sequence adjacent), built on the device by attn_plan_kernel.  Workgroup j of the persistent attention grid takes the
-// items j, j + G, j + 2G, ... -- one from every tier of the sorted list, so the loads differ by about one short item.
-struct AttnItem {
-    int32_t tok0, len, group, pad;
-};
-
-__global__ __launch_bounds__(1024) void attn_plan_kernel(const int32_t *__restrict__ lens, const int32_t *__restrict__ cu, int B,
-                                                         int S, int groups, AttnItem *__restrict__ plan) {
-    __shared__ int s_len[1024];
-    const int tid = threadIdx.x;
-    int l = 0;
-    if (tid < B) {
-        l = lens[tid];
-        l = l < 1 ? 1 : (l > S ? S : l);  // (what token_map_kernel packs)
-    }
-    s_len[tid] = tid < B ? l : -1;
-    __syncthreads();
-    if (tid >= B) return;
-    int rank = 0;  // sequences that come first: longer ones, and equally long ones with a smaller index
-    for (int j = 0; j < B; ++j) {
-        const int o = s_len[j];
-        rank += (o > l || (o == l && j < tid)) ? 1 : 0;
-    }
-    const int t0 = cu[tid];
-    for (int g = 0; g < groups; ++g) plan[(size_t)rank * groups + g] = AttnItem{t0, l, g, 0};
-}
 
 template <int DH, int HP>
 __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k,
@@ -941,14 +932,6 @@ static bool attn_pair(int heads, int d_head) {
     return d_head == 32 && heads % 2 == 0 && !(ev && ev[0] == '0');
 }
 int attention_groups(int heads, int d_head) { return attn_pair(heads, d_head) ? heads / 2 : heads; }
-
-hipError_t launch_attention_plan(hipStream_t s, const int32_t *lens, const int32_t *cu, int B, int max_len, int heads, int d_head,
-                                 void *plan) {
-    if (B < 1 || B > 1024 || max_len < 1 || max_len > kAttnQ) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_plan_kernel, dim3(1), dim3(1024), 0, s, lens, cu, B, max_len, attention_groups(heads, d_head),
-                       reinterpret_cast<AttnItem *>(plan));
-    return hipGetLastError();
-}
 
 hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt, const void *plan, int B,
                             int heads, int d_head, int hidden, bf16_t *ctx) {
