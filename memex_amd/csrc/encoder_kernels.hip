@@ -924,12 +924,12 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
 
 static size_t attn_lds(int d) { return (size_t)2 * 2 * kAttnStage * d * 2 + 16; }
 
-// head groups of a stage: d = 32 stages two adjacent heads together (q / k / ctx rows in 128-byte pieces instead of 64:
-// 403 MB per pass of 131k tokens took 111-118 us alone in 64-byte pieces, 87-93 in 128-byte ones; the launch itself is bound
-// by its exp2 either way; MEMEX_HIP_ATTN_PAIR=0: one head per stage)
+// head groups of a stage: one head, or (MEMEX_HIP_ATTN_PAIR=1, d = 32) two adjacent heads -- q / k / ctx rows in 128-byte pieces
+// instead of 64: 403 MB per pass of 131k tokens take 87-93 us alone instead of 111-118, but the launch is bound by its exp2
+// and the paired form keeps one more register than it has (166 against 173 us): off by default
 static bool attn_pair(int heads, int d_head) {
     const char *ev = getenv("MEMEX_HIP_ATTN_PAIR");
-    return d_head == 32 && heads % 2 == 0 && !(ev && ev[0] == '0');
+    return d_head == 32 && heads % 2 == 0 && ev && ev[0] == '1';
 }
 int attention_groups(int heads, int d_head) { return attn_pair(heads, d_head) ? heads / 2 : heads; }
 

@@ -73,7 +73,7 @@ if os.path.exists(l6):
     g = lambda n, k: 2.0 * T * n * k / 1e9
     st = rows(l6)
     qk = "pgemm_kernel<2>" if "pgemm_kernel<2>" in st else "gemm_kernel<2,2,2,2,32,4>"
-    att32 = "attention_kernel<32,2>" if "attention_kernel<32,2>" in st else "attention_kernel<32,1>"
+    att32 = "attention_kernel<32,1>" if "attention_kernel<32,1>" in st else "attention_kernel<32,2>"
     # scripts/gpu_encoder_prof.py l6: 2048 chunks = 8 passes, 3 encodes, 6 layers
     table(f"all-MiniLM-L6-v2 shape (hidden 384, ffn 1536), one layer at {T} tokens [{os.path.basename(l6)}]", st, 6, 24, H, F, [
         (qk, 1, g(2 * H, H), 3 * act, "QK projection"),

@@ -297,9 +297,9 @@ def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
                 assert (1.0 - cos).max() <= TOL, cos
         cos = (outs[0] * outs[1]).sum(1) / np.linalg.norm(outs[0], axis=1) / np.linalg.norm(outs[1], axis=1)
         assert (1.0 - cos).max() <= 1e-4, (scale, cos)
-        # d = 32 stages two adjacent heads together by default; one head per stage does the same arithmetic per head: the
-        # same bits -- except that a redo takes both heads of a pair through the running-maximum loop (scale 4)
-        monkeypatch.setenv("MEMEX_HIP_ATTN_PAIR", "0")
+        # d = 32 can stage two adjacent heads together (MEMEX_HIP_ATTN_PAIR=1): the same arithmetic per head, the same bits --
+        # except that a redo takes both heads of a pair through the running-maximum loop (scale 4)
+        monkeypatch.setenv("MEMEX_HIP_ATTN_PAIR", "1")
         for i, safe in enumerate(("0", "1")):
             monkeypatch.setenv("MEMEX_HIP_ATTN_SAFE", safe)
             with Encoder(cfg, w) as enc:
