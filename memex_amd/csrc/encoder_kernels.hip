@@ -582,10 +582,10 @@ hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden
 
 // ---------------------------------------------------------------------------------------------
 // K3: attention.  A persistent grid of one workgroup per CU, 16 waves x 32 queries (sequences of <= 512 tokens); a workgroup
-// walks its share of the pass's (sequence, head group) items, longest sequences first (the plan token_map_kernel writes).  K ([keys][d]) and V^T ([d][keys]) stream through LDS in STAGES of 256
-// keys, double-buffered, moved by LDS-DMA (global -> LDS, 1 KiB per wave-instruction, no registers): the DMA of stage
-// j+1 -- the other half of the keys, or the next head -- is issued when the barrier that ends stage j-1 has passed and
-// lands under the key loop of stage j; a counted s_waitcnt + ONE barrier per stage.  (Round 4: the form this replaces
+// walks its share of the pass's (sequence, head group) items, longest sequences first (the plan token_map_kernel writes).
+// K ([keys][d]) and V^T ([d][keys]) stream through LDS in STAGES of 256 keys, double-buffered, moved by LDS-DMA (global -> LDS, 1 KiB per wave-instruction, no registers): the DMA of stage
+// j+1 -- the other half of the keys, or the next item -- is issued (a piece per key block) behind the barrier that ends stage
+// j-1 and lands under the key loop of stage j; a counted s_waitcnt + ONE barrier per stage.  (Round 4: the form this replaces
 // loaded a head into registers, waited, wrote LDS, ran the loop; with the loop skipped a launch still took 209 of 341
 // us at d = 64 and 113 of 161 at d = 32 -- 805 / 403 MB at ~4 TB/s, none of it overlapped with the loop.  A register
 // prefetch of the next head under the loop needs 32 more VGPRs than the 128 a 16-wave workgroup has at d = 64.)
