@@ -256,7 +256,13 @@ typedef struct mx_encoder_cfg {
                            (MiniLM, bge); 2 for RoBERTa-style checkpoints such as all-distilroberta-v1
                            (embedding.rs:29,159: position ids start at padding_idx + 1; such models also
                            have max_pos = 514, type_vocab = 1, ln_eps = 1e-5)                  */
+    int32_t precision;  /* MX_PREC_BF16 (0, the default: bf16 operands, f32 accumulation -- the ingest path) |
+                           MX_PREC_BF16X3: every GEMM operand carried as hi + lo bf16 (three MFMA products per
+                           f32 product), f32 hidden state and f32 attention -- scores BETWEEN embeddings within
+                           1e-4 of the f32 CPU path (embedding.rs:109) also under checkpoint-like weights, where
+                           the bf16 path moves them by up to 1e-2; about 6x slower        */
 } mx_encoder_cfg;
+enum { MX_PREC_BF16 = 0, MX_PREC_BF16X3 = 1 };
 
 /*
  * Weight blob: f32, little-endian, tensors concatenated in this order (HF BertModel names,

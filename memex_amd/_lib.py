@@ -19,6 +19,7 @@ MX_EINVAL, MX_EDEVICE, MX_EINSERT, MX_ESEARCH, MX_EIO, MX_EUNSUPPORTED, MX_ENOME
 MX_SEARCH_AUTO, MX_SEARCH_EXACT = 0, 1
 MX_CORPUS_F32, MX_CORPUS_BF16 = 0, 1
 MX_POOL_MEAN, MX_POOL_CLS = 0, 1
+MX_PREC_BF16, MX_PREC_BF16X3 = 0, 1
 
 # every symbol include/memex_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -60,7 +61,7 @@ class EncoderCfg(ctypes.Structure):
     _fields_ = [("layers", ctypes.c_int32), ("hidden", ctypes.c_int32), ("heads", ctypes.c_int32),
                 ("ffn", ctypes.c_int32), ("vocab", ctypes.c_int32), ("max_pos", ctypes.c_int32),
                 ("type_vocab", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("pooling", ctypes.c_int32),
-                ("normalize", ctypes.c_int32), ("pos_offset", ctypes.c_int32)]
+                ("normalize", ctypes.c_int32), ("pos_offset", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
 class EncoderStats(ctypes.Structure):
@@ -149,6 +150,8 @@ def _declare(L: ctypes.CDLL) -> None:
     L.mx_tokenizer_destroy.argtypes = [vp]
     L.mx_encoder_weight_bytes.restype = ctypes.c_size_t
     L.mx_encoder_weight_bytes.argtypes = [P(EncoderCfg)]
+    L.mx_index_stats_size.restype = ctypes.c_size_t
+    L.mx_index_stats_size.argtypes = []
 
 
 def _load_torch_runtime_first() -> None:
@@ -178,6 +181,11 @@ def lib() -> ctypes.CDLL:
                                                 "(python -c 'import __graft_entry__ as g; g.build()')")
             L = ctypes.CDLL(LIB_PATH)
             _declare(L)
+            # ABI handshake: mx_index_stats grows at the end from release to release; a binding older or newer than the
+            # library must not read past / short of what the library writes
+            if L.mx_index_stats_size() != ctypes.sizeof(IndexStats):
+                raise MemexHipError(MX_EINVAL, f"{LIB_PATH}: mx_index_stats is {L.mx_index_stats_size()} bytes, this binding "
+                                               f"declares {ctypes.sizeof(IndexStats)} (library / binding version mismatch)")
             _lib = L
         return _lib
 

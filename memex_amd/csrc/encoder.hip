@@ -45,10 +45,14 @@ struct Layer {
     bf16_t *wo2 = nullptr;   // [H, F]
     bf16_t *wf = nullptr;    // wo, wi and wo2 once more, as tail_kernel's per-wave fragment streams (fused tail only)
     float *bo2 = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+    // MX_PREC_BF16X3: the same four matrices with k tripled, [hi | hi | lo] (upload_weight3); the bf16 ones above stay null
+    bf16_t *wqkv3 = nullptr, *wo3 = nullptr, *wi3 = nullptr, *wo23 = nullptr;
 };
 
-std::once_flag g_enc_once;
-hipError_t g_enc_setup = hipSuccess;
+// kernel attributes (dynamic LDS sizes) are per device: set up once on every device an encoder is created on.  The grid
+// sizes the kernels derive from the CU count are taken from the first device (the GPUs of a node are identical).
+std::mutex g_enc_setup_mu;
+bool g_enc_setup_done[64] = {};
 std::mutex g_enc_reg_mu;
 std::map<std::string, mx_encoder *> g_enc_registry;
 
@@ -65,6 +69,10 @@ struct mx_encoder {
     // workspace (grown on demand)
     int ws_rows = 0, ws_seqs = 0, ws_ids = 0;
     bf16_t *x = nullptr, *x1 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *hbuf = nullptr;
+    // MX_PREC_BF16X3 workspace: f32 hidden state / QKV / GEMM result, split (3x wide) GEMM operands
+    float *xf = nullptr, *qkvf = nullptr, *af = nullptr;
+    bf16_t *xs = nullptr, *ctxs = nullptr, *hs = nullptr;
+    bool precise = false;
     int32_t *cu = nullptr, *tok_seq = nullptr, *tok_pos = nullptr, *lens_dev = nullptr, *ids_dev = nullptr;
     void *attn_plan = nullptr;  // attention work list of the pass in flight (kAttnPlanBytesPerSeq per sequence)
     float *out_dev = nullptr;
@@ -98,6 +106,29 @@ int upload_weight(mx_encoder *e, const float *src, size_t rows, size_t k, bf16_t
     return MX_OK;
 }
 
+// the bf16x3 form of a Linear weight: k tripled, [hi | hi | lo] against activations split as [hi | lo | hi]
+// (encoder_precise.hip), K-blocked like upload_weight's
+int upload_weight3(mx_encoder *e, const float *src, size_t rows, size_t k, bf16_t **dst) {
+    std::vector<uint16_t> tmp(rows * 3 * k);
+    auto at = [&](size_t r, size_t c) -> uint16_t & { return tmp[((c >> 5) * rows + r) * 32 + (c & 31)]; };
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < k; ++c) {
+            const float w = src[r * k + c];
+            const uint16_t hi = f32_to_bf16(w);
+            uint32_t hb = (uint32_t)hi << 16;
+            float hf;
+            memcpy(&hf, &hb, 4);
+            const uint16_t lo = f32_to_bf16(w - hf);
+            at(r, c) = hi;
+            at(r, k + c) = hi;
+            at(r, 2 * k + c) = lo;
+        }
+    MX_HIP(hipMalloc(dst, tmp.size() * sizeof(uint16_t)));
+    e->allocs.push_back(*dst);
+    MX_HIP(hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return MX_OK;
+}
+
 // wo [H, H], wi [F, H] and wo2 [H, F] -> the fused tail kernel's per-wave fragment streams (encoder_tail.hip)
 int upload_tail_stream(mx_encoder *e, const float *wo, const float *wi, const float *wo2, size_t F, bf16_t **dst) {
     std::vector<uint16_t> st(tail_stream_elems((int)F));
@@ -110,10 +141,12 @@ int upload_tail_stream(mx_encoder *e, const float *wo, const float *wi, const fl
 
 void free_ws(mx_encoder *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);  // nothing queued may still use the buffers
-    void *ptrs[] = {e->x, e->x1, e->q, e->k, e->vt, e->ctx, e->hbuf, e->tok_seq, e->tok_pos};
+    void *ptrs[] = {e->x, e->x1, e->q, e->k, e->vt, e->ctx, e->hbuf, e->tok_seq, e->tok_pos, e->xf, e->qkvf, e->af, e->xs, e->ctxs, e->hs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     e->x = e->x1 = e->q = e->k = e->vt = e->ctx = e->hbuf = nullptr;
+    e->xf = e->qkvf = e->af = nullptr;
+    e->xs = e->ctxs = e->hs = nullptr;
     e->tok_seq = e->tok_pos = nullptr;
     e->ws_rows = 0;
 }
@@ -123,12 +156,25 @@ int ensure_ws(mx_encoder *e, int rows, int seqs, int n_ids) {
     if (rows > e->ws_rows) {
         free_ws(e);
         const size_t r = (size_t)rows;
+        if (e->precise) {
+            auto zalloc = [&](void **b, size_t bytes) -> hipError_t {
+                hipError_t he = hipMalloc(b, bytes);
+                return he != hipSuccess ? he : hipMemsetAsync(*b, 0, bytes, e->stream);
+            };
+            MX_HIP(zalloc((void **)&e->xf, r * H * sizeof(float)));
+            MX_HIP(zalloc((void **)&e->qkvf, r * 3 * H * sizeof(float)));
+            MX_HIP(zalloc((void **)&e->af, r * H * sizeof(float)));
+            MX_HIP(zalloc((void **)&e->xs, r * 3 * H * sizeof(uint16_t)));
+            MX_HIP(zalloc((void **)&e->ctxs, r * 3 * H * sizeof(uint16_t)));
+            MX_HIP(zalloc((void **)&e->hs, r * 3 * F * sizeof(uint16_t)));
+        }
         bf16_t **bufs[] = {&e->x, &e->q, &e->k, &e->vt, &e->ctx};
         for (bf16_t **b : bufs) {
+            if (e->precise) break;
             MX_HIP(hipMalloc(b, r * H * sizeof(uint16_t)));
             MX_HIP(hipMemsetAsync(*b, 0, r * H * sizeof(uint16_t), e->stream));
         }
-        if (!e->fused_tail) {  // x1 [rows, H] and the [rows, ffn] MLP intermediate only exist GEMM by GEMM:
+        if (!e->fused_tail && !e->precise) {  // x1 [rows, H] and the [rows, ffn] MLP intermediate only exist GEMM by GEMM:
             // the fused tail kernel keeps both on chip (and is the faster path at every pass size, a
             // single short query included: 0.49 vs 0.58 ms)
             MX_HIP(hipMalloc(&e->x1, r * H * sizeof(uint16_t)));
@@ -193,6 +239,37 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
     hipStream_t st = e->stream;
     if ((size_t)attention_groups(heads, dh) * 16 > kAttnPlanBytesPerSeq) return fail(MX_EINVAL, "more than 16 head groups per sequence");
     MX_HIP(launch_token_map(st, d_lens, B, S, e->cu, e->tok_seq, e->tok_pos, t_pad, heads, dh, e->attn_plan));
+    if (e->precise) {
+        // MX_PREC_BF16X3 (encoder_precise.hip): split operands through gemm_kernel with k tripled, f32 everywhere else
+        MX_HIP(launch_embed_ln_precise(st, d_ids, S, e->tok_seq, e->tok_pos, t_pad, H, e->word, e->pos, e->type0, e->eg, e->eb,
+                                       c.ln_eps, c.vocab, e->xf, e->xs));
+        for (const Layer &L : e->layers) {
+            GemmParams g{};
+            g.a = e->xs; g.lda = 3 * H; g.w = L.wqkv3; g.w_rows = 3 * H; g.bias = L.bqkv; g.m = t_pad; g.n = 3 * H; g.k = 3 * H;
+            g.out_f32 = e->qkvf; g.ldo = 3 * H;
+            MX_HIP(launch_gemm(st, EPI_F32, g));
+            MX_HIP(launch_attention_f32(st, e->qkvf, e->cu, d_lens, B, max_len, heads, dh, H, e->ctxs));
+            GemmParams o{};
+            o.a = e->ctxs; o.lda = 3 * H; o.w = L.wo3; o.w_rows = H; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = 3 * H;
+            o.out_f32 = e->af; o.ldo = H;
+            MX_HIP(launch_gemm(st, EPI_F32, o));
+            MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, t_pad, H, L.ln1g, L.ln1b, c.ln_eps));
+            GemmParams f1{};
+            f1.a = e->xs; f1.lda = 3 * H; f1.w = L.wi3; f1.w_rows = F; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = 3 * H;
+            f1.out = e->hs; f1.ldo = 3 * F;
+            MX_HIP(launch_gemm(st, EPI_GELU_SPLIT, f1));
+            GemmParams f2{};
+            f2.a = e->hs; f2.lda = 3 * F; f2.w = L.wo23; f2.w_rows = H; f2.bias = L.bo2; f2.m = t_pad; f2.n = H; f2.k = 3 * F;
+            f2.out_f32 = e->af; f2.ldo = H;
+            MX_HIP(launch_gemm(st, EPI_F32, f2));
+            MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, t_pad, H, L.ln2g, L.ln2b, c.ln_eps));
+        }
+        MX_HIP(launch_pool(st, nullptr, e->xf, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
+        e->stats.sequences += (uint64_t)B;
+        e->stats.tokens += tokens;
+        e->stats.flops += (double)c.layers * ((double)tokens * (8.0 * H * H + 4.0 * (double)H * F) + attn_flops);
+        return MX_OK;
+    }
     MX_HIP(launch_embed_ln(st, d_ids, S, e->tok_seq, e->tok_pos, t_pad, H, e->word, e->pos, e->type0, e->eg, e->eb,
                            c.ln_eps, c.vocab, e->x));
     const float qscale = (float)(1.4426950408889634 / std::sqrt((double)dh));
@@ -243,7 +320,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         f2.out = e->x; f2.ldo = H; f2.res = e->x1; f2.ldres = H; f2.gamma = L.ln2g; f2.beta = L.ln2b; f2.eps = c.ln_eps;
         MX_HIP(gemm_res_ln(f2));
     }
-    MX_HIP(launch_pool(st, e->x, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
+    MX_HIP(launch_pool(st, e->x, nullptr, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
     // no synchronisation here: the passes of one call queue up on the stream (same workspace, stream order)
     e->stats.sequences += (uint64_t)B;
     e->stats.tokens += tokens;
@@ -310,6 +387,8 @@ int check_cfg(const mx_encoder_cfg *c) {
     if (c->pos_offset < 0 || c->pos_offset >= c->max_pos) return fail(MX_EINVAL, "pos_offset %d outside [0, max_pos)", c->pos_offset);
     if (c->pooling != MX_POOL_MEAN && c->pooling != MX_POOL_CLS) return fail(MX_EINVAL, "pooling %d", c->pooling);
     if (!(c->ln_eps >= 0.0f)) return fail(MX_EINVAL, "ln_eps");
+    if (c->precision != MX_PREC_BF16 && c->precision != MX_PREC_BF16X3) return fail(MX_EINVAL, "precision %d", c->precision);
+    if (c->precision == MX_PREC_BF16X3 && c->ffn % 192) return fail(MX_EUNSUPPORTED, "ffn %d: MX_PREC_BF16X3 needs a multiple of 192", c->ffn);
     return MX_OK;
 }
 
@@ -342,20 +421,25 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     if (device < 0 || device >= ndev) return fail(MX_EDEVICE, "device %d out of range (have %d)", device, ndev);
     DeviceGuard g(device);
     if (!g.ok) return fail(MX_EDEVICE, "hipSetDevice(%d) failed", device);
-    std::call_once(g_enc_once, [] {
-        g_enc_setup = encoder_kernels_setup();
-        if (g_enc_setup == hipSuccess) g_enc_setup = pgemm_setup();
-        if (g_enc_setup == hipSuccess) g_enc_setup = tail_setup();
-    });
-    if (g_enc_setup != hipSuccess)
-        return fail(MX_EDEVICE, "encoder kernel setup failed: %s", hipGetErrorString(g_enc_setup));
+    {
+        std::lock_guard<std::mutex> lk(g_enc_setup_mu);
+        if (device >= 64 || !g_enc_setup_done[device]) {
+            hipError_t se = encoder_kernels_setup();
+            if (se == hipSuccess) se = pgemm_setup();
+            if (se == hipSuccess) se = tail_setup();
+            if (se == hipSuccess) se = precise_setup();
+            if (se != hipSuccess) return fail(MX_EDEVICE, "encoder kernel setup failed: %s", hipGetErrorString(se));
+            if (device < 64) g_enc_setup_done[device] = true;
+        }
+    }
 
     mx_encoder *e = new mx_encoder();
     e->cfg = *cfg;
     e->device = device;
     {
         const char *ev = getenv("MEMEX_HIP_UNFUSED_TAIL");
-        e->fused_tail = tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
+        e->precise = cfg->precision == MX_PREC_BF16X3;
+        e->fused_tail = !e->precise && tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
         const char *pv = getenv("MEMEX_HIP_PGEMM");
         e->pgemm = !(pv && pv[0] == '0');
     }
@@ -397,20 +481,24 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
             memcpy(wqkv.data() + part * H * H, take(H * H), H * H * sizeof(float));
             memcpy(bqkv.data() + part * H, take(H), H * sizeof(float));
         }
-        MX_TRY(upload_weight(e, wqkv.data(), 3 * H, H, &L.wqkv));
+        if (e->precise) MX_TRY(upload_weight3(e, wqkv.data(), 3 * H, H, &L.wqkv3));
+        else MX_TRY(upload_weight(e, wqkv.data(), 3 * H, H, &L.wqkv));
         MX_TRY(upload_f32(e, bqkv.data(), 3 * H, &L.bqkv));
         const float *wo_src = take(H * H);
-        MX_TRY(upload_weight(e, wo_src, H, H, &L.wo));
+        if (e->precise) MX_TRY(upload_weight3(e, wo_src, H, H, &L.wo3));
+        else MX_TRY(upload_weight(e, wo_src, H, H, &L.wo));
         const float *bo_src = take(H), *g1_src = take(H), *be1_src = take(H);
         MX_TRY(upload_f32(e, bo_src, H, &L.bo));
         MX_TRY(upload_f32(e, g1_src, H, &L.ln1g));
         MX_TRY(upload_f32(e, be1_src, H, &L.ln1b));
         const float *wi_src = take(F * H);
-        MX_TRY(upload_weight(e, wi_src, F, H, &L.wi));
+        if (e->precise) MX_TRY(upload_weight3(e, wi_src, F, H, &L.wi3));
+        else MX_TRY(upload_weight(e, wi_src, F, H, &L.wi));
         const float *b1_src = take(F);
         MX_TRY(upload_f32(e, b1_src, F, &L.bi));
         const float *wo2_src = take(H * F);
-        MX_TRY(upload_weight(e, wo2_src, H, F, &L.wo2));
+        if (e->precise) MX_TRY(upload_weight3(e, wo2_src, H, F, &L.wo23));
+        else MX_TRY(upload_weight(e, wo2_src, H, F, &L.wo2));
         if (e->fused_tail) MX_TRY(upload_tail_stream(e, wo_src, wi_src, wo2_src, F, &L.wf));
         const float *b2_src = take(H), *g2_src = take(H), *be2_src = take(H);
         MX_TRY(upload_f32(e, b2_src, H, &L.bo2));

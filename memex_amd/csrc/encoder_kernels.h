@@ -24,6 +24,9 @@ enum GemmEpilogue {
     EPI_VT = 4,           // N = H: v, feature-major (transposed) into out_vt
     EPI_BIAS_RES_LN = 3,  // out = bf16(LayerNorm(acc + bias + residual))   (BN == N == hidden)
     EPI_BIAS_RES = 5,     // out = bf16(bf16(acc + bias) + residual): pgemm_kernel only, launch_ln_rows applies the LayerNorm
+    // the bf16x3 ("precise") encoder, encoder_precise.hip: operands arrive split, results leave in f32 or split again
+    EPI_F32 = 6,          // out_f32 = acc + bias                              ([M, N] f32, row pitch ldo)
+    EPI_GELU_SPLIT = 7,   // out = split3(gelu_erf(acc + bias))                ([M, 3N] bf16, row pitch ldo: hi | lo | hi)
 };
 
 struct GemmParams {
@@ -46,6 +49,7 @@ struct GemmParams {
     const float *gamma;   // EPI_BIAS_RES_LN
     const float *beta;
     float eps;
+    float *out_f32;       // EPI_F32
 };
 
 // the layer tail (encoder_tail.hip), hidden = 384:
@@ -108,8 +112,24 @@ int attention_groups(int heads, int d_head);
 hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt, const void *plan, int B,
                             int heads, int d_head, int hidden, bf16_t *ctx);
 
-// masked mean (or CLS) over tokens + optional L2 normalise -> out [B, H] f32
-hipError_t launch_pool(hipStream_t s, const bf16_t *x, const int32_t *cu, const int32_t *lens, int B, int hidden,
+// masked mean (or CLS) over tokens + optional L2 normalise -> out [B, H] f32; xf != nullptr: the f32 hidden state instead of x
+hipError_t launch_pool(hipStream_t s, const bf16_t *x, const float *xf, const int32_t *cu, const int32_t *lens, int B, int hidden,
                        int pooling_cls, int normalize, float *out);
+
+// ---- the bf16x3 ("precise") encoder (encoder_precise.hip): every GEMM operand travels as THREE bf16 column blocks
+// [hi | lo | hi] (activations, width 3K) against [hi | hi | lo] (weights), so that the unchanged bf16 MFMA loop sums
+// hi*hi + lo*hi + hi*lo -- 16 significant bits per operand instead of 8; the hidden state, the GEMM results and the whole
+// attention core stay in f32.
+hipError_t precise_setup();
+// x[t] = LayerNorm(word[id] + pos[p] + type[0]) -> xf [t_pad, H] f32 and xs [t_pad, 3H] split
+hipError_t launch_embed_ln_precise(hipStream_t s, const int32_t *ids, int S, const int32_t *tok_seq, const int32_t *tok_pos,
+                                   int t_pad, int hidden, const float *word, const float *pos, const float *type0,
+                                   const float *gamma, const float *beta, float eps, int vocab, float *xf, bf16_t *xs);
+// xf[r] = LayerNorm(a[r] + xf[r]) in place (f32), xs[r] = split3(xf[r])
+hipError_t launch_add_ln_split(hipStream_t s, const float *a, float *xf, bf16_t *xs, int rows, int hidden, const float *gamma,
+                               const float *beta, float eps);
+// softmax(q k^T / sqrt(d) + mask) v in f32 (v_mfma_f32_32x32x2_f32) from qkv [t_pad, 3H] f32 (q | k | v) -> ctxs [t_pad, 3H] split
+hipError_t launch_attention_f32(hipStream_t s, const float *qkv, const int32_t *cu, const int32_t *lens, int B, int S, int heads,
+                                int d_head, int hidden, bf16_t *ctxs);
 
 }  // namespace mx

@@ -201,6 +201,41 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
         for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
 #endif
+    if constexpr (EPI == EPI_F32 || EPI == EPI_GELU_SPLIT) {
+        // ---- the bf16x3 encoder's epilogues, straight from the accumulators (a lane owns row m = its l31 and 4 consecutive
+        // columns per register group: 16-byte f32 / 8-byte bf16 stores; these GEMMs multiply three times the k of the bf16
+        // path, their stores are a few per cent of the launch)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int ncol = n0 + wn * 96 + j * 32 + 8 * rg + 4 * h;
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(p.bias + ncol);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const size_t grow = (size_t)(m0 + wm * 32 * MI + i * 32 + l31);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + b4[e];
+                    if constexpr (EPI == EPI_F32) {
+                        *reinterpret_cast<f32x4 *>(p.out_f32 + grow * p.ldo + ncol) = v;
+                    } else {
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float g = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));  // exact-erf GELU
+                            hi[e] = (__bf16)g;
+                            lo[e] = (__bf16)(g - (float)hi[e]);
+                        }
+                        bf16_t *o = p.out + grow * p.ldo + ncol;
+                        *reinterpret_cast<bf16x4 *>(o) = hi;
+                        *reinterpret_cast<bf16x4 *>(o + p.n) = lo;
+                        *reinterpret_cast<bf16x4 *>(o + 2 * p.n) = hi;
+                    }
+                }
+            }
+        return;
+    }
     __syncthreads();  // all waves are done with the ring: its space becomes the output tile
 
     // ---- epilogue, one 128-row group at a time (the bf16 output tile of a group fits the ring's
@@ -360,6 +395,8 @@ hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
         case EPI_BIAS_GELU: return big_ff ? gemm_go<EPI_BIAS_GELU, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_BIAS_GELU, 2, 2, 2, 32, 4>(s, p);
         case EPI_QKV: return big_qk ? gemm_go<EPI_QKV, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_QKV, 2, 2, 2, 32, 4>(s, p);
         case EPI_VT: return big_vt ? gemm_go<EPI_VT, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_VT, 2, 2, 2, 32, 4>(s, p);
+        case EPI_F32: return gemm_go<EPI_F32, 2, 2, 2, 32, 4>(s, p);
+        case EPI_GELU_SPLIT: return gemm_go<EPI_GELU_SPLIT, 2, 2, 2, 32, 4>(s, p);
         case EPI_BIAS_RES_LN:
             if (p.n == 384) return gemm_go<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>(s, p);
             if (p.n == 768) return gemm_go<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>(s, p);
@@ -976,7 +1013,8 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
 // ---------------------------------------------------------------------------------------------
 // K5: pooling + L2 normalise
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void pool_kernel(const bf16_t *__restrict__ x, const int32_t *__restrict__ cu,
+template <typename T>
+__global__ __launch_bounds__(1024) void pool_kernel(const T *__restrict__ x, const int32_t *__restrict__ cu,
                                                     const int32_t *__restrict__ lens, int hidden, int pooling_cls,
                                                     int normalize, float *__restrict__ out) {
     // 1024 threads = hidden/8 column chunks (16-byte loads) x token stripes; partial sums meet in LDS
@@ -992,9 +1030,19 @@ __global__ __launch_bounds__(1024) void pool_kernel(const bf16_t *__restrict__ x
     if (st < stripes) {
         float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int t = st; t < len; t += stripes) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + (size_t)(tok0 + t) * hidden + ch * 8);
+            if constexpr (std::is_same<T, float>::value) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(x + (size_t)(tok0 + t) * hidden + ch * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(x + (size_t)(tok0 + t) * hidden + ch * 8 + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+                for (int e = 0; e < 4; ++e) {
+                    a[e] += v0[e];
+                    a[4 + e] += v1[e];
+                }
+            } else {
+                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + (size_t)(tok0 + t) * hidden + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+            }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) s_part[st * hidden + ch * 8 + e] = a[e];
@@ -1018,10 +1066,11 @@ __global__ __launch_bounds__(1024) void pool_kernel(const bf16_t *__restrict__ x
     if (tid < hidden) out[(size_t)b * hidden + tid] = v * sc;
 }
 
-hipError_t launch_pool(hipStream_t s, const bf16_t *x, const int32_t *cu, const int32_t *lens, int B, int hidden,
+hipError_t launch_pool(hipStream_t s, const bf16_t *x, const float *xf, const int32_t *cu, const int32_t *lens, int B, int hidden,
                        int pooling_cls, int normalize, float *out) {
     if (hidden > 1024 || hidden % 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(1024), 0, s, x, cu, lens, hidden, pooling_cls, normalize, out);
+    if (xf) hipLaunchKernelGGL(pool_kernel<float>, dim3(B), dim3(1024), 0, s, xf, cu, lens, hidden, pooling_cls, normalize, out);
+    else hipLaunchKernelGGL(pool_kernel<bf16_t>, dim3(B), dim3(1024), 0, s, x, cu, lens, hidden, pooling_cls, normalize, out);
     return hipGetLastError();
 }
 
@@ -1031,6 +1080,8 @@ hipError_t encoder_kernels_setup() {
     if ((e = gemm_attr<EPI_BIAS_GELU, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_QKV, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_VT, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_F32, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_GELU_SPLIT, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_GELU, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_QKV, 2, 4, 4, 32, 3>()) != hipSuccess) return e;

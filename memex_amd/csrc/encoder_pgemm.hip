@@ -464,7 +464,8 @@ hipError_t pgemm_setup() {
     g_pgemm_cus = prop.multiProcessorCount / 8 * 8;  // one workgroup per CU, a multiple of the XCD count
     if (const char *ev = getenv("MEMEX_HIP_PGEMM_SKEW")) g_pgemm_skew = atoi(ev);
     if (const char *ev = getenv("MEMEX_HIP_PGEMM_CUS")) g_pgemm_cus = atoi(ev) / 8 * 8;
-    return g_pgemm_cus >= 8 ? hipSuccess : hipErrorInvalidDevice;
+    if (g_pgemm_cus < 8) g_pgemm_cus = 0;  // pgemm is optional: pgemm_supported() then says no and gemm_kernel runs every pass
+    return hipSuccess;
 }
 
 // shapes pgemm_kernel takes: whole 256 x 256 tiles, k-tiles of 64, 32-bit byte offsets, the q / k split on a wave edge

@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -235,7 +236,7 @@ std::once_flag g_scan_once;
 hipError_t g_scan_setup_err = hipSuccess;
 std::mutex g_rccl_mu;
 Rccl g_rccl;
-bool g_rccl_broken = false;  // an initialisation hung: no further attempts in this process
+std::atomic<bool> g_rccl_broken{false};  // an initialisation hung: no further attempts in this process (indexes open concurrently)
 
 bool load_rccl() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
@@ -431,10 +432,17 @@ int ensure_out(mx_index *idx, int k) {
     return MX_OK;
 }
 
-int ensure_exact(mx_index *idx, int k) {
+// EXACT path scratch for passes of `gcap` queries (4 / 8 / 16 / 32: the kernel's query-per-thread buckets).  The EXACT path
+// is the correctness backstop -- one doubly-overflowed query, one k > 256 search -- so it asks for what THIS batch needs
+// (4 B per row and query of the pass), not for a full group, and on a full device it settles for smaller passes.
+int ensure_exact(mx_index *idx, int k, int *gcap) {
     Scratch &s = idx->s;
-    const size_t need = exact_group_scratch_bytes(idx->n, k);
-    if (s.exact_bytes < need) {
+    for (int g = *gcap;; g /= 2) {
+        const size_t need = exact_group_scratch_bytes(idx->n, k, g);
+        if (s.exact_bytes >= need) {
+            *gcap = g;
+            return MX_OK;
+        }
         if (s.exact_scratch) {
             MX_HIP(hipStreamSynchronize(idx->stream));
             (void)hipFree(s.exact_scratch);
@@ -446,11 +454,15 @@ int ensure_exact(mx_index *idx, int k) {
             s.exact_bytes = want;
         } else {
             (void)hipGetLastError();
-            MX_HIP(hipMalloc(&s.exact_scratch, need));
-            s.exact_bytes = need;
+            if (hipMalloc(&s.exact_scratch, need) == hipSuccess) s.exact_bytes = need;
+            else (void)hipGetLastError();
         }
+        if (s.exact_bytes >= need) {
+            *gcap = g;
+            return MX_OK;
+        }
+        if (g <= 4) return fail(MX_ENOMEM, "hipMalloc(EXACT-path scratch, %zu bytes) failed", need);
     }
-    return MX_OK;
 }
 
 // device buffers being built by ensure_capacity: freed unless handed over
@@ -672,17 +684,20 @@ uint32_t sample_stride(uint64_t full_tiles, int nwg, int k, bool filt8, int ds) 
     return (uint32_t)std::max<uint64_t>(1, full_tiles / std::max<uint64_t>(target, 1));
 }
 
+constexpr size_t kExactKeepBytes = 256ull << 20;  // EXACT-path scratch kept between batches up to this size
+
 int run_exact(mx_index *idx, const std::vector<int> &qs, int k, uint64_t *d_ids, float *d_scores, float *d_dists,
               int32_t *d_nfound) {
     if (qs.empty()) return MX_OK;
-    int rc = ensure_exact(idx, k);
+    int gcap = qs.size() <= 4 ? 4 : qs.size() <= 8 ? 8 : qs.size() <= 16 ? 16 : kExactGroup;
+    int rc = ensure_exact(idx, k, &gcap);
     if (rc != MX_OK) return rc;
     Scratch &s = idx->s;
-    // groups of up to 32 queries share one pass over the rows (launch_exact_group); the groups of a batch reuse the scratch
-    // in stream order
-    for (size_t g0 = 0; g0 < qs.size(); g0 += kExactGroup) {
+    // groups of up to gcap (<= 32) queries share one pass over the rows (launch_exact_group); the groups of a batch reuse the
+    // scratch in stream order
+    for (size_t g0 = 0; g0 < qs.size(); g0 += (size_t)gcap) {
         ExactGroup grp{};
-        grp.n = (int)std::min<size_t>(kExactGroup, qs.size() - g0);
+        grp.n = (int)std::min<size_t>((size_t)gcap, qs.size() - g0);
         for (int j = 0; j < grp.n; ++j) grp.q[j] = qs[g0 + j];
         MX_HIP(launch_exact_group(idx->stream, k, idx->ds, idx->compressed ? nullptr : idx->x, idx->xh, idx->n, idx->idmap, s.qpad,
                                   s.qnorm2, grp, s.exact_scratch, d_ids, d_scores, d_dists, d_nfound));
@@ -997,6 +1012,11 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         rc = run_exact(idx, exact, k, d_ids, d_scores, d_dists, d_nfound);
         if (rc != MX_OK) return rc;
         MX_HIP(hipStreamSynchronize(st));
+        if (idx->mode == MX_SEARCH_AUTO && idx->s.exact_bytes > kExactKeepBytes) {  // a large scratch does not stay behind a fallback batch
+            (void)hipFree(idx->s.exact_scratch);
+            idx->s.exact_scratch = nullptr;
+            idx->s.exact_bytes = 0;
+        }
     }
     // (fast path with nothing left to do: finish_kernel's completion word was stored after every result of
     // the batch had been fenced to device scope -- the results are in HBM, nothing else is queued)
@@ -1015,6 +1035,27 @@ void sync_shard_streams(mx_index *idx) {
         DeviceGuard dg(sh->device);
         if (sh->stream) (void)hipStreamSynchronize(sh->stream);
     }
+}
+
+// the same with a deadline (after a failed collective part of it may sit on some shard's stream and never complete):
+// polls hipStreamQuery; false = a stream did not drain in time
+bool sync_shard_streams_within(mx_index *idx, double seconds) {
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(seconds);
+    for (mx_index *sh : idx->shards) {
+        DeviceGuard dg(sh->device);
+        if (!sh->stream) continue;
+        for (;;) {
+            const hipError_t e = hipStreamQuery(sh->stream);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) {
+                (void)hipGetLastError();
+                return false;
+            }
+            if (std::chrono::steady_clock::now() > t_end) return false;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    return true;
 }
 
 int ensure_composite_buffers(mx_index *idx, int k) {
@@ -1177,10 +1218,9 @@ int composite_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_i
                 const char *e = getenv("MEMEX_HIP_TEST_RCCL_FAIL");
                 return e && e[0] == '1';
             }();
-            static bool injected = false;
+            static std::atomic<bool> injected{false};
             int e = 0, e2 = 0;
-            if (inject && !injected) {
-                injected = true;
+            if (inject && !injected.exchange(true)) {
                 e = 1;
             } else {
                 e = g_rccl.GroupStart();
@@ -1194,7 +1234,10 @@ int composite_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_i
                 // is host-synchronised at this point (search_batch returned), so the blocks are complete.
                 fprintf(stderr, "memex-hip: RCCL all-gather failed (%s); the sharded index continues on peer copies\n",
                         g_rccl.GetErrorString && (e > 1 || e2) ? g_rccl.GetErrorString(e ? e : e2) : "error");
-                sync_shard_streams(idx);
+                // (part of the group may have been queued on some shard streams before the failure: wait with a deadline, and
+                // give the batch up rather than hang the caller if a stream never drains)
+                if (!sync_shard_streams_within(idx, 10.0))
+                    return fail(MX_EDEVICE, "RCCL all-gather failed and a shard stream did not drain within 10 s");
                 idx->use_rccl = false;
                 idx->stats.exchange_fallbacks += 1;
                 enable_peer_access(idx);
@@ -1487,7 +1530,7 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
 extern "C" {
 
 const char *mx_last_error(void) { return last_error_slot().c_str(); }
-const char *mx_version(void) { return "memex-hip 0.4.0 (gfx950)"; }
+const char *mx_version(void) { return "memex-hip 0.5.0 (gfx950)"; }
 size_t mx_index_stats_size(void) { return sizeof(mx_index_stats); }
 
 int mx_device_count(int *n) {

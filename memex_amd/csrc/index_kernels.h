@@ -212,7 +212,7 @@ struct ExactGroup {
     int n;
     int q[kExactGroup];
 };
-size_t exact_group_scratch_bytes(uint64_t n_rows, int k);
+size_t exact_group_scratch_bytes(uint64_t n_rows, int k, int gcap);  // gcap: queries per pass the dist array holds (<= kExactGroup)
 hipError_t launch_exact_group(hipStream_t s, int k, int ds, const float *x, const void *xh, uint64_t n_rows, const IdMap &idmap,
                               const float *qpad, const double *qnorm2, const ExactGroup &grp, void *scratch, uint64_t *ids,
                               float *scores, float *dists, int32_t *n_found);

@@ -833,6 +833,13 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     uint32_t nwv = 0;  // those of them below n_rows (a rolled-back append may have left later ones)
     for (uint32_t i = 0; i < nw; ++i) nwv += (uint64_t)p.wild_rows[i] < p.n_rows ? 1u : 0u;  // ascending: a prefix
     const uint32_t mt = m2 + nwv;
+    if (mt > (uint32_t)kCandCap) {
+        // keys[] shares ent[]'s kCandCap entries and the raw query sits right behind them: a duplicate-heavy corpus can
+        // keep (nearly) kCandCap survivors, and the wide-norm rows on top would run into qv[].  Workgroup-uniform: the
+        // host rescans the query with theta_retry and, if that overflows as well, answers it on the EXACT path.
+        if (tid == 0) p.overflow[q] = 1;
+        return;
+    }
     if (mt <= stage_rows) {
         if (tid < (int)m2) srow[tid] = ent[tid].row;
         else if (tid < (int)mt) srow[tid] = p.wild_rows[tid - (int)m2];
@@ -1173,13 +1180,19 @@ __global__ __launch_bounds__(256) void xsel_emit_kernel(int k, uint32_t kk, IdMa
     }
 }
 
-size_t exact_group_scratch_bytes(uint64_t n_rows, int k) {
+// scratch layout: hist | state | eq_cnt | sel (the fixed part, sized for a full group) | dist [gcap][n_rows]
+static size_t exact_fixed_bytes(uint64_t kk) {
+    size_t b = (size_t)kExactGroup * kXBins * sizeof(uint32_t)               // hist
+               + (size_t)kExactGroup * 4 * sizeof(uint32_t)                  // state
+               + (size_t)kExactGroup * kExactSlices * sizeof(uint32_t);      // eq_cnt
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)kExactGroup * (kk ? kk : 1) * sizeof(uint64_t);             // sel
+    return (b + 255) & ~(size_t)255;
+}
+
+size_t exact_group_scratch_bytes(uint64_t n_rows, int k, int gcap) {
     const uint64_t kk = n_rows < (uint64_t)k ? n_rows : (uint64_t)k;
-    return (size_t)kExactGroup * n_rows * sizeof(uint32_t)                 // dist
-           + (size_t)kExactGroup * kXBins * sizeof(uint32_t)               // hist
-           + (size_t)kExactGroup * 4 * sizeof(uint32_t)                    // state
-           + (size_t)kExactGroup * kExactSlices * sizeof(uint32_t)         // eq_cnt
-           + (size_t)kExactGroup * (kk ? kk : 1) * sizeof(uint64_t) + 64;  // sel
+    return exact_fixed_bytes(kk) + (size_t)gcap * n_rows * sizeof(uint32_t) + 64;
 }
 
 hipError_t launch_exact_group(hipStream_t s, int k, int ds, const float *x, const void *xh, uint64_t n_rows, const IdMap &idmap,
@@ -1188,11 +1201,11 @@ hipError_t launch_exact_group(hipStream_t s, int k, int ds, const float *x, cons
     if (grp.n <= 0) return hipSuccess;
     const uint32_t kk = (uint32_t)(n_rows < (uint64_t)k ? n_rows : (uint64_t)k);
     char *base = static_cast<char *>(scratch);
-    uint32_t *dist = reinterpret_cast<uint32_t *>(base);
-    uint32_t *hist = dist + (size_t)kExactGroup * n_rows;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(base);
     uint32_t *state = hist + (size_t)kExactGroup * kXBins;
     uint32_t *eq_cnt = state + kExactGroup * 4;
     uint64_t *sel = reinterpret_cast<uint64_t *>(((uintptr_t)(eq_cnt + (size_t)kExactGroup * kExactSlices) + 15) & ~(uintptr_t)15);
+    uint32_t *dist = reinterpret_cast<uint32_t *>(base + exact_fixed_bytes(kk));  // [grp.n][n_rows]: the caller sized it for >= grp.n queries
     if (kk > 0) {
         hipError_t e = hipMemsetAsync(hist, 0, ((size_t)kExactGroup * kXBins + kExactGroup * 4) * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;

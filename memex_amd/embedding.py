@@ -209,6 +209,29 @@ class SentenceEmbedder:
             raise err
         return th, cls(q)
 
+    @classmethod
+    def from_pretrained_dir(cls, path: str, model_config: ModelConfig = ModelConfig(), device: int = 0,
+                            precision: str = "bf16", encoder_key: Optional[str] = None):
+        """``create_model()`` from a LOCAL sentence-transformers directory -- the files
+        ``SentenceEmbeddingsBuilder::remote(..)`` downloads (embedding.rs:99-100): ``modules.json``, ``config.json``,
+        ``sentence_bert_config.json``, ``1_Pooling/config.json``, ``model.safetensors`` / ``pytorch_model.bin``,
+        ``vocab.txt`` (:mod:`memex_amd.pretrained`).  Returns ``(thread, embedder)`` like :meth:`spawn`; a model the HIP
+        encoder does not run (a ``2_Dense`` module, max pooling, ...) raises :class:`SetupError`."""
+        from .pretrained import UnsupportedModel, load_pretrained_dir
+        try:
+            cfg, tensors, vocab, info = load_pretrained_dir(path, precision)
+        except (UnsupportedModel, OSError, KeyError, ValueError) as e:
+            raise SetupError(f"Unable to load model <{path}>: {e}") from e
+        if vocab is None:
+            raise SetupError(f"Unable to load model <{path}>: no vocab.txt (WordPiece models only)")
+        from .tokenizer import WordPieceTokenizer
+        try:
+            tok = WordPieceTokenizer(vocab, lowercase=info["do_lower_case"])
+        except Exception as e:
+            raise SetupError(f"Unable to load model <{path}>: {e}") from e
+        return cls.spawn(model_config, weights=tensors, tokenizer=tok, device=device, encoder_config=cfg,
+                         encoder_key=encoder_key)
+
     @staticmethod
     def _runner(q, ready, model_config, weights, tokenizer, device, encoder_config, seed, encoder_key=None):
         try:

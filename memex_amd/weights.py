@@ -31,6 +31,8 @@ class EncoderConfig:
     normalize: bool = True
     max_seq_length: int = 256  # sentence_bert_config.json truncation
     pos_offset: int = 0        # 0 = BERT; 2 = RoBERTa-style (position ids start at padding_idx + 1)
+    precision: str = "bf16"    # "bf16" (default: bf16 operands, the ingest path) | "bf16x3" (split operands, f32 hidden state
+                               # and attention: f32-grade scores at ~1/6 of the speed; include/memex_hip.h MX_PREC_BF16X3)
 
     def as_dict(self) -> dict:
         return asdict(self)

@@ -32,6 +32,9 @@ def test_encoder_vs_transformers_golden(lib_built):
     (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000), 9, 77, 6),          # mean pooling at H=768
     (dict(layers=6, hidden=768, heads=12, ffn=3072, vocab=3000, max_pos=514, type_vocab=1, ln_eps=1e-5, pos_offset=2),
      3, 512, 7),                                                                     # all-distilroberta-v1 shape (embedding.rs:29)
+    (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000, precision="bf16x3"), 6, 256, 1),   # the split-operand mode
+    (dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls", precision="bf16x3"), 3, 160, 4),
+    (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000, normalize=False, precision="bf16x3"), 5, 512, 8),
 ])
 def test_encoder_vs_oracle(kw, B, S, seed, lib_built):
     from memex_amd.encoder import Encoder
@@ -48,9 +51,10 @@ def test_encoder_vs_oracle(kw, B, S, seed, lib_built):
         again = enc.encode(ids, lens)
     ref = bert_oracle.encode(w, cfg.as_dict(), ids, lens)
     assert np.isfinite(out).all()
-    assert (1.0 - _cos(out.astype(np.float64), ref)).max() <= TOL
+    precise = cfg.precision == "bf16x3"
+    assert (1.0 - _cos(out.astype(np.float64), ref)).max() <= (1e-7 if precise else TOL)
     if not cfg.normalize:
-        np.testing.assert_allclose(np.linalg.norm(out, axis=1), np.linalg.norm(ref, axis=1), rtol=2e-2)
+        np.testing.assert_allclose(np.linalg.norm(out, axis=1), np.linalg.norm(ref, axis=1), rtol=1e-4 if precise else 2e-2)
     np.testing.assert_array_equal(out, again)                      # deterministic
 
 
@@ -93,9 +97,11 @@ def test_batch_composition_does_not_change_a_row(lib_built):
         alone = enc.encode(ids2[1:2, :13], lens[1:2])
         many = enc.encode(np.repeat(ids, 200, axis=0), np.repeat(lens, 200))     # 1400 seqs: several passes
     np.testing.assert_array_equal(full[1], alone[0])
-    np.testing.assert_array_equal(many[::200], full[np.arange(7)] if False else many[::200])
+    # hidden 384: the large-pass GEMMs (pgemm_kernel) and the small-pass ones sum k in the same order and share the
+    # epilogue arithmetic, so the 1400-sequence call (two passes of >= 32768 rows) returns the 7-sequence call's bits
+    np.testing.assert_array_equal(many[::200], full)
     np.testing.assert_array_equal(many.reshape(7, 200, -1)[:, 0], many.reshape(7, 200, -1)[:, 199])
-    assert (1.0 - _cos(many.reshape(7, 200, -1)[:, 5].astype(np.float64), full.astype(np.float64))).max() < 1e-6
+    np.testing.assert_array_equal(many.reshape(7, 200, -1)[:, 5], full)
 
 
 def test_bad_arguments(lib_built):
@@ -225,7 +231,8 @@ def test_large_passes_run_their_gemms_on_pgemm_kernel(lib_built, monkeypatch):
     (dict(layers=4, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 80, 512, 53),     # bge-base layers, 41k rows: pgemm_kernel + ln_rows_kernel
     (dict(layers=4, hidden=384, heads=12, ffn=1536, vocab=3000), 96, 512, 54),                    # MiniLM layers, large pass
 ])
-def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, lib_built):
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, precision, lib_built):
     """Trained checkpoints carry what random weights do not: outlier hidden dimensions (LayerNorm gains ~20, biases
     +-30 on a handful of dimensions in every layer) and attention logits of +-60.  Those are the bf16 hazards --
     activation range through the residual stream, the pre-LayerNorm sums the large-pass path rounds to bf16, the
@@ -235,7 +242,7 @@ def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, lib_built
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, checkpoint_like_weights
     from oracle import bert_oracle
-    cfg = EncoderConfig(**kw)
+    cfg = EncoderConfig(**kw, precision=precision)
     w = checkpoint_like_weights(cfg, seed)
     rng = np.random.default_rng(seed)
     ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
@@ -247,20 +254,28 @@ def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, lib_built
     sub = slice(0, min(B, 8))
     ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub])
     cos = _cos(out[sub].astype(np.float64), ref)
-    assert (1.0 - cos).max() <= TOL, (kw, cos)
+    assert (1.0 - cos).max() <= (TOL if precision == "bf16" else 1e-6), (kw, cos)
     # what the search sees: the cosines BETWEEN embeddings.  These weights put a large common component into every
     # embedding (pairwise cosines ~0.96) and most of its energy into five dimensions of magnitude 20-60, where a bf16 step
     # is 0.125-0.25: the row-wise cosine above is the easy half.  Measured (round 4): the pairwise cosines move by up to
     # 1.3e-3 with mean pooling (256+ tokens average the rounding noise) and by ~1e-2 with CLS pooling (one token, twelve
-    # layers of bf16 hidden states; gemm_kernel and pgemm_kernel paths alike) -- the price of a bf16 residual stream under
-    # such outliers, stated in DESIGN.md section 4.  Bounded here so that a regression shows.
+    # layers; gemm_kernel and pgemm_kernel paths alike).  Round 5: a numpy emulation of every rounding point
+    # (scripts/encoder_rounding_sim.py) shows that this is NOT the residual stream -- with the hidden state, the GEMM results
+    # and the final output all kept in f32 the error stays at 1e-2; with the weights ALONE rounded to bf16 it is 6e-3: a
+    # logit of +-60 carries a bf16 error of 0.1 and moves its softmax weight by 10 % -- and that every operand needs 13+
+    # significant bits for 1e-3.  precision="bf16x3" (encoder_precise.hip: split operands, f32 hidden state, f32 attention)
+    # gives them 16 and must hold north_star's 1e-3 on the scores, CLS and mean alike; the bf16 default keeps its measured
+    # bounds, labelled as what they are.
     o = out[sub].astype(np.float64)
     o /= np.linalg.norm(o, axis=1, keepdims=True)
     r = ref / np.linalg.norm(ref, axis=1, keepdims=True)
     pair = np.abs(o @ o.T - r @ r.T).max()
-    print(f"checkpoint-like weights {kw['layers']}x{kw['hidden']} B={B} S={S}: max(1 - cos) = {(1.0 - cos).max():.2e}, "
+    print(f"checkpoint-like weights {kw['layers']}x{kw['hidden']} B={B} S={S} {precision}: max(1 - cos) = {(1.0 - cos).max():.2e}, "
           f"max |pairwise cosine error| = {pair:.2e}")
-    assert pair <= (2.5e-2 if cfg.pooling == "cls" else 2.5e-3), (kw, pair)
+    if precision == "bf16x3":
+        assert pair <= 1e-3, (kw, pair)                               # north_star: cosine scores within 1e-3
+    else:
+        assert pair <= (2.5e-2 if cfg.pooling == "cls" else 2.5e-3), (kw, pair)   # bf16 operands: measured, not the bar
 
 
 def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):

@@ -1,0 +1,141 @@
+"""Loading what the reference loads (embedding.rs:99-100): a sentence-transformers directory -> EncoderConfig + tensors +
+vocab.  The directory is written here by `transformers` (``BertModel(config).save_pretrained``, random init -- pretrained
+checkpoints are not reachable offline) plus the sentence-transformers side files, then read back by
+``memex_amd.pretrained.load_pretrained_dir``; on the GPU box the embedder built from it is compared with the f64 oracle fed
+the same tensors and the same token ids."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from test_tokenizer import make_vocab
+
+
+def make_st_dir(root, *, hidden=384, layers=2, heads=12, ffn=1536, pooling="mean", normalize=True, max_seq_length=128,
+                weights="safetensors", dense=False, hidden_act="gelu", pooling_modes=None, seed=0):
+    """A sentence-transformers model directory with a random-init BERT of the given shape and a synthetic vocabulary."""
+    import torch
+    from transformers import BertConfig, BertModel
+    vocab = make_vocab()
+    torch.manual_seed(seed)
+    hc = BertConfig(vocab_size=len(vocab), hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                    intermediate_size=ffn, max_position_embeddings=512, hidden_act=hidden_act)
+    model = BertModel(hc, add_pooling_layer=False).eval()
+    with torch.no_grad():  # trained-looking LayerNorms / biases instead of the ones / zeros of a fresh init
+        for n, p in model.named_parameters():
+            if n.endswith("LayerNorm.weight"):
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            elif n.endswith(".bias"):
+                p.copy_(0.05 * torch.randn_like(p))
+            elif "embeddings" in n:
+                p.copy_(0.05 * torch.randn_like(p))
+            else:
+                p.copy_(torch.randn_like(p) / p.shape[1] ** 0.5)
+    os.makedirs(root, exist_ok=True)
+    model.save_pretrained(root, safe_serialization=(weights == "safetensors"))
+    if weights == "bin" and not os.path.exists(os.path.join(root, "pytorch_model.bin")):
+        torch.save(model.state_dict(), os.path.join(root, "pytorch_model.bin"))
+        for f in ("model.safetensors",):
+            if os.path.exists(os.path.join(root, f)):
+                os.remove(os.path.join(root, f))
+    with open(os.path.join(root, "vocab.txt"), "w", encoding="utf-8") as f:
+        f.write("\n".join(vocab) + "\n")
+    mods = [{"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+            {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}]
+    if dense:
+        mods.append({"idx": 2, "name": "2", "path": "2_Dense", "type": "sentence_transformers.models.Dense"})
+    if normalize:
+        mods.append({"idx": len(mods), "name": str(len(mods)), "path": f"{len(mods)}_Normalize", "type": "sentence_transformers.models.Normalize"})
+    json.dump(mods, open(os.path.join(root, "modules.json"), "w"))
+    json.dump({"max_seq_length": max_seq_length, "do_lower_case": False}, open(os.path.join(root, "sentence_bert_config.json"), "w"))
+    json.dump({"do_lower_case": True, "tokenizer_class": "BertTokenizer"}, open(os.path.join(root, "tokenizer_config.json"), "w"))
+    os.makedirs(os.path.join(root, "1_Pooling"), exist_ok=True)
+    pm = pooling_modes or {"pooling_mode_cls_token": pooling == "cls", "pooling_mode_mean_tokens": pooling == "mean",
+                           "pooling_mode_max_tokens": False, "pooling_mode_mean_sqrt_len_tokens": False}
+    json.dump({"word_embedding_dimension": hidden, **pm}, open(os.path.join(root, "1_Pooling", "config.json"), "w"))
+    return model, vocab
+
+
+@pytest.mark.parametrize("weights", ["safetensors", "bin"])
+def test_directory_round_trip(tmp_path, weights):
+    from memex_amd.pretrained import load_pretrained_dir
+    from memex_amd.weights import pack_weights, tensor_order
+    d = str(tmp_path / "st")
+    model, vocab = make_st_dir(d, hidden=384, layers=2, pooling="cls", max_seq_length=200, weights=weights)
+    cfg, tensors, vpath, info = load_pretrained_dir(d)
+    assert (cfg.layers, cfg.hidden, cfg.heads, cfg.ffn, cfg.vocab, cfg.max_pos, cfg.type_vocab) == (2, 384, 12, 1536, len(vocab), 512, 2)
+    assert cfg.pooling == "cls" and cfg.normalize is True and cfg.max_seq_length == 200 and cfg.pos_offset == 0
+    assert abs(cfg.ln_eps - 1e-12) < 1e-18 and cfg.precision == "bf16"
+    assert vpath == os.path.join(d, "vocab.txt") and info["do_lower_case"] is True and info["modules"] == ["Transformer", "Pooling", "Normalize"]
+    sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    for name, shape in tensor_order(cfg):
+        np.testing.assert_array_equal(tensors[name], sd[name])
+    blob = pack_weights(tensors, cfg)
+    assert blob.dtype == np.float32 and blob.size == sum(int(np.prod(s)) for _, s in tensor_order(cfg))
+    assert load_pretrained_dir(d, precision="bf16x3")[0].precision == "bf16x3"
+
+
+def test_unsupported_models_are_refused(tmp_path):
+    """What the HIP encoder does not implement must fail loudly (MX_EUNSUPPORTED's Python face), not be approximated."""
+    from memex_amd.pretrained import UnsupportedModel, load_pretrained_dir
+    make_st_dir(str(tmp_path / "dense"), layers=1, dense=True)
+    with pytest.raises(UnsupportedModel, match="2_Dense"):
+        load_pretrained_dir(str(tmp_path / "dense"))
+    make_st_dir(str(tmp_path / "maxpool"), layers=1, pooling_modes={"pooling_mode_cls_token": False, "pooling_mode_mean_tokens": False,
+                                                                     "pooling_mode_max_tokens": True})
+    with pytest.raises(UnsupportedModel, match="pooling"):
+        load_pretrained_dir(str(tmp_path / "maxpool"))
+    make_st_dir(str(tmp_path / "relu"), layers=1, hidden_act="relu")
+    with pytest.raises(UnsupportedModel, match="hidden_act"):
+        load_pretrained_dir(str(tmp_path / "relu"))
+    make_st_dir(str(tmp_path / "ot"), layers=1)
+    os.remove(str(tmp_path / "ot" / "model.safetensors"))
+    open(str(tmp_path / "ot" / "rust_model.ot"), "wb").write(b"PK")
+    with pytest.raises(UnsupportedModel, match="rust_model.ot"):
+        load_pretrained_dir(str(tmp_path / "ot"))
+    with pytest.raises(FileNotFoundError):
+        load_pretrained_dir(str(tmp_path / "nowhere"))
+    # a tensor whose shape contradicts config.json
+    make_st_dir(str(tmp_path / "bad"), layers=1)
+    hc = json.load(open(str(tmp_path / "bad" / "config.json")))
+    hc["intermediate_size"] = 768
+    json.dump(hc, open(str(tmp_path / "bad" / "config.json"), "w"))
+    with pytest.raises(ValueError, match="shape"):
+        load_pretrained_dir(str(tmp_path / "bad"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,heads,ffn,pooling", [(384, 12, 1536, "mean"), (768, 12, 3072, "cls")])
+def test_embedder_from_pretrained_dir_matches_the_oracle(tmp_path, lib_built, hidden, heads, ffn, pooling):
+    """SentenceEmbedder.from_pretrained_dir: config + weights + native tokenizer from the directory; embeddings within 1e-3
+    of the f64 oracle fed the same tensors and the ids the HF tokenizer produces for the same vocabulary."""
+    from tokenizers import BertWordPieceTokenizer
+    from memex_amd import embedding as E
+    from memex_amd.pretrained import load_pretrained_dir
+    from oracle import bert_oracle
+    d = str(tmp_path / "st")
+    make_st_dir(d, hidden=hidden, layers=3, heads=heads, ffn=ffn, pooling=pooling, max_seq_length=64, seed=5)
+    texts = ["What does Biden say about taxes?", "The STATE of the Union 2023 -- unbelievable, isn't it?!",
+             "tokenizing long words and don't re-embed; they've said: \"we'll do it\".", "hello world " * 60]
+    th, emb = E.SentenceEmbedder.from_pretrained_dir(d)
+    got = np.asarray([emb.encode_single(t).vector for t in texts], dtype=np.float64)
+    segs = emb.encode("the tax state union " * 200)                 # segment_text through the directory's vocabulary
+    emb.shutdown()
+    cfg, tensors, vpath, _ = load_pretrained_dir(d)
+    hf = BertWordPieceTokenizer(vpath, lowercase=True)
+    hf.enable_truncation(max_length=cfg.max_seq_length)
+    encs = [hf.encode(t) for t in texts]
+    S = max(len(e.ids) for e in encs)
+    ids = np.zeros((len(texts), S), dtype=np.int32)
+    lens = np.asarray([len(e.ids) for e in encs], dtype=np.int32)
+    for i, e in enumerate(encs):
+        ids[i, :len(e.ids)] = e.ids
+    assert lens.max() == 64                                           # the long text hit max_seq_length
+    ref = bert_oracle.encode(tensors, cfg.as_dict(), ids, lens)
+    cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
+    assert (1.0 - cos).max() <= 1e-3, cos
+    assert len(segs) == 1 + int(np.ceil((800 - 256) / 170)) and all(len(s.vector) == hidden for s in segs)
+    with pytest.raises(E.SetupError):
+        make_st_dir(str(tmp_path / "dense"), layers=1, dense=True)
+        E.SentenceEmbedder.from_pretrained_dir(str(tmp_path / "dense"))
