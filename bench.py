@@ -489,6 +489,40 @@ def traffic_from_profile(rows_total: int, dim: int, world: int, scan: str):
     return None
 
 
+def query_latency_leg(idx, k: int, calls: int = 200):
+    """What one search request costs end to end on the device side of the host API (handlers.rs:61-81: embed the query
+    text, search the collection): `encode` of ONE short query (host ids in, host embedding out: mx_encoder_encode) followed by
+    `search` of that vector (host pointers: mx_index_search) against the headline corpus, per call, p50 / p99 over `calls`
+    calls -- for the reference's two MiniLM models (all-MiniLM-L12-v2 is its default, embedding.rs:67)."""
+    from memex_amd import weights as W
+    from memex_amd.encoder import Encoder
+    out = {"calls": calls, "query_tokens": 16, "k": k,
+           "note": "host API both ways; the search leg is one query against the headline corpus (scan at the stream's rate)"}
+    rng = np.random.default_rng(5)
+    for name, cfg in (("all-MiniLM-L6-v2", W.ALL_MINILM_L6_V2), ("all-MiniLM-L12-v2", W.ALL_MINILM_L12_V2)):
+        enc = Encoder(cfg, W.pack_weights(W.synthetic_weights(cfg, 0), cfg))
+        ids = rng.integers(1000, cfg.vocab, size=(1, 16)).astype(np.int32)
+        lens = np.array([16], dtype=np.int32)
+        for _ in range(10):
+            v = enc.encode(ids, lens)
+            idx.search(v, k)
+        te, ts = [], []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            v = enc.encode(ids, lens)
+            t1 = time.perf_counter()
+            idx.search(v, k)
+            t2 = time.perf_counter()
+            te.append((t1 - t0) * 1e3)
+            ts.append((t2 - t1) * 1e3)
+        enc.close()
+        te, ts = np.asarray(te), np.asarray(ts)
+        out[name] = {"encode_ms_p50": float(np.percentile(te, 50)), "encode_ms_p99": float(np.percentile(te, 99)),
+                     "search_ms_p50": float(np.percentile(ts, 50)), "search_ms_p99": float(np.percentile(ts, 99)),
+                     "total_ms_p50": float(np.percentile(te + ts, 50)), "total_ms_p99": float(np.percentile(te + ts, 99))}
+    return out
+
+
 class SearchBuffers:
     def __init__(self, batch: int, k: int):
         import torch
@@ -741,6 +775,10 @@ def run(a):
                                   "ids_equal_full_batch": bool(torch.equal(bb.ids[:256], ids_main))}
             del qb_, bb
 
+    qlat = None
+    if single and small_steps > 0:
+        qlat = query_latency_leg(idx, k)
+
     # ---- recall@10 against the all-f64 EXACT path on a few queries (oracle-level parity at smaller
     # sizes and the oracle-based 10M check live in tests/; the EXACT path is itself oracle-checked there)
     recall = recall_exact_order = merged_ok = None
@@ -771,6 +809,7 @@ def run(a):
     if single and a.side_steps > 0:
         sides["host_api"] = host_api
         sides["small_batches"] = small
+        sides["query_latency"] = qlat
         other_data = "clustered" if a.data == "gaussian" else "gaussian"
         sides[other_data] = side_leg(rows_total, a.dim, a.batch, k, a.side_steps, other_data)
         if a.data == "gaussian":  # embedding-like rows (decaying spectrum + common mean direction), the library's own choice of copy

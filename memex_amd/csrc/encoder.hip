@@ -73,6 +73,10 @@ struct mx_encoder {
     float *xf = nullptr, *qkvf = nullptr, *af = nullptr;
     bf16_t *xs = nullptr, *ctxs = nullptr, *hs = nullptr;
     bool precise = false;
+    // small passes (<= kSmallRows packed rows, fused-tail models): x1 of the layer in flight, the MLP's partial products
+    bf16_t *sp_x1 = nullptr;
+    float *sp_part = nullptr;
+    bool small_pass = true;   // MEMEX_HIP_SMALL=0: small passes take the large-pass kernels (tests, A/B)
     int32_t *cu = nullptr, *tok_seq = nullptr, *tok_pos = nullptr, *lens_dev = nullptr, *ids_dev = nullptr;
     void *attn_plan = nullptr;  // attention work list of the pass in flight (kAttnPlanBytesPerSeq per sequence)
     float *out_dev = nullptr;
@@ -288,7 +292,17 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         }
         return launch_gemm(st, EPI_BIAS_RES_LN, gp);
     };
+    const bool small = e->small_pass && t_pad <= kSmallRows;
     for (const Layer &L : e->layers) {
+        if (small) {
+            // query-time passes (encoder_small.hip): projections by one wave per 32 features, the MLP split over the ffn chunks
+            MX_HIP(launch_sp_qkv(st, e->x, L.wqkv, L.bqkv, t_pad, (int)rows, qscale, e->q, e->k, e->vt, t_pad));
+            MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->attn_plan, B, heads, dh, H, e->ctx));
+            MX_HIP(launch_sp_out_ln(st, e->ctx, e->x, L.wo, L.bo, L.ln1g, L.ln1b, c.ln_eps, t_pad, (int)rows, e->sp_x1));
+            MX_HIP(launch_sp_ffn(st, e->sp_x1, L.wf, L.bi, F, t_pad, (int)rows, e->sp_part));
+            MX_HIP(launch_sp_reduce_ln(st, e->sp_part, F, t_pad, (int)rows, L.bo2, e->sp_x1, L.ln2g, L.ln2b, c.ln_eps, e->x));
+            continue;
+        }
         GemmParams g{};
         g.a = e->x; g.lda = H; g.w = L.wqkv; g.w_rows = 3 * H; g.w_row0 = 0; g.bias = L.bqkv; g.m = t_pad; g.n = 2 * H; g.k = H;
         g.out = e->q; g.out_k = e->k; g.ldo = H; g.hidden = H; g.qscale = qscale;
@@ -363,7 +377,10 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
         if (rc != MX_OK) return rc;
     }
     if (e->profiling) MX_HIP(hipEventRecord(e->ev1, e->stream));
-    MX_HIP(napping_sync(e->stream, e->ev_done));  // results complete in d_out when the call returns (the thread naps meanwhile)
+    // results complete in d_out when the call returns.  The thread naps meanwhile -- except through a query-sized call (one
+    // small pass: 0.2-0.4 ms), where a 50 us nap granularity would be a fifth of the latency: those are polled through
+    const bool query_sized = passes.size() == 1 && max_rows + 32 <= kSmallRows;
+    MX_HIP(napping_sync(e->stream, e->ev_done, query_sized ? 1000 : 100));
     if (e->profiling) {
         float ms = 0.f;
         MX_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
@@ -428,6 +445,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
             if (se == hipSuccess) se = pgemm_setup();
             if (se == hipSuccess) se = tail_setup();
             if (se == hipSuccess) se = precise_setup();
+            if (se == hipSuccess) se = small_setup();
             if (se != hipSuccess) return fail(MX_EDEVICE, "encoder kernel setup failed: %s", hipGetErrorString(se));
             if (device < 64) g_enc_setup_done[device] = true;
         }
@@ -442,6 +460,8 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         e->fused_tail = !e->precise && tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
         const char *pv = getenv("MEMEX_HIP_PGEMM");
         e->pgemm = !(pv && pv[0] == '0');
+        const char *sv = getenv("MEMEX_HIP_SMALL");
+        e->small_pass = e->fused_tail && !(sv && sv[0] == '0');
     }
     auto bail = [&](int code) {
         destroy_impl(e);
@@ -504,6 +524,18 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         MX_TRY(upload_f32(e, b2_src, H, &L.bo2));
         MX_TRY(upload_f32(e, g2_src, H, &L.ln2g));
         MX_TRY(upload_f32(e, be2_src, H, &L.ln2b));
+    }
+    if (e->small_pass) {
+        void *px = nullptr, *pp = nullptr;
+        if (hipMalloc(&px, (size_t)kSmallRows * H * sizeof(uint16_t)) != hipSuccess ||
+            hipMalloc(&pp, (size_t)(F / 128) * kSmallRows * H * sizeof(float)) != hipSuccess) {
+            if (px) (void)hipFree(px);
+            return bail(fail(MX_ENOMEM, "hipMalloc(small-pass workspace) failed"));
+        }
+        e->allocs.push_back(px);
+        e->allocs.push_back(pp);
+        e->sp_x1 = static_cast<bf16_t *>(px);
+        e->sp_part = static_cast<float *>(pp);
     }
 #undef MX_TRY
     *out = e;

@@ -76,6 +76,7 @@ struct TailParams {
     // at the same time
     int skew_shift, skew_hi, skew_iters;
     unsigned long long *trace;  // scripts/tail_ubench.hip only (MX_TAIL_TRACE): [blocks][8] phase timestamps
+    int stop_after_ln1;         // ctx != nullptr only: write x1 = LayerNorm1(x + Wo ctx + bo) to `out` and stop (small passes)
 };
 hipError_t tail_setup();
 bool tail_supported(int hidden, int ffn);
@@ -115,6 +116,20 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
 // masked mean (or CLS) over tokens + optional L2 normalise -> out [B, H] f32; xf != nullptr: the f32 hidden state instead of x
 hipError_t launch_pool(hipStream_t s, const bf16_t *x, const float *xf, const int32_t *cu, const int32_t *lens, int B, int hidden,
                        int pooling_cls, int normalize, float *out);
+
+// ---- small passes of the hidden-384 encoder (encoder_small.hip): query-time embedding.  m = padded packed rows (multiple
+// of 64), rows = the packed rows that can hold tokens (the rest of the pass is padding and is not computed)
+constexpr int kSmallRows = 512;  // passes of at most this many packed rows take the small-pass layer
+hipError_t small_setup();
+hipError_t launch_sp_qkv(hipStream_t s, const bf16_t *x, const bf16_t *wqkv, const float *bqkv, int m, int rows, float qscale, bf16_t *q,
+                         bf16_t *k, bf16_t *vt, int ldvt);
+// x1 = LayerNorm1(xres + ctx Wo^T + bo); wo in the GEMMs' K-blocked layout
+hipError_t launch_sp_out_ln(hipStream_t s, const bf16_t *ctx, const bf16_t *xres, const bf16_t *wo, const float *bo, const float *gamma,
+                            const float *beta, float eps, int m, int rows, bf16_t *x1);
+// part [f / 128][m][384] f32: the MLP's partial products per ffn chunk (wf: tail_kernel's weight streams)
+hipError_t launch_sp_ffn(hipStream_t s, const bf16_t *x1, const bf16_t *wf, const float *b1, int f, int m, int rows, float *part);
+hipError_t launch_sp_reduce_ln(hipStream_t s, const float *part, int f, int m, int rows, const float *b2, const bf16_t *x1, const float *gamma,
+                               const float *beta, float eps, bf16_t *out);
 
 // ---- the bf16x3 ("precise") encoder (encoder_precise.hip): every GEMM operand travels as THREE bf16 column blocks
 // [hi | lo | hi] (activations, width 3K) against [hi | hi | lo] (weights), so that the unchanged bf16 MFMA loop sums

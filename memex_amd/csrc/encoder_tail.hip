@@ -366,6 +366,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_s_barrier();
         bf16x8 x1r[CPT];
         ln_rows(rs, p.ln1g, p.ln1b, [&](int c, const bf16x8 &o) __attribute__((always_inline)) { x1r[c] = o; });
+        if (p.stop_after_ln1) {  // small passes (encoder_small.hip): x1 leaves here, the MLP runs split over the ffn dimension
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                *reinterpret_cast<bf16x8 *>(p.out + (size_t)(m0 + ln_row) * p.ldo + (c * TPR + ln_prt) * 8) = x1r[c];
+            return;
+        }
         __builtin_amdgcn_s_barrier();  // staging tile consumed: its space becomes the x1 tile
 #pragma unroll
         for (int c = 0; c < CPT; ++c) *reinterpret_cast<bf16x8 *>(x_tile_chunk(c)) = x1r[c];

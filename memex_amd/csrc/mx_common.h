@@ -52,8 +52,8 @@ inline uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
 
 // Host wait for everything queued on `st` that does not burn a core: hipStreamSynchronize / hipEventSynchronize poll
 // with the runtime's default scheduling policy (100 % of a core, scripts/gpu_wait_modes.py).  Record `ev`, poll it
-// for ~100 us (short work returns at once), then nap 50 us between polls.  MEMEX_HIP_SPIN=1: plain synchronize.
-inline hipError_t napping_sync(hipStream_t st, hipEvent_t ev) {
+// for `spin_us` (short work returns at once), then nap 50 us between polls.  MEMEX_HIP_SPIN=1: plain synchronize.
+inline hipError_t napping_sync(hipStream_t st, hipEvent_t ev, int spin_us = 100) {
     static const bool spin = [] {
         const char *sp = getenv("MEMEX_HIP_SPIN");
         return sp && sp[0] == '1';
@@ -65,7 +65,7 @@ inline hipError_t napping_sync(hipStream_t st, hipEvent_t ev) {
     for (;;) {
         e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) {
             struct timespec ts = {0, 50 * 1000};
             (void)clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
         }

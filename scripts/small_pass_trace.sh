@@ -1,7 +1,9 @@
 #!/bin/bash
-# one 16-token query through the MiniLM-L6 encoder: kernel time against the span of a call (how launch-bound is it?)
+# one small call through the MiniLM-L6 encoder: kernel time against the span of a call (how launch-bound is it?)
+# usage: small_pass_trace.sh [B S]   (default 1 16)
+B=${1:-1}; S=${2:-16}
 mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp
-cat > /tmp/one.py <<'PY'
+cat > /tmp/one.py <<PY
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np
@@ -9,11 +11,11 @@ from memex_amd.encoder import Encoder
 from memex_amd import weights as W
 cfg = W.ALL_MINILM_L6_V2
 enc = Encoder(cfg, W.synthetic_weights(cfg, 0))
-ids = np.random.default_rng(0).integers(1000, cfg.vocab, (1, 16)).astype(np.int32); lens = np.full((1,), 16, dtype=np.int32)
+ids = np.random.default_rng(0).integers(1000, cfg.vocab, ($B, $S)).astype(np.int32); lens = np.full(($B,), $S, dtype=np.int32)
 for _ in range(20): enc.encode(ids, lens)
 PY
 rm -rf /tmp/tr; rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tr -- python /tmp/one.py > /dev/null 2>&1
-python - > $GRAFT_REPO_ROOT/gpurun_out/r4_small_pass_trace.txt <<'PY'
+python - > $GRAFT_REPO_ROOT/gpurun_out/small_pass_trace.txt <<'PY'
 import csv, glob
 k = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-40:]) for r in csv.DictReader(open(glob.glob("/tmp/tr/**/*_kernel_trace.csv", recursive=True)[0]))))
 # last call: the kernels after the last token_map
@@ -27,4 +29,4 @@ for (s, e, n), (s2, _, _) in zip(last, last[1:] + [last[-1]]):
 calls = [k[a][0] for a in idx]
 print("call period (token_map to token_map), us:", [round((b - a) / 1e3) for a, b in zip(calls[-6:], calls[-5:])])
 PY
-cat $GRAFT_REPO_ROOT/gpurun_out/r4_small_pass_trace.txt
+cat $GRAFT_REPO_ROOT/gpurun_out/small_pass_trace.txt

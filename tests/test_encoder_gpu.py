@@ -59,13 +59,14 @@ def test_encoder_vs_oracle(kw, B, S, seed, lib_built):
 
 
 @pytest.mark.parametrize("hidden,ffn", [(384, 1536), (768, 3072)])
-def test_attention_stage_and_block_boundaries(hidden, ffn, lib_built):
+def test_attention_stage_and_block_boundaries(hidden, ffn, lib_built, monkeypatch):
     """attention_kernel streams keys in stages of 256 and blocks of 32, masks only the last block of a sequence, and
     lets the buffer bounds drop the rows past a sequence's end: lengths on every one of those edges, both head widths
     (d = 32 staged two heads at a time, d = 64), against the oracle; one sequence alone == the same sequence in the batch."""
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, synthetic_weights
     from oracle import bert_oracle
+    monkeypatch.setenv("MEMEX_HIP_SMALL", "0")   # one sequence alone and in the batch through the same kernels: same bits
     cfg = EncoderConfig(layers=2, hidden=hidden, heads=12, ffn=ffn, vocab=3000)
     w = synthetic_weights(cfg, 31)
     rng = np.random.default_rng(31)
@@ -81,8 +82,12 @@ def test_attention_stage_and_block_boundaries(hidden, ffn, lib_built):
         np.testing.assert_array_equal(out[i], alone[j])
 
 
-def test_batch_composition_does_not_change_a_row(lib_built):
-    """Varlen packing: a sequence's embedding must not depend on its batch neighbours / padding ids."""
+@pytest.mark.parametrize("small", ["1", "0"])
+def test_batch_composition_does_not_change_a_row(small, lib_built, monkeypatch):
+    """Varlen packing: a sequence's embedding must not depend on its batch neighbours / padding ids.  Passes of the same
+    kind return the same bits; a small pass (<= 512 packed rows: encoder_small.hip sums the MLP's ffn chunks in another order)
+    agrees with a large one to 1 - cos <= 1e-6, and bit for bit when MEMEX_HIP_SMALL=0 routes it through the large-pass kernels."""
+    monkeypatch.setenv("MEMEX_HIP_SMALL", small)
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, synthetic_weights
     cfg = EncoderConfig(layers=3, hidden=384, heads=12, ffn=1536, vocab=3000)
@@ -99,9 +104,48 @@ def test_batch_composition_does_not_change_a_row(lib_built):
     np.testing.assert_array_equal(full[1], alone[0])
     # hidden 384: the large-pass GEMMs (pgemm_kernel) and the small-pass ones sum k in the same order and share the
     # epilogue arithmetic, so the 1400-sequence call (two passes of >= 32768 rows) returns the 7-sequence call's bits
-    np.testing.assert_array_equal(many[::200], full)
     np.testing.assert_array_equal(many.reshape(7, 200, -1)[:, 0], many.reshape(7, 200, -1)[:, 199])
-    np.testing.assert_array_equal(many.reshape(7, 200, -1)[:, 5], full)
+    np.testing.assert_array_equal(many.reshape(7, 200, -1)[:, 5], many[::200])
+    if small == "0":
+        np.testing.assert_array_equal(many[::200], full)
+    else:
+        assert (1.0 - _cos(many[::200].astype(np.float64), full.astype(np.float64))).max() <= 1e-4
+        assert np.abs(many[::200] - full).max() <= 1e-3
+
+
+@pytest.mark.parametrize("layers,B,S,seed", [(6, 1, 16, 61), (12, 1, 128, 62), (6, 8, 32, 63), (3, 5, 77, 64), (2, 1, 1, 65)])
+def test_small_pass_matches_large_pass(layers, B, S, seed, lib_built, monkeypatch):
+    """Query-time passes (<= 512 packed rows, hidden 384) run encoder_small.hip -- one wave per 32 projection features, the MLP
+    split over its ffn chunks -- with the operands, MFMA shape and rounding points of the large-pass kernels; only the f32
+    summation order of the MLP's chunk products differs.  Both against the f64 oracle within the 1e-3 bar, and against each
+    other far inside it."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    from oracle import bert_oracle
+    cfg = EncoderConfig(layers=layers, hidden=384, heads=12, ffn=1536, vocab=3000)
+    w = synthetic_weights(cfg, seed)
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
+    lens = rng.integers(max(1, S // 2), S + 1, size=B).astype(np.int32)
+    outs = []
+    for small in ("1", "0"):
+        monkeypatch.setenv("MEMEX_HIP_SMALL", small)
+        with Encoder(cfg, w) as enc:
+            outs.append(enc.encode(ids, lens))
+            np.testing.assert_array_equal(outs[-1], enc.encode(ids, lens))
+            if B > 1:                                                     # a row alone == the row in its batch (both small passes)
+                np.testing.assert_array_equal(outs[-1][1], enc.encode(ids[1:2, :lens[1]], lens[1:2])[0])
+    ref = bert_oracle.encode(w, cfg.as_dict(), ids, lens)
+    for o in outs:
+        assert np.isfinite(o).all()
+        assert (1.0 - _cos(o.astype(np.float64), ref)).max() <= TOL
+    assert (outs[0] != outs[1]).any() or layers * B * S <= 2, "the small-pass kernels did not run"
+    # two bf16 forward passes whose f32 sums run in different orders round a few hidden-state elements differently per layer:
+    # they sit as far from each other as each sits from the oracle (measured: 1e-7 at 6 layers x 16 tokens, 1e-5 at 12 x 128)
+    d_small_large = (1.0 - _cos(outs[0].astype(np.float64), outs[1].astype(np.float64))).max()
+    print(f"small vs large pass L{layers} B={B} S={S}: 1 - cos = {d_small_large:.2e}; vs oracle "
+          f"{(1.0 - _cos(outs[0].astype(np.float64), ref)).max():.2e} / {(1.0 - _cos(outs[1].astype(np.float64), ref)).max():.2e}")
+    assert d_small_large <= 1e-4
 
 
 def test_bad_arguments(lib_built):
@@ -178,6 +222,7 @@ def test_fused_layer_tail_equals_gemm_by_gemm_path(lib_built, monkeypatch):
         ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
         lens = rng.integers(S // 2 + S // 4, S + 1, B).astype(np.int32)
         outs = []
+        monkeypatch.setenv("MEMEX_HIP_SMALL", "0")   # (small passes have kernels of their own: test_small_pass_matches_large_pass)
         for unfused in ("1", "0"):
             monkeypatch.setenv("MEMEX_HIP_UNFUSED_TAIL", unfused)
             with Encoder(cfg, w) as enc:
@@ -360,7 +405,9 @@ def test_embedder_batches_concurrent_requests(lib_built):
     for i in range(len(texts)):
         want = alone[i] if i % 3 else [single[i]]
         assert [r.content for r in got[i]] == [r.content for r in want]
-        np.testing.assert_array_equal(np.float32([r.vector for r in got[i]]), np.float32([r.vector for r in want]))
+        # (a lone short request is a small pass, the same text inside a combined batch may ride a large one: same rounding
+        # points, another f32 summation order of the MLP chunks -- equal to ~1e-7 in cosine, not in bits)
+        np.testing.assert_allclose(np.float32([r.vector for r in got[i]]), np.float32([r.vector for r in want]), atol=1e-3, rtol=0)
 
 
 def test_keyed_encoder_is_shared_and_refcounted(lib_built):
