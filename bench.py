@@ -408,7 +408,8 @@ def cfg2_leg(n_seg: int, batch: int, k: int, steps: int):
            "search_note": "corpus is Infinity-Cache resident (154 MB): report only, not an HBM roofline point",
            "fallback_queries": int(sst.fallback_queries), "retry_queries": int(sst.retry_queries),
            "candidates_per_query": sst.candidates / max(1, sst.queries), "scan": scan_of(sst),
-           "filter_demotions": int(first_st.filter_demotions + sst.filter_demotions), "ids_equal_exact_path": same}
+           "filter_demotions": int(first_st.filter_demotions + sst.filter_demotions), "filter_centred": int(sst.filter_centred),
+           "approx_err_bound": sst.approx_err_bound, "ids_equal_exact_path": same}
     del ids, lens, vec, q, bufs
     torch.cuda.empty_cache()
     return out
@@ -613,6 +614,7 @@ def leg_report(st, dt: float, steps: int, workload: str, dim: int, batch: int, r
             "ms_per_step": dt / steps * 1e3, "candidates_per_query": st.candidates / max(1, st.queries),
             "retry_queries": int(st.retry_queries), "fallback_queries": int(st.fallback_queries),
             "approx_err_bound": st.approx_err_bound, "scan": scan_of(st), "filter_demotions": int(st.filter_demotions),
+            "filter_centred": int(st.filter_centred),
             "ms_outside_collect_launch": dt / steps * 1e3 - st.scan_ms / max(1, st.scan_launches),
             "roofline": roofline_of(st, scan_of(st), dim, batch, rows, 1)}
 

@@ -207,6 +207,8 @@ typedef struct mx_index_stats {
     uint64_t filter_promotions; /* times a demoted index got its int8 copy back (the collection had doubled since)  */
     uint64_t listed_rows;       /* rows on the side list finish_kernel adds to every query: zero norm, or a norm outside [1e-15, 1e15] */
     uint64_t exchange_fallbacks;/* sharded index: times the RCCL exchange failed at run time and peer copies took over  */
+    uint64_t filter_centred;    /* 1 = the bf16 copy holds the rows minus their component along the corpus mean direction
+                                   (a rebuilt copy of a corpus that sits in a cone: a several times tighter certificate)   */
 } mx_index_stats;
 /* sizeof(mx_index_stats) of the library that is loaded: a shim compares it with its own at start-up (the struct grows
  * at the end from version to version; mx_version() names the release). */

@@ -54,7 +54,8 @@ class IndexStats(ctypes.Structure):
                 ("filter_copy_bytes", ctypes.c_uint64), ("retry_queries", ctypes.c_uint64),
                 ("approx_err_bound", ctypes.c_double), ("filter_kind", ctypes.c_uint64),
                 ("filter_demotions", ctypes.c_uint64), ("filter_promotions", ctypes.c_uint64),
-                ("listed_rows", ctypes.c_uint64), ("exchange_fallbacks", ctypes.c_uint64)]
+                ("listed_rows", ctypes.c_uint64), ("exchange_fallbacks", ctypes.c_uint64),
+                ("filter_centred", ctypes.c_uint64)]
 
 
 class EncoderCfg(ctypes.Structure):

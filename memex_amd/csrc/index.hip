@@ -87,6 +87,7 @@ struct Scratch {
     float *qstage = nullptr;       // [256, dim] host->device query staging
     float *qscale = nullptr;       // [256] quantisation step of each query (8-bit filter copy)
     float *qa = nullptr, *qb = nullptr;  // [256] a row's filter-score bound is qa + qb * residual (launch_prep_queries)
+    float *qmean = nullptr;        // [256] a_q of the centred bf16 copy
     uint64_t *out_ids = nullptr;   // [256, kcap] device outputs for the host API
     float *out_scores = nullptr;
     float *out_dists = nullptr;
@@ -186,6 +187,12 @@ struct mx_index {
     uint64_t demoted_at_rows = 0;  // rows the index held when an automatic int8 copy was demoted to bf16 (0: never); the
                                    // int8 copy gets another try once the collection has doubled (add_device_locked)
     float *tsc = nullptr;
+    // centred bf16 copy (f32 corpus, up to kMaxKC slots; launch_shadow): `amean` lives with every such copy, `centred` says
+    // whether it was built around `mean` (a full rebuild of a populated index: a demotion, mx_index_set_filter_copy)
+    float *amean = nullptr;      // [cap] a_c = (c/|c|) . mean
+    float *mean = nullptr;       // [ds] unit direction; msum: [ds] scratch of its computation
+    float *msum = nullptr;
+    bool centred = false;
     // compressed corpus (mx_index_set_corpus_mode): xh is the ONLY copy of the rows; x / scale are not
     // allocated, appends pass through the small f32 staging window xs / ss
     bool compressed = false;
@@ -295,13 +302,14 @@ int free_index(mx_index *idx) {
         if (p) (void)hipFree(p);
     };
     F(idx->x); F(idx->scale); F(idx->xh); F(idx->tsc); F(idx->flags); F(idx->xs); F(idx->ss); F(idx->zero_rows); F(idx->wild_list);
+    F(idx->amean); F(idx->mean); F(idx->msum);
     Scratch &s = idx->s;
     F(s.qfrag); F(s.qpad); F(s.qnorm2); F(s.theta); F(s.theta_retry); F(s.todo); F(s.dev_flags); F(s.done_ctr);
     if (s.host_flags) (void)hipHostFree(s.host_flags);
     if (s.host_sum) (void)hipHostFree(s.host_sum);
     for (void *hp : {(void *)s.h_q, (void *)s.h_ids, (void *)s.h_scores, (void *)s.h_dists, (void *)s.h_nf})
         if (hp) (void)hipHostFree(hp);
-    F(s.qstage); F(s.qscale); F(s.qa); F(s.qb); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
+    F(s.qstage); F(s.qscale); F(s.qa); F(s.qb); F(s.qmean); F(s.out_ids); F(s.out_scores); F(s.out_dists); F(s.out_nfound);
     F(s.exact_scratch); F(s.max_err);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
@@ -400,6 +408,8 @@ int ensure_scratch(mx_index *idx) {
     MX_HIP(hipMalloc(&s.qscale, kMaxBatch * sizeof(float)));
     MX_HIP(hipMalloc(&s.qa, kMaxBatch * sizeof(float)));
     MX_HIP(hipMalloc(&s.qb, kMaxBatch * sizeof(float)));
+    MX_HIP(hipMalloc(&s.qmean, kMaxBatch * sizeof(float)));
+    MX_HIP(hipMemsetAsync(s.qmean, 0, kMaxBatch * sizeof(float), idx->stream));
     MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_q), (size_t)kMaxBatch * idx->dim * sizeof(float), hipHostMallocDefault));
     MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_nf), kMaxBatch * sizeof(int32_t), hipHostMallocDefault));
     MX_HIP(hipMalloc(&s.max_err, sizeof(float)));
@@ -495,7 +505,7 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
         idx->cap = want;
         return MX_OK;
     }
-    DevBuf nx, nsc, nh, nts;
+    DevBuf nx, nsc, nh, nts, nam;
     const size_t rowb = (size_t)idx->ds * sizeof(float);
     MX_HIP(hipMalloc(&nx.p, want * rowb));
     MX_HIP(hipMalloc(&nsc.p, want * sizeof(float)));
@@ -524,6 +534,13 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
                 const size_t tused = (size_t)(used_rows / kTile8Rows) * 4 * sizeof(float);
                 if (tused) MX_HIP(hipMemcpyAsync(nts.p, idx->tsc, tused, hipMemcpyDeviceToDevice, idx->stream));
                 MX_HIP(hipMemsetAsync(static_cast<char *>(nts.p) + tused, 0, tb - tused, idx->stream));
+            } else if (idx->kc <= kMaxKC && hipMalloc(&nam.p, want * sizeof(float)) == hipSuccess) {
+                // the a_c array of a (possibly centred) bf16 copy grows with it
+                const size_t aused = idx->amean && idx->xh ? (size_t)idx->n * sizeof(float) : 0;
+                if (aused) MX_HIP(hipMemcpyAsync(nam.p, idx->amean, aused, hipMemcpyDeviceToDevice, idx->stream));
+                MX_HIP(hipMemsetAsync(static_cast<char *>(nam.p) + aused, 0, want * sizeof(float) - aused, idx->stream));
+            } else {
+                (void)hipGetLastError();
             }
             if (!idx->xh && idx->n) {  // (re)enabled on a populated index
                 const uint32_t t1 = (uint32_t)((idx->n + kTileRows - 1) / kTileRows);
@@ -537,12 +554,17 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
     MX_HIP(hipStreamSynchronize(idx->stream));
     if (idx->x) (void)hipFree(idx->x);
     if (idx->scale) (void)hipFree(idx->scale);
+    // (a centred copy stays centred only if its a_c array came along: a copy built afresh above is a plain one)
+    const bool keep_centre = idx->centred && idx->xh && idx->amean && nh.p && nam.p;
     if (idx->xh) (void)hipFree(idx->xh);
     if (idx->tsc) (void)hipFree(idx->tsc);
+    if (idx->amean) (void)hipFree(idx->amean);
     idx->x = static_cast<float *>(nx.release());
     idx->scale = static_cast<float *>(nsc.release());
     idx->xh = nh.release();
     idx->tsc = static_cast<float *>(nts.release());
+    idx->amean = static_cast<float *>(nam.release());
+    idx->centred = keep_centre;
     idx->cap = want;
     return MX_OK;
 }
@@ -625,7 +647,9 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
         const uint32_t h0 = (uint32_t)(row_lo / kTileRows), h1 = (uint32_t)((row_hi + kTileRows - 1) / kTileRows);
         if (idx->filter_i8)  // both halves of the last 64-row scan tile: the one past row_hi becomes zeros with step 0
             return launch_shadow8(idx->stream, idx->x, idx->scale, idx->ds, h0, (uint32_t)round_up(std::max(h1, h0 + 1), 2), row_hi, idx->xh, idx->tsc, idx->flags + 2);
-        return launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, h0, std::max(h1, h0 + 1), idx->xh, idx->flags + 2);
+        const bool ctr = idx->centred && idx->amean && idx->mean;
+        return launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, h0, std::max(h1, h0 + 1), idx->xh, idx->flags + 2, 0, 0, ~0ull,
+                             ctr ? idx->mean : nullptr, ctr ? idx->amean : nullptr);
     };
     if (idx->xh) MX_HIP(refilter(idx->n, idx->n + n));
     uint32_t fl[5] = {0, 0, 0, 0, 0};
@@ -707,7 +731,7 @@ int run_exact(mx_index *idx, const std::vector<int> &qs, int k, uint64_t *d_ids,
 
 // builds the filter copy of kind (i8 ? int8 : bf16) from the f32 rows, complete before it replaces whatever copy is resident
 int build_filter_copy(mx_index *idx, bool i8) {
-    DevBuf nh, nts, nec;
+    DevBuf nh, nts, nec, nam;
     const size_t hb = (size_t)idx->cap * idx->ds * (i8 ? 1 : 2), tb = (size_t)(idx->cap / kTile8Rows) * 4 * sizeof(float);
     hipError_t e = hipMalloc(&nh.p, hb);
     if (e == hipSuccess && i8) e = hipMalloc(&nts.p, tb);
@@ -721,16 +745,45 @@ int build_filter_copy(mx_index *idx, bool i8) {
     if (i8) MX_HIP(hipMemsetAsync(nts.p, 0, tb, idx->stream));
     MX_HIP(hipMemsetAsync(ec, 0, sizeof(uint32_t), idx->stream));
     const uint32_t t1 = (uint32_t)((idx->n + kTileRows - 1) / kTileRows);
+    // A bf16 copy rebuilt from a populated index is CENTRED on the rows' mean direction (launch_shadow): a corpus that an
+    // int8 certificate could not resolve is a dense one, and embedding corpora are dense because they sit in a cone -- what
+    // is left of a row after its component along the cone's axis is removed is several times shorter, and so is the
+    // rounding error the scan's certificate has to cover (MEMEX_HIP_CENTRE=0: never).
+    static const bool centre_ok = [] {
+        const char *e = getenv("MEMEX_HIP_CENTRE");
+        return !(e && e[0] == '0');
+    }();
+    bool centre = false;
+    if (!i8 && idx->kc <= kMaxKC && hipMalloc(&nam.p, (size_t)idx->cap * sizeof(float)) == hipSuccess) {
+        MX_HIP(hipMemsetAsync(nam.p, 0, (size_t)idx->cap * sizeof(float), idx->stream));
+        if (centre_ok && idx->n >= 256) {
+            if (!idx->mean) MX_HIP(hipMalloc(reinterpret_cast<void **>(&idx->mean), (size_t)idx->ds * sizeof(float)));
+            if (!idx->msum) MX_HIP(hipMalloc(reinterpret_cast<void **>(&idx->msum), ((size_t)idx->ds + 1) * sizeof(float)));
+            MX_HIP(launch_mean_dir(idx->stream, idx->x, idx->scale, idx->n, idx->ds, idx->msum, idx->mean));
+            // worth it only for a corpus that does sit in a cone: |mean of the unit rows| = the typical a_c; below 0.3 the
+            // centred rows are < 5 % shorter and the scan's extra epilogue work buys nothing
+            float msq = 0.f;
+            MX_HIP(hipMemcpyAsync(&msq, idx->msum + idx->ds, sizeof(float), hipMemcpyDeviceToHost, idx->stream));
+            MX_HIP(hipStreamSynchronize(idx->stream));
+            centre = std::isfinite(msq) && msq / (float)idx->n >= 0.3f;
+        }
+    } else if (!i8) {
+        (void)hipGetLastError();
+    }
     if (i8)
         MX_HIP(launch_shadow8(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)round_up(t1, 2), idx->n, nh.p, static_cast<float *>(nts.p), ec));
     else
-        MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, t1, nh.p, ec));
+        MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, t1, nh.p, ec, 0, 0, ~0ull, centre ? idx->mean : nullptr,
+                             centre ? static_cast<float *>(nam.p) : nullptr));
     MX_HIP(hipMemcpyAsync(idx->flags + 2, ec, sizeof(uint32_t), hipMemcpyDeviceToDevice, idx->stream));
     MX_HIP(hipStreamSynchronize(idx->stream));
     if (idx->xh) (void)hipFree(idx->xh);
     if (idx->tsc) (void)hipFree(idx->tsc);
+    if (idx->amean) (void)hipFree(idx->amean);
     idx->xh = nh.release();
     idx->tsc = static_cast<float *>(nts.release());
+    idx->amean = static_cast<float *>(nam.release());
+    idx->centred = centre;
     idx->filter_i8 = i8;
     idx->i8_batches = idx->i8_retry_batches = 0;
     for (double &w : idx->wait_ema_us) w = 0.0;
@@ -781,10 +834,13 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         return search_batch(idx, d_q + (size_t)kWideBatch * idx->dim, B - kWideBatch, k, d_ids + o, d_scores + o,
                             d_dists ? d_dists + o : nullptr, d_nfound + kWideBatch);
     }
+    // the bf16 copy of this index is centred on its rows' mean direction (build_filter_copy): queries are split the same way
+    const bool centred = idx->centred && idx->xh && !filt8 && !wide && !idx->compressed && idx->amean && idx->mean && idx->kc <= kMaxKC;
     LaneLease lease;  // every return below is host-synchronised with the kernels that used the lane buffers
     if ((rc = lease.take(idx, x2 ? 2 : 1)) != MX_OK) return rc;
     MX_HIP(launch_prep_queries(st, d_q, B, idx->dim, idx->ds, s.qfrag, s.qpad, s.qnorm2, s.theta, s.e1,
-                               idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags, s.qa, s.qb, filt8, s.qscale));
+                               idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags, s.qa, s.qb, filt8, s.qscale,
+                               centred ? idx->mean : nullptr, s.qmean));
     const uint32_t *h_ovf = s.host_flags, *h_qfl = s.host_flags + 3 * kMaxBatch;
     auto any_bad_query = [&] {
         uint32_t bad = 0;
@@ -920,6 +976,8 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         p.qscale = s.qscale;
         p.qa = s.qa;
         p.qb = s.qb;
+        p.amean = centred ? idx->amean : nullptr;
+        p.qmean = s.qmean;
         auto scan = [&](bool collect) {
             if (filt8) return launch_scan8(st, idx->kc, collect, idx->nwg, p, x2);
             if (wide) return launch_scan16w(st, idx->kc, collect, idx->nwg, p);
@@ -1425,6 +1483,7 @@ int clear_locked(mx_index *idx) {
         idx->total = 0;
     } else {
         idx->n = 0;  // ids restart at 1 (local.rs:50,63); HBM is kept for reuse
+        idx->centred = false;  // (the centre belonged to the rows that are gone: appends refill the copy uncentred)
         idx->wild_rows = 0;
         idx->n_zero = 0;
         idx->n_wild = 0;
@@ -1944,8 +2003,11 @@ int mx_index_set_filter_copy(mx_index *idx, int on) {
             MX_HIP(hipStreamSynchronize(idx->stream));
             (void)hipFree(idx->xh);
             if (idx->tsc) (void)hipFree(idx->tsc);
+            if (idx->amean) (void)hipFree(idx->amean);
             idx->xh = nullptr;
             idx->tsc = nullptr;
+            idx->amean = nullptr;
+            idx->centred = false;
         }
         return MX_OK;
     };
@@ -1983,8 +2045,9 @@ int mx_index_set_corpus_mode(mx_index *idx, int mode) {
     auto F = [](void *p) {
         if (p) (void)hipFree(p);
     };
-    F(idx->x); F(idx->scale); F(idx->xh); F(idx->tsc);
-    idx->x = nullptr; idx->scale = nullptr; idx->xh = nullptr; idx->tsc = nullptr;
+    F(idx->x); F(idx->scale); F(idx->xh); F(idx->tsc); F(idx->amean);
+    idx->x = nullptr; idx->scale = nullptr; idx->xh = nullptr; idx->tsc = nullptr; idx->amean = nullptr;
+    idx->centred = false;
     idx->cap = 0;
     idx->compressed = mode == MX_CORPUS_BF16;
     idx->want_filter = true;
@@ -2031,6 +2094,7 @@ int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
             acc.filter_demotions += s1.filter_demotions;
             acc.filter_promotions += s1.filter_promotions;
             acc.listed_rows += s1.listed_rows;
+            acc.filter_centred = std::max(acc.filter_centred, s1.filter_centred);
         }
         *out = acc;
         return MX_OK;
@@ -2049,6 +2113,7 @@ int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
     idx->stats.filter_kind = !idx->xh ? 0u : (idx->filter_i8 && !idx->compressed ? 2u : 3u);
     idx->stats.filter_copy_bytes = idx->xh ? (uint64_t)idx->cap * idx->ds * (idx->filter_i8 && !idx->compressed ? 1ull : 2ull) : 0;
     idx->stats.listed_rows = idx->n_zero + idx->n_wild;
+    idx->stats.filter_centred = idx->centred && idx->xh && !idx->filter_i8 ? 1u : 0u;
     *out = idx->stats;
     return MX_OK;
 }

@@ -25,7 +25,8 @@ constexpr int kMaxKC = 6;          // k-chunks per row the MFMA scan supports (d
 // in MFMA A-fragment order in HBM, so the LDS image is a linear copy and needs no conversion pass
 constexpr int kSlot16Bytes = kTileRows * kChunkFloats * 2;
 constexpr int kRing16 = 16;        // 16 x 8 KiB = 128 KiB ring, 15 slots in flight
-constexpr int kScan16LdsBytes = kRing16 * kSlot16Bytes;
+constexpr int kMeanRing16 = 32;    // tiles whose a_c values (centred copy: 128 B per tile in a 256-B entry) can be in flight
+constexpr int kScan16LdsBytes = kRing16 * kSlot16Bytes + kMeanRing16 * 256 + 1024;  // slot ring | a_c ring | a_q of the 256 queries
 // wide rows (scan16w_kernel, 768 < dim_pad <= 1536): the k-steps of a row are dealt to two waves, 128 queries per
 // launch; the ring plus 16 KiB in which the even-slot waves hand their partial sums to the odd-slot waves
 constexpr int kMaxKC16 = 12;
@@ -93,6 +94,11 @@ struct ScanParams {
     const float *tscale = nullptr;  // [cap_rows / 64][4]: quantisation steps of a tile's two halves, then their residual bounds
     const float *qscale = nullptr;  // [256] quantisation step of each query
     const float *qa = nullptr, *qb = nullptr;  // [256] a row's bound is qa + qb * residual (launch_prep_queries)
+    // centred bf16 copy (scan16_kernel, launch_shadow): the copy holds r_c = c/|c| - a_c m for a fixed unit direction m (the
+    // corpus mean direction), amean[row] = a_c; the query fragments hold r_q = q/|q| - a_q m, qmean[q] = a_q; a row's score
+    // is a_q a_c + (MFMA sum over r_q r_c).  null: the copy holds c/|c| itself.
+    const float *amean = nullptr;   // [cap_rows]
+    const float *qmean = nullptr;   // [256]
 };
 
 // launches ---------------------------------------------------------------------------------
@@ -125,8 +131,16 @@ hipError_t launch_scan16w(hipStream_t s, int kc, bool collect, int nwg, const Sc
 // src_tile0: x / scale hold the rows of tiles src_tile0 .. (a staging window; 0 = the whole store).
 // Only rows in [row_lo, row_hi) are (re)written: a 16-byte fragment belongs to ONE row, so rows of a
 // tile that are already in the copy stay untouched.
+// Centred form (mean != nullptr; f32 corpora only): with a_c = (c/|c|) . mean the copy holds bf16(c/|c| - a_c mean) and
+// amean[row] = a_c; ec_max then tracks |stored - (c/|c| - a_c mean)|.  Embedding corpora sit in a cone around a common
+// direction: what is left after removing it is several times shorter than the unit vector, and so is its bf16 rounding
+// error -- the scan's certificate.
 hipError_t launch_shadow(hipStream_t s, const float *x, const float *scale, int ds, uint32_t tile0, uint32_t tile1,
-                         void *xh, uint32_t *ec_max, uint32_t src_tile0 = 0, uint64_t row_lo = 0, uint64_t row_hi = ~0ull);
+                         void *xh, uint32_t *ec_max, uint32_t src_tile0 = 0, uint64_t row_lo = 0, uint64_t row_hi = ~0ull,
+                         const float *mean = nullptr, float *amean = nullptr);
+// mean[ds] = normalised sum of c/|c| over rows [0, n) (zeros when the sum vanishes); msum: [ds + 1] f32 scratch, on return
+// msum[ds] = |sum of c/|c||
+hipError_t launch_mean_dir(hipStream_t s, const float *x, const float *scale, uint64_t n, int ds, float *msum, float *mean);
 // compressed corpus -> f32 rows [n, d]
 hipError_t launch_unshadow(hipStream_t s, const void *xh, int ds, int d, uint64_t row0, uint64_t n, float *out);
 
@@ -144,7 +158,8 @@ hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, flo
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag,
                                float *qpad, double *qnorm2, float *theta, float *e1, const uint32_t *ec_max,
                                uint32_t *overflow, uint32_t *flags, float *qa, float *qb, bool filt8 = false,
-                               float *qscale = nullptr);
+                               float *qscale = nullptr, const float *mean = nullptr, float *qmean = nullptr);
+// mean / qmean: the centred bf16 copy (ScanParams::amean): fragments of q/|q| - a_q mean, qmean[q] = a_q
 // qa / qb [256]: the bound of one row's filter score is qa + qb * (residual of the row's half tile); scans that know
 // one residual for all rows get qa = e1, qb = 0
 // filt8: fragments for the 8-bit filter copy (scan8.hip: int8 [8 waves][ds/32][64 lanes][16]) and qscale[256] = the

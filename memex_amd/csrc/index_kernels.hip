@@ -208,12 +208,15 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
                                                            float *__restrict__ e1, const uint32_t *__restrict__ ec_max,
                                                            uint32_t *__restrict__ overflow, uint32_t *__restrict__ flags,
                                                            int filt8, float *__restrict__ qscale,
-                                                           float *__restrict__ qa, float *__restrict__ qb) {
+                                                           float *__restrict__ qa, float *__restrict__ qb,
+                                                           const float *__restrict__ mean, float *__restrict__ qmean) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
     float *s_row = reinterpret_cast<float *>(psm);  // [d] this query (coalesced load; the chain reads LDS)
     __shared__ float s_inv;
     __shared__ uint32_t s_red[4];
     __shared__ uint32_t s_bad[4];
+    __shared__ double s_dot[4];
+    __shared__ float s_rq[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const bool live = b < B;
@@ -274,18 +277,38 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
             r2 += r * r;
         }
     } else {
+        // centred bf16 copy (ScanParams::amean): a_q = (q/|q|) . mean in f64, the fragments hold r_q = q/|q| - a_q mean
+        float aq = 0.0f;
+        if (mean) {
+            double dp = 0.0;
+            for (int dim = tid; dim < d; dim += 256) dp += (double)(s_row[dim] * inv) * (double)mean[dim];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dp += __shfl_xor(dp, o);
+            if ((tid & 63) == 0) s_dot[tid >> 6] = dp;
+            __syncthreads();
+            aq = (float)(s_dot[0] + s_dot[1] + s_dot[2] + s_dot[3]);
+            if (tid == 0) qmean[b] = aq;
+        }
         const int ksteps = ds / 16;
+        float rq2 = 0.0f;  // |r_q|^2 (centred) -- the factor of the rows' residual in the bound
         for (int dim = tid; dim < ds; dim += 256) {
             const float v = dim < d ? s_row[dim] : 0.0f;
             qpad[(size_t)b * ds + dim] = v;
             // MFMA 32x32x16 B-operand: lane l holds B[k = 8*(l>>5)+i][n = l&31]
             const int ks = dim >> 4, hh = (dim >> 3) & 1, i = dim & 7;
             const int lane = hh * 32 + col;
-            const float vn = v * inv;
+            float vn = v * inv;
+            if (mean && dim < d) vn = __builtin_fmaf(-aq, mean[dim], vn);
             const __bf16 vb = (__bf16)vn;
             qfrag[(((size_t)w * ksteps + ks) * 64 + lane) * 8 + i] = vb;
             const float r = (float)vb - vn;
             r2 += r * r;
+            rq2 += vn * vn;
+        }
+        if (mean) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rq2 += __shfl_xor(rq2, o);
+            if ((tid & 63) == 0) s_rq[tid >> 6] = rq2;
         }
     }
 #pragma unroll
@@ -310,6 +333,12 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
             const float ec = __uint_as_float(*ec_max) * 1.01f + 1e-6f;
             e = ec + eq + ec * eq + kAccSlack;
             if (!filt8) e = fminf(kApproxErr + ec * ec, e);  // two bf16 roundings have an a-priori bound as well
+            if (mean && !filt8) {
+                // centred copy: cos = a_q a_c + r_q . r_c exactly (a_c, a_q are the stored f32 values, r := unit vector - a m),
+                // |r^_q . r^_c - r_q . r_c| <= |r_q| Ec + (|r_c| + Ec) Eq <= |r_q| Ec + Eq + Ec Eq   (|r_c| <= 1 + 1e-6)
+                const float rq = sqrtf(s_rq[0] + s_rq[1] + s_rq[2] + s_rq[3]) * 1.001f + 1e-6f;
+                e = fminf(e, rq * ec + eq * 1.0001f + ec * eq + kAccSlack);
+            }
         }
         e1[b] = e;
         // the bound of ONE row is a + b * (its residual): with a residual per half tile (8-bit copy, scan8.hip) the
@@ -322,11 +351,53 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
 
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag, float *qpad,
                                double *qnorm2, float *theta, float *e1, const uint32_t *ec_max, uint32_t *overflow,
-                               uint32_t *flags, float *qa, float *qb, bool filt8, float *qscale) {
+                               uint32_t *flags, float *qa, float *qb, bool filt8, float *qscale, const float *mean, float *qmean) {
+    if (filt8 || !qmean) mean = nullptr;
     // one block per query slot: 256 slots (a pass computes all of them), 512 for a batch of more than 256
     hipLaunchKernelGGL(prep_queries_kernel, dim3(B > kPassBatch ? kMaxBatch : kPassBatch), dim3(256),
                        sizeof(float) * ((size_t)d + (filt8 ? 2 * (size_t)ds + kRotMaxBlocks * kRotMaxBlocks : 0)), s, q, B, d, ds,
-                       (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags, filt8 ? 1 : 0, qscale, qa, qb);
+                       (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags, filt8 ? 1 : 0, qscale, qa, qb, mean, qmean);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// mean direction of the normalised rows (the centre of a centred bf16 copy, launch_shadow)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mean_sum_kernel(const float *__restrict__ x, const float *__restrict__ scale, uint64_t n, int ds,
+                                                       float *__restrict__ msum) {
+    // a workgroup walks a contiguous share of the rows; thread t sums columns t, t + 256, ... (coalesced along a row)
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
+    for (int c = threadIdx.x; c < ds; c += 256) {
+        float acc = 0.0f;
+        for (uint64_t r = r0; r < r1; ++r) acc = __builtin_fmaf(x[r * (uint64_t)ds + c], scale[r], acc);
+        atomicAdd(&msum[c], acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void mean_norm_kernel(float *__restrict__ msum, int ds, float *__restrict__ mean) {
+    __shared__ double s_p[4];
+    double p = 0.0;
+    for (int c = threadIdx.x; c < ds; c += 256) p += (double)msum[c] * (double)msum[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = p;
+    __syncthreads();
+    const double n2 = s_p[0] + s_p[1] + s_p[2] + s_p[3];
+    const double inv = n2 > 1e-30 && n2 < 1e30 ? 1.0 / sqrt(n2) : 0.0;  // a vanishing (or non-finite) sum: no centre
+    for (int c = threadIdx.x; c < ds; c += 256) mean[c] = (float)((double)msum[c] * inv);
+    __syncthreads();
+    if (threadIdx.x == 0) msum[ds] = (float)sqrt(n2);  // |sum of the unit rows|: the host decides whether centring pays
+}
+
+hipError_t launch_mean_dir(hipStream_t s, const float *x, const float *scale, uint64_t n, int ds, float *msum, float *mean) {
+    hipError_t e = hipMemsetAsync(msum, 0, (size_t)ds * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    if (n > 0) {
+        const unsigned blocks = (unsigned)(n < 2048 ? n : 2048);
+        hipLaunchKernelGGL(mean_sum_kernel, dim3(blocks), dim3(256), 0, s, x, scale, n, ds, msum);
+    }
+    hipLaunchKernelGGL(mean_norm_kernel, dim3(1), dim3(256), 0, s, msum, ds, mean);
     return hipGetLastError();
 }
 

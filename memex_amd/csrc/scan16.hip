@@ -55,6 +55,27 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 static_assert(kRing16 == 16, "waits below assume a 16-slot ring with 15 slots in flight");
 
+namespace {
+template <int N>
+using ic16 = std::integral_constant<int, N>;
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for16(F &&f) {
+    if constexpr (B < E) {
+        f(ic16<B>{});
+        static_for16<B + 1, E>(f);
+    }
+}
+// DMA operations a wave has issued after the one of slot j+1 when it waits for that slot: the slots lo .. hi (relative to the
+// tile start), plus the one a_c operation of every tile that starts among them (as scan8_kernel's tile scales)
+template <int KC>
+constexpr int ops_after16(int lo, int hi) {
+    int n = 0;
+    for (int i = lo; i <= hi; ++i) n += 1 + (i % KC == 0 ? 1 : 0);
+    return n;
+}
+static_assert(ops_after16<3>(2, 14) == 17 && ops_after16<6>(5, 17) == 15 && ops_after16<1>(2, 14) == 26, "");
+}  // namespace
+
 // Ablation switch for scripts/scan16_ubench.hip only (0 = production kernel):
 //   1 = DMA + waits + barriers, 2 = + fragment reads (no MFMA), 4 = everything except the DMA
 //   (compute on whatever LDS holds).  MX_SCAN16_CLOCK: lane_cnt receives the workgroup's s_memtime
@@ -113,9 +134,22 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
     // the vmcnt arithmetic uniform (exactly one DMA op per slot per wave, dead or alive).
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t is_ti = 0;  // tiles opened so far
+    // Centred copy (ScanParams::amean): the tile's 32 values a_c travel in the same stream, one 128-byte operation issued right
+    // before the tile's first slot -- they have landed when that slot has.  (A scalar load per tile exposes an HBM latency
+    // per tile -- a tile is 1.4 us of work --, a vector load puts its own wait on the ring's vmcnt.)  Every wave issues it,
+    // also for a plain copy (num_records = 0: no memory touched): same bytes, same LDS address, and the waits below stay
+    // wave-uniform compile-time arithmetic.
+    const bool centred = p.amean != nullptr;
+    const uint32_t lane4 = (uint32_t)lane * 4u;
     auto open_tile = [&]() {
-        const char *base = reinterpret_cast<const char *>(p.xh) + (size_t)(t0 + is_ti * tstep) * tilebytes;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, is_ti < nT ? tilebytes : 0u, 0x00020000);
+        const uint32_t tile = t0 + is_ti * tstep;
+        const bool live_tile = is_ti < nT;
+        __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)(p.amean + (size_t)tile * kTileRows), 0,
+                                                                         live_tile && centred ? (uint32_t)(kTileRows * 4) : 0u, 0x00020000);
+        char *adst = smem + __builtin_amdgcn_readfirstlane(kRing16 * kSlot16Bytes + (is_ti & (kMeanRing16 - 1)) * 256);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_void *)adst, 4, lane4, 0, 0, 0);
+        const char *base = reinterpret_cast<const char *>(p.xh) + (size_t)tile * tilebytes;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live_tile ? tilebytes : 0u, 0x00020000);
         ++is_ti;
     };
     auto issue = [&](int kci, uint32_t ring_pos) {  // kci is a compile-time constant at every call site
@@ -138,12 +172,17 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
     for (int i = 0; i < kRing16 - 1; ++i) issue(i % KC, (uint32_t)i);
 
     bf16x8 a[R];
-    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // slot 0 landed (14 newer may be in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ops_after16<KC>(1, kRing16 - 2)) : "memory");  // slot 0 (and its tile's a_c) landed
     __builtin_amdgcn_s_barrier();
 #if MX_SCAN16_ABLATE != 1
 #pragma unroll
     for (int ks = 0; ks < R; ++ks) a[ks] = *reinterpret_cast<const bf16x8 *>(smem + lane16 + ks * 1024);
 #endif
+
+    // a_q of this lane's query waits in LDS behind the rings (1 KiB; a register held across the loop is one more than the
+    // 768-dim kernel has): written and read by the same wave, so program order is all the synchronisation it needs
+    float *aq_lds = reinterpret_cast<float *>(smem + kRing16 * kSlot16Bytes + kMeanRing16 * 256) + wave * 32 + m;
+    if (centred && lane < 32) *aq_lds = p.qmean[wave * 32 + m];
 
     uint32_t rp = 0;  // ring position of the slot being multiplied
 #pragma unroll 1
@@ -152,13 +191,13 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f, acc1[r] = 0.0f;
 
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
+        static_for16<0, KC>([&](auto kct) __attribute__((always_inline)) {
+            constexpr int kc = decltype(kct)::value;
             const uint32_t rp1 = (rp + 1) & (kRing16 - 1);
             const uint32_t rpi = (rp + kRing16 - 1) & (kRing16 - 1);  // ring position of slot j+15 = of slot j-1
             // Slot j+1 (the ring reads ahead into it) must have landed; slots 0 .. j+14 are issued ->
-            // 13 newer may be in flight.
-            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            // the 13 newer ones (and the a_c operations of the tiles that start among them) may be in flight.
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ops_after16<KC>(kc + 2, kc + kRing16 - 2)) : "memory");
             // One barrier per slot: every wave's piece of slot j+1 is in LDS, and every wave has
             // consumed (MFMA issued) its fragments of slot j-1, whose ring position is refilled below.
             __builtin_amdgcn_s_barrier();
@@ -166,7 +205,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
             if (!live) {
                 issue((kc + kRing16 - 1) % KC, rpi);
                 rp = rp1;
-                continue;
+                return;
             }
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
@@ -197,7 +236,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
                 __builtin_amdgcn_sched_barrier(0);
             }
             rp = rp1;
-        }
+        });
 
         if (!live) continue;
         // ---- tile epilogue: lane holds query (wave*32 + m), rows (r&3) + 8*(r>>2) + 4*h.
@@ -206,6 +245,16 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = DUAL ? acc[r] + acc1[r] : acc[r];
+        if (centred) {  // score = a_q a_c + r_q . r_c; this lane's rows: (r & 3) + 8 (r >> 2) + 4 h
+            const float aq = *aq_lds;
+            const f32x4 *am = reinterpret_cast<const f32x4 *>(smem + kRing16 * kSlot16Bytes + (ti & (kMeanRing16 - 1)) * 256) + (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a4 = am[2 * j];  // rows 8 j + 4 h .. + 3
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * j + e] = __builtin_fmaf(aq, a4[e], v[4 * j + e]);
+            }
+        }
         float mx = fmaxf(fmaxf(v[0], v[1]), v[2]);
 #pragma unroll
         for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, v[r]), v[r + 1]);
@@ -250,23 +299,56 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan16_kernel(const ScanParam
 __global__ __launch_bounds__(256) void shadow_kernel(const float *__restrict__ x, const float *__restrict__ scale,
                                                      int ds, uint32_t tile0, uint32_t tile1,
                                                      bf16x8 *__restrict__ xh, uint32_t *__restrict__ ec_max,
-                                                     uint32_t src_tile0, uint64_t row_lo, uint64_t row_hi) {
+                                                     uint32_t src_tile0, uint64_t row_lo, uint64_t row_hi,
+                                                     const float *__restrict__ mean, float *__restrict__ amean) {
     // per row: |bf16(c/|c|) - c/|c||^2 (the row's share of the scan's error bound) and |bf16(c/|c|)|^2
     __shared__ float s_r2[kTileRows], s_n2[kTileRows];
+    __shared__ double s_a[kTileRows];  // centred form: a_c = (c/|c|) . mean, summed in f64 (the identity
+                                       // c/|c| = a_c mean + r_c must hold to ~1e-7 for the scan's certificate)
     const uint32_t frags = (uint32_t)(ds / 16) * 64u;  // fragments per tile
     float worst = 0.0f;
     for (uint32_t t = tile0 + blockIdx.x; t < tile1; t += gridDim.x) {
         const float *xt = x + (size_t)(t - src_tile0) * kTileRows * ds;
         bf16x8 *ot = xh + (size_t)t * frags;
-        if (threadIdx.x < kTileRows) s_r2[threadIdx.x] = 0.0f, s_n2[threadIdx.x] = 0.0f;
+        if (threadIdx.x < kTileRows) s_r2[threadIdx.x] = 0.0f, s_n2[threadIdx.x] = 0.0f, s_a[threadIdx.x] = 0.0;
         __syncthreads();
+        if (mean) {
+            for (uint32_t f = threadIdx.x; f < frags; f += 256) {
+                const uint32_t ks = f >> 6, l = f & 63, mm = l & 31, hh = l >> 5;
+                const uint64_t grow = (uint64_t)t * kTileRows + mm;
+                if (grow < row_lo || grow >= row_hi) continue;
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(xt + (size_t)mm * ds + ks * 16 + hh * 8);
+                const f32x4 *mp = reinterpret_cast<const f32x4 *>(mean + ks * 16 + hh * 8);
+                const float sc = scale[(size_t)(t - src_tile0) * kTileRows + mm];
+                const f32x4 lo = src[0] * sc, hi = src[1] * sc, m0 = mp[0], m1 = mp[1];
+                double d = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d += (double)lo[i] * (double)m0[i] + (double)hi[i] * (double)m1[i];
+                atomicAdd(&s_a[mm], d);
+            }
+            __syncthreads();
+            if (threadIdx.x < kTileRows) {
+                const uint64_t grow = (uint64_t)t * kTileRows + threadIdx.x;
+                if (grow >= row_lo && grow < row_hi) amean[grow] = (float)s_a[threadIdx.x];
+            }
+        }
         for (uint32_t f = threadIdx.x; f < frags; f += 256) {
             const uint32_t ks = f >> 6, l = f & 63, mm = l & 31, hh = l >> 5;
             const uint64_t grow = (uint64_t)t * kTileRows + mm;
             if (grow < row_lo || grow >= row_hi) continue;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(xt + (size_t)mm * ds + ks * 16 + hh * 8);
             const float sc = scale[(size_t)(t - src_tile0) * kTileRows + mm];  // 1/|c|; 0 for a zero-norm row -> stored as zeros
-            const f32x4 lo = src[0] * sc, hi = src[1] * sc;
+            f32x4 lo = src[0] * sc, hi = src[1] * sc;
+            if (mean) {  // r_c = c/|c| - a_c mean, with the a_c the scan will use (the f32 value just stored)
+                const float ac = (float)s_a[mm];
+                const f32x4 *mp = reinterpret_cast<const f32x4 *>(mean + ks * 16 + hh * 8);
+                const f32x4 m0 = mp[0], m1 = mp[1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo[i] = __builtin_fmaf(-ac, m0[i], lo[i]);
+                    hi[i] = __builtin_fmaf(-ac, m1[i], hi[i]);
+                }
+            }
             bf16x8 o;
             o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
             o[4] = (__bf16)hi[0]; o[5] = (__bf16)hi[1]; o[6] = (__bf16)hi[2]; o[7] = (__bf16)hi[3];
@@ -283,8 +365,8 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float *__restrict__ x
         }
         __syncthreads();
         if (threadIdx.x < kTileRows) {
-            // the stored row is not exactly unit: ||c^| - 1| enters the bound when the copy is the corpus
-            const float dev = s_n2[threadIdx.x] > 0.0f ? fabsf(sqrtf(s_n2[threadIdx.x]) - 1.0f) : 0.0f;
+            // the stored row is not exactly unit: ||c^| - 1| enters the bound when the copy is the corpus (never centred)
+            const float dev = !mean && s_n2[threadIdx.x] > 0.0f ? fabsf(sqrtf(s_n2[threadIdx.x]) - 1.0f) : 0.0f;
             worst = fmaxf(worst, fmaxf(sqrtf(s_r2[threadIdx.x]), dev));
         }
         __syncthreads();
@@ -297,11 +379,13 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float *__restrict__ x
 }
 
 hipError_t launch_shadow(hipStream_t s, const float *x, const float *scale, int ds, uint32_t tile0, uint32_t tile1,
-                         void *xh, uint32_t *ec_max, uint32_t src_tile0, uint64_t row_lo, uint64_t row_hi) {
+                         void *xh, uint32_t *ec_max, uint32_t src_tile0, uint64_t row_lo, uint64_t row_hi, const float *mean,
+                         float *amean) {
     if (tile1 <= tile0) return hipSuccess;
+    if (mean && !amean) return hipErrorInvalidValue;
     const uint32_t blocks = tile1 - tile0 < 16384u ? tile1 - tile0 : 16384u;
     hipLaunchKernelGGL(shadow_kernel, dim3(blocks), dim3(256), 0, s, x, scale, ds, tile0, tile1,
-                       reinterpret_cast<bf16x8 *>(xh), ec_max, src_tile0, row_lo, row_hi);
+                       reinterpret_cast<bf16x8 *>(xh), ec_max, src_tile0, row_lo, row_hi, mean, amean);
     return hipGetLastError();
 }
 

@@ -1,0 +1,117 @@
+"""The CENTRED bf16 filter copy (scan16.hip / launch_shadow): a bf16 copy rebuilt from a populated
+index whose rows sit in a cone holds r_c = c/|c| - a_c m (m = the rows' mean direction) plus a_c per row; the scan scores
+a_q a_c + r_q . r_c.  The residual vectors are several times shorter than the unit rows, and so is the rounding error the
+certificate covers -- corpora that used to overflow into retry passes and the EXACT path (embeddings of one model: a narrow
+cone) are answered by the first pass.  Results stay bit-identical to the oracle (reference arithmetic: local.rs:71-91 +
+DistCosine); what is checked on top is that the certificate holds and that it did get tighter."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def cone_rows(rng, n, d, spread=0.2, axis_seed=1):
+    """rows = axis + spread * noise (unit-variance total): mean pairwise cosine 1 / (1 + spread^2) ~ 0.96 at 0.2"""
+    axis = np.random.default_rng(axis_seed).standard_normal(d).astype(np.float32)
+    axis /= np.linalg.norm(axis)
+    x = axis[None, :] + (spread / np.sqrt(d)) * rng.standard_normal((n, d), dtype=np.float32)
+    return (x * rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)).astype(np.float32)   # random lengths: the path normalises
+
+
+def _equal(idx, X, Q, k, oracle):
+    oi, od, os_, onf = oracle.search(X, Q, k)
+    ids, sc, di, nf = idx.search(Q, k)
+    np.testing.assert_array_equal(ids, oi)
+    np.testing.assert_array_equal(bits(di), bits(od))
+    np.testing.assert_array_equal(bits(sc), bits(os_))
+    np.testing.assert_array_equal(nf, onf)
+
+
+@pytest.mark.parametrize("n,d,B,seed", [(50000, 384, 64, 1), (30000, 768, 256, 2), (20000, 100, 33, 3), (40000, 512, 40, 4)])
+def test_centred_copy_certificate_and_parity(n, d, B, seed, oracle, lib_built):
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(seed)
+    X = cone_rows(rng, n, d)
+    X[17] = 0.0                                    # a zero-norm row (stored as zeros, a_c = 0, listed)
+    X[100:140] = X[99]                             # exact duplicates
+    Q = cone_rows(rng, B, d)
+    Q[0] = X[99]
+    with FlatIndex(d) as idx:
+        idx.add(X[: n - 5000])
+        idx.set_filter_copy("bf16")                # rebuilt from the resident rows: centred
+        assert idx.stats().filter_centred == 1 and idx.stats().filter_kind == 3
+        idx.set_profiling(True)
+        _equal(idx, X[: n - 5000], Q, 10, oracle)
+        st = idx.stats()
+        assert st.fallback_queries == 0 and st.retry_queries == 0
+        # the certificate holds, and it is several times tighter than a plain bf16 copy's (0.0041-0.0045 on unit rows)
+        assert 0.0 < st.max_abs_err <= st.approx_err_bound <= 0.0016, (st.max_abs_err, st.approx_err_bound)
+        # appends after the centre was fixed: a partly filled tile, then growth past the capacity (the a_c array moves along)
+        idx.add(X[n - 5000: n - 4990])
+        idx.add(X[n - 4990:])
+        assert idx.stats().filter_centred == 1
+        _equal(idx, X, Q, 10, oracle)
+        _equal(idx, X, Q[:3], 100, oracle)
+        big = cone_rows(rng, 3 * n, d)
+        idx.add(big)
+        assert idx.stats().filter_centred == 1
+        XX = np.concatenate([X, big])
+        _equal(idx, XX, Q[:16], 10, oracle)
+        assert idx.stats().fallback_queries == 0
+        idx.clear()
+        assert idx.stats().filter_centred == 0
+
+
+def test_rows_without_a_cone_stay_uncentred(oracle, lib_built):
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((20000, 384), dtype=np.float32)
+    Q = rng.standard_normal((8, 384), dtype=np.float32)
+    with FlatIndex(384) as idx:
+        idx.add(X)
+        idx.set_filter_copy("bf16")
+        assert idx.stats().filter_centred == 0     # |mean of the unit rows| ~ 0.007: nothing to remove
+        _equal(idx, X, Q, 10, oracle)
+        idx.clear()
+        idx.add(cone_rows(rng, 20000, 384))
+        idx.set_filter_copy("i8")
+        idx.set_filter_copy("bf16")
+        assert idx.stats().filter_centred == 1
+        idx.clear()                                # the centre goes with the rows it was computed from
+        assert idx.stats().filter_centred == 0
+        idx.add(X)
+        _equal(idx, X, Q, 10, oracle)
+
+
+def test_narrow_cone_1m_is_answered_without_the_exact_path(oracle, lib_built):
+    """1M rows in a narrow cone (mean pairwise cosine >= 0.95; every row has ~100 near copies at cosine 0.99:
+    the shape of bench.py's enc_like leg), the library's own choice of copy: the int8 certificate cannot resolve it, the copy is
+    demoted ONCE to a centred bf16 copy, and from then on no query needs the retry pass or the EXACT path; ids / dists /
+    scores equal the oracle's bit for bit."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(6)
+    d, n_src, n = 384, 10000, 1_000_000
+    src = cone_rows(rng, n_src, d, spread=0.2)
+    src /= np.linalg.norm(src, axis=1, keepdims=True)
+    pick = rng.integers(0, n_src, n)
+    X = (src[pick] + (0.1 / np.sqrt(d)) * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    Q = cone_rows(rng, 256, d, spread=0.2)
+    sub = X[:2000] / np.linalg.norm(X[:2000], axis=1, keepdims=True)
+    assert (sub @ sub.T).mean() >= 0.95
+    with FlatIndex(d) as idx:
+        idx.add(X)
+        first = idx.search(Q, 10)
+        st0 = idx.stats()
+        assert st0.filter_demotions == 1 and st0.filter_kind == 3 and st0.filter_centred == 1, (st0.filter_demotions, st0.filter_kind)
+        idx.reset_stats()
+        ids, sc, di, nf = idx.search(Q, 10)
+        st = idx.stats()
+        assert st.fallback_queries == 0 and st.retry_queries == 0, (st.fallback_queries, st.retry_queries)
+        assert st.candidates / 256 < 2000
+        oi, od, os_, onf = oracle.search(X, Q[:24], 10)
+        for got in (first, (ids, sc, di, nf)):
+            np.testing.assert_array_equal(got[0][:24], oi)
+            np.testing.assert_array_equal(bits(got[2][:24]), bits(od))
+            np.testing.assert_array_equal(bits(got[1][:24]), bits(os_))
