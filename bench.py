@@ -479,7 +479,7 @@ def traffic_from_profile(rows_total: int, dim: int, world: int, scan: str):
            (768, "i8"): "scan8_768"}.get((dim, scan))
     if world != 1 or rows_total != 10_000_000 or tag is None:
         return None
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_traffic.json")
         if os.path.exists(path):
             try:
@@ -638,6 +638,26 @@ def side_leg(rows: int, dim: int, batch: int, k: int, steps: int, data: str):
     del idx, q, bufs
     torch.cuda.empty_cache()
     return out
+
+
+def sharded_one_device_leg(rows: int, dim: int, batch: int, k: int, steps: int, shards: int) -> float:
+    """ms per step of the in-library sharded index with `shards` logical shards, all on device 0 (a wiring + overhead probe)."""
+    import torch
+    from memex_amd.index import FlatIndex
+    idx = FlatIndex(dim, key=None, device=0, devices=[0] * shards)
+    idx.reserve(rows)
+    fill_index(idx, rows, dim, 0, rows, "gaussian")
+    q = make_queries(batch, dim, "gaussian")
+    bufs = SearchBuffers(batch, k)
+    torch.cuda.synchronize()
+
+    def step():
+        idx.search_device(q, k, bufs.ids, bufs.scores, bufs.dists, bufs.nf)
+    dt, _ = timed_steps(idx, step, torch.cuda.synchronize, 3, steps, 1)
+    idx.close()
+    del idx, q, bufs
+    torch.cuda.empty_cache()
+    return dt / steps * 1e3
 
 
 def run(a):
@@ -822,8 +842,22 @@ def run(a):
             # cost (prep, sample, theta, finish) against 1/8 of the scan -- a one-GPU proxy for strong scaling (no exchange)
             for nm, dm in (("shard_1p25Mx384", 384), ("shard_1p25Mx768", 768)):
                 leg = side_leg(1_250_000, dm, a.batch, k, a.side_steps, "gaussian")
-                leg["predicted_n8_qps"] = a.batch / leg["ms_per_step"] * 1e3
-                leg["note"] = "one shard of an 8-way split, no exchange or merge in the step: an upper bound on the 8-GPU rate"
+                leg["predicted_n8_qps_no_exchange"] = a.batch / leg["ms_per_step"] * 1e3
+                # the exchange + merge term, timed on this one device: the in-library sharded index with EIGHT logical shards
+                # on device 0 answers the same batch (its shards take turns on the GPU, each step host-synchronised like the
+                # plain leg, then peer copies of the eight [ids | dists] blocks and merge_kernel); what it takes beyond eight
+                # plain shard steps is what a step of the 8-GPU job adds to one shard step -- with peer copies where the real
+                # job has ONE RCCL all-gather of 8 x 30 KB over xGMI (tens of us; unmeasured: no multi-GPU node yet)
+                try:
+                    t8 = sharded_one_device_leg(8 * 1_250_000, dm, a.batch, k, a.side_steps, 8)
+                    extra = max(0.0, t8 - 8.0 * leg["ms_per_step"])
+                    leg["eight_logical_shards_ms_per_step"] = t8
+                    leg["exchange_and_merge_ms"] = extra
+                    leg["predicted_n8_qps"] = a.batch / (leg["ms_per_step"] + extra) * 1e3
+                    leg["note"] = ("predicted_n8_qps = batch / (one shard step + exchange + merge), the last two timed with 8 logical "
+                                   "shards on one device (peer copies instead of the RCCL all-gather); a prediction, not a measurement")
+                except Exception as e:  # noqa: BLE001 -- a side leg must not fail the bench
+                    leg["exchange_and_merge_error"] = repr(e)[:300]
                 sides[nm] = leg
         if a.enc_like_rows > 0:
             sides["enc_like_10M"] = enc_like_leg(a.enc_like_rows, 100_000, a.batch, k, a.side_steps)

@@ -1,5 +1,8 @@
 #!/bin/bash
+# round-5 record: the full GPU suite, then the profile recipe (kernel stats, PMC traffic, power logs, default bench line)
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_centred_gpu.py tests/test_search_gpu.py tests/test_compressed_gpu.py tests/test_random_ops_gpu.py tests/test_cfg2_gpu.py -m gpu -x -q 2>&1 | tail -30 > gpurun_out/r5_tests5.txt
-cat gpurun_out/r5_tests5.txt
-timeout 600 python scripts/gpu_enc_like.py 10000000 20 > gpurun_out/r5_enc_like_after.json 2> gpurun_out/r5_enc_like_after.err; tail -c 1500 gpurun_out/r5_enc_like_after.json; tail -5 gpurun_out/r5_enc_like_after.err
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r5_tests_full.txt
+cat gpurun_out/r5_tests_full.txt
+timeout 3000 bash scripts/profile_search.sh r5 > gpurun_out/r5_profile.log 2>&1
+tail -5 gpurun_out/r5_profile.log
+ls gpurun_out/prof_r5 | head -50

@@ -270,6 +270,30 @@ def test_large_passes_run_their_gemms_on_pgemm_kernel(lib_built, monkeypatch):
         assert (1.0 - _cos(outs[1][sub].astype(np.float64), ref)).max() <= TOL, kw
 
 
+def test_a_row_across_the_pass_size_regimes(lib_built):
+    """A text's embedding depends (in its last bits) on how many packed rows share its pass -- three kernel sets, stated in
+    include/memex_hip.h: hidden 384: small passes (<= 512 rows: encoder_small.hip) / everything else; hidden 768: passes
+    below / from 32768 rows (gemm_kernel with the fused Add&LayerNorm / pgemm_kernel + ln_rows_kernel).  Same rounding
+    points, other f32 summation orders (and one more bf16 rounding of the pre-LayerNorm sum at >= 32768 rows): the same rows
+    on either side of each threshold must agree far inside the 1e-3 bar."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    rng = np.random.default_rng(71)
+    for kw, S, b_small, b_large in ((dict(layers=4, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 512, 63, 64),
+                                    (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000), 64, 7, 8)):
+        cfg = EncoderConfig(**kw)
+        w = synthetic_weights(cfg, 71)
+        ids = rng.integers(1000, cfg.vocab, size=(b_large, S)).astype(np.int32)
+        lens = np.full(b_large, S, dtype=np.int32)
+        with Encoder(cfg, w) as enc:
+            below = enc.encode(ids[:b_small], lens[:b_small])     # 63 x 512 = 32256 rows (+32 < 32768) / 7 x 64 = 448 (+32 <= 512)
+            above = enc.encode(ids, lens)                         # 64 x 512 = 32768 / 8 x 64 = 512 (+32 > 512)
+        d = (1.0 - _cos(below.astype(np.float64), above[:b_small].astype(np.float64))).max()
+        print(f"hidden {cfg.hidden}: the same {b_small} rows in a pass below / above the threshold: 1 - cos = {d:.2e}")
+        assert (below != above[:b_small]).any(), "both calls took the same kernels: the thresholds moved?"
+        assert d <= 5e-5, (kw, d)
+
+
 @pytest.mark.parametrize("kw,B,S,seed", [
     (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000), 12, 256, 51),                    # all-MiniLM-L6-v2 shape: fused tail
     (dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 6, 200, 52),     # bge-base shape: gemm_kernel path

@@ -105,6 +105,40 @@ def test_unsupported_models_are_refused(tmp_path):
         load_pretrained_dir(str(tmp_path / "bad"))
 
 
+def test_cpp_loader_agrees_with_the_python_one(tmp_path, lib_built):
+    """include/memex_pretrained.hpp (the C++ host mirror's loader): same configuration, same weight blob byte for byte,
+    same refusals as memex_amd.pretrained."""
+    import subprocess
+    from memex_amd.pretrained import load_pretrained_dir
+    from memex_amd.weights import pack_weights
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_pretrained")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "test_pretrained.cpp"), "-o", exe, "-L", os.path.join(root, "memex_amd"),
+                           "-lmemex_hip", "-lpthread", "-Wl,-rpath," + os.path.join(root, "memex_amd")])
+    d = str(tmp_path / "st")
+    make_st_dir(d, hidden=384, layers=2, pooling="cls", max_seq_length=200)
+    r = subprocess.run([exe, d, "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK "), r.stdout + r.stderr
+    f = r.stdout.split()
+    cfg, tensors, vpath, info = load_pretrained_dir(d, precision="bf16x3")
+    blob = pack_weights(tensors, cfg)
+    with np.errstate(over="ignore"):  # position-weighted sum of the 32-bit words, mod 2^64 (as the C++ side computes it)
+        h = int((blob.view(np.uint32).astype(np.uint64) * np.arange(1, blob.size + 1, dtype=np.uint64)).sum(dtype=np.uint64))
+    assert [int(v) for v in f[1:8]] == [cfg.layers, cfg.hidden, cfg.heads, cfg.ffn, cfg.vocab, cfg.max_pos, cfg.type_vocab]
+    assert abs(float(f[8]) - cfg.ln_eps) < 1e-15 and [int(v) for v in f[9:13]] == [1, 1, 0, 1]      # cls, normalize, pos_offset, bf16x3
+    assert int(f[13]) == cfg.max_seq_length == 200 and int(f[14]) == 1 and int(f[15]) == blob.nbytes
+    assert f[16] == f"{h:016x}" and f[17] == vpath
+    for name, kw in (("dense", dict(dense=True)), ("relu", dict(hidden_act="relu")),
+                     ("maxpool", dict(pooling_modes={"pooling_mode_cls_token": False, "pooling_mode_mean_tokens": False, "pooling_mode_max_tokens": True}))):
+        make_st_dir(str(tmp_path / name), layers=1, **kw)
+        r = subprocess.run([exe, str(tmp_path / name)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 3 and r.stdout.startswith("REFUSED"), (name, r.stdout + r.stderr)
+    make_st_dir(str(tmp_path / "bin"), layers=1, weights="bin")
+    r = subprocess.run([exe, str(tmp_path / "bin")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "safetensors" in r.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("hidden,heads,ffn,pooling", [(384, 12, 1536, "mean"), (768, 12, 3072, "cls")])
 def test_embedder_from_pretrained_dir_matches_the_oracle(tmp_path, lib_built, hidden, heads, ffn, pooling):
