@@ -113,8 +113,10 @@ def test_batch_composition_does_not_change_a_row(small, lib_built, monkeypatch):
         assert np.abs(many[::200] - full).max() <= 1e-3
 
 
-@pytest.mark.parametrize("layers,B,S,seed", [(6, 1, 16, 61), (12, 1, 128, 62), (6, 8, 32, 63), (3, 5, 77, 64), (2, 1, 1, 65)])
-def test_small_pass_matches_large_pass(layers, B, S, seed, lib_built, monkeypatch):
+@pytest.mark.parametrize("layers,B,S,seed,ffn", [(6, 1, 16, 61, 1536), (12, 1, 128, 62, 1536), (6, 8, 32, 63, 1536), (3, 5, 77, 64, 1536),
+                                                 (2, 1, 1, 65, 1536), (3, 2, 40, 66, 768), (3, 3, 33, 67, 384), (2, 1, 480, 68, 256),
+                                                 (2, 4, 120, 69, 1152)])
+def test_small_pass_matches_large_pass(layers, B, S, seed, ffn, lib_built, monkeypatch):
     """Query-time passes (<= 512 packed rows, hidden 384) run encoder_small.hip -- one wave per 32 projection features, the MLP
     split over its ffn chunks -- with the operands, MFMA shape and rounding points of the large-pass kernels; only the f32
     summation order of the MLP's chunk products differs.  Both against the f64 oracle within the 1e-3 bar, and against each
@@ -122,7 +124,7 @@ def test_small_pass_matches_large_pass(layers, B, S, seed, lib_built, monkeypatc
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, synthetic_weights
     from oracle import bert_oracle
-    cfg = EncoderConfig(layers=layers, hidden=384, heads=12, ffn=1536, vocab=3000)
+    cfg = EncoderConfig(layers=layers, hidden=384, heads=12, ffn=ffn, vocab=3000)   # (ffn / 128 chunks: 2 .. 12 positions in the weight stream)
     w = synthetic_weights(cfg, seed)
     rng = np.random.default_rng(seed)
     ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
