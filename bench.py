@@ -640,8 +640,9 @@ def side_leg(rows: int, dim: int, batch: int, k: int, steps: int, data: str):
     return out
 
 
-def sharded_one_device_leg(rows: int, dim: int, batch: int, k: int, steps: int, shards: int) -> float:
-    """ms per step of the in-library sharded index with `shards` logical shards, all on device 0 (a wiring + overhead probe)."""
+def sharded_one_device_leg(rows: int, dim: int, batch: int, k: int, steps: int, shards: int):
+    """(ms per step, ms of it in the serial tail: mx_index_stats.exchange_ms) of the in-library sharded index with `shards`
+    logical shards, all on device 0 (a wiring + overhead probe)."""
     import torch
     from memex_amd.index import FlatIndex
     idx = FlatIndex(dim, key=None, device=0, devices=[0] * shards)
@@ -653,11 +654,11 @@ def sharded_one_device_leg(rows: int, dim: int, batch: int, k: int, steps: int, 
 
     def step():
         idx.search_device(q, k, bufs.ids, bufs.scores, bufs.dists, bufs.nf)
-    dt, _ = timed_steps(idx, step, torch.cuda.synchronize, 3, steps, 1)
+    dt, st = timed_steps(idx, step, torch.cuda.synchronize, 3, steps, 1)
     idx.close()
     del idx, q, bufs
     torch.cuda.empty_cache()
-    return dt / steps * 1e3
+    return dt / steps * 1e3, st.exchange_ms / steps
 
 
 def run(a):
@@ -849,13 +850,17 @@ def run(a):
                 # plain shard steps is what a step of the 8-GPU job adds to one shard step -- with peer copies where the real
                 # job has ONE RCCL all-gather of 8 x 30 KB over xGMI (tens of us; unmeasured: no multi-GPU node yet)
                 try:
-                    t8 = sharded_one_device_leg(8 * 1_250_000, dm, a.batch, k, a.side_steps, 8)
-                    extra = max(0.0, t8 - 8.0 * leg["ms_per_step"])
+                    t8, tail = sharded_one_device_leg(8 * 1_250_000, dm, a.batch, k, a.side_steps, 8)
+                    # a shard's own share of a sharded step (its scan pipeline + the query copy in + its block copied out) and
+                    # the serial tail behind the last shard (mx_index_stats.exchange_ms: merge_kernel, n_found, synchronise)
+                    shard_local = max(leg["ms_per_step"], (t8 - tail) / 8.0)
                     leg["eight_logical_shards_ms_per_step"] = t8
-                    leg["exchange_and_merge_ms"] = extra
-                    leg["predicted_n8_qps"] = a.batch / (leg["ms_per_step"] + extra) * 1e3
-                    leg["note"] = ("predicted_n8_qps = batch / (one shard step + exchange + merge), the last two timed with 8 logical "
-                                   "shards on one device (peer copies instead of the RCCL all-gather); a prediction, not a measurement")
+                    leg["shard_local_ms"] = shard_local
+                    leg["serial_tail_ms"] = tail
+                    leg["exchange_and_merge_ms"] = shard_local - leg["ms_per_step"] + tail
+                    leg["predicted_n8_qps"] = a.batch / (shard_local + tail) * 1e3
+                    leg["note"] = ("predicted_n8_qps = batch / (one shard's share of a sharded step + the serial tail), both timed with 8 "
+                                   "logical shards on one device (peer copies instead of the RCCL all-gather); a prediction, not a measurement")
                 except Exception as e:  # noqa: BLE001 -- a side leg must not fail the bench
                     leg["exchange_and_merge_error"] = repr(e)[:300]
                 sides[nm] = leg

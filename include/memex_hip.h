@@ -209,6 +209,9 @@ typedef struct mx_index_stats {
     uint64_t exchange_fallbacks;/* sharded index: times the RCCL exchange failed at run time and peer copies took over  */
     uint64_t filter_centred;    /* 1 = the bf16 copy holds the rows minus their component along the corpus mean direction
                                    (a rebuilt copy of a corpus that sits in a cone: a several times tighter certificate)   */
+    double exchange_ms;         /* sharded index: host time from "every shard has answered" to "merged result complete" (the
+                                   all-gather or peer copies' tail, merge_kernel, n_found, one synchronise): the serial tail of
+                                   a step that the shards' own work does not hide                                           */
 } mx_index_stats;
 /* sizeof(mx_index_stats) of the library that is loaded: a shim compares it with its own at start-up (the struct grows
  * at the end from version to version; mx_version() names the release). */

@@ -55,7 +55,7 @@ class IndexStats(ctypes.Structure):
                 ("approx_err_bound", ctypes.c_double), ("filter_kind", ctypes.c_uint64),
                 ("filter_demotions", ctypes.c_uint64), ("filter_promotions", ctypes.c_uint64),
                 ("listed_rows", ctypes.c_uint64), ("exchange_fallbacks", ctypes.c_uint64),
-                ("filter_centred", ctypes.c_uint64)]
+                ("filter_centred", ctypes.c_uint64), ("exchange_ms", ctypes.c_double)]
 
 
 class EncoderCfg(ctypes.Structure):

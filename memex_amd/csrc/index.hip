@@ -1267,6 +1267,7 @@ int composite_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_i
         }
     mx_index *s0 = idx->shards[0];
     DeviceGuard dg(s0->device);
+    const auto t_tail = std::chrono::steady_clock::now();  // every shard has answered: what follows is the step's serial tail
     const bool copies_pending = idx->use_rccl;  // the shards left their blocks in place for the all-gather
     if (k > 0) {
         if (idx->use_rccl) {
@@ -1313,6 +1314,7 @@ int composite_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_i
     }
     MX_HIP(launch_fill_nfound(s0->stream, d_nfound, B, (int32_t)std::min<uint64_t>((uint64_t)k, idx->total)));
     MX_HIP(hipStreamSynchronize(s0->stream));
+    idx->stats.exchange_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tail).count();
     idx->stats.searches += 1;
     idx->stats.queries += (uint64_t)B;
     return MX_OK;
@@ -2095,6 +2097,7 @@ int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
             acc.filter_promotions += s1.filter_promotions;
             acc.listed_rows += s1.listed_rows;
             acc.filter_centred = std::max(acc.filter_centred, s1.filter_centred);
+            // (exchange_ms is counted on the composite)
         }
         *out = acc;
         return MX_OK;

@@ -114,7 +114,7 @@ def test_batch_composition_does_not_change_a_row(small, lib_built, monkeypatch):
 
 
 @pytest.mark.parametrize("layers,B,S,seed,ffn", [(6, 1, 16, 61, 1536), (12, 1, 128, 62, 1536), (6, 8, 32, 63, 1536), (3, 5, 77, 64, 1536),
-                                                 (2, 1, 1, 65, 1536), (3, 2, 40, 66, 768), (3, 3, 33, 67, 384), (2, 1, 480, 68, 256),
+                                                 (2, 1, 1, 65, 1536), (3, 2, 40, 66, 768), (3, 3, 33, 67, 384), (2, 1, 480, 68, 384),
                                                  (2, 4, 120, 69, 1152)])
 def test_small_pass_matches_large_pass(layers, B, S, seed, ffn, lib_built, monkeypatch):
     """Query-time passes (<= 512 packed rows, hidden 384) run encoder_small.hip -- one wave per 32 projection features, the MLP
@@ -124,7 +124,7 @@ def test_small_pass_matches_large_pass(layers, B, S, seed, ffn, lib_built, monke
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, synthetic_weights
     from oracle import bert_oracle
-    cfg = EncoderConfig(layers=layers, hidden=384, heads=12, ffn=ffn, vocab=3000)   # (ffn / 128 chunks: 2 .. 12 positions in the weight stream)
+    cfg = EncoderConfig(layers=layers, hidden=384, heads=12, ffn=ffn, vocab=3000)   # (ffn / 128 chunks: 3 .. 12 positions in the weight stream)
     w = synthetic_weights(cfg, seed)
     rng = np.random.default_rng(seed)
     ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
