@@ -115,3 +115,27 @@ def test_narrow_cone_1m_is_answered_without_the_exact_path(oracle, lib_built):
             np.testing.assert_array_equal(got[0][:24], oi)
             np.testing.assert_array_equal(bits(got[2][:24]), bits(od))
             np.testing.assert_array_equal(bits(got[1][:24]), bits(os_))
+
+
+def test_sharded_index_over_a_cone_corpus(oracle, lib_built):
+    """Every shard of the in-library sharded index judges (and demotes, and centres) its own copy: three logical shards over a
+    narrow-cone corpus still answer with the oracle's bits, and none of them needs the EXACT path after its demotion."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(8)
+    d, n_src, n = 384, 3000, 240_000
+    src = cone_rows(rng, n_src, d)
+    src /= np.linalg.norm(src, axis=1, keepdims=True)
+    X = (src[rng.integers(0, n_src, n)] + (0.1 / np.sqrt(d)) * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    Q = cone_rows(rng, 64, d)
+    oi, od, os_, onf = oracle.search(X, Q, 10)
+    with FlatIndex(d, devices=[0, 0, 0], block_rows=4096) as idx:
+        idx.add(X)
+        for _ in range(2):
+            ids, sc, di, nf = idx.search(Q, 10)
+            np.testing.assert_array_equal(ids, oi)
+            np.testing.assert_array_equal(bits(di), bits(od))
+            np.testing.assert_array_equal(bits(sc), bits(os_))
+        idx.reset_stats()
+        idx.search(Q, 10)
+        st = idx.stats()
+        assert st.fallback_queries == 0 and st.filter_centred == 1, (st.fallback_queries, st.filter_centred, st.filter_kind)

@@ -169,6 +169,32 @@ def test_many_exact_ties_are_ordered_in_the_finish_kernel(oracle, lib_built):
         assert st.fallback_queries == 0 and st.retry_queries == 0
 
 
+def test_full_candidate_list_plus_listed_rows_does_not_overrun(oracle, lib_built):
+    """finish_kernel appends the listed wide-norm rows to its survivors, and the key array behind them holds
+    exactly kCandCap = 16384 entries with the raw query right behind it.  16380 exact copies of a row (they all survive every
+    stage: not "too many", the list is just full) plus ten listed rows used to write past the array while other threads were
+    still reading the query.  Such a query now takes the retry / EXACT route: same bits as the oracle, and the fallback shows."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(29)
+    X = rng.standard_normal((60000, 128), dtype=np.float32)
+    X[20000:36380] = X[11]
+    for i in range(10):
+        X[100 + i] *= np.float32(1e-22 if i % 2 else 1e19)
+    Q = rng.standard_normal((3, 128), dtype=np.float32)
+    Q[0] = X[11]
+    oi, od, os_, onf = oracle.search(X, Q, 10)
+    with FlatIndex(128) as idx:
+        idx.add(X)
+        for kind in (None, "bf16"):
+            if kind is not None:
+                idx.set_filter_copy(kind)
+            ids, sc, di, nf = idx.search(Q, 10)
+            np.testing.assert_array_equal(ids, oi)
+            np.testing.assert_array_equal(bits(di), bits(od))
+            np.testing.assert_array_equal(bits(sc), bits(os_))
+        assert idx.stats().listed_rows == 10 and idx.stats().fallback_queries >= 1
+
+
 def _rows_with_cosine(rng, q, cosines):
     """Rows c with cos(q, c) = cosines[i] (up to f32 rounding): cos*q^ + sin*u, u random, u _|_ q."""
     qh = (q / np.linalg.norm(q)).astype(np.float64)
