@@ -541,6 +541,12 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
                 MX_HIP(hipMemsetAsync(static_cast<char *>(nam.p) + aused, 0, want * sizeof(float) - aused, idx->stream));
             } else {
                 (void)hipGetLastError();
+                if (idx->centred && idx->xh && idx->n) {
+                    // no room for the a_c array of a CENTRED copy: the fragments just copied hold c/|c| - a_c m and would be
+                    // read as c/|c| -- rewrite the copy as a plain one from the rows (rare: 4 bytes per row did not fit)
+                    const uint32_t t1c = (uint32_t)((idx->n + kTileRows - 1) / kTileRows);
+                    MX_HIP(launch_shadow(idx->stream, fx, fsc, idx->ds, 0, t1c, nh.p, idx->flags + 2));
+                }
             }
             if (!idx->xh && idx->n) {  // (re)enabled on a populated index
                 const uint32_t t1 = (uint32_t)((idx->n + kTileRows - 1) / kTileRows);
