@@ -35,6 +35,9 @@ def test_encoder_vs_transformers_golden(lib_built):
     (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000, precision="bf16x3"), 6, 256, 1),   # the split-operand mode
     (dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls", precision="bf16x3"), 3, 160, 4),
     (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000, normalize=False, precision="bf16x3"), 5, 512, 8),
+    (dict(layers=3, hidden=768, heads=12, ffn=3072, vocab=3000, max_pos=514, type_vocab=1, ln_eps=1e-5, pos_offset=2,
+          precision="bf16x3"), 4, 300, 9),                                           # RoBERTa-style tables in the split-operand mode
+    (dict(layers=2, hidden=384, heads=6, ffn=768, vocab=3000, pooling="cls", precision="bf16x3"), 7, 90, 10),   # head dim 64 at hidden 384
 ])
 def test_encoder_vs_oracle(kw, B, S, seed, lib_built):
     from memex_amd.encoder import Encoder
@@ -148,6 +151,27 @@ def test_small_pass_matches_large_pass(layers, B, S, seed, ffn, lib_built, monke
     print(f"small vs large pass L{layers} B={B} S={S}: 1 - cos = {d_small_large:.2e}; vs oracle "
           f"{(1.0 - _cos(outs[0].astype(np.float64), ref)).max():.2e} / {(1.0 - _cos(outs[1].astype(np.float64), ref)).max():.2e}")
     assert d_small_large <= 1e-4
+
+
+def test_host_call_paths_agree(lib_built):
+    """mx_encoder_encode has two transports: query-sized calls (<= 4096 ids in <= 64 sequences) go through one pinned mapped
+    page the kernels read and write in place, larger ones through copy commands; mx_encoder_encode_device takes device
+    pointers.  Same kernels behind all three: the same bits."""
+    import torch
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    cfg = EncoderConfig(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000)
+    w = synthetic_weights(cfg, 81)
+    rng = np.random.default_rng(81)
+    with Encoder(cfg, w) as enc:
+        for B, S in ((64, 64), (65, 63), (1, 4096 // 8), (3, 7)):
+            ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
+            lens = rng.integers(1, S + 1, size=B).astype(np.int32)
+            host = enc.encode(ids, lens)
+            d_out = torch.zeros((B, cfg.hidden), device="cuda")
+            enc.encode_device(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda(), d_out)
+            np.testing.assert_array_equal(host, d_out.cpu().numpy())
+            np.testing.assert_array_equal(host, enc.encode(ids, lens))
 
 
 def test_bad_arguments(lib_built):

@@ -173,3 +173,9 @@ def test_embedder_from_pretrained_dir_matches_the_oracle(tmp_path, lib_built, hi
     with pytest.raises(E.SetupError):
         make_st_dir(str(tmp_path / "dense"), layers=1, dense=True)
         E.SentenceEmbedder.from_pretrained_dir(str(tmp_path / "dense"))
+    # the same directory in the split-operand mode: f32-grade agreement with the oracle
+    th, emb = E.SentenceEmbedder.from_pretrained_dir(d, precision="bf16x3")
+    got3 = np.asarray([emb.encode_single(t).vector for t in texts], dtype=np.float64)
+    emb.shutdown()
+    cos3 = (got3 * ref).sum(1) / np.linalg.norm(got3, axis=1) / np.linalg.norm(ref, axis=1)
+    assert (1.0 - cos3).max() <= 1e-7, cos3
