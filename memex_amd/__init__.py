@@ -8,6 +8,7 @@ calls raise.  Layout:
 * ``index``     ``FlatIndex``: object wrapper over ``mx_index_*``
 * ``storage``   mirror of the reference's ``VectorStore`` / ``HnswStore`` / ``get_vector_storage``
 * ``weights``   encoder configs, HF-name weight packing, seeded synthetic weights
+* ``pretrained`` a local sentence-transformers directory -> config + tensors + vocab (what rust-bert downloads)
 * ``embedding`` mirror of the reference's ``SentenceEmbedder`` actor over ``mx_encoder_*``
 * ``sharded``   row-sharded multi-GPU index (one process per GPU, RCCL all-gather merge)
 """

@@ -9,7 +9,10 @@
 // Per call: sequences are packed back to back (no padding FLOPs), then
 //   embed+LN -> L x { QKV GEMM -> attention -> out-proj GEMM(+res+LN) -> FFN1 GEMM(+GELU)
 //                     -> FFN2 GEMM(+res+LN) } -> pool (+L2 normalise)
-// with bf16 activations/weights, f32 accumulation and f32 LayerNorm/softmax/GELU.
+// with bf16 activations/weights, f32 accumulation and f32 LayerNorm/softmax/GELU.  Three kernel sets serve that layer:
+// large passes (pgemm_kernel / the fused tail_kernel), passes of <= 512 rows of the hidden-384 models (encoder_small.hip:
+// query-time embedding, embedding.rs:146-151), and MX_PREC_BF16X3 (encoder_precise.hip: split bf16 operands, f32 hidden
+// state and attention) -- see include/memex_hip.h for what a caller can observe of the difference.
 #include <algorithm>
 #include <cstdlib>
 #include <cmath>
