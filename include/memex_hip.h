@@ -329,7 +329,7 @@ int mx_encoder_get_stats(mx_encoder *enc, mx_encoder_stats *out);
 int mx_encoder_reset_stats(mx_encoder *enc);
 
 /* =====================================================================================
- * WordPiece tokenizer + sliding-window segmenter (host code; replaces the `tokenizers` crate
+ * WordPiece / byte-level BPE tokenizer + sliding-window segmenter (host code; replaces the `tokenizers` crate
  * calls of segment_text, lib/libmemex/src/llm/embedding.rs:155-198, and the tokenisation rust-bert
  * performs inside model.encode, embedding.rs:109)
  * ===================================================================================== */
@@ -339,6 +339,12 @@ typedef struct mx_tokenizer mx_tokenizer;
  * the uncased MiniLM / bge models.  Replaces Tokenizer::from_pretrained (embedding.rs:163). */
 int mx_tokenizer_create(const char *vocab_path, int lowercase, mx_tokenizer **out);
 int mx_tokenizer_create_from_memory(const char *vocab, size_t nbytes, int lowercase, mx_tokenizer **out);
+/* Byte-level BPE: the tokenizer of all-distilroberta-v1, the third model segment_text accepts (embedding.rs:159): GPT-2
+ * pre-tokenizer regex, bytes -> printable code points, BPE over vocab.json + merges.txt (needs <s> </s> <pad>), <s> .. </s>
+ * as the special tokens, ByteLevel decoder.  Every call below works on either kind of handle. */
+int mx_tokenizer_create_bpe(const char *vocab_json_path, const char *merges_path, mx_tokenizer **out);
+int mx_tokenizer_create_bpe_from_memory(const char *vocab_json, size_t n_vocab, const char *merges, size_t n_merges,
+                                        mx_tokenizer **out);
 void mx_tokenizer_destroy(mx_tokenizer *tok);
 int mx_tokenizer_vocab_size(mx_tokenizer *tok, int *n);
 

@@ -260,7 +260,8 @@ class SafeTensors {
 struct PretrainedModel {
     mx_encoder_cfg cfg{};
     std::vector<float> weights;   // the blob mx_encoder_create takes (include/memex_hip.h)
-    std::string vocab_path;       // "" when the directory has no vocab.txt (not a WordPiece model)
+    std::string vocab_path;       // vocab.txt of a WordPiece model ("" otherwise): mx_tokenizer_create
+    std::string vocab_json_path, merges_path;  // byte-level BPE files of a RoBERTa-family model ("" otherwise): mx_tokenizer_create_bpe
     size_t max_seq_length = 0;    // sentence_bert_config.json
     bool do_lower_case = true;    // tokenizer_config.json (default: BERT uncased)
     std::vector<std::string> modules;  // module types of modules.json in order
@@ -332,6 +333,12 @@ inline PretrainedModel load_pretrained_dir(const std::string &dir, int precision
     for (const std::string &v : {dir + "/vocab.txt", tdir + "/vocab.txt"})
         if (file_exists(v)) {
             pm.vocab_path = v;
+            break;
+        }
+    for (const std::string &d2 : {dir, tdir})
+        if (file_exists(d2 + "/vocab.json") && file_exists(d2 + "/merges.txt")) {
+            pm.vocab_json_path = d2 + "/vocab.json";
+            pm.merges_path = d2 + "/merges.txt";
             break;
         }
     if (!file_exists(tdir + "/model.safetensors"))

@@ -32,7 +32,8 @@ EXPORTS = [
     "mx_encoder_weight_bytes", "mx_encoder_create", "mx_encoder_open", "mx_encoder_wait_stream", "mx_encoder_destroy", "mx_encoder_encode",
     "mx_encoder_encode_device", "mx_encoder_set_profiling", "mx_encoder_get_stats",
     "mx_encoder_reset_stats",
-    "mx_tokenizer_create", "mx_tokenizer_create_from_memory", "mx_tokenizer_destroy", "mx_tokenizer_vocab_size",
+    "mx_tokenizer_create", "mx_tokenizer_create_from_memory", "mx_tokenizer_create_bpe", "mx_tokenizer_create_bpe_from_memory",
+    "mx_tokenizer_destroy", "mx_tokenizer_vocab_size",
     "mx_tokenizer_encode", "mx_tokenizer_decode", "mx_tokenizer_segment", "mx_tokenizer_encode_batch",
 ]
 
@@ -133,6 +134,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "mx_encoder_reset_stats": [vp],
         "mx_tokenizer_create": [cp, i32, P(vp)],
         "mx_tokenizer_create_from_memory": [cp, ctypes.c_size_t, i32, P(vp)],
+        "mx_tokenizer_create_bpe": [cp, cp, P(vp)],
+        "mx_tokenizer_create_bpe_from_memory": [cp, ctypes.c_size_t, cp, ctypes.c_size_t, P(vp)],
         "mx_tokenizer_vocab_size": [vp, P(i32)],
         "mx_tokenizer_encode": [vp, cp, i32, vp, i32, P(i32)],
         "mx_tokenizer_decode": [vp, vp, i32, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)],

@@ -17,7 +17,8 @@ reference                  here
 Tokenisation stays on the host.  The reference downloads the pretrained ``tokenizer.json`` from the
 HF hub (embedding.rs:163); that is impossible offline, so the tokenizer is passed in: a path to a BERT
 ``vocab.txt`` selects the NATIVE WordPiece tokenizer / segmenter (``mx_tokenizer_*``,
-``csrc/tokenizer.cpp``, parity-tested against the ``tokenizers`` package), a ``tokenizer.json`` path or
+``csrc/tokenizer.cpp``, parity-tested against the ``tokenizers`` package), a pair ``(vocab.json, merges.txt)`` the native
+byte-level BPE tokenizer (all-distilroberta-v1), a ``tokenizer.json`` path or
 ``tokenizers.Tokenizer`` object is adapted, and with nothing given :class:`WhitespaceHashTokenizer` --
 a clearly labelled STAND-IN with the same windowing arithmetic -- keeps the plumbing runnable.
 """
@@ -147,6 +148,12 @@ class HFTokenizerAdapter:
 def _as_tokenizer(tokenizer, vocab: int):
     if tokenizer is None:
         return WhitespaceHashTokenizer(vocab)
+    if isinstance(tokenizer, (tuple, list)) and len(tokenizer) == 2:        # (vocab.json, merges.txt): native byte-level BPE
+        from .tokenizer import ByteLevelBpeTokenizer
+        try:
+            return ByteLevelBpeTokenizer(*tokenizer)
+        except Exception as e:
+            raise SetupError(f"Unable to load model <{tokenizer[0]}>") from e
     if isinstance(tokenizer, str) and tokenizer.endswith(".txt"):
         from .tokenizer import WordPieceTokenizer           # native WordPiece over a BERT vocab.txt
         try:
@@ -222,11 +229,12 @@ class SentenceEmbedder:
             cfg, tensors, vocab, info = load_pretrained_dir(path, precision)
         except (UnsupportedModel, OSError, KeyError, ValueError) as e:
             raise SetupError(f"Unable to load model <{path}>: {e}") from e
-        if vocab is None:
-            raise SetupError(f"Unable to load model <{path}>: no vocab.txt (WordPiece models only)")
-        from .tokenizer import WordPieceTokenizer
+        if vocab is None and info["bpe_files"] is None:
+            raise SetupError(f"Unable to load model <{path}>: neither vocab.txt (WordPiece) nor vocab.json + merges.txt (byte-level BPE)")
+        from .tokenizer import ByteLevelBpeTokenizer, WordPieceTokenizer
         try:
-            tok = WordPieceTokenizer(vocab, lowercase=info["do_lower_case"])
+            tok = (WordPieceTokenizer(vocab, lowercase=info["do_lower_case"]) if vocab is not None
+                   else ByteLevelBpeTokenizer(*info["bpe_files"]))
         except Exception as e:
             raise SetupError(f"Unable to load model <{path}>: {e}") from e
         return cls.spawn(model_config, weights=tensors, tokenizer=tok, device=device, encoder_config=cfg,

@@ -8,7 +8,8 @@ lib/libmemex/src/llm/embedding.rs:99-100; rust-bert 0.21.0) 
     sentence_bert_config.json         max_seq_length, do_lower_case
     1_Pooling/config.json             pooling mode
     model.safetensors | pytorch_model.bin | rust_model.ot      weights
-    vocab.txt (+ tokenizer_config.json)                        WordPiece vocabulary
+    vocab.txt (+ tokenizer_config.json)                        WordPiece vocabulary   (BERT family)
+    vocab.json + merges.txt                                    byte-level BPE         (RoBERTa family: all-distilroberta-v1)
 
 and builds the model from them.  :func:`load_pretrained_dir` reads the same files from a LOCAL directory (this build has no
 network: the day a checkpoint is reachable the path is pointed at its directory) into an :class:`EncoderConfig`, the tensor
@@ -60,7 +61,8 @@ def _load_state(path: str) -> Dict[str, np.ndarray]:
 def load_pretrained_dir(path: str, precision: str = "bf16") -> Tuple[EncoderConfig, Dict[str, np.ndarray], Optional[str], dict]:
     """-> (EncoderConfig, tensors by HF name, path of vocab.txt or None, info).
 
-    ``info``: ``do_lower_case``, ``model_type``, ``modules`` (the pipeline's module types in order)."""
+    ``info``: ``do_lower_case``, ``model_type``, ``modules`` (the pipeline's module types in order), ``bpe_files``
+    (``(vocab.json, merges.txt)`` of a byte-level BPE tokenizer, or None)."""
     if not os.path.isdir(path):
         raise FileNotFoundError(path)
     modules_path = os.path.join(path, "modules.json")
@@ -132,9 +134,13 @@ def load_pretrained_dir(path: str, precision: str = "bf16") -> Tuple[EncoderConf
         tensors[name] = a
 
     vocab = next((p for p in (os.path.join(path, "vocab.txt"), os.path.join(tdir, "vocab.txt")) if os.path.exists(p)), None)
+    # RoBERTa-family checkpoints (all-distilroberta-v1) ship a byte-level BPE tokenizer instead: vocab.json + merges.txt
+    bpe = next(((os.path.join(d_, "vocab.json"), os.path.join(d_, "merges.txt")) for d_ in (path, tdir)
+                if os.path.exists(os.path.join(d_, "vocab.json")) and os.path.exists(os.path.join(d_, "merges.txt"))), None)
     lower = sb.get("do_lower_case")
     tc_path = os.path.join(path, "tokenizer_config.json")
     if os.path.exists(tc_path):
         lower = _read_json(tc_path).get("do_lower_case", lower)
-    info = {"do_lower_case": True if lower is None else bool(lower), "model_type": mtype, "modules": module_types}
+    info = {"do_lower_case": True if lower is None else bool(lower), "model_type": mtype, "modules": module_types,
+            "bpe_files": bpe}
     return cfg, tensors, vocab, info

@@ -11,15 +11,11 @@ import numpy as np
 from ._lib import check, lib
 
 
-class WordPieceTokenizer:
-    def __init__(self, vocab, lowercase: bool = True):
-        """``vocab``: path to a BERT ``vocab.txt`` or a list of tokens (index = id)."""
-        h = ctypes.c_void_p()
-        if isinstance(vocab, str):
-            check(lib().mx_tokenizer_create(vocab.encode(), 1 if lowercase else 0, ctypes.byref(h)))
-        else:
-            blob = "\n".join(vocab).encode("utf-8")
-            check(lib().mx_tokenizer_create_from_memory(blob, len(blob), 1 if lowercase else 0, ctypes.byref(h)))
+class _NativeTokenizer:
+    """What both kinds of ``mx_tokenizer`` handle offer (the calls of segment_text and of rust-bert's tokenisation)."""
+    _h = None
+
+    def _finish(self, h) -> None:
         self._h = h
         n = ctypes.c_int(0)
         check(lib().mx_tokenizer_vocab_size(self._h, ctypes.byref(n)))
@@ -72,3 +68,24 @@ class WordPieceTokenizer:
         check(lib().mx_tokenizer_encode_batch(self._h, arr, B, max_seq_length, ids.ctypes.data_as(ctypes.c_void_p),
                                               max_seq_length, lens.ctypes.data_as(ctypes.c_void_p), ctypes.byref(S)))
         return np.ascontiguousarray(ids[:, : S.value]), lens
+
+
+class WordPieceTokenizer(_NativeTokenizer):
+    def __init__(self, vocab, lowercase: bool = True):
+        """``vocab``: path to a BERT ``vocab.txt`` or a list of tokens (index = id)."""
+        h = ctypes.c_void_p()
+        if isinstance(vocab, str):
+            check(lib().mx_tokenizer_create(vocab.encode(), 1 if lowercase else 0, ctypes.byref(h)))
+        else:
+            blob = "\n".join(vocab).encode("utf-8")
+            check(lib().mx_tokenizer_create_from_memory(blob, len(blob), 1 if lowercase else 0, ctypes.byref(h)))
+        self._finish(h)
+
+
+class ByteLevelBpeTokenizer(_NativeTokenizer):
+    """The RoBERTa-family tokenizer (all-distilroberta-v1, embedding.rs:29,159): ``vocab.json`` + ``merges.txt``."""
+
+    def __init__(self, vocab_json: str, merges: str):
+        h = ctypes.c_void_p()
+        check(lib().mx_tokenizer_create_bpe(vocab_json.encode(), merges.encode(), ctypes.byref(h)))
+        self._finish(h)

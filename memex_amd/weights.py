@@ -43,7 +43,8 @@ ALL_MINILM_L12_V2 = EncoderConfig(layers=12, hidden=384, heads=12, ffn=1536, max
 BGE_BASE_EN = EncoderConfig(layers=12, hidden=768, heads=12, ffn=3072, pooling="cls", max_seq_length=512)
 # all-distilroberta-v1 (embedding.rs:29): DistilRoBERTa = 6 RoBERTa layers.  Same encoder stack as
 # BERT; the embeddings differ: one token type, 514 positions used from row 2 on, LayerNorm eps 1e-5.
-# (Its byte-level BPE tokenizer is not covered: segment_text rejects the model too, embedding.rs:156-161.)
+# Its tokenizer is byte-level BPE (vocab.json + merges.txt): memex_amd.tokenizer.ByteLevelBpeTokenizer; segment_text accepts
+# the model (embedding.rs:159).
 ALL_DISTILROBERTA_V1 = EncoderConfig(layers=6, hidden=768, heads=12, ffn=3072, vocab=50265, max_pos=514, type_vocab=1,
                                      ln_eps=1e-5, max_seq_length=512, pos_offset=2)
 

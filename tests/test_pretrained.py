@@ -179,3 +179,88 @@ def test_embedder_from_pretrained_dir_matches_the_oracle(tmp_path, lib_built, hi
     emb.shutdown()
     cos3 = (got3 * ref).sum(1) / np.linalg.norm(got3, axis=1) / np.linalg.norm(ref, axis=1)
     assert (1.0 - cos3).max() <= 1e-7, cos3
+
+
+def make_roberta_dir(root, *, hidden=768, layers=2, heads=12, ffn=3072, max_seq_length=64, seed=0):
+    """A sentence-transformers directory of the RoBERTa family (all-distilroberta-v1's shape): RobertaModel weights,
+    a byte-level BPE tokenizer trained here (vocab.json + merges.txt), mean pooling + normalise."""
+    import torch
+    from tokenizers import ByteLevelBPETokenizer
+    from transformers import RobertaConfig, RobertaModel
+    from test_tokenizer_bpe import CORPUS, SPECIALS
+    os.makedirs(root, exist_ok=True)
+    tr = ByteLevelBPETokenizer()
+    tr.train_from_iterator(CORPUS, vocab_size=700, min_frequency=1, special_tokens=SPECIALS, show_progress=False)
+    tr.save_model(root)
+    vocab = json.load(open(os.path.join(root, "vocab.json"), encoding="utf-8"))
+    torch.manual_seed(seed)
+    hc = RobertaConfig(vocab_size=len(vocab), hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                       intermediate_size=ffn, max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5,
+                       pad_token_id=vocab["<pad>"], bos_token_id=vocab["<s>"], eos_token_id=vocab["</s>"])
+    model = RobertaModel(hc, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("LayerNorm.weight"):
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            elif n.endswith(".bias"):
+                p.copy_(0.05 * torch.randn_like(p))
+            elif "embeddings" in n:
+                p.copy_(0.05 * torch.randn_like(p))
+            else:
+                p.copy_(torch.randn_like(p) / p.shape[1] ** 0.5)
+    model.save_pretrained(root, safe_serialization=True)
+    json.dump([{"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+               {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"},
+               {"idx": 2, "name": "2", "path": "2_Normalize", "type": "sentence_transformers.models.Normalize"}],
+              open(os.path.join(root, "modules.json"), "w"))
+    json.dump({"max_seq_length": max_seq_length, "do_lower_case": False}, open(os.path.join(root, "sentence_bert_config.json"), "w"))
+    os.makedirs(os.path.join(root, "1_Pooling"), exist_ok=True)
+    json.dump({"word_embedding_dimension": hidden, "pooling_mode_cls_token": False, "pooling_mode_mean_tokens": True,
+               "pooling_mode_max_tokens": False, "pooling_mode_mean_sqrt_len_tokens": False},
+              open(os.path.join(root, "1_Pooling", "config.json"), "w"))
+    return model, vocab
+
+
+def test_roberta_directory_is_recognised(tmp_path):
+    from memex_amd.pretrained import load_pretrained_dir
+    d = str(tmp_path / "rb")
+    model, vocab = make_roberta_dir(d, layers=1)
+    cfg, tensors, vpath, info = load_pretrained_dir(d)
+    assert (cfg.hidden, cfg.max_pos, cfg.type_vocab, cfg.pos_offset, cfg.pooling, cfg.normalize) == (768, 514, 1, 2, "mean", True)
+    assert abs(cfg.ln_eps - 1e-5) < 1e-12 and vpath is None and info["model_type"] == "roberta"
+    assert info["bpe_files"] == (os.path.join(d, "vocab.json"), os.path.join(d, "merges.txt"))
+    np.testing.assert_array_equal(tensors["embeddings.position_embeddings.weight"], model.state_dict()["embeddings.position_embeddings.weight"].numpy())
+
+
+@pytest.mark.gpu
+def test_roberta_embedder_from_pretrained_dir_matches_the_oracle(tmp_path, lib_built):
+    """The third model segment_text accepts (all-distilroberta-v1's shape): RoBERTa-style embeddings (pos_offset 2) + the native
+    byte-level BPE tokenizer, end to end from the directory; the oracle gets the same tensors and the ids `tokenizers` produces."""
+    from tokenizers import ByteLevelBPETokenizer
+    from tokenizers.processors import RobertaProcessing
+    from memex_amd import embedding as E
+    from memex_amd.pretrained import load_pretrained_dir
+    from oracle import bert_oracle
+    d = str(tmp_path / "rb")
+    make_roberta_dir(d, layers=3, max_seq_length=48, seed=6)
+    texts = ["What does Biden say about taxes?", "Café résumé naïve Zürich ÜBER -- 🙂!", "don't re-embed; they've said: \"we'll do it\".",
+             "the tax " * 80]
+    th, emb = E.SentenceEmbedder.from_pretrained_dir(d, E.ModelConfig(model=E.EmbeddingsModelType.AllDistilrobertaV1))
+    got = np.asarray([emb.encode_single(t).vector for t in texts], dtype=np.float64)
+    segs = emb.encode("the tax state union " * 150)
+    emb.shutdown()
+    cfg, tensors, _, info = load_pretrained_dir(d)
+    hf = ByteLevelBPETokenizer(*info["bpe_files"])
+    hf._tokenizer.post_processor = RobertaProcessing(("</s>", hf.token_to_id("</s>")), ("<s>", hf.token_to_id("<s>")))
+    hf.enable_truncation(max_length=cfg.max_seq_length)
+    encs = [hf.encode(t) for t in texts]
+    S = max(len(e.ids) for e in encs)
+    ids = np.full((len(texts), S), hf.token_to_id("<pad>"), dtype=np.int32)
+    lens = np.asarray([len(e.ids) for e in encs], dtype=np.int32)
+    for i, e in enumerate(encs):
+        ids[i, :len(e.ids)] = e.ids
+    assert lens.max() == 48
+    ref = bert_oracle.encode(tensors, cfg.as_dict(), ids, lens)
+    cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
+    assert (1.0 - cos).max() <= 1e-3, cos
+    assert len(segs) >= 2 and all(len(s.vector) == 768 for s in segs)
