@@ -10,6 +10,7 @@ calls raise.  Layout:
 * ``weights``   encoder configs, HF-name weight packing, seeded synthetic weights
 * ``pretrained`` a local sentence-transformers directory -> config + tensors + vocab (what rust-bert downloads)
 * ``embedding`` mirror of the reference's ``SentenceEmbedder`` actor over ``mx_encoder_*``
+* ``tasks``     the two callers of the path (worker ingest, API search) with the reference's segment ids
 * ``sharded``   row-sharded multi-GPU index (one process per GPU, RCCL all-gather merge)
 """
 from ._lib import MemexHipError, build, device_count, lib  # noqa: F401

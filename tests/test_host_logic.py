@@ -93,3 +93,62 @@ def test_resident_registry_is_keyed_by_device_set(tmp_path):
     b = storage.HipFlatStore(storage_path=str(tmp_path), device=0, devices=[0, 1])
     c = storage.HipFlatStore(storage_path=str(tmp_path), device=0, devices=[0, 1])
     assert a._rkey() != b._rkey() and b._rkey() == c._rkey()
+
+
+def test_reference_segment_ids():
+    """The worker names a segment v5(NAMESPACE, "{doc_uuid}-{idx}") with doc_uuid = v5(NAMESPACE, task_id)
+    (tasks.rs:36-40, db/document.rs:73-74, lib.rs:6).  RFC 4122 v5 is SHA-1 based: checked here against an independent
+    hashlib computation, so the ids do not depend on the uuid module's own implementation."""
+    import hashlib
+    import uuid
+    from memex_amd import tasks as T
+    ns = uuid.UUID("5fdfe40a-de2c-11ed-bfa7-00155deae876")
+    assert T.NAMESPACE == ns
+
+    def v5(name: str) -> str:
+        h = bytearray(hashlib.sha1(ns.bytes + name.encode()).digest()[:16])
+        h[6] = (h[6] & 0x0F) | 0x50
+        h[8] = (h[8] & 0x3F) | 0x80
+        return str(uuid.UUID(bytes=bytes(h)))
+
+    for task_id in (1, 42, 10 ** 12):
+        doc = T.document_uuid(task_id)
+        assert doc == v5(str(task_id))
+        for idx in (0, 1, 54):
+            assert T.segment_uuid(doc, idx) == v5(f"{doc}-{idx}")
+    assert T.document_uuid(1) != T.document_uuid(2) and len(T.document_uuid(1)) == 36
+
+
+def test_process_embeddings_and_search_docs_call_sequence():
+    """tasks.rs:9-66 / handlers.rs:72-85 without the SQL: what reaches add_vectors / search, with stand-in client and embedder."""
+    from memex_amd import tasks as T
+    from memex_amd.embedding import EmbeddingResult
+
+    class Emb:
+        def encode(self, text):
+            return [EmbeddingResult(content=f"w{i}", vector=[float(i), 1.0]) for i in range(3)]
+
+        def encode_single(self, text):
+            return None if not text else EmbeddingResult(content=text, vector=[1.0, 0.0])
+
+    class Client:
+        def __init__(self):
+            self.added, self.queries = [], []
+
+        def add_vectors(self, pts):
+            self.added += list(pts)
+
+        def search(self, vec, limit):
+            self.queries.append((list(vec), limit))
+            return [(p._id, 0.5) for p in self.added[:limit]]
+
+    c = Client()
+    out = T.process_embeddings(c, Emb(), 7, "some document")
+    doc = T.document_uuid(7)
+    assert [v._id for v in c.added] == [T.segment_uuid(doc, i) for i in range(3)] and out == c.added
+    assert all(v.document_id == doc and v.segment_id == i and v.text == f"w{i}" for i, v in enumerate(c.added))
+    assert T.search_docs(c, Emb(), "what about taxes?", 2) == [(c.added[0]._id, 0.5), (c.added[1]._id, 0.5)]
+    assert c.queries == [([1.0, 0.0], 2)]
+    import pytest
+    with pytest.raises(ValueError):
+        T.search_docs(c, Emb(), "")

@@ -78,7 +78,15 @@ def test_cfg1_ingest_and_query_with_the_native_tokenizer(tmp_path, oracle, lib_b
     th, emb = E.SentenceEmbedder.spawn(mc, weights=w, tokenizer=vocab_path, encoder_config=cfg)
     segs = emb.encode(doc)                                             # tasks.rs:19
     qres = emb.encode_single(query)                                    # handlers.rs:72
+    # the two callers themselves (memex_amd/tasks.py = tasks.rs:9-66 / handlers.rs:72-85 without the SQL): worker handle
+    # ingests task 1, API handle searches; ids are the reference's v5 uuids
+    from memex_amd import tasks as T
+    uri2 = f"hnsw://{tmp_path / 'store2'}"
+    written = T.process_embeddings(get_vector_storage(uri2, "test"), emb, 1, doc)
+    hits = T.search_docs(get_vector_storage(uri2, "test"), emb, query, 3)
     emb.shutdown()
+    assert [v._id for v in written] == [T.segment_uuid(T.document_uuid(1), i) for i in range(len(segs))]
+    assert [v.text for v in written] == [s_.content for s_ in segs]
 
     # ---- CPU path, tokenisation: the `tokenizers` package with the reference's call sequence
     hf = E.HFTokenizerAdapter(BertWordPieceTokenizer(vocab_path, lowercase=True)._tokenizer)
@@ -108,7 +116,10 @@ def test_cfg1_ingest_and_query_with_the_native_tokenizer(tmp_path, oracle, lib_b
     oi, _, os_, _ = oracle.search(vecs, q, 3)                          # identical f32 vectors -> bit-exact
     assert [g[0] for g in got] == [f"seg-{int(i) - 1}" for i in oi[0]]
     np.testing.assert_array_equal(np.float32([g[1] for g in got]), os_[0])
+    assert [h[0] for h in hits] == [written[int(i) - 1]._id for i in oi[0]]       # the callers' route: same neighbours, by uuid
+    np.testing.assert_array_equal(np.float32([h[1] for h in hits]), os_[0])
     _, _, cpu_scores, _ = oracle.search(ref, qref, 3)                  # the all-CPU pipeline
     assert np.abs(np.float32([g[1] for g in got]) - cpu_scores[0]).max() <= TOL
     get_vector_storage(uri, "test").delete_collection()
+    get_vector_storage(uri2, "test").delete_collection()
     evict_resident()
