@@ -172,11 +172,6 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
         for (int g = 0; g < QG * 2; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][r] = 0;
-#ifdef MX_SCAN8_SHAPE_PROBE
-        i32x4 pacc[QG * 4];
-#pragma unroll
-        for (int g = 0; g < QG * 4; ++g) pacc[g] = i32x4{0, 0, 0, 0};
-#endif
 
         static_for<0, KC>([&](auto kct) __attribute__((always_inline)) {
             constexpr int kc = decltype(kct)::value;
@@ -190,14 +185,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
 #pragma unroll
                 for (int f = 0; f < 8; ++f) {
 #pragma unroll
-                    for (int g = 0; g < QG; ++g) {
-#ifdef MX_SCAN8_SHAPE_PROBE  /* scripts/scan8_ubench.hip: the same operand traffic on v_mfma_i32_16x16x64_i8 (two per 32x32x32; values meaningless) */
-                        pacc[(g * 2 + (f & 1)) * 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[f % R], qf[g * KC * 4 + kc * 4 + (f >> 1)], pacc[(g * 2 + (f & 1)) * 2], 0, 0, 0);
-                        pacc[(g * 2 + (f & 1)) * 2 + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[f % R], qf[g * KC * 4 + kc * 4 + (f >> 1)], pacc[(g * 2 + (f & 1)) * 2 + 1], 0, 0, 0);
-#else
+                    for (int g = 0; g < QG; ++g)
                         acc[g * 2 + (f & 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[g * KC * 4 + kc * 4 + (f >> 1)], acc[g * 2 + (f & 1)], 0, 0, 0);
-#endif
-                    }
                     a[f % R] = *reinterpret_cast<const i32x4 *>(smem + (f + R < 8 ? fb0 : fb1) + ((f + R) & 7) * 1024);
                     if (f == 1) issue((kc + kRing16 - 1) % KC, rpi);
                     __builtin_amdgcn_sched_barrier(0);
@@ -209,12 +198,6 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
         });
 
         if (!live) continue;
-#ifdef MX_SCAN8_SHAPE_PROBE
-#pragma unroll
-        for (int g = 0; g < QG * 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[g][r] = pacc[2 * g][r], acc[g][4 + r] = pacc[2 * g + 1][r];
-#endif
         // ---- tile epilogue, per half: lane holds query (vw*32 + m), rows (r&3) + 8*(r>>2) + 4*(lane>>5) of the half
         // (read with inline asm: hipcc puts s_waitcnt vmcnt(0) in front of a plain LDS load that it thinks an LDS-DMA
         // may have written, which would drain the ring once per tile; the scales landed with the tile's first slot)
