@@ -20,7 +20,8 @@
 #include <cmath>
 
 // Ablation switch for scripts/gemm_ubench.hip only (0 = production kernels); bits for gemm_kernel:
-//   1 = no DMA inside the k loop (the ring keeps the prologue's tiles), 2 = no epilogue (accumulators kept alive)
+//   1 = no DMA inside the k loop (the ring keeps the prologue's tiles), 2 = no epilogue (accumulators kept alive),
+//   4 = MFMA shape probe (16x16x32 on the same operand traffic; outputs meaningless)
 #ifndef MX_GEMM_ABLATE
 #define MX_GEMM_ABLATE 0
 #endif
@@ -170,6 +171,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
         __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt landed; stage (kt-1)%S is free
         if (!(MX_GEMM_ABLATE & 1) && kt + S - 1 < nk) issue_tile(kt + S - 1);
         const char *st = smem + (kt % S) * G::STAGE;
+#if (MX_GEMM_ABLATE & 4)  /* scripts/gemm_ubench.hip: the k-tile's operand traffic on v_mfma_f32_16x16x32_bf16 (4 per pair of 32x32x16; values meaningless) */
+        {
+            bf16x8 af2[2][MI], bf2[2][3];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t sw = ks == 0 ? sw0 : sw1;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af2[ks][i] = *reinterpret_cast<const bf16x8 *>(st + a_row + i * 32 * (BK * 2) + sw);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) bf2[ks][j] = *reinterpret_cast<const bf16x8 *>(st + w_row + j * 32 * (BK * 2) + sw);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        f32x4 t = {acc[i][j][4 * c], acc[i][j][4 * c + 1], acc[i][j][4 * c + 2], acc[i][j][4 * c + 3]};
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf2[c & 1][j], af2[c >> 1][i], t, 0, 0, 0);
+                        acc[i][j][4 * c] = t[0], acc[i][j][4 * c + 1] = t[1], acc[i][j][4 * c + 2] = t[2], acc[i][j][4 * c + 3] = t[3];
+                    }
+        }
+        if (false)
+#endif
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const uint32_t sw = ks == 0 ? sw0 : sw1;
