@@ -359,6 +359,15 @@ int mx_tokenizer_decode(mx_tokenizer *tok, const int32_t *ids, int n, int skip_s
  * out receives the segments as consecutive NUL-terminated strings; *nbytes = total bytes. */
 int mx_tokenizer_segment(mx_tokenizer *tok, const char *text, int max_length, int stride, char *out, size_t cap,
                          size_t *nbytes, int *n_segments);
+/* segment_text for a batch of documents (what the ingest worker's queue holds: tasks.rs:17-19, up to five tasks at a time,
+ * worker/lib.rs:36): the documents are dealt to host threads.  out: the windows of text 0, then of text 1, ..., each
+ * NUL-terminated; n_segments[i] = windows of text i.  *nbytes is always the size needed; out is filled only when cap covers
+ * it (call again with a larger buffer otherwise). */
+int mx_tokenizer_segment_batch(mx_tokenizer *tok, const char *const *texts, int n_texts, int max_length, int stride,
+                               char *out, size_t cap, size_t *nbytes, int32_t *n_segments);
+/* Test hook: the WordPiece encoder stage by stage (normalize -> pre-tokenize -> WordPiece, as embedding.rs:181's encode is
+ * usually described) -- mx_tokenizer_encode runs the same steps in one pass; tests hold the two against each other. */
+int mx_tokenizer_encode_staged(mx_tokenizer *tok, const char *text, int32_t *ids, int cap, int *n);
 /* Batch for mx_encoder_encode: [CLS] .. [SEP], truncated to max_seq_length, padded with [PAD] to
  * row pitch s_cap; lens[b] = tokens incl. specials; *S = longest row (<= s_cap or MX_EINVAL). */
 int mx_tokenizer_encode_batch(mx_tokenizer *tok, const char *const *texts, int B, int max_seq_length, int32_t *ids,

@@ -35,6 +35,7 @@ EXPORTS = [
     "mx_tokenizer_create", "mx_tokenizer_create_from_memory", "mx_tokenizer_create_bpe", "mx_tokenizer_create_bpe_from_memory",
     "mx_tokenizer_destroy", "mx_tokenizer_vocab_size",
     "mx_tokenizer_encode", "mx_tokenizer_decode", "mx_tokenizer_segment", "mx_tokenizer_encode_batch",
+    "mx_tokenizer_segment_batch", "mx_tokenizer_encode_staged",
 ]
 
 
@@ -141,6 +142,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "mx_tokenizer_decode": [vp, vp, i32, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)],
         "mx_tokenizer_segment": [vp, cp, i32, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t), P(i32)],
         "mx_tokenizer_encode_batch": [vp, P(cp), i32, i32, vp, i32, vp, P(i32)],
+        "mx_tokenizer_segment_batch": [vp, P(cp), i32, i32, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t), vp],
+        "mx_tokenizer_encode_staged": [vp, cp, vp, i32, P(i32)],
     }
     for name, argtypes in sig.items():
         fn = getattr(L, name)

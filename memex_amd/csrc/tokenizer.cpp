@@ -23,6 +23,7 @@
 // decoder with Rust's lossy UTF-8 (a window of segment_text may cut a character in two).  tests/test_tokenizer_bpe.py checks
 // ids, decoded text and windows against `tokenizers.ByteLevelBPETokenizer` on a vocabulary trained offline, fuzz included.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -35,11 +36,61 @@
 
 using namespace mx;
 
+// Vocabulary lookup of the WordPiece loop: open addressing over polynomial hashes, so that the hash of every candidate
+// substring word[s, e) is two multiplications away from the word's prefix hashes (the greedy longest-match loop tries them
+// from the longest down) and no candidate is copied.  Keys live in one arena; the first id wins for duplicate strings,
+// as with the map this replaces.
+struct PieceTable {
+    struct Slot { uint64_t h; uint32_t off; uint32_t len; int32_t id; };
+    std::vector<Slot> slots;
+    std::string arena;
+    uint64_t mask = 0;
+    size_t max_len = 0;  // longest key in bytes: longer candidates cannot match
+    static constexpr uint64_t kBase = 0x100000001b3ull * 31 + 2;  // odd
+    static uint64_t hash_bytes(const char *p, size_t n) {
+        uint64_t h = 0;
+        for (size_t i = 0; i < n; ++i) h = h * kBase + (uint64_t)(unsigned char)p[i] + 1;
+        return h;
+    }
+    static size_t spread(uint64_t h) { return (size_t)((h ^ (h >> 29)) * 0x9e3779b97f4a7c15ull >> 20); }
+    void build(const std::vector<std::pair<std::string, int32_t>> &keys) {
+        size_t cap = 64;
+        while (cap < keys.size() * 2 + 2) cap <<= 1;
+        slots.assign(cap, Slot{0, 0, 0, -1});
+        mask = cap - 1;
+        for (const auto &kv : keys) {
+            const uint64_t h = hash_bytes(kv.first.data(), kv.first.size());
+            size_t i = spread(h) & mask;
+            bool dup = false;
+            while (slots[i].id >= 0) {
+                if (slots[i].h == h && slots[i].len == kv.first.size() && memcmp(arena.data() + slots[i].off, kv.first.data(), kv.first.size()) == 0) { dup = true; break; }
+                i = (i + 1) & mask;
+            }
+            if (dup) continue;
+            slots[i] = Slot{h, (uint32_t)arena.size(), (uint32_t)kv.first.size(), kv.second};
+            arena += kv.first;
+            max_len = std::max(max_len, kv.first.size());
+        }
+    }
+    int32_t find(uint64_t h, const char *p, size_t n) const {
+        for (size_t i = spread(h) & mask;; i = (i + 1) & mask) {
+            const Slot &sl = slots[i];
+            if (sl.id < 0) return -1;
+            if (sl.h == h && sl.len == n && memcmp(arena.data() + sl.off, p, n) == 0) return sl.id;
+        }
+    }
+};
+
 struct mx_tokenizer {
     std::vector<std::string> vocab;
     std::unordered_map<std::string, int32_t> index;
     bool lowercase = true;
     int32_t pad = 0, unk = 100, cls = 101, sep = 102, mask = 103;
+    // WordPiece fast path: every token by its full string (a word's first piece) / the "##x" tokens by x (continuations);
+    // the decoder's per-token strings, cleaned up once: [2 id] = as the first token of a text, [2 id + 1] = as a later one
+    PieceTable full, cont;
+    std::vector<uint32_t> dec_off;
+    std::string dec_arena;
     // byte-level BPE (kind 1): merge ranks by "left right", the byte <-> code point tables of the ByteLevel stage
     int kind = 0;
     std::unordered_map<std::string, int32_t> merges;
@@ -50,26 +101,29 @@ struct mx_tokenizer {
 namespace {
 
 // ---- UTF-8 ---------------------------------------------------------------------------------------
+// one code point from a NUL-terminated string (0xfffd for a malformed sequence: an invalid lead byte is consumed alone, a
+// sequence cut short ends in front of the byte that does not continue it)
+inline uint32_t next_cp(const unsigned char *&p) {
+    uint32_t c = *p;
+    int n = 0;
+    if (c < 0x80) n = 0;
+    else if ((c >> 5) == 0x6) { c &= 0x1f; n = 1; }
+    else if ((c >> 4) == 0xe) { c &= 0x0f; n = 2; }
+    else if ((c >> 3) == 0x1e) { c &= 0x07; n = 3; }
+    else { ++p; return 0xfffd; }
+    ++p;
+    for (int i = 0; i < n; ++i) {
+        if ((*p & 0xc0) != 0x80) return 0xfffd;
+        c = (c << 6) | (*p & 0x3f);
+        ++p;
+    }
+    return c;
+}
+
 std::vector<uint32_t> decode_utf8(const char *s) {
     std::vector<uint32_t> out;
     const unsigned char *p = reinterpret_cast<const unsigned char *>(s);
-    while (*p) {
-        uint32_t c = *p;
-        int n = 0;
-        if (c < 0x80) n = 0;
-        else if ((c >> 5) == 0x6) { c &= 0x1f; n = 1; }
-        else if ((c >> 4) == 0xe) { c &= 0x0f; n = 2; }
-        else if ((c >> 3) == 0x1e) { c &= 0x07; n = 3; }
-        else { out.push_back(0xfffd); ++p; continue; }
-        ++p;
-        bool ok = true;
-        for (int i = 0; i < n; ++i) {
-            if ((*p & 0xc0) != 0x80) { ok = false; break; }
-            c = (c << 6) | (*p & 0x3f);
-            ++p;
-        }
-        out.push_back(ok ? c : 0xfffd);
-    }
+    while (*p) out.push_back(next_cp(p));
     return out;
 }
 
@@ -200,8 +254,119 @@ void wordpiece(const mx_tokenizer *t, const std::string &word, std::vector<int32
 std::vector<int32_t> bpe_encode_plain(const mx_tokenizer *t, const char *text);
 std::string bpe_decode_ids(const mx_tokenizer *t, const int32_t *ids, int n, bool skip_special);
 
+// ---- the WordPiece path as it runs: one pass over the bytes, no per-word or per-candidate allocation -------------------------
+// (normalize / pre_tokenize / wordpiece above are the same steps spelled out stage by stage: mx_tokenizer_encode_staged;
+// tests/test_tokenizer.py holds the two against each other and this one against the `tokenizers` package)
+struct PowTable {
+    uint64_t p[401];
+    PowTable() {
+        p[0] = 1;
+        for (int i = 1; i <= 400; ++i) p[i] = p[i - 1] * PieceTable::kBase;
+    }
+};
+const PowTable kPow;
+
+// one pre-tokenised word (<= 100 code points, else [UNK]) -> its pieces, greedy longest match first
+void wordpiece_fast(const mx_tokenizer *t, const char *w, size_t wn, std::vector<int32_t> &ids) {
+    uint16_t cpb[102];  // byte offsets of the code-point boundaries
+    size_t n = 0;
+    for (size_t i = 0; i < wn; ++i)
+        if ((w[i] & 0xc0) != 0x80) {
+            if (n == 100) { ids.push_back(t->unk); return; }  // max_input_chars_per_word
+            cpb[n++] = (uint16_t)i;
+        }
+    cpb[n] = (uint16_t)wn;
+    uint64_t H[401];  // prefix hashes: hash(w[a, b)) = H[b] - H[a] * base^(b - a)
+    H[0] = 0;
+    for (size_t i = 0; i < wn; ++i) H[i + 1] = H[i] * PieceTable::kBase + (uint64_t)(unsigned char)w[i] + 1;
+    const size_t start = ids.size();
+    size_t s = 0;
+    while (s < n) {
+        const PieceTable &tb = s ? t->cont : t->full;
+        int32_t found = -1;
+        size_t e = n;
+        for (; e > s; --e) {
+            const size_t len = (size_t)cpb[e] - cpb[s];
+            if (len > tb.max_len) continue;
+            found = tb.find(H[cpb[e]] - H[cpb[s]] * kPow.p[len], w + cpb[s], len);
+            if (found >= 0) break;
+        }
+        if (found < 0) {  // any failing piece -> the whole word is [UNK]
+            ids.resize(start);
+            ids.push_back(t->unk);
+            return;
+        }
+        ids.push_back(found);
+        s = e;
+    }
+}
+
+void encode_wordpiece(const mx_tokenizer *t, const char *text, std::vector<int32_t> &ids) {
+    std::string cur;
+    cur.reserve(64);
+    std::vector<uint32_t> folded;
+    auto flush = [&] {
+        if (!cur.empty()) {
+            wordpiece_fast(t, cur.data(), cur.size(), ids);
+            cur.clear();
+        }
+    };
+    auto emit = [&](uint32_t c) {  // a normalised code point through the pre-tokenizer
+        if (c == ' ' || is_whitespace(c)) {
+            flush();
+        } else if (is_punct(c)) {
+            flush();
+            append_utf8(cur, c);
+            flush();
+        } else {
+            append_utf8(cur, c);
+        }
+    };
+    const bool lower = t->lowercase;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(text);
+    while (*p) {
+        if (*p < 0x80) {  // ASCII: clean_text, lower-casing and the pre-tokenizer's classes inline
+            const unsigned char c = *p++;
+            if (c == ' ' || c == '\t' || c == '\n' || c == '\r') { flush(); continue; }
+            if (c < 0x20 || c == 0x7f) continue;
+            if ((c >= 33 && c <= 47) || (c >= 58 && c <= 64) || (c >= 91 && c <= 96) || (c >= 123 && c <= 126)) {
+                flush();
+                const char b = (char)c;
+                wordpiece_fast(t, &b, 1, ids);
+                continue;
+            }
+            cur.push_back((char)((lower && c >= 'A' && c <= 'Z') ? c + 32 : c));
+            continue;
+        }
+        const uint32_t c = next_cp(p);
+        if (c == 0xfffd || is_dropped(c)) continue;
+        if (is_whitespace(c)) { flush(); continue; }
+        if (is_cjk(c)) {
+            flush();
+            emit(c);
+            flush();
+            continue;
+        }
+        if (lower) {
+            folded.clear();
+            fold_append(folded, c);
+            for (uint32_t x : folded) emit(x);
+        } else {
+            emit(c);
+        }
+    }
+    flush();
+}
+
 std::vector<int32_t> encode_plain(const mx_tokenizer *t, const char *text) {
     if (t->kind == 1) return bpe_encode_plain(t, text);
+    std::vector<int32_t> ids;
+    encode_wordpiece(t, text, ids);
+    return ids;
+}
+
+// the stage-by-stage form (tests only: mx_tokenizer_encode_staged)
+std::vector<int32_t> encode_staged(const mx_tokenizer *t, const char *text) {
     std::vector<int32_t> ids;
     for (const std::string &w : pre_tokenize(normalize(t, text))) wordpiece(t, w, ids);
     return ids;
@@ -220,27 +385,37 @@ void replace_all(std::string &s, const std::string &a, const std::string &b) {
 }
 
 // WordPiece decoder (prefix "##", cleanup = true), as tokenizers::decoders::wordpiece
-std::string decode_ids(const mx_tokenizer *t, const int32_t *ids, int n, bool skip_special) {
-    if (t->kind == 1) return bpe_decode_ids(t, ids, n, skip_special);
-    std::string out;
+// what token `id` contributes to a decoded text as its first token / as a later one
+std::string decoded_token(const mx_tokenizer *t, int32_t id, bool first) {
+    std::string tok = t->vocab[id];
+    if (!first) {
+        if (tok.rfind("##", 0) == 0) tok = tok.substr(2);
+        else tok = " " + tok;
+    }
+    // clean-up runs per token in tokenizers 0.14 (decoders::wordpiece::cleanup)
+    replace_all(tok, " .", "."); replace_all(tok, " ?", "?"); replace_all(tok, " !", "!"); replace_all(tok, " ,", ",");
+    replace_all(tok, " ' ", "'"); replace_all(tok, " n't", "n't"); replace_all(tok, " 'm", "'m");
+    replace_all(tok, " do not", " don't"); replace_all(tok, " 's", "'s"); replace_all(tok, " 've", "'ve");
+    replace_all(tok, " 're", "'re");
+    return tok;
+}
+
+void decode_append(const mx_tokenizer *t, const int32_t *ids, int n, bool skip_special, std::string &out) {
     bool first = true;
     for (int i = 0; i < n; ++i) {
         const int32_t id = ids[i];
         if (id < 0 || id >= (int32_t)t->vocab.size()) continue;
         if (skip_special && is_special(t, id)) continue;
-        std::string tok = t->vocab[id];
-        if (!first) {
-            if (tok.rfind("##", 0) == 0) tok = tok.substr(2);
-            else tok = " " + tok;
-        }
-        // clean-up runs per token in tokenizers 0.14 (decoders::wordpiece::cleanup)
-        replace_all(tok, " .", "."); replace_all(tok, " ?", "?"); replace_all(tok, " !", "!"); replace_all(tok, " ,", ",");
-        replace_all(tok, " ' ", "'"); replace_all(tok, " n't", "n't"); replace_all(tok, " 'm", "'m");
-        replace_all(tok, " do not", " don't"); replace_all(tok, " 's", "'s"); replace_all(tok, " 've", "'ve");
-        replace_all(tok, " 're", "'re");
-        out += tok;
+        const size_t e = 2 * (size_t)id + (first ? 0 : 1);  // the clean-up is per token: both forms were prepared once (finish_vocab)
+        out.append(t->dec_arena.data() + t->dec_off[e], t->dec_off[e + 1] - t->dec_off[e]);
         first = false;
     }
+}
+
+std::string decode_ids(const mx_tokenizer *t, const int32_t *ids, int n, bool skip_special) {
+    if (t->kind == 1) return bpe_decode_ids(t, ids, n, skip_special);
+    std::string out;
+    decode_append(t, ids, n, skip_special, out);
     return out;
 }
 
@@ -487,6 +662,19 @@ int finish_vocab(mx_tokenizer *t) {
     if (!need("[PAD]", t->pad) || !need("[UNK]", t->unk) || !need("[CLS]", t->cls) || !need("[SEP]", t->sep))
         return fail(MX_EINVAL, "vocabulary lacks [PAD]/[UNK]/[CLS]/[SEP]");
     if (!need("[MASK]", t->mask)) t->mask = -1;
+    std::vector<std::pair<std::string, int32_t>> all, cont;
+    for (size_t i = 0; i < t->vocab.size(); ++i) {
+        all.emplace_back(t->vocab[i], (int32_t)i);
+        if (t->vocab[i].size() > 2 && t->vocab[i].compare(0, 2, "##") == 0) cont.emplace_back(t->vocab[i].substr(2), (int32_t)i);
+    }
+    t->full.build(all);
+    t->cont.build(cont);
+    t->dec_off.assign(1, 0u);
+    for (size_t i = 0; i < t->vocab.size(); ++i)
+        for (int later = 0; later < 2; ++later) {
+            t->dec_arena += decoded_token(t, (int32_t)i, later == 0);
+            t->dec_off.push_back((uint32_t)t->dec_arena.size());
+        }
     return MX_OK;
 }
 
@@ -586,12 +774,9 @@ int mx_tokenizer_decode(mx_tokenizer *t, const int32_t *ids, int n, int skip_spe
     return MX_OK;
 }
 
-int mx_tokenizer_segment(mx_tokenizer *t, const char *text, int max_length, int stride, char *out, size_t cap,
-                         size_t *nbytes, int *n_segments) {
-    if (!t || !text || !nbytes || !n_segments) return fail(MX_EINVAL, "null argument");
-    if (max_length < 1 || stride < 0 || stride >= max_length) return fail(MX_EINVAL, "need 0 <= stride < max_length");
+// segment_text's windows of one text, each NUL-terminated, appended to buf; -> number of windows
+static int segment_into(const mx_tokenizer *t, const char *text, int max_length, int stride, std::string &buf) {
     const std::vector<int32_t> ids = encode_plain(t, text);  // no special tokens (embedding.rs:181)
-    std::string buf;
     int nseg = 0;
     const size_t len = ids.size(), offset = (size_t)(max_length - stride);
     if (len == 0) {
@@ -602,15 +787,75 @@ int mx_tokenizer_segment(mx_tokenizer *t, const char *text, int max_length, int 
     for (size_t start = 0; start < len && !end; start += offset) {
         const size_t stop = std::min(start + (size_t)max_length, len);
         end = stop == len;
-        std::string seg = decode_ids(t, ids.data() + start, (int)(stop - start), true);
-        if (nseg == 0) replace_all(seg, " ' ", "'");  // only the first window (embedding.rs:183 vs :189-194)
-        buf += seg;
+        if (nseg == 0) {  // only the first window gets the replace (embedding.rs:183 vs :189-194)
+            std::string seg = decode_ids(t, ids.data() + start, (int)(stop - start), true);
+            replace_all(seg, " ' ", "'");
+            buf += seg;
+        } else if (t->kind == 1) {
+            buf += decode_ids(t, ids.data() + start, (int)(stop - start), true);
+        } else {
+            decode_append(t, ids.data() + start, (int)(stop - start), true, buf);
+        }
         buf.push_back('\0');
         ++nseg;
     }
+    return nseg;
+}
+
+int mx_tokenizer_segment(mx_tokenizer *t, const char *text, int max_length, int stride, char *out, size_t cap,
+                         size_t *nbytes, int *n_segments) {
+    if (!t || !text || !nbytes || !n_segments) return fail(MX_EINVAL, "null argument");
+    if (max_length < 1 || stride < 0 || stride >= max_length) return fail(MX_EINVAL, "need 0 <= stride < max_length");
+    std::string buf;
+    *n_segments = segment_into(t, text, max_length, stride, buf);
     *nbytes = buf.size();
-    *n_segments = nseg;
     if (out && cap >= buf.size()) memcpy(out, buf.data(), buf.size());
+    return MX_OK;
+}
+
+// segment_text for a batch of documents (the ingest worker drains its queue: tasks.rs:17-19 runs one document per task, up to
+// five tasks at a time, worker/lib.rs:36): documents are independent and the tokenizer is read-only, so they are dealt to
+// host threads.  out: the windows of text 0, then of text 1, ... each NUL-terminated; n_segments[i] = windows of text i.
+// nbytes is always the size needed; out is filled only when cap covers it (call again with a larger buffer otherwise).
+int mx_tokenizer_segment_batch(mx_tokenizer *t, const char *const *texts, int n_texts, int max_length, int stride, char *out,
+                               size_t cap, size_t *nbytes, int32_t *n_segments) {
+    if (!t || (n_texts > 0 && (!texts || !n_segments)) || !nbytes || n_texts < 0) return fail(MX_EINVAL, "null argument");
+    if (max_length < 1 || stride < 0 || stride >= max_length) return fail(MX_EINVAL, "need 0 <= stride < max_length");
+    for (int i = 0; i < n_texts; ++i)
+        if (!texts[i]) return fail(MX_EINVAL, "texts[%d] is null", i);
+    std::vector<std::string> bufs((size_t)n_texts);
+    std::atomic<int> next{0};
+    auto work = [&] {
+        for (int i; (i = next.fetch_add(1)) < n_texts;) n_segments[i] = segment_into(t, texts[i], max_length, stride, bufs[(size_t)i]);
+    };
+    const int nthr = std::min<int>((int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u), n_texts);
+    if (nthr <= 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (int i = 0; i < nthr; ++i) pool.emplace_back(work);
+        for (auto &th : pool) th.join();
+    }
+    size_t total = 0;
+    for (const std::string &b : bufs) total += b.size();
+    *nbytes = total;
+    if (out && cap >= total) {
+        size_t o = 0;
+        for (const std::string &b : bufs) {
+            memcpy(out + o, b.data(), b.size());
+            o += b.size();
+        }
+    }
+    return MX_OK;
+}
+
+// the stage-by-stage WordPiece encoder (normalize -> pre_tokenize -> wordpiece), for tests that hold the one-pass form against it
+int mx_tokenizer_encode_staged(mx_tokenizer *t, const char *text, int32_t *ids, int cap, int *n) {
+    if (!t || !text || !n || (cap > 0 && !ids)) return fail(MX_EINVAL, "null argument");
+    if (t->kind != 0) return fail(MX_EUNSUPPORTED, "WordPiece handles only");
+    const std::vector<int32_t> v = encode_staged(t, text);
+    *n = (int)v.size();
+    for (int i = 0; i < (int)v.size() && i < cap; ++i) ids[i] = v[i];
     return MX_OK;
 }
 

@@ -171,10 +171,13 @@ def _as_tokenizer(tokenizer, vocab: int):
     return HFTokenizerAdapter(tokenizer)
 
 
+_SEGMENTABLE = (EmbeddingsModelType.AllMiniLmL12V2, EmbeddingsModelType.AllMiniLmL6V2,
+                EmbeddingsModelType.AllDistilrobertaV1)                          # embedding.rs:156-161
+
+
 def segment_text(model_config: ModelConfig, text: str, tokenizer=None) -> List[str]:
     """embedding.rs:155-198: sliding windows of ``max_length`` tokens overlapping by ``stride``."""
-    if model_config.model not in (EmbeddingsModelType.AllMiniLmL12V2, EmbeddingsModelType.AllMiniLmL6V2,
-                                  EmbeddingsModelType.AllDistilrobertaV1):
+    if model_config.model not in _SEGMENTABLE:
         raise SetupError("Model not supported yet")                              # :160
     tok = _as_tokenizer(tokenizer, 30522)
     try:
@@ -268,13 +271,23 @@ class SentenceEmbedder:
                 except queue.Empty:
                     break
             work = []                                                            # (reply, segments)
-            for msg in msgs:
-                if msg is None:
-                    stop = True
-                    continue
-                text, segment, reply = msg
+            live = [m for m in msgs if m is not None]
+            stop = len(live) != len(msgs)
+            # the documents of the drained requests are segmented together (mx_tokenizer_segment_batch: one host thread per
+            # document) -- at the encoder's rate the segmenter is the ingest bottleneck
+            presegmented = {}
+            to_seg = [i for i, (_, segment, _) in enumerate(live) if segment]
+            if len(to_seg) > 1 and hasattr(tok, "windows_batch") and model_config.model in _SEGMENTABLE:
                 try:
-                    segs = segment_text(model_config, text, tok) if segment else [text]   # :103-107
+                    for i, segs in zip(to_seg, tok.windows_batch([live[i][0] for i in to_seg], model_config.max_length,
+                                                                 model_config.stride)):
+                        presegmented[i] = segs
+                except Exception:
+                    presegmented = {}                                            # one bad text: fall back to per-request errors
+            for i, (text, segment, reply) in enumerate(live):
+                try:
+                    segs = presegmented[i] if i in presegmented else \
+                        segment_text(model_config, text, tok) if segment else [text]      # :103-107
                     work.append((reply, segs))
                 except Exception as e:
                     reply.put(e)

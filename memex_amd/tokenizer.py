@@ -50,13 +50,32 @@ class _NativeTokenizer:
 
     def windows(self, text: str, max_length: int, stride: int) -> List[str]:
         """segment_text: detokenised windows of ``max_length`` tokens overlapping by ``stride``."""
-        raw = text.encode("utf-8").replace(b"\0", b"")
-        nb, ns = ctypes.c_size_t(0), ctypes.c_int(0)
-        check(lib().mx_tokenizer_segment(self._h, raw, max_length, stride, None, 0, ctypes.byref(nb), ctypes.byref(ns)))
-        buf = ctypes.create_string_buffer(nb.value)
-        check(lib().mx_tokenizer_segment(self._h, raw, max_length, stride, buf, nb.value, ctypes.byref(nb), ctypes.byref(ns)))
-        parts = buf.raw[: nb.value].split(b"\0")[: ns.value]
-        return [p.decode("utf-8") for p in parts]
+        return self.windows_batch([text], max_length, stride)[0]
+
+    def windows_batch(self, texts: Sequence[str], max_length: int, stride: int) -> List[List[str]]:
+        """segment_text for several documents in one call (``mx_tokenizer_segment_batch``: one host thread per document)."""
+        n = len(texts)
+        if n == 0:
+            return []
+        raws = [t.encode("utf-8").replace(b"\0", b"") for t in texts]
+        arr = (ctypes.c_char_p * n)(*raws)
+        nseg = (ctypes.c_int32 * n)()
+        nb = ctypes.c_size_t(0)
+        # decoded windows overlap by stride / (max_length - stride) and gain a space per isolated punctuation mark: this
+        # estimate covers ordinary text in one call; the call reports the size it needs when it does not
+        cap = int(sum(len(r) for r in raws) * (2.0 + stride / max(1, max_length - stride))) + 64 * n + 64
+        for _ in range(2):
+            buf = ctypes.create_string_buffer(cap)
+            check(lib().mx_tokenizer_segment_batch(self._h, arr, n, max_length, stride, buf, cap, ctypes.byref(nb), nseg))
+            if nb.value <= cap:
+                break
+            cap = nb.value
+        parts = buf.raw[: nb.value].split(b"\0")
+        out, o = [], 0
+        for i in range(n):
+            out.append([p.decode("utf-8") for p in parts[o:o + nseg[i]]])
+            o += nseg[i]
+        return out
 
     def encode_batch(self, texts: Sequence[str], max_seq_length: int) -> Tuple[np.ndarray, np.ndarray]:
         """-> (ids int32 [B,S], lens int32 [B]) with [CLS]/[SEP], truncated, [PAD]-padded to the batch max."""
@@ -80,6 +99,15 @@ class WordPieceTokenizer(_NativeTokenizer):
             blob = "\n".join(vocab).encode("utf-8")
             check(lib().mx_tokenizer_create_from_memory(blob, len(blob), 1 if lowercase else 0, ctypes.byref(h)))
         self._finish(h)
+
+    def encode_staged(self, text: str) -> List[int]:
+        """The stage-by-stage encoder (test hook: ``encode`` runs the same steps in one pass)."""
+        raw = text.encode("utf-8").replace(b"\0", b"")
+        cap = max(16, len(raw) + 2)
+        ids = (ctypes.c_int32 * cap)()
+        n = ctypes.c_int(0)
+        check(lib().mx_tokenizer_encode_staged(self._h, raw, ids, cap, ctypes.byref(n)))
+        return list(ids[: n.value])
 
 
 class ByteLevelBpeTokenizer(_NativeTokenizer):

@@ -215,3 +215,111 @@ def test_unicode_fuzz_matches_hf(uni_toks):
             want = hf.encode(t, add_special_tokens=False).ids
             got = mine.encode(t, False)
             assert got == want, (lower, [hex(ord(c)) for c in t])
+
+
+# ---- the one-pass encoder (hash-table WordPiece, prepared decoder strings) and the document batch ------------------------
+def _big_vocab(rng):
+    """A BERT-sized vocabulary of word-like stems and ## continuations over a small alphabet (so that random words
+    split into several pieces and some fail to split at all)."""
+    letters = list("etaoinshrdlcumwfgypbvkjxqz")
+    word = lambda n: "".join(rng.choice(letters, size=n))
+    stems, conts = set(), set()
+    while len(stems) < 12000:
+        stems.add(word(int(rng.integers(1, 8))))
+    while len(conts) < 6000:
+        conts.add("##" + word(int(rng.integers(1, 5))))
+    toks = SPECIALS + letters[:20] + ["##" + c for c in letters[:23]] + sorted(stems) + sorted(conts) + PUNCT + \
+        [str(i) for i in range(10)] + ["é", "über", "##ß", "中"]
+    seen, out = set(), []
+    for t in toks:
+        if t not in seen:
+            seen.add(t)
+            out.append(t)
+    return out, sorted(stems), letters
+
+
+@pytest.fixture(scope="module")
+def big_toks(lib_built, tmp_path_factory):
+    from tokenizers import BertWordPieceTokenizer
+    from memex_amd.tokenizer import WordPieceTokenizer
+    rng = np.random.default_rng(77)
+    vocab, stems, letters = _big_vocab(rng)
+    p = tmp_path_factory.mktemp("vocab_big") / "vocab.txt"
+    p.write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    return BertWordPieceTokenizer(str(p), lowercase=True), WordPieceTokenizer(str(p), lowercase=True), stems, letters
+
+
+def _doc(rng, stems, letters, chars):
+    ws, n = [], 0
+    while n < chars:
+        r = rng.random()
+        if r < 0.6:
+            w = stems[int(rng.zipf(1.3)) % len(stems)]
+        elif r < 0.9:
+            w = "".join(rng.choice(letters, size=int(rng.integers(3, 14))))     # splits into pieces, or [UNK]
+        elif r < 0.93:
+            w = "".join(rng.choice(letters, size=int(rng.integers(95, 108))))   # around max_input_chars_per_word = 100
+        else:
+            w = str(rng.choice([",", ".", "'s", "--", "(x)", "2023", "Über", "café", "don't", "中文", "a­b", "\t", "\n\n"]))
+        if rng.random() < 0.1:
+            w = w.capitalize()
+        ws.append(w)
+        n += len(w) + 1
+    return " ".join(ws)
+
+
+def test_one_pass_encoder_matches_staged_and_hf_on_a_bert_sized_vocabulary(big_toks):
+    hf, mine, stems, letters = big_toks
+    rng = np.random.default_rng(3)
+    for _ in range(30):
+        t = _doc(rng, stems, letters, int(rng.integers(10, 4000)))
+        ids = mine.encode(t)
+        assert ids == mine.encode_staged(t)
+        assert ids == hf.encode(t, add_special_tokens=False).ids
+        assert mine.decode(ids, True) == hf.decode(ids, skip_special_tokens=True)
+    # the 100-code-point limit: 100 letters are still split, 101 are [UNK] (also when the characters are multi-byte)
+    for ch in ("e", "é"):
+        for n in (99, 100, 101):
+            w = ch * n
+            assert mine.encode(w) == mine.encode_staged(w) == hf.encode(w, add_special_tokens=False).ids, (ch, n)
+
+
+def test_one_pass_encoder_matches_staged_on_unicode_fuzz(uni_toks):
+    rng = np.random.default_rng(99)
+    for lower, (_, mine) in uni_toks.items():
+        for _ in range(3000):
+            n = int(rng.integers(1, 40))
+            cps = [int(rng.integers(0x20, 0x3000)) if rng.random() < 0.7 else int(rng.integers(0x3000, 0x1fb00)) for _ in range(n)]
+            t = "".join(chr(c) for c in cps if not 0xd800 <= c <= 0xdfff)
+            assert mine.encode(t) == mine.encode_staged(t), (lower, [hex(c) for c in cps])
+        for raw in (b"ab\xffcd \xe2\x82 x", b"\xc3", b"x\xf0\x9f\x99y", b"\x80\x80 a", b"a\xed\xa0\x80b"):   # malformed UTF-8: both forms drop the same bytes
+            import ctypes
+            from memex_amd._lib import check, lib
+            outs = []
+            for fn, extra in ((lib().mx_tokenizer_encode, (0,)), (lib().mx_tokenizer_encode_staged, ())):
+                ids = (ctypes.c_int32 * 64)()
+                k = ctypes.c_int(0)
+                check(fn(mine._h, raw, *extra, ids, 64, ctypes.byref(k)))
+                outs.append(list(ids[: k.value]))
+            assert outs[0] == outs[1], raw
+
+
+def test_windows_batch_equals_one_document_at_a_time(big_toks):
+    """mx_tokenizer_segment_batch deals documents to host threads: every document's windows must be the reference call
+    sequence's (embedding.rs:173-195), whatever its neighbours."""
+    hf, mine, stems, letters = big_toks
+    rng = np.random.default_rng(11)
+    docs = [_doc(rng, stems, letters, int(rng.integers(0, 30000))) for _ in range(40)] + ["", "   ", "x", "' a ' b"]
+    got = mine.windows_batch(docs, 256, 86)
+    assert len(got) == len(docs)
+    hf.enable_truncation(max_length=256, stride=86)
+    for d, w in zip(docs, got):
+        enc = hf.encode(d, add_special_tokens=False)
+        want = [hf.decode(enc.ids, skip_special_tokens=True).replace(" ' ", "'")]
+        want += [hf.decode(o.ids, skip_special_tokens=True) for o in enc.overflowing]
+        assert w == want
+    hf.no_truncation()
+    assert mine.windows_batch([], 256, 86) == []
+    # a text whose windows outgrow the first buffer estimate (every character becomes "c " + overlap): the call is repeated
+    dense = "." * 5000
+    assert mine.windows_batch([dense], 8, 7)[0] == mine.windows(dense, 8, 7) and len(mine.windows(dense, 8, 7)) == 4993
