@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--ingest-chunks", type=int, default=262_144, help="512-token chunks per GPU for the ingest leg (0 = skip)")
     ap.add_argument("--bge-chunks", type=int, default=24_576, help="N=1 only: 512-token chunks of the bge-base-en ingest leg (0 = skip)")
     ap.add_argument("--cfg2-segments", type=int, default=100_000, help="N=1 only: segments of the configs[1] end-to-end leg (0 = skip)")
+    ap.add_argument("--text-docs", type=int, default=200, help="N=1 only: documents of the text-ingest leg (segmenter + encoder + add; 0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=0.5,
                     help="untimed steps of the same work run in front of every timed region until this much time has passed: the "
                          "package needs ~0.7 s of continuous load to settle at its power-capped clock (profiles/r3_power_scan8.log), "
@@ -412,6 +413,138 @@ def cfg2_leg(n_seg: int, batch: int, k: int, steps: int):
            "approx_err_bound": sst.approx_err_bound, "ids_equal_exact_path": same}
     del ids, lens, vec, q, bufs
     torch.cuda.empty_cache()
+    return out
+
+
+def _synthetic_vocab_and_docs(n_docs: int, chars: int, seed: int = 0):
+    """A BERT-sized WordPiece vocabulary (30522 entries: word-like stems and ## continuations over the alphabet) and `n_docs`
+    documents of ~`chars` characters (the reference's example document, state_of_the_union_2023.json, holds 42,099): Zipf-distributed
+    vocabulary words, out-of-vocabulary words that split into pieces, punctuation, capitals."""
+    rng = np.random.default_rng(seed)
+    letters = list("etaoinshrdlcumwfgypbvkjxqz")
+    word = lambda n: "".join(rng.choice(letters, size=n))  # noqa: E731
+    specials = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    stems, conts = set(), set()
+    while len(stems) < 20000:
+        stems.add(word(int(rng.integers(1, 8))))
+    while len(conts) < 10000:
+        conts.add("##" + word(int(rng.integers(1, 5))))
+    stems = sorted(stems)
+    vocab = specials + letters + ["##" + c for c in letters] + stems + sorted(conts) + list("!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~") + \
+        [str(i) for i in range(10)]
+    seen = set()
+    vocab = [v for v in vocab if not (v in seen or seen.add(v))]
+    while len(vocab) < 30522:
+        vocab.append(f"[unused{len(vocab)}]")
+    oov = np.array([word(int(n)) for n in rng.integers(4, 12, 4096)])       # out-of-vocabulary words: split into pieces or [UNK]
+    marks = np.array([",", ".", "'s", "--", "(", ")", "2023", "Biden's"])
+    stems_a = np.array(stems)
+    docs = []
+    for _ in range(n_docs):
+        m = chars // 4                                                         # more words than needed, cut to size below
+        r = rng.random(m)
+        ws = np.where(r < 0.7, stems_a[rng.zipf(1.3, m) % len(stems_a)],
+                      np.where(r < 0.95, oov[rng.integers(0, len(oov), m)], marks[rng.integers(0, len(marks), m)]))
+        cap = rng.random(m) < 0.1
+        text = " ".join(w.capitalize() if c else w for w, c in zip(ws.tolist(), cap.tolist()))
+        docs.append(text[:text.rfind(" ", 0, chars)])
+    return vocab, docs
+
+
+def text_ingest_leg(n_docs: int, workers: int = 5, cpu_too: bool = True):
+    """The reference's ingest flow from TEXT (BASELINE configs[0] scaled up): `workers` threads
+    -- the reference runs up to five ingest tasks at a time, worker/lib.rs:36 -- each take documents off a list and call
+    process_embeddings (tasks.rs:9-66): segment_text (native WordPiece, windows 256/86, embedding.rs:155-198) -> model.encode of the
+    windows (the reference's default model, all-MiniLM-L12-v2 shape, seeded weights, max_seq_length 128) -> add_vectors.  One
+    long-lived embedder and one resident collection; concurrent requests are segmented and embedded together.
+    Beside it, on the host cores: the segmenter alone, native against the `tokenizers` package -- the Python binding of the very
+    crate the reference calls (lib/libmemex/Cargo.toml:31) -- on the same documents and the same call sequence."""
+    import tempfile
+    import threading
+    from memex_amd import tasks
+    from memex_amd.embedding import ModelConfig, SentenceEmbedder
+    from memex_amd.storage import get_vector_storage
+    from memex_amd.tokenizer import WordPieceTokenizer
+
+    vocab, docs = _synthetic_vocab_and_docs(n_docs, 42_000)
+    chars = sum(len(d) for d in docs)
+    tok = WordPieceTokenizer(vocab, lowercase=True)
+    out = {"workload": f"{n_docs} documents x ~42k characters -> segment_text (256/86) -> all-MiniLM-L12-v2 shape (seeded weights, "
+                       f"max_seq_length 128) -> add_vectors, {workers} concurrent process_embeddings callers",
+           "documents": n_docs, "characters": chars}
+    # ---- the segmenter alone (host code; this is the part the reference's crate can be timed against)
+    t0 = time.perf_counter()
+    one = [tok.windows(d, 256, 86) for d in docs[:16]]
+    t_one = (time.perf_counter() - t0) / max(1, sum(len(d) for d in docs[:16]))
+    t0 = time.perf_counter()
+    segs = tok.windows_batch(docs, 256, 86)
+    t_batch = time.perf_counter() - t0
+    assert segs[:16] == one
+    n_win = sum(len(s_) for s_ in segs)
+    out["windows"] = n_win
+    out["segmenter"] = {"native_one_thread_MBps": 1e-6 / t_one, "native_batch_MBps": chars / t_batch / 1e6,
+                        "native_batch_docs_per_s": n_docs / t_batch, "host_threads": min(os.cpu_count() or 1, 64, n_docs)}
+    if cpu_too:
+        try:
+            import tempfile as _tf
+            from tokenizers import BertWordPieceTokenizer
+            with _tf.TemporaryDirectory() as td:
+                vp = os.path.join(td, "vocab.txt")
+                with open(vp, "w", encoding="utf-8") as f:
+                    f.write("\n".join(vocab) + "\n")
+                hf = BertWordPieceTokenizer(vp, lowercase=True)
+            hf.enable_truncation(max_length=256, stride=86)
+            sample = docs[:8]
+            t0 = time.perf_counter()
+            ref = []
+            for d in sample:                                                # embedding.rs:173-195
+                e = hf.encode(d, add_special_tokens=False)
+                w = [hf.decode(e.ids, skip_special_tokens=True).replace(" ' ", "'")]
+                w += [hf.decode(o.ids, skip_special_tokens=True) for o in e.overflowing]
+                ref.append(w)
+            t_ref = time.perf_counter() - t0
+            out["segmenter"]["cpu_baseline"] = {
+                "value": sum(len(d) for d in sample) / t_ref / 1e6, "unit": "MB/s of text", "cores": 1, "kind": "reference",
+                "sample": f"{len(sample)} of the documents through the `tokenizers` package (binding of the crate the reference links), "
+                          f"the call sequence of embedding.rs:173-195, {t_ref:.2f}s",
+                "windows_equal_native": ref == segs[:len(sample)]}
+        except Exception as e:  # noqa: BLE001 -- the baseline must never fail the bench
+            out["segmenter"]["cpu_baseline"] = {"error": repr(e)[:200]}
+    # ---- the flow
+    th, emb = SentenceEmbedder.spawn(ModelConfig(), tokenizer=tok, allow_synthetic=True)
+    with tempfile.TemporaryDirectory() as td:
+        client = get_vector_storage("hip://" + td, "bench_text")
+        tasks.process_embeddings(client, emb, 0, docs[0])                  # warm-up (encoder set-up, first save)
+        nxt, lock, errs = [1], threading.Lock(), []
+
+        def worker():
+            while True:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= n_docs:
+                    return
+                try:
+                    tasks.process_embeddings(client, emb, i, docs[i])
+                except Exception as e:  # noqa: BLE001
+                    errs.append(repr(e))
+                    return
+        t0 = time.perf_counter()
+        ts = [threading.Thread(target=worker) for _ in range(workers)]
+        for t_ in ts:
+            t_.start()
+        for t_ in ts:
+            t_.join()
+        dt = time.perf_counter() - t0
+        hits = tasks.search_docs(client, emb, segs[3][0], 3)               # the text of a stored window finds that window
+        out.update({"value": (n_docs - 1) / dt, "unit": "documents/s", "windows_per_s": (n_win - len(segs[0])) / dt,
+                    "text_MBps": (chars - len(docs[0])) / dt / 1e6, "seconds": dt, "errors": errs[:3],
+                    "query_finds_its_window": bool(hits) and hits[0][0] == tasks.segment_uuid(tasks.document_uuid(3), 0)
+                    and hits[0][1] > 0.999})
+        client.delete_collection()
+    emb.shutdown()
+    th.join()
+    tok.close()
     return out
 
 
@@ -868,6 +1001,11 @@ def run(a):
             sides["enc_like_10M"] = enc_like_leg(a.enc_like_rows, 100_000, a.batch, k, a.side_steps)
         if a.cfg2_segments > 0:
             sides["cfg2"] = cfg2_leg(a.cfg2_segments, a.batch, k, a.side_steps)
+        if a.text_docs > 0:
+            try:
+                sides["text_ingest"] = text_ingest_leg(a.text_docs, cpu_too=not a.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001 -- a side leg must not fail the bench
+                sides["text_ingest"] = {"error": repr(e)[:300]}
     ingest = None
     if a.ingest_chunks > 0:
         ingest = ingest_leg(a.ingest_chunks, dev, world, not a.no_cpu_baseline, devices=shard_devs if in_library and not one_device else None)

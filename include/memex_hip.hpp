@@ -512,10 +512,114 @@ struct WhitespaceHashTokenizer {
     }
 };
 
-inline std::vector<std::string> segment_text(const ModelConfig &mc, const std::string &text) {  // embedding.rs:155-198
+// The native tokenizer / segmenter (mx_tokenizer_*: WordPiece over a BERT vocab.txt, or byte-level BPE over vocab.json +
+// merges.txt for the RoBERTa family): what Tokenizer::from_pretrained + with_truncation + encode / decode give
+// segment_text (embedding.rs:163-195) and what rust-bert does to the segments before the forward.
+class Tokenizer {
+  public:
+    static std::shared_ptr<Tokenizer> wordpiece(const std::string &vocab_txt, bool lowercase = true) {
+        mx_tokenizer *h = nullptr;
+        if (mx_tokenizer_create(vocab_txt.c_str(), lowercase ? 1 : 0, &h) != MX_OK)
+            throw EmbeddingError(EmbeddingError::SetupError, mx_last_error());  // "Unable to load model", :166-169
+        return std::shared_ptr<Tokenizer>(new Tokenizer(h));
+    }
+    static std::shared_ptr<Tokenizer> wordpiece_from_tokens(const std::vector<std::string> &tokens, bool lowercase = true) {
+        std::string blob;
+        for (const std::string &t : tokens) blob += t, blob += '\n';
+        mx_tokenizer *h = nullptr;
+        if (mx_tokenizer_create_from_memory(blob.data(), blob.size(), lowercase ? 1 : 0, &h) != MX_OK)
+            throw EmbeddingError(EmbeddingError::SetupError, mx_last_error());
+        return std::shared_ptr<Tokenizer>(new Tokenizer(h));
+    }
+    static std::shared_ptr<Tokenizer> bpe(const std::string &vocab_json, const std::string &merges_txt) {
+        mx_tokenizer *h = nullptr;
+        if (mx_tokenizer_create_bpe(vocab_json.c_str(), merges_txt.c_str(), &h) != MX_OK)
+            throw EmbeddingError(EmbeddingError::SetupError, mx_last_error());
+        return std::shared_ptr<Tokenizer>(new Tokenizer(h));
+    }
+    ~Tokenizer() { mx_tokenizer_destroy(h_); }
+    Tokenizer(const Tokenizer &) = delete;
+    Tokenizer &operator=(const Tokenizer &) = delete;
+
+    std::vector<int32_t> encode(const std::string &text, bool add_special_tokens = false) const {
+        std::vector<int32_t> ids(text.size() + 2);
+        int n = 0;
+        check(mx_tokenizer_encode(h_, text.c_str(), add_special_tokens ? 1 : 0, ids.data(), (int)ids.size(), &n), text);
+        ids.resize((size_t)n);
+        return ids;
+    }
+    std::string decode(const std::vector<int32_t> &ids, bool skip_special_tokens = true) const {
+        size_t nb = 0;
+        check(mx_tokenizer_decode(h_, ids.data(), (int)ids.size(), skip_special_tokens ? 1 : 0, nullptr, 0, &nb), "");
+        std::string out(nb, '\0');
+        check(mx_tokenizer_decode(h_, ids.data(), (int)ids.size(), skip_special_tokens ? 1 : 0, out.data(), nb, &nb), "");
+        out.resize(nb ? nb - 1 : 0);
+        return out;
+    }
+    // segment_text's windows for several documents in one call (documents are dealt to host threads)
+    std::vector<std::vector<std::string>> windows_batch(const std::vector<std::string> &texts, size_t max_length, size_t stride) const {
+        std::vector<const char *> ptrs;
+        size_t bytes = 0;
+        for (const std::string &t : texts) ptrs.push_back(t.c_str()), bytes += t.size();
+        std::vector<int32_t> nseg(texts.size());
+        std::string buf(bytes * 3 + 64 * texts.size() + 64, '\0');
+        size_t nb = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            check(mx_tokenizer_segment_batch(h_, ptrs.data(), (int)texts.size(), (int)max_length, (int)stride, buf.data(), buf.size(), &nb,
+                                             nseg.data()), "");
+            if (nb <= buf.size()) break;
+            buf.assign(nb, '\0');
+        }
+        std::vector<std::vector<std::string>> out(texts.size());
+        const char *p = buf.data();
+        for (size_t i = 0; i < texts.size(); ++i)
+            for (int32_t k = 0; k < nseg[i]; ++k) {
+                out[i].emplace_back(p);
+                p += out[i].back().size() + 1;
+            }
+        return out;
+    }
+    std::vector<std::string> windows(const std::string &text, size_t max_length, size_t stride) const {
+        return windows_batch({text}, max_length, stride)[0];
+    }
+    // [CLS] .. [SEP] rows, truncated to max_seq_length, [PAD]-padded to the batch maximum S
+    void encode_batch(const std::vector<std::string> &texts, size_t max_seq_length, std::vector<int32_t> &ids, std::vector<int32_t> &lens,
+                      int &S) const {
+        std::vector<const char *> ptrs;
+        for (const std::string &t : texts) ptrs.push_back(t.c_str());
+        std::vector<int32_t> wide(texts.size() * max_seq_length);
+        lens.assign(texts.size(), 0);
+        S = 0;
+        check(mx_tokenizer_encode_batch(h_, ptrs.data(), (int)texts.size(), (int)max_seq_length, wide.data(), (int)max_seq_length,
+                                        lens.data(), &S), "");
+        ids.resize(texts.size() * (size_t)S);
+        for (size_t b = 0; b < texts.size(); ++b)
+            std::copy(wide.begin() + b * max_seq_length, wide.begin() + b * max_seq_length + S, ids.begin() + b * (size_t)S);
+    }
+    int vocab_size() const {
+        int n = 0;
+        mx_tokenizer_vocab_size(h_, &n);
+        return n;
+    }
+
+  private:
+    explicit Tokenizer(mx_tokenizer *h) : h_(h) {}
+    static void check(int rc, const std::string &text) {
+        if (rc != MX_OK) throw EmbeddingError(EmbeddingError::EncodingFailure, text.empty() ? mx_last_error() : text);  // :176-179
+    }
+    mx_tokenizer *h_;
+};
+
+inline void check_segmentable(const ModelConfig &mc) {
     if (mc.model != EmbeddingsModelType::AllMiniLmL12V2 && mc.model != EmbeddingsModelType::AllMiniLmL6V2 &&
         mc.model != EmbeddingsModelType::AllDistilrobertaV1)
         throw EmbeddingError(EmbeddingError::SetupError, "Model not supported yet");  // :160
+}
+
+// embedding.rs:155-198.  `tok`: the model's tokenizer; without one the whitespace stand-in above (tests and benchmarks only)
+inline std::vector<std::string> segment_text(const ModelConfig &mc, const std::string &text, const Tokenizer *tok = nullptr) {
+    check_segmentable(mc);
+    if (tok) return tok->windows(text, mc.max_length, mc.stride);
     return WhitespaceHashTokenizer{}.windows(text, mc.max_length, mc.stride);
 }
 
@@ -524,14 +628,15 @@ inline std::vector<std::string> segment_text(const ModelConfig &mc, const std::s
 class SentenceEmbedder {
   public:
     // `weights`: f32 blob in the order documented in memex_hip.h for `cfg`.
+    // `tok`: the model's tokenizer (Tokenizer::wordpiece / ::bpe); nullptr = the whitespace stand-in (tests, benchmarks).
     static std::pair<std::thread, std::shared_ptr<SentenceEmbedder>> spawn(const ModelConfig &mc, const mx_encoder_cfg &cfg,
                                                                            std::vector<float> weights, size_t max_seq_length,
-                                                                           int device = 0) {
+                                                                           int device = 0, std::shared_ptr<Tokenizer> tok = nullptr) {
         auto self = std::shared_ptr<SentenceEmbedder>(new SentenceEmbedder());
         std::promise<std::string> ready;
         auto fut = ready.get_future();
-        std::thread th([self, mc, cfg, w = std::move(weights), max_seq_length, device, pr = std::move(ready)]() mutable {
-            self->runner(mc, cfg, w, max_seq_length, device, pr);
+        std::thread th([self, mc, cfg, w = std::move(weights), max_seq_length, device, tok, pr = std::move(ready)]() mutable {
+            self->runner(mc, cfg, w, max_seq_length, device, tok, pr);
         });
         const std::string err = fut.get();
         if (!err.empty()) {
@@ -572,7 +677,7 @@ class SentenceEmbedder {
         return fut.get();
     }
     void runner(const ModelConfig &mc, const mx_encoder_cfg &cfg, const std::vector<float> &w, size_t max_seq_length, int device,
-                std::promise<std::string> &ready) {
+                const std::shared_ptr<Tokenizer> &native, std::promise<std::string> &ready) {
         mx_encoder *enc = nullptr;
         int rc = mx_encoder_create(&cfg, w.data(), w.size() * sizeof(float), device, &enc);  // create_model(), :99-100
         if (rc != MX_OK) {
@@ -597,13 +702,28 @@ class SentenceEmbedder {
                 cv_.notify_all();
             }
             std::vector<std::pair<Msg *, std::vector<std::string>>> work;
-            for (Msg &m : msgs) {
+            // the documents of the drained requests are segmented together (one host thread per document)
+            std::vector<std::vector<std::string>> pre;
+            std::vector<size_t> pre_of(msgs.size(), (size_t)-1);
+            if (native) {
+                std::vector<std::string> docs;
+                for (size_t i = 0; i < msgs.size(); ++i)
+                    if (!msgs[i].stop && msgs[i].segment) pre_of[i] = docs.size(), docs.push_back(msgs[i].text);
+                try {
+                    check_segmentable(mc);
+                    if (docs.size() > 1) pre = native->windows_batch(docs, mc.max_length, mc.stride);
+                } catch (...) {  // reported per request below
+                }
+            }
+            for (size_t i = 0; i < msgs.size(); ++i) {
+                Msg &m = msgs[i];
                 if (m.stop) {
                     stop = true;
                     continue;
                 }
                 try {
-                    work.emplace_back(&m, m.segment ? segment_text(mc, m.text) : std::vector<std::string>{m.text});  // :103-107
+                    if (m.segment && pre_of[i] < pre.size()) work.emplace_back(&m, std::move(pre[pre_of[i]]));
+                    else work.emplace_back(&m, m.segment ? segment_text(mc, m.text, native.get()) : std::vector<std::string>{m.text});  // :103-107
                 } catch (...) {
                     m.reply->set_exception(std::current_exception());
                 }
@@ -614,7 +734,8 @@ class SentenceEmbedder {
                 for (auto &wk : work) flat.insert(flat.end(), wk.second.begin(), wk.second.end());
                 std::vector<int32_t> ids, lens;
                 int S = 0;
-                tok.encode_batch(flat, max_seq_length, ids, lens, S);
+                if (native) native->encode_batch(flat, max_seq_length, ids, lens, S);
+                else tok.encode_batch(flat, max_seq_length, ids, lens, S);
                 std::vector<float> out(flat.size() * (size_t)cfg.hidden);
                 rc = mx_encoder_encode(enc, ids.data(), lens.data(), (int)flat.size(), S, out.data());  // model.encode, :109
                 if (rc != MX_OK) throw EmbeddingError(EmbeddingError::EncodingFailure, mx_last_error());

@@ -384,4 +384,20 @@ inline PretrainedModel load_pretrained_dir(const std::string &dir, int precision
     return pm;
 }
 
+// The model's own tokenizer: WordPiece over vocab.txt, or byte-level BPE over vocab.json + merges.txt
+inline std::shared_ptr<Tokenizer> pretrained_tokenizer(const PretrainedModel &pm) {
+    if (!pm.vocab_path.empty()) return Tokenizer::wordpiece(pm.vocab_path, pm.do_lower_case);
+    if (!pm.vocab_json_path.empty() && !pm.merges_path.empty()) return Tokenizer::bpe(pm.vocab_json_path, pm.merges_path);
+    throw EmbeddingError(EmbeddingError::SetupError, "Unable to load model: neither vocab.txt nor vocab.json + merges.txt");
+}
+
+// SentenceEmbedder::spawn(&ModelConfig) with create_model() reading a LOCAL sentence-transformers directory
+// (embedding.rs:84-100): encoder + native tokenizer from the files the reference downloads
+inline std::pair<std::thread, std::shared_ptr<SentenceEmbedder>> spawn_pretrained(const std::string &dir, const ModelConfig &mc = ModelConfig{},
+                                                                                  int device = 0, int precision = MX_PREC_BF16) {
+    PretrainedModel pm = load_pretrained_dir(dir, precision);
+    std::shared_ptr<Tokenizer> tok = pretrained_tokenizer(pm);
+    return SentenceEmbedder::spawn(mc, pm.cfg, std::move(pm.weights), pm.max_seq_length, device, tok);
+}
+
 }  // namespace memex

@@ -1,9 +1,12 @@
 #!/bin/bash
 mkdir -p gpurun_out
-O=gpurun_out/r5_gemm_shape_probe.txt
+O=gpurun_out/r5_text_ingest.txt
 : > $O
-for rep in 1 2; do for a in 0 4; do
-  timeout 200 build_ub/gemm_ub_a$a 131072 384 1536 100 >> $O 2>&1
-done; done
-for a in 0 4; do timeout 200 build_ub/gemm_ub_a$a 131072 768 3072 50 >> $O 2>&1; done
+nproc >> $O
+timeout 900 python -m pytest tests/test_cpp_host.py tests/test_pipeline_native_gpu.py tests/test_pretrained.py -m gpu -x -q 2>&1 | tail -5 >> $O
+timeout 600 python -c "
+import json, bench
+print(json.dumps(bench.text_ingest_leg(200), indent=1))
+print(json.dumps(bench.text_ingest_leg(200, workers=32, cpu_too=False), indent=1))
+" >> $O 2>&1
 cat $O

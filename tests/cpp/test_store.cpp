@@ -163,6 +163,44 @@ static void test_embedder_actor() {  // embedding.rs:78-152 with a seeded 1-laye
     CHECK(gate);
     emb->shutdown();
     th.join();
+
+    // the same actor with the NATIVE tokenizer (mx_tokenizer_*): segments are the tokenizer's windows, concurrent ingest
+    // requests are segmented together (mx_tokenizer_segment_batch) and answered like single ones
+    std::vector<std::string> vocab{"[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "w", ".", ","};
+    for (int d = 0; d < 10; ++d) vocab.push_back("##" + std::to_string(d));
+    while (vocab.size() < 30522) vocab.push_back("[unused" + std::to_string(vocab.size()) + "]");
+    auto tok = Tokenizer::wordpiece_from_tokens(vocab);
+    std::vector<float> w2(n);
+    for (auto &x : w2) x = nd(rng);
+    auto [th2, emb2] = SentenceEmbedder::spawn(ModelConfig{}, cfg, std::move(w2), 128, 0, tok);
+    std::vector<std::string> docs(6);
+    for (int d = 0; d < 6; ++d)
+        for (int i = 0; i < 150 + 90 * d; ++i) docs[d] += "W" + std::to_string((i * 7 + d) % 97) + (i % 11 == 0 ? ", " : " ");
+    std::vector<std::vector<EmbeddingResult>> alone;
+    for (auto &d : docs) alone.push_back(emb2->encode(d));
+    for (int d = 0; d < 6; ++d) {
+        const auto want = tok->windows(docs[d], 256, 86);
+        CHECK(alone[d].size() == want.size() && want.size() >= 2);
+        for (size_t i = 0; i < want.size(); ++i) CHECK(alone[d][i].content == want[i] && alone[d][i].vector.size() == 384);
+        CHECK(want[0].rfind("w", 0) == 0);  // lower-cased, detokenised text
+    }
+    std::vector<std::vector<EmbeddingResult>> together(6);
+    {
+        std::vector<std::thread> ts;
+        for (int d = 0; d < 6; ++d) ts.emplace_back([&, d] { together[d] = emb2->encode(docs[d]); });
+        for (auto &t : ts) t.join();
+    }
+    for (int d = 0; d < 6; ++d) {
+        CHECK(together[d].size() == alone[d].size());
+        for (size_t i = 0; i < alone[d].size(); ++i) {
+            CHECK(together[d][i].content == alone[d][i].content);
+            double dot = 0;
+            for (int j = 0; j < 384; ++j) dot += (double)together[d][i].vector[j] * alone[d][i].vector[j];
+            CHECK(dot > 1.0 - 1e-4);  // a row's embedding does not depend on its batch (pass regimes: include/memex_hip.h)
+        }
+    }
+    emb2->shutdown();
+    th2.join();
 }
 
 int main(int argc, char **argv) {

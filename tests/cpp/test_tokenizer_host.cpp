@@ -1,0 +1,53 @@
+// memex::Tokenizer (include/memex_hip.hpp) over the C ABI's mx_tokenizer_*: prints what tests/test_cpp_host.py compares with the
+// `tokenizers` package -- ids, decoded text, segment_text windows (one call per document and one batch call).  No GPU.
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "memex_hip.hpp"
+
+static unsigned long long fnv(const std::string &s) {
+    unsigned long long h = 1469598103934665603ull;
+    for (unsigned char c : s) h = (h ^ c) * 1099511628211ull;
+    return h;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 2;
+    try {
+        auto tok = memex::Tokenizer::wordpiece(argv[1], true);
+        std::vector<std::string> docs;
+        std::ifstream f(argv[2]);
+        for (std::string line; std::getline(f, line);) docs.push_back(line);
+        const auto batch = tok->windows_batch(docs, 256, 86);
+        if (batch.size() != docs.size()) return 3;
+        for (size_t d = 0; d < docs.size(); ++d) {
+            const auto ids = tok->encode(docs[d]);
+            unsigned long long hi = 1469598103934665603ull;
+            for (int32_t id : ids) hi = (hi ^ (unsigned long long)(unsigned)id) * 1099511628211ull;
+            const auto one = tok->windows(docs[d], 256, 86);
+            if (one != batch[d]) return 4;
+            unsigned long long hw = 0;
+            for (const auto &w : one) hw = hw * 31 + fnv(w);
+            std::printf("DOC %zu ids %zu %016llx dec %016llx win %zu %016llx\n", d, ids.size(), hi, fnv(tok->decode(ids)), one.size(), hw);
+        }
+        std::vector<int32_t> ids, lens;
+        int S = 0;
+        tok->encode_batch(docs, 128, ids, lens, S);
+        long total = 0;
+        for (int32_t l : lens) total += l;
+        std::printf("BATCH S %d rows %zu tokens %ld vocab %d\n", S, lens.size(), total, tok->vocab_size());
+        bool refused = false;
+        try {
+            memex::Tokenizer::wordpiece("/nonexistent/vocab.txt");
+        } catch (const memex::EmbeddingError &e) {
+            refused = e.kind() == memex::EmbeddingError::SetupError;
+        }
+        std::printf(refused ? "OK tokenizer host\n" : "missing vocabulary not refused\n");
+        return refused ? 0 : 5;
+    } catch (const std::exception &e) {
+        std::printf("FAILED %s\n", e.what());
+        return 1;
+    }
+}

@@ -41,6 +41,56 @@ def test_shard_pool_hand_off(tmp_path):
     assert r.returncode == 0 and "OK shard pool" in r.stdout, r.stdout + r.stderr
 
 
+def test_cpp_tokenizer_class_matches_the_tokenizers_package(tmp_path, lib_built):
+    """memex::Tokenizer (the C++ host's face of mx_tokenizer_*): ids, decoded text and segment_text windows of a few
+    documents equal the `tokenizers` package's (the crate the reference calls, embedding.rs:163-195)."""
+    import numpy as np
+    from tokenizers import BertWordPieceTokenizer
+    from test_tokenizer import STEMS, make_vocab
+    exe = str(tmp_path / "test_tokenizer_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_tokenizer_host.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "memex_amd"), "-lmemex_hip", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "memex_amd")])
+    vocab = tmp_path / "vocab.txt"
+    vocab.write_text("\n".join(make_vocab()) + "\n", encoding="utf-8")
+    rng = np.random.default_rng(8)
+    pieces = STEMS + ["don't", "it's", "' quoted '", "end.", "Biden's", "Ünion", "中文", "x-y"]
+    docs = [" ".join(rng.choice(pieces, size=int(n))) for n in (3, 40, 300, 900, 1500)] + ["", "the"]
+    (tmp_path / "docs.txt").write_text("\n".join(docs) + "\n", encoding="utf-8")
+    r = subprocess.run([exe, str(vocab), str(tmp_path / "docs.txt")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK tokenizer host" in r.stdout, r.stdout + r.stderr
+
+    def fnv(b: bytes) -> int:
+        h = 1469598103934665603
+        for c in b:
+            h = ((h ^ c) * 1099511628211) & (2 ** 64 - 1)
+        return h
+    hf = BertWordPieceTokenizer(str(vocab), lowercase=True)
+    lines = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("DOC")]
+    assert len(lines) == len(docs)
+    total = 0
+    for d, ln in zip(docs, lines):
+        hf.no_truncation()
+        ids = hf.encode(d, add_special_tokens=False).ids
+        hi = 1469598103934665603
+        for i in ids:
+            hi = ((hi ^ i) * 1099511628211) & (2 ** 64 - 1)
+        hf.enable_truncation(max_length=256, stride=86)
+        enc = hf.encode(d, add_special_tokens=False)
+        wins = [hf.decode(enc.ids, skip_special_tokens=True).replace(" ' ", "'")] + \
+            [hf.decode(o.ids, skip_special_tokens=True) for o in enc.overflowing]
+        hw = 0
+        for w in wins:
+            hw = (hw * 31 + fnv(w.encode("utf-8"))) & (2 ** 64 - 1)
+        assert int(ln[3]) == len(ids) and int(ln[4], 16) == hi, d[:40]
+        assert int(ln[6], 16) == fnv(hf.decode(ids, skip_special_tokens=True).encode("utf-8"))
+        assert int(ln[8]) == len(wins) and int(ln[9], 16) == hw
+        total += min(len(ids), 126) + 2
+    batch = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("BATCH")][0]
+    assert int(batch[2]) == 128 and int(batch[4]) == len(docs) and int(batch[6]) == total
+
+
 @pytest.mark.gpu
 def test_cpp_reference_tests(tmp_path, lib_built):
     exe = _build(tmp_path, lib_built)
