@@ -94,6 +94,11 @@ struct mx_tokenizer {
     // byte-level BPE (kind 1): merge ranks by "left right", the byte <-> code point tables of the ByteLevel stage
     int kind = 0;
     std::unordered_map<std::string, int32_t> merges;
+    // ... the same merges over token ids (a << 32 | b -> rank, id of the merged token) when every merge's operands and product
+    // are vocabulary entries -- the case for every trained byte-level BPE; the string form stays for files that break that rule
+    std::unordered_map<uint64_t, std::pair<int32_t, int32_t>> pair_rank;
+    int32_t byte_id[256];
+    bool bpe_ids = false;
     std::string byte_chr[256];                      // byte -> its printable code point, UTF-8 encoded
     std::unordered_map<uint32_t, uint8_t> chr_byte;  // code point -> byte
 };
@@ -424,7 +429,7 @@ std::string decode_ids(const mx_tokenizer *t, const int32_t *ids, int n, bool sk
 
 bool bpe_letter(uint32_t c) { return c < 0x80 ? ((c | 0x20) >= 'a' && (c | 0x20) <= 'z') : in_ranges(kBpeLetterRanges, c); }
 bool bpe_number(uint32_t c) { return c < 0x80 ? (c >= '0' && c <= '9') : in_ranges(kBpeNumberRanges, c); }
-bool bpe_space(uint32_t c) { return in_ranges(kBpeSpaceRanges, c); }
+bool bpe_space(uint32_t c) { return c < 0x80 ? (c == ' ' || (c >= 9 && c <= 13)) : in_ranges(kBpeSpaceRanges, c); }
 bool bpe_other(uint32_t c) { return !bpe_space(c) && !bpe_letter(c) && !bpe_number(c); }
 
 // strict UTF-8 -> code points; an ill-formed sequence yields U+FFFD per maximal subpart (Rust's from_utf8_lossy, which the
@@ -522,14 +527,52 @@ void bpe_word(const mx_tokenizer *t, const std::string &bytes, std::vector<int32
     }
 }
 
+// bpe_word over token ids: the lowest-ranked adjacent pair, every occurrence of it merged left to right, until none is left
+void bpe_word_ids(const mx_tokenizer *t, const std::string &bytes, std::vector<int32_t> &ids) {
+    std::vector<int32_t> sym(bytes.size()), next;
+    for (size_t k = 0; k < bytes.size(); ++k) sym[k] = t->byte_id[(unsigned char)bytes[k]];
+    while (sym.size() > 1) {
+        int32_t best = INT32_MAX, merged = -1, a = 0, b = 0;
+        for (size_t k = 0; k + 1 < sym.size(); ++k) {
+            auto it = t->pair_rank.find((uint64_t)(uint32_t)sym[k] << 32 | (uint32_t)sym[k + 1]);
+            if (it != t->pair_rank.end() && it->second.first < best) {
+                best = it->second.first;
+                merged = it->second.second;
+                a = sym[k];
+                b = sym[k + 1];
+            }
+        }
+        if (best == INT32_MAX) break;
+        next.clear();
+        for (size_t k = 0; k < sym.size();) {
+            if (k + 1 < sym.size() && sym[k] == a && sym[k + 1] == b) { next.push_back(merged); k += 2; }
+            else { next.push_back(sym[k]); ++k; }
+        }
+        sym.swap(next);
+    }
+    ids.insert(ids.end(), sym.begin(), sym.end());
+}
+
 std::vector<int32_t> bpe_encode_plain(const mx_tokenizer *t, const char *text) {
     const size_t nb = strlen(text);
     const std::vector<uint32_t> cp = decode_utf8_lossy(reinterpret_cast<const unsigned char *>(text), nb);
     std::vector<int32_t> ids;
+    // words repeat (Zipf): each distinct pre-token of this text is merged once (the cache lives for the call: no shared state
+    // between the host threads of a batch)
+    std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> seen;  // word -> [begin, end) in `pieces`
+    std::vector<int32_t> pieces;
+    std::string bytes;
     for (const auto &pc : bpe_pre_tokenize(cp)) {
-        std::string bytes;
+        bytes.clear();
         for (size_t k = pc.first; k < pc.second; ++k) append_utf8(bytes, cp[k]);
-        bpe_word(t, bytes, ids);
+        auto it = seen.find(bytes);
+        if (it == seen.end()) {
+            const uint32_t b0 = (uint32_t)pieces.size();
+            if (t->bpe_ids) bpe_word_ids(t, bytes, pieces);
+            else bpe_word(t, bytes, pieces);
+            it = seen.emplace(bytes, std::make_pair(b0, (uint32_t)pieces.size())).first;
+        }
+        ids.insert(ids.end(), pieces.begin() + it->second.first, pieces.begin() + it->second.second);
     }
     return ids;
 }
@@ -541,15 +584,7 @@ std::string bpe_decode_ids(const mx_tokenizer *t, const int32_t *ids, int n, boo
         const int32_t id = ids[i];
         if (id < 0 || id >= (int32_t)t->vocab.size()) continue;
         if (skip_special && (id == t->pad || id == t->unk || id == t->cls || id == t->sep || id == t->mask)) continue;
-        const std::string &tok = t->vocab[id];
-        std::string mapped;
-        bool ok = true;
-        for (uint32_t c : decode_utf8_lossy(reinterpret_cast<const unsigned char *>(tok.data()), tok.size())) {
-            auto it = t->chr_byte.find(c);
-            if (it == t->chr_byte.end()) { ok = false; break; }
-            mapped.push_back((char)it->second);
-        }
-        bytes += ok ? mapped : tok;
+        bytes.append(t->dec_arena.data() + t->dec_off[(size_t)id], t->dec_off[(size_t)id + 1] - t->dec_off[(size_t)id]);
     }
     std::string out;
     for (uint32_t c : decode_utf8_lossy(reinterpret_cast<const unsigned char *>(bytes.data()), bytes.size())) append_utf8(out, c);
@@ -647,6 +682,39 @@ int finish_bpe(mx_tokenizer *t, std::istream &merges) {
         return fail(MX_EINVAL, "vocabulary lacks <s> / </s> / <pad>");
     need("<unk>", t->unk);
     need("<mask>", t->mask);
+    // the ByteLevel decoder's bytes of every token, once (a token with a character outside the byte alphabet stands for its own UTF-8)
+    t->dec_off.assign(1, 0u);
+    for (const std::string &tok : t->vocab) {
+        std::string mapped;
+        bool ok = true;
+        for (uint32_t c : decode_utf8_lossy(reinterpret_cast<const unsigned char *>(tok.data()), tok.size())) {
+            auto it = t->chr_byte.find(c);
+            if (it == t->chr_byte.end()) { ok = false; break; }
+            mapped.push_back((char)it->second);
+        }
+        t->dec_arena += ok ? mapped : tok;
+        t->dec_off.push_back((uint32_t)t->dec_arena.size());
+    }
+    t->bpe_ids = true;
+    for (int b = 0; b < 256 && t->bpe_ids; ++b) {
+        auto it = t->index.find(t->byte_chr[b]);
+        if (it == t->index.end()) t->bpe_ids = false;
+        else t->byte_id[b] = it->second;
+    }
+    for (const auto &m : t->merges) {
+        if (!t->bpe_ids) break;
+        const size_t sp = m.first.find(' ');
+        auto a = t->index.find(m.first.substr(0, sp)), b = t->index.find(m.first.substr(sp + 1));
+        auto ab = t->index.find(m.first.substr(0, sp) + m.first.substr(sp + 1));
+        if (a == t->index.end() || b == t->index.end() || ab == t->index.end() || m.first.find(' ', sp + 1) != std::string::npos) {
+            t->bpe_ids = false;
+            break;
+        }
+        t->pair_rank.emplace((uint64_t)(uint32_t)a->second << 32 | (uint32_t)b->second, std::make_pair(m.second, ab->second));
+    }
+    // two different strings must not share an id pair's product by accident: the id form is only used when ids and strings are
+    // in bijection for everything a merge can produce (vocab.json maps distinct strings to distinct ids by construction)
+    if (!t->bpe_ids) t->pair_rank.clear();
     return MX_OK;
 }
 
