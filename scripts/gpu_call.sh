@@ -1,12 +1,11 @@
 #!/bin/bash
 mkdir -p gpurun_out
-O=gpurun_out/r5_text_ingest.txt
+O=gpurun_out/r5_text_ingest_profile.txt
 : > $O
-nproc >> $O
-timeout 900 python -m pytest tests/test_cpp_host.py tests/test_pipeline_native_gpu.py tests/test_pretrained.py -m gpu -x -q 2>&1 | tail -5 >> $O
+timeout 300 python scripts/gpu_text_ingest_profile.py 50 >> $O 2>&1
 timeout 600 python -c "
 import json, bench
-print(json.dumps(bench.text_ingest_leg(200), indent=1))
-print(json.dumps(bench.text_ingest_leg(200, workers=32, cpu_too=False), indent=1))
+r = bench.text_ingest_leg(200, cpu_too=False); print(json.dumps({k: r[k] for k in ('value','windows_per_s','text_MBps','seconds','errors','query_finds_its_window')}))
+r = bench.text_ingest_leg(200, workers=16, cpu_too=False); print('16 workers', json.dumps({k: r[k] for k in ('value','windows_per_s','text_MBps','seconds','errors','query_finds_its_window')}))
 " >> $O 2>&1
 cat $O
