@@ -12,25 +12,36 @@ pytestmark = pytest.mark.gpu
 
 import os
 
-_CASES = [(384, 1), (100, 2), (1024, 3), (3, 4), (640, 5), (1536, 6)]
+_CASES = [(384, 1), (100, 2), (1024, 3), (3, 4), (640, 5), (1536, 6),
+          # negative seed = rows in a cone around one direction (what an encoder produces): the bf16 copy is centred when it is
+          # rebuilt (index.hip::build_filter_copy), appends extend it with the mean of the day it was built
+          (384, -7), (768, -8), (200, -9)]
 # MEMEX_TEST_SOAK=n: n more seeded sequences per width (a one-off soak run, not part of the default suite)
-_CASES += [(d, 100 + 10 * i + j) for i in range(int(os.environ.get("MEMEX_TEST_SOAK", "0"))) for j, d in enumerate((384, 256, 512, 768, 1024, 130))]
+_CASES += [(d, (100 + 10 * i + j) * (-1 if j % 2 else 1)) for i in range(int(os.environ.get("MEMEX_TEST_SOAK", "0")))
+           for j, d in enumerate((384, 256, 512, 768, 1024, 130))]
 
 
 @pytest.mark.parametrize("d,seed", _CASES)
 def test_random_operation_sequences(d, seed, oracle, lib_built, tmp_path):
     from memex_amd import _lib
     from memex_amd.index import FlatIndex
-    rng = np.random.default_rng(seed)
+    cone = seed < 0
+    rng = np.random.default_rng(abs(seed))
+    axis = rng.standard_normal(d).astype(np.float32)
+    axis /= np.linalg.norm(axis)
     rows = np.zeros((0, d), dtype=np.float32)
     kinds = ["i8", "bf16", False, True]
+    centred_seen = False
     idx = FlatIndex(d)
     try:
         for step in range(36):
             op = rng.choice(["add", "add", "add", "kind", "bad", "clear", "saveload", "grow"], p=[.3, .2, .1, .15, .08, .04, .08, .05])
             if op == "add" or rows.shape[0] == 0:
                 n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 200, 1000, 4097]))
-                X = (rng.standard_normal((n, d)) * rng.uniform(0.1, 10.0, (n, 1))).astype(np.float32)
+                X = rng.standard_normal((n, d))
+                if cone and rng.random() < 0.85:                   # (now and then a batch from outside the cone)
+                    X = axis + X * (rng.uniform(0.2, 1.5) / np.sqrt(d))
+                X = (X * rng.uniform(0.1, 10.0, (n, 1))).astype(np.float32)
                 if n > 2 and rng.random() < 0.3:
                     X[rng.integers(0, n)] = 0                      # a zero-norm row
                 if n > 40 and rng.random() < 0.3:
@@ -60,9 +71,15 @@ def test_random_operation_sequences(d, seed, oracle, lib_built, tmp_path):
             assert len(idx) == rows.shape[0]
             if rows.shape[0] == 0:
                 continue
+            if cone and step == 14 and rows.shape[0] >= 256:
+                idx.set_filter_copy("bf16")                        # rebuilt from the rows of the day: must come out centred
+                centred_seen = True
+                assert idx.stats().filter_centred == 1
             B = int(rng.choice([1, 5, 33, 130, 300, 512]))
             k = int(rng.choice([1, 10, 40]))
             Q = rng.standard_normal((B, d)).astype(np.float32)
+            if cone:
+                Q[::2] = axis + Q[::2] * (0.7 / np.sqrt(d))          # half of the queries from inside the cone
             Q[0] = rows[int(rng.integers(0, rows.shape[0]))] * 2.0   # a query that is a row (or a zero row: dist 0 to all)
             ids, sc, di, nf = idx.search(Q, k)
             oi, od, os_, onf = oracle.search(rows, Q, k)
@@ -70,6 +87,8 @@ def test_random_operation_sequences(d, seed, oracle, lib_built, tmp_path):
             np.testing.assert_array_equal(bits(di), bits(od))
             np.testing.assert_array_equal(bits(sc), bits(os_))
             np.testing.assert_array_equal(nf, onf)
-        assert idx.stats().fallback_queries == 0 or d == 3     # (3 dims: many exact ties -> the EXACT path is legitimate)
+        assert centred_seen or not cone
+        assert idx.stats().fallback_queries == 0 or d == 3 or cone  # (3 dims: many exact ties -> the EXACT path is legitimate;
+        #                                                             a cone of a few thousand rows may be denser than a certificate)
     finally:
         idx.close()
