@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-O=gpurun_out/r5_soak.txt
+O=gpurun_out/r5_cone_seq.txt
 : > $O
-MEMEX_TEST_SOAK=5 timeout 1500 python -m pytest tests/test_random_ops_gpu.py -m gpu -x -q 2>&1 | tail -8 >> $O
+timeout 600 python -m pytest tests/test_random_ops_gpu.py -m gpu -q -k "7 or 8 or 9" 2>&1 | tail -60 >> $O
 cat $O
