@@ -35,6 +35,7 @@
 //   1 = no DMA inside the loop (the ring keeps the prologue's tiles), 2 = no epilogue (accumulators kept alive),
 //   4 = no stagger between the wave rows, 8 = s_setprio 1 around the MFMA sections (measured slower: 306 against 281 us
 //   on the QK projection of a hidden-768 layer), 16 = no bias loads in the epilogue (a constant)
+// (bit 32: MFMA shape probe, 16x16x32 on the same operand traffic)
 #ifndef MX_PGEMM_ABLATE
 #define MX_PGEMM_ABLATE 0
 #endif
@@ -280,6 +281,17 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
         if (FM) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, c, 0, 0, 0);
         else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0);
     };
+#if MX_PGEMM_ABLATE & 32  /* scripts/gemm_ubench.hip: MFMA shape probe -- two k-steps' operand traffic on four v_mfma_f32_16x16x32_bf16 (values meaningless) */
+    auto mma2 = [&](const bf16x8 &w0, const bf16x8 &w1, const bf16x8 &a0, const bf16x8 &a1, f32x16 &c) __attribute__((always_inline)) {
+        typedef __attribute__((ext_vector_type(4))) float f32x4p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4p t = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+            t = __builtin_amdgcn_mfma_f32_16x16x32_bf16((q & 1) ? w1 : w0, (q >> 1) ? a1 : a0, t, 0, 0, 0);
+            c[4 * q] = t[0], c[4 * q + 1] = t[1], c[4 * q + 2] = t[2], c[4 * q + 3] = t[3];
+        }
+    };
+#endif
     auto section_end = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -354,11 +366,19 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
         reads_done();
         if (!lead_epi) section_end();
         prio(1);
+#if MX_PGEMM_ABLATE & 32
+#pragma unroll
+        for (int kp = 0; kp < 4; kp += 2) {
+            mma2(blo[kp], blo[kp + 1], af[0][kp], af[0][kp + 1], acc[0][0]);
+            mma2(blo[kp], blo[kp + 1], af[1][kp], af[1][kp + 1], acc[1][0]);
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             mma(blo[ks], af[0][ks], acc[0][0]);
             mma(blo[ks], af[1][ks], acc[1][0]);
         }
+#endif
         prio(0);
         section_end();
         // ---------------- phase 1: load B-hi; stage A-lo(g+2) ----------------
@@ -370,11 +390,19 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
         reads_done();
         section_end();
         prio(1);
+#if MX_PGEMM_ABLATE & 32
+#pragma unroll
+        for (int kp = 0; kp < 4; kp += 2) {
+            mma2(bhi[kp], bhi[kp + 1], af[0][kp], af[0][kp + 1], acc[0][1]);
+            mma2(bhi[kp], bhi[kp + 1], af[1][kp], af[1][kp + 1], acc[1][1]);
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             mma(bhi[ks], af[0][ks], acc[0][1]);
             mma(bhi[ks], af[1][ks], acc[1][1]);
         }
+#endif
         prio(0);
         section_end();
         // ---------------- phase 2: load A-hi; stage B-lo(g+2) ----------------
@@ -388,11 +416,19 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
         reads_done();
         section_end();
         prio(1);
+#if MX_PGEMM_ABLATE & 32
+#pragma unroll
+        for (int kp = 0; kp < 4; kp += 2) {
+            mma2(bhi[kp], bhi[kp + 1], af[0][kp], af[0][kp + 1], acc[2][1]);
+            mma2(bhi[kp], bhi[kp + 1], af[1][kp], af[1][kp + 1], acc[3][1]);
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             mma(bhi[ks], af[0][ks], acc[2][1]);
             mma(bhi[ks], af[1][ks], acc[3][1]);
         }
+#endif
         prio(0);
         section_end();
         // ---------------- phase 3: stage B-hi(g+2); everything of k-tile g+1 has landed ----------------
@@ -412,11 +448,19 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
         B1 ^= (uint32_t)kBuf;
         section_end();
         prio(1);
+#if MX_PGEMM_ABLATE & 32
+#pragma unroll
+        for (int kp = 0; kp < 4; kp += 2) {
+            mma2(blo[kp], blo[kp + 1], af[0][kp], af[0][kp + 1], acc[2][0]);
+            mma2(blo[kp], blo[kp + 1], af[1][kp], af[1][kp + 1], acc[3][0]);
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             mma(blo[ks], af[0][ks], acc[2][0]);
             mma(blo[ks], af[1][ks], acc[3][0]);
         }
+#endif
         prio(0);
         section_end();
         if (++c_kt == nk) {  // the tile is complete
