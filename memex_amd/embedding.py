@@ -261,13 +261,46 @@ class SentenceEmbedder:
             ready.put(e if isinstance(e, EmbeddingError) else SetupError(str(e)))
             return
         ready.put(None)
+        # Two stages, one thread each, a slot of one batch between them: while the GPU embeds batch i (a C call, no GIL) this
+        # thread segments and tokenises batch i+1 -- host work per document (segment + tokenise its windows) is about as long
+        # as its encoder pass, so the stages hide each other.  The reference's runner does both in turn per message (:101-109).
+        staged: "queue.Queue" = queue.Queue(maxsize=1)
+
+        def gpu_stage():
+            while True:
+                item = staged.get()
+                if item is None:
+                    return
+                work, flat, ids, lens = item
+                busy.set()
+                try:
+                    vecs = enc.encode(ids, lens)                                 # model.encode(&segments), :109
+                    if len(vecs) != len(flat):
+                        raise EncodingFailure("# of embeddings doesn't match # of segments")
+                    o = 0
+                    for reply, segs in work:
+                        reply.put([EmbeddingResult(content=s_, vector=v)
+                                   for s_, v in zip(segs, vecs[o:o + len(segs)])])
+                        o += len(segs)
+                except Exception as e:
+                    for reply, _ in work:
+                        reply.put(e)
+                finally:
+                    busy.clear()
+        busy = threading.Event()
+        gpu = threading.Thread(target=gpu_stage, daemon=True)
+        gpu.start()
         stop = False
         while not stop:
             msgs = [q.get()]
             # Requests that queued up while the previous batch was on the GPU are embedded together
             # (SURVEY section 8 f-2): one tokenizer call, one encoder call.  The reference's runner takes
             # one message per model.encode (:101-109); a row's embedding does not depend on its batch.
-            while len(msgs) < 64:
+            # With the GPU stage idle only half of what is waiting is taken: synchronous callers (the worker's five tasks) come
+            # back with their next document only after a reply, so two smaller batches keep both stages busy where one batch of
+            # everything would leave this stage waiting for the GPU and then the GPU waiting for this stage.
+            limit = 64 if (busy.is_set() or not staged.empty()) else max(1, (1 + q.qsize()) // 2)
+            while len(msgs) < limit:
                 try:
                     msgs.append(q.get_nowait())
                 except queue.Empty:
@@ -298,17 +331,13 @@ class SentenceEmbedder:
             try:
                 flat = [s_ for _, segs in work for s_ in segs]
                 ids, lens = tok.encode_batch(flat, cfg.max_seq_length)
-                vecs = enc.encode(ids, lens)                                     # model.encode(&segments), :109
-                if len(vecs) != len(flat):
-                    raise EncodingFailure("# of embeddings doesn't match # of segments")
-                o = 0
-                for reply, segs in work:
-                    reply.put([EmbeddingResult(content=s_, vector=v)
-                               for s_, v in zip(segs, vecs[o:o + len(segs)])])
-                    o += len(segs)
             except Exception as e:
                 for reply, _ in work:
                     reply.put(e)
+                continue
+            staged.put((work, flat, ids, lens))
+        staged.put(None)
+        gpu.join()
         enc.close()
 
     def _call(self, text: str, segment: bool):
