@@ -686,22 +686,84 @@ class SentenceEmbedder {
         }
         ready.set_value("");
         WhitespaceHashTokenizer tok{cfg.vocab};
+        // Two stages: this thread segments and tokenises batch i+1 while `gpu` has batch i in mx_encoder_encode (host work per
+        // document is about as long as its encoder pass).  A slot of one batch between them.
+        using Reply = std::shared_ptr<std::promise<std::vector<EmbeddingResult>>>;
+        struct Batch {
+            std::vector<std::pair<Reply, std::vector<std::string>>> work;
+            std::vector<int32_t> ids, lens;
+            int S = 0;
+            size_t rows = 0;
+            bool last = false;
+        };
+        std::mutex smu;
+        std::condition_variable scv;
+        std::unique_ptr<Batch> slot;
+        bool gpu_busy = false;
+        std::thread gpu([&] {
+            for (;;) {
+                std::unique_ptr<Batch> b;
+                {
+                    std::unique_lock<std::mutex> lk(smu);
+                    scv.wait(lk, [&] { return slot != nullptr; });
+                    b = std::move(slot);
+                    gpu_busy = true;
+                    scv.notify_all();
+                }
+                if (b->last) return;
+                try {
+                    std::vector<float> out(b->rows * (size_t)cfg.hidden);
+                    const int erc = mx_encoder_encode(enc, b->ids.data(), b->lens.data(), (int)b->rows, b->S, out.data());  // model.encode, :109
+                    if (erc != MX_OK) throw EmbeddingError(EmbeddingError::EncodingFailure, mx_last_error());
+                    size_t o = 0;
+                    for (auto &wk : b->work) {
+                        std::vector<EmbeddingResult> res;
+                        for (size_t i = 0; i < wk.second.size(); ++i, ++o)
+                            res.push_back({wk.second[i], std::vector<float>(out.begin() + o * cfg.hidden, out.begin() + (o + 1) * cfg.hidden)});
+                        wk.first->set_value(std::move(res));
+                    }
+                } catch (...) {
+                    for (auto &wk : b->work) {
+                        try {
+                            wk.first->set_exception(std::current_exception());
+                        } catch (const std::future_error &) {  // already answered before the failure
+                        }
+                    }
+                }
+                std::lock_guard<std::mutex> lk(smu);
+                gpu_busy = false;
+            }
+        });
+        auto hand_over = [&](std::unique_ptr<Batch> b) {
+            std::unique_lock<std::mutex> lk(smu);
+            scv.wait(lk, [&] { return slot == nullptr; });
+            slot = std::move(b);
+            scv.notify_all();
+        };
         bool stop = false;
         while (!stop) {
             // requests that queued up while the previous batch was on the GPU are embedded together
             // (the reference's runner takes one message per model.encode, :101-109; a row's embedding
-            // does not depend on its batch)
+            // does not depend on its batch).  With the GPU stage idle only half of what is waiting is taken:
+            // synchronous callers come back with their next document only after a reply, so two smaller
+            // batches keep both stages busy.
             std::vector<Msg> msgs;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return !q_.empty(); });
-                while (!q_.empty() && msgs.size() < 64) {
+                bool idle;
+                {
+                    std::lock_guard<std::mutex> slk(smu);  // (the GPU stage never takes mu_: no lock-order cycle)
+                    idle = !gpu_busy && slot == nullptr;
+                }
+                const size_t limit = idle ? std::max<size_t>(1, (q_.size() + 1) / 2) : 64;
+                while (!q_.empty() && msgs.size() < limit) {
                     msgs.push_back(std::move(q_.front()));
                     q_.pop_front();
                 }
                 cv_.notify_all();
             }
-            std::vector<std::pair<Msg *, std::vector<std::string>>> work;
+            auto batch = std::make_unique<Batch>();
             // the documents of the drained requests are segmented together (one host thread per document)
             std::vector<std::vector<std::string>> pre;
             std::vector<size_t> pre_of(msgs.size(), (size_t)-1);
@@ -722,39 +784,31 @@ class SentenceEmbedder {
                     continue;
                 }
                 try {
-                    if (m.segment && pre_of[i] < pre.size()) work.emplace_back(&m, std::move(pre[pre_of[i]]));
-                    else work.emplace_back(&m, m.segment ? segment_text(mc, m.text, native.get()) : std::vector<std::string>{m.text});  // :103-107
+                    if (m.segment && pre_of[i] < pre.size()) batch->work.emplace_back(m.reply, std::move(pre[pre_of[i]]));
+                    else batch->work.emplace_back(m.reply, m.segment ? segment_text(mc, m.text, native.get()) : std::vector<std::string>{m.text});  // :103-107
                 } catch (...) {
                     m.reply->set_exception(std::current_exception());
                 }
             }
-            if (work.empty()) continue;
+            if (batch->work.empty()) continue;
             try {
                 std::vector<std::string> flat;
-                for (auto &wk : work) flat.insert(flat.end(), wk.second.begin(), wk.second.end());
-                std::vector<int32_t> ids, lens;
-                int S = 0;
-                if (native) native->encode_batch(flat, max_seq_length, ids, lens, S);
-                else tok.encode_batch(flat, max_seq_length, ids, lens, S);
-                std::vector<float> out(flat.size() * (size_t)cfg.hidden);
-                rc = mx_encoder_encode(enc, ids.data(), lens.data(), (int)flat.size(), S, out.data());  // model.encode, :109
-                if (rc != MX_OK) throw EmbeddingError(EmbeddingError::EncodingFailure, mx_last_error());
-                size_t o = 0;
-                for (auto &wk : work) {
-                    std::vector<EmbeddingResult> res;
-                    for (size_t i = 0; i < wk.second.size(); ++i, ++o)
-                        res.push_back({wk.second[i], std::vector<float>(out.begin() + o * cfg.hidden, out.begin() + (o + 1) * cfg.hidden)});
-                    wk.first->reply->set_value(std::move(res));
-                }
+                for (auto &wk : batch->work) flat.insert(flat.end(), wk.second.begin(), wk.second.end());
+                if (native) native->encode_batch(flat, max_seq_length, batch->ids, batch->lens, batch->S);
+                else tok.encode_batch(flat, max_seq_length, batch->ids, batch->lens, batch->S);
+                batch->rows = flat.size();
             } catch (...) {
-                for (auto &wk : work) {
-                    try {
-                        wk.first->reply->set_exception(std::current_exception());
-                    } catch (const std::future_error &) {  // already answered before the failure
-                    }
-                }
+                for (auto &wk : batch->work) wk.first->set_exception(std::current_exception());
+                continue;
             }
+            hand_over(std::move(batch));
         }
+        {
+            auto fin = std::make_unique<Batch>();
+            fin->last = true;
+            hand_over(std::move(fin));
+        }
+        gpu.join();
         mx_encoder_destroy(enc);
     }
 };
