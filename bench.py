@@ -598,8 +598,15 @@ def enc_like_leg(rows: int, n_seg: int, batch: int, k: int, steps: int):
     out["scan_before_first_batch"] = kind0
     out["filter_demotions"] = int(first.filter_demotions + st.filter_demotions)
     out["first_batch"] = {"retry_queries": int(first.retry_queries), "fallback_queries": int(first.fallback_queries)}
+    # the answers on the (centred) filter copy against the library's all-f64 EXACT path, a few queries
+    from memex_amd import _lib
+    nq = min(4, batch)
+    e = SearchBuffers(nq, k)
+    idx.set_search_mode(_lib.MX_SEARCH_EXACT)
+    idx.search_device(q[:nq].contiguous(), k, e.ids, e.scores, e.dists, e.nf)
+    out["ids_equal_exact_path"] = bool(torch.equal(bufs.ids[:nq], e.ids)) and bool(torch.equal(bufs.dists[:nq], e.dists))
     idx.close()
-    del idx, vec, q, bufs, ids
+    del idx, vec, q, bufs, ids, e
     torch.cuda.empty_cache()
     return out
 
