@@ -13,7 +13,10 @@
 //   llm/embedding.rs:11-22 EmbeddingError / Result       EmbeddingError, EmbeddingResult
 //   llm/embedding.rs:58-73 ModelConfig                   ModelConfig (L12-v2, 256, 86)
 //   llm/embedding.rs:78-152 SentenceEmbedder             SentenceEmbedder::spawn/encode/encode_single
-//   llm/embedding.rs:155-198 segment_text                segment_text (stand-in tokenizer, see below)
+//   llm/embedding.rs:155-198 segment_text                segment_text (native Tokenizer; a whitespace stand-in without one)
+//   llm/embedding.rs:163-195 tokenizers crate calls      Tokenizer (mx_tokenizer_*: WordPiece / byte-level BPE)
+//   worker/tasks.rs:9-66    process_embeddings           process_embeddings (+ uuid5 / document_uuid / segment_uuid)
+//   api/.../handlers.rs:55-109 handle_search_docs        search_docs
 //
 // The reference's async fns are blocking calls here (the C ABI is synchronous); the Rust shim in
 // INTEGRATION.md wraps them in `async fn` again.
@@ -812,5 +815,96 @@ class SentenceEmbedder {
         mx_encoder_destroy(enc);
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The two callers of the hot path, as far as the path goes (no SQL, no HTTP): what the worker does with a document
+// (lib/worker/src/tasks.rs:9-66) and what the API does with a query (lib/api/src/endpoints/collections/handlers.rs:55-109).
+// Segment ids are the reference's own: RFC 4122 version-5 UUIDs over its NAMESPACE (lib/libmemex/src/lib.rs:6).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace detail {
+inline void sha1(const std::string &msg, uint8_t out[20]) {
+    uint32_t h[5] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u, 0xc3d2e1f0u};
+    std::string m = msg;
+    const uint64_t bits = (uint64_t)msg.size() * 8;
+    m.push_back((char)0x80);
+    while (m.size() % 64 != 56) m.push_back('\0');
+    for (int i = 7; i >= 0; --i) m.push_back((char)((bits >> (8 * i)) & 0xff));
+    auto rol = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+    for (size_t off = 0; off < m.size(); off += 64) {
+        uint32_t w[80];
+        for (int i = 0; i < 16; ++i)
+            w[i] = (uint32_t)(uint8_t)m[off + 4 * i] << 24 | (uint32_t)(uint8_t)m[off + 4 * i + 1] << 16 |
+                   (uint32_t)(uint8_t)m[off + 4 * i + 2] << 8 | (uint32_t)(uint8_t)m[off + 4 * i + 3];
+        for (int i = 16; i < 80; ++i) w[i] = rol(w[i - 3] ^ w[i - 8] ^ w[i - 14] ^ w[i - 16], 1);
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4];
+        for (int i = 0; i < 80; ++i) {
+            uint32_t f, k;
+            if (i < 20) f = (b & c) | (~b & d), k = 0x5a827999u;
+            else if (i < 40) f = b ^ c ^ d, k = 0x6ed9eba1u;
+            else if (i < 60) f = (b & c) | (b & d) | (c & d), k = 0x8f1bbcdcu;
+            else f = b ^ c ^ d, k = 0xca62c1d6u;
+            const uint32_t t = rol(a, 5) + f + e + k + w[i];
+            e = d, d = c, c = rol(b, 30), b = a, a = t;
+        }
+        h[0] += a, h[1] += b, h[2] += c, h[3] += d, h[4] += e;
+    }
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = (uint8_t)(h[i] >> (24 - 8 * j));
+}
+}  // namespace detail
+
+// Uuid::new_v5(namespace, name): SHA-1 over the namespace's 16 bytes and the name, version and variant bits set
+inline std::string uuid5(const std::string &namespace_uuid, const std::string &name) {
+    std::string bytes;
+    int hi = -1;
+    for (char c : namespace_uuid) {
+        if (c == '-') continue;
+        const int v = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
+        if (v < 0) throw std::invalid_argument("uuid5: bad namespace");
+        if (hi < 0) hi = v;
+        else bytes.push_back((char)(hi << 4 | v)), hi = -1;
+    }
+    if (bytes.size() != 16 || hi >= 0) throw std::invalid_argument("uuid5: bad namespace");
+    uint8_t d[20];
+    detail::sha1(bytes + name, d);
+    d[6] = (uint8_t)((d[6] & 0x0f) | 0x50);
+    d[8] = (uint8_t)((d[8] & 0x3f) | 0x80);
+    static const char *hex = "0123456789abcdef";
+    std::string out;
+    for (int i = 0; i < 16; ++i) {
+        if (i == 4 || i == 6 || i == 8 || i == 10) out.push_back('-');
+        out.push_back(hex[d[i] >> 4]);
+        out.push_back(hex[d[i] & 15]);
+    }
+    return out;
+}
+
+inline const std::string &memex_namespace() {  // lib/libmemex/src/lib.rs:6
+    static const std::string ns = "5fdfe40a-de2c-11ed-bfa7-00155deae876";
+    return ns;
+}
+// db/document.rs:74: Uuid::new_v5(&NAMESPACE, task.id.to_string().as_bytes())
+inline std::string document_uuid(int64_t task_id) { return uuid5(memex_namespace(), std::to_string(task_id)); }
+// tasks.rs:36-40: Uuid::new_v5(&NAMESPACE, format!("{doc_uuid}-{idx}").as_bytes())
+inline std::string segment_uuid(const std::string &doc_uuid, size_t idx) { return uuid5(memex_namespace(), doc_uuid + "-" + std::to_string(idx)); }
+
+// tasks.rs:9-66 without the SQL: embedder.encode(content) -> one VectorData per window -> client.add_vectors.  Returns the
+// VectorData the reference also writes to its `embeddings` table; a failing add_vectors is the caller's to log (it throws here).
+inline std::vector<VectorData> process_embeddings(VectorStorage &client, SentenceEmbedder &embedder, int64_t task_id, const std::string &content) {
+    const std::vector<EmbeddingResult> embeddings = embedder.encode(content);  // :19
+    const std::string doc = document_uuid(task_id);                            // :28
+    std::vector<VectorData> vectors;
+    for (size_t idx = 0; idx < embeddings.size(); ++idx)                       // :34-56
+        vectors.push_back(VectorData{segment_uuid(doc, idx), doc, embeddings[idx].content, embeddings[idx].vector, idx});
+    client.add_vectors(vectors);                                               // :59
+    return vectors;
+}
+
+// handlers.rs:72-85: embed the query, search; std::invalid_argument("Invalid query") where the handler rejects (:74-78)
+inline std::vector<VectorSearchResult> search_docs(VectorStorage &client, SentenceEmbedder &embedder, const std::string &query, size_t limit = 10) {
+    const std::optional<EmbeddingResult> res = embedder.encode_single(query);
+    if (!res) throw std::invalid_argument("Invalid query");
+    return client.search(res->vector, limit);
+}
 
 }  // namespace memex

@@ -133,7 +133,7 @@ static void test_per_request_handles(const std::string &tmp) {
     HipFlatStore::evict_resident();
 }
 
-static void test_embedder_actor() {  // embedding.rs:78-152 with a seeded 1-layer MiniLM-shaped encoder
+static void test_embedder_actor(const std::string &g_tmp) {  // embedding.rs:78-152 with a seeded 1-layer MiniLM-shaped encoder
     mx_encoder_cfg cfg{1, 384, 12, 1536, 30522, 512, 2, 1e-12f, MX_POOL_MEAN, 1};
     const size_t n = mx_encoder_weight_bytes(&cfg) / sizeof(float);
     std::vector<float> w(n);
@@ -199,6 +199,24 @@ static void test_embedder_actor() {  // embedding.rs:78-152 with a seeded 1-laye
             CHECK(dot > 1.0 - 1e-4);  // a row's embedding does not depend on its batch (pass regimes: include/memex_hip.h)
         }
     }
+    // the two callers of the path: tasks.rs:9-66 (document -> named segments -> add_vectors) and handlers.rs:55-109
+    // (query -> encode_single -> search); ids are the reference's v5 UUIDs
+    {
+        auto store = get_vector_storage("hip://" + g_tmp + "/callers", "docs");
+        std::vector<std::vector<VectorData>> written;
+        for (int d = 0; d < 3; ++d) written.push_back(process_embeddings(store, *emb2, 100 + d, docs[d]));
+        for (int d = 0; d < 3; ++d) {
+            CHECK(written[d].size() == alone[d].size());
+            const std::string doc = document_uuid(100 + d);
+            for (size_t i = 0; i < written[d].size(); ++i)
+                CHECK(written[d][i]._id == segment_uuid(doc, i) && written[d][i].document_id == doc && written[d][i].segment_id == i &&
+                      written[d][i].text == alone[d][i].content);
+        }
+        // the text of a stored window finds that window
+        auto hits = search_docs(store, *emb2, written[1][1].text, 3);
+        CHECK(hits.size() == 3 && hits[0].first == written[1][1]._id && hits[0].second > 0.999f);
+        store.delete_collection();
+    }
     emb2->shutdown();
     th2.join();
 }
@@ -211,7 +229,7 @@ int main(int argc, char **argv) {
     test_delete_all(tmp);
     test_factory_and_errors(tmp);
     test_per_request_handles(tmp);
-    test_embedder_actor();
+    test_embedder_actor(tmp);
     std::printf("OK 6 tests\n");
     return 0;
 }

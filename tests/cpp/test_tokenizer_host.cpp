@@ -44,6 +44,12 @@ int main(int argc, char **argv) {
         } catch (const memex::EmbeddingError &e) {
             refused = e.kind() == memex::EmbeddingError::SetupError;
         }
+        // the reference's ids (RFC 4122 v5 over lib.rs:6's NAMESPACE): printed for the Python side to compare with uuid.uuid5
+        for (long task : {0L, 1L, 42L, 123456789L}) {
+            const std::string doc = memex::document_uuid(task);
+            std::printf("UUID %ld %s %s %s\n", task, doc.c_str(), memex::segment_uuid(doc, 0).c_str(), memex::segment_uuid(doc, 71).c_str());
+        }
+        std::printf("UUID5 %s\n", memex::uuid5("6ba7b810-9dad-11d1-80b4-00c04fd430c8", "www.example.org").c_str());
         std::printf(refused ? "OK tokenizer host\n" : "missing vocabulary not refused\n");
         return refused ? 0 : 5;
     } catch (const std::exception &e) {

@@ -87,6 +87,13 @@ def test_cpp_tokenizer_class_matches_the_tokenizers_package(tmp_path, lib_built)
         assert int(ln[6], 16) == fnv(hf.decode(ids, skip_special_tokens=True).encode("utf-8"))
         assert int(ln[8]) == len(wins) and int(ln[9], 16) == hw
         total += min(len(ids), 126) + 2
+    import uuid
+    from memex_amd import tasks
+    for ln in (l_.split() for l_ in r.stdout.splitlines() if l_.startswith("UUID ")):    # tasks.rs:36-40, db/document.rs:74
+        doc = tasks.document_uuid(int(ln[1]))
+        assert ln[2:] == [doc, tasks.segment_uuid(doc, 0), tasks.segment_uuid(doc, 71)]
+    known = [l_.split()[1] for l_ in r.stdout.splitlines() if l_.startswith("UUID5 ")]
+    assert known == [str(uuid.uuid5(uuid.NAMESPACE_DNS, "www.example.org"))]
     batch = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("BATCH")][0]
     assert int(batch[2]) == 128 and int(batch[4]) == len(docs) and int(batch[6]) == total
 
