@@ -10,7 +10,10 @@
  * Conventions
  *   - every function returns MX_OK (0) or a negative mx_status; mx_last_error() is thread-local.
  *   - nothing aborts or throws across this boundary (contrast: the reference panics at
- *     storage/local.rs:83 and :31).
+ *     storage/local.rs:83 and :31): every entry point is a function-try-block, a C++ exception inside
+ *     the library (std::bad_alloc -> MX_ENOMEM, anything else -> MX_EDEVICE "internal error: ...")
+ *     comes back as a status code; helper threads and the leader of a combined search hand their
+ *     exceptions to the callers they serve the same way.
  *   - the caller owns every input buffer (copied/consumed before return) and every output buffer.
  *   - handles are safe to use from several threads; calls on one handle are serialised inside.
  *   - "_device" variants take pointers into the HBM of the handle's device (for callers that keep

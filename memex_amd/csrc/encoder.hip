@@ -430,7 +430,7 @@ size_t mx_encoder_weight_bytes(const mx_encoder_cfg *c) {
     return n * sizeof(float);
 }
 
-int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nbytes, int device, mx_encoder **out) {
+int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nbytes, int device, mx_encoder **out) try {
     if (!out) return fail(MX_EINVAL, "out is null");
     *out = nullptr;
     int rc = check_cfg(cfg);
@@ -547,6 +547,8 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
 #undef MX_TRY
     *out = e;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 static void destroy_impl(mx_encoder *e) {
@@ -585,7 +587,7 @@ void mx_encoder_destroy(mx_encoder *e) {
 // open of `key` uploads the weights, later opens return the SAME resident encoder (ref-counted; calls
 // on it are serialised inside).  weights may be NULL when the key is expected to be resident.
 int mx_encoder_open(const char *key, const mx_encoder_cfg *cfg, const void *weights, size_t nbytes, int device,
-                    mx_encoder **out) {
+                    mx_encoder **out) try {
     if (!out) return fail(MX_EINVAL, "out is null");
     *out = nullptr;
     const std::string k = key ? key : "";
@@ -608,15 +610,19 @@ int mx_encoder_open(const char *key, const mx_encoder_cfg *cfg, const void *weig
     g_enc_registry[k] = e;
     *out = e;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_encoder_wait_stream(mx_encoder *e, void *stream) {
+int mx_encoder_wait_stream(mx_encoder *e, void *stream) try {
     if (!e) return fail(MX_EINVAL, "null encoder");
     std::lock_guard<std::mutex> lk(e->mu);
     DeviceGuard g(e->device);
     MX_HIP(hipEventRecord(e->ev_wait, static_cast<hipStream_t>(stream)));
     MX_HIP(hipStreamWaitEvent(e->stream, e->ev_wait, 0));
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 static int check_call(mx_encoder *e, const void *ids, const void *lens, int B, int S, const void *out) {
@@ -629,7 +635,7 @@ static int check_call(mx_encoder *e, const void *ids, const void *lens, int B, i
     return MX_OK;
 }
 
-int mx_encoder_encode_device(mx_encoder *e, const int32_t *d_ids, const int32_t *d_lens, int B, int S, float *d_out) {
+int mx_encoder_encode_device(mx_encoder *e, const int32_t *d_ids, const int32_t *d_lens, int B, int S, float *d_out) try {
     int rc = check_call(e, d_ids, d_lens, B, S, d_out);
     if (rc != MX_OK || B == 0) return rc;
     std::lock_guard<std::mutex> lk(e->mu);
@@ -641,9 +647,11 @@ int mx_encoder_encode_device(mx_encoder *e, const int32_t *d_ids, const int32_t 
     MX_HIP(hipMemcpyAsync(h_lens.data(), d_lens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     MX_HIP(hipStreamSynchronize(e->stream));
     return encode_all(e, d_ids, h_lens.data(), d_lens, B, S, d_out);
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_encoder_encode(mx_encoder *e, const int32_t *ids, const int32_t *lens, int B, int S, float *out) {
+int mx_encoder_encode(mx_encoder *e, const int32_t *ids, const int32_t *lens, int B, int S, float *out) try {
     int rc = check_call(e, ids, lens, B, S, out);
     if (rc != MX_OK || B == 0) return rc;
     std::lock_guard<std::mutex> lk(e->mu);
@@ -675,27 +683,35 @@ int mx_encoder_encode(mx_encoder *e, const int32_t *ids, const int32_t *lens, in
     if (rc != MX_OK) return rc;
     MX_HIP(hipMemcpy(out, e->out_dev, (size_t)B * e->cfg.hidden * sizeof(float), hipMemcpyDeviceToHost));
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_encoder_set_profiling(mx_encoder *e, int on) {
+int mx_encoder_set_profiling(mx_encoder *e, int on) try {
     if (!e) return fail(MX_EINVAL, "null encoder");
     std::lock_guard<std::mutex> lk(e->mu);
     e->profiling = on != 0;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_encoder_get_stats(mx_encoder *e, mx_encoder_stats *out) {
+int mx_encoder_get_stats(mx_encoder *e, mx_encoder_stats *out) try {
     if (!e || !out) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(e->mu);
     *out = e->stats;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_encoder_reset_stats(mx_encoder *e) {
+int mx_encoder_reset_stats(mx_encoder *e) try {
     if (!e) return fail(MX_EINVAL, "null encoder");
     std::lock_guard<std::mutex> lk(e->mu);
     e->stats = mx_encoder_stats{};
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 }  // extern "C"

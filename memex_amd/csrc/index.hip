@@ -1253,7 +1253,11 @@ int composite_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_i
             }
             return MX_OK;
         };
-        rcs[g] = run();
+        try {  // (a helper thread of the pool: an exception must not leave it)
+            rcs[g] = run();
+        } catch (...) {
+            rcs[g] = guard_exception();
+        }
         if (rcs[g] != MX_OK) errs[g] = last_error_slot();
     };
     // the query batch must be complete on shards[0]'s stream before other devices read it
@@ -1600,7 +1604,7 @@ const char *mx_last_error(void) { return last_error_slot().c_str(); }
 const char *mx_version(void) { return "memex-hip 0.5.0 (gfx950)"; }
 size_t mx_index_stats_size(void) { return sizeof(mx_index_stats); }
 
-int mx_device_count(int *n) {
+int mx_device_count(int *n) try {
     if (!n) return fail(MX_EINVAL, "null argument");
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
@@ -1610,9 +1614,11 @@ int mx_device_count(int *n) {
     }
     *n = c;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_open(const char *key, int dim, int device, mx_index **out) {
+int mx_index_open(const char *key, int dim, int device, mx_index **out) try {
     if (!out) return fail(MX_EINVAL, "out is null");
     *out = nullptr;
     if (dim < 1 || dim > (1 << 16)) return fail(MX_EINVAL, "dim %d out of range", dim);
@@ -1636,9 +1642,11 @@ int mx_index_open(const char *key, int dim, int device, mx_index **out) {
     if (!k.empty()) g_registry[k] = raw;
     *out = raw;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_open_sharded(const char *key, int dim, int n_dev, const int *devices, uint64_t block_rows, mx_index **out) {
+int mx_index_open_sharded(const char *key, int dim, int n_dev, const int *devices, uint64_t block_rows, mx_index **out) try {
     if (!out) return fail(MX_EINVAL, "out is null");
     *out = nullptr;
     if (dim < 1 || dim > (1 << 16)) return fail(MX_EINVAL, "dim %d out of range", dim);
@@ -1743,14 +1751,18 @@ int mx_index_open_sharded(const char *key, int dim, int n_dev, const int *device
     if (!k.empty()) g_registry[k] = raw;
     *out = raw;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 // how the shards of `idx` exchange their top-k blocks: 0 = not sharded, 1 = copies into a slot per shard on
 // devices[0] (peer-to-peer between devices), 2 = RCCL all-gather
-int mx_index_exchange(mx_index *idx, int *kind) {
+int mx_index_exchange(mx_index *idx, int *kind) try {
     if (!idx || !kind) return fail(MX_EINVAL, "null argument");
     *kind = !idx->composite() ? 0 : (idx->use_rccl ? 2 : 1);
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 void mx_index_close(mx_index *idx) {
@@ -1763,23 +1775,29 @@ void mx_index_close(mx_index *idx) {
     free_index(idx);
 }
 
-int mx_index_dim(mx_index *idx, int *dim) {
+int mx_index_dim(mx_index *idx, int *dim) try {
     if (!idx || !dim) return fail(MX_EINVAL, "null argument");
     *dim = idx->dim;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_n_shards(mx_index *idx, int *n) {
+int mx_index_n_shards(mx_index *idx, int *n) try {
     if (!idx || !n) return fail(MX_EINVAL, "null argument");
     *n = idx->composite() ? (int)idx->shards.size() : 1;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_size(mx_index *idx, uint64_t *n) {
+int mx_index_size(mx_index *idx, uint64_t *n) try {
     if (!idx || !n) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     *n = rows_of(idx);
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 static int reserve_locked(mx_index *idx, uint64_t rows) {
@@ -1798,21 +1816,25 @@ static int reserve_locked(mx_index *idx, uint64_t rows) {
     return ensure_capacity(idx, rows);
 }
 
-int mx_index_reserve(mx_index *idx, uint64_t rows) {
+int mx_index_reserve(mx_index *idx, uint64_t rows) try {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
     return reserve_locked(idx, rows);
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_set_id_offset(mx_index *idx, uint64_t off) {
+int mx_index_set_id_offset(mx_index *idx, uint64_t off) try {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->idmap.id_offset = off;
     for (mx_index *sh : idx->shards) sh->idmap.id_offset = off;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_wait_stream(mx_index *idx, void *stream) {
+int mx_index_wait_stream(mx_index *idx, void *stream) try {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
     mx_index *t = idx->composite() ? idx->shards[0] : idx;
@@ -1824,9 +1846,11 @@ int mx_index_wait_stream(mx_index *idx, void *stream) {
     MX_HIP(hipEventRecord(t->ev_wait, static_cast<hipStream_t>(stream)));
     MX_HIP(hipStreamWaitEvent(t->stream, t->ev_wait, 0));
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_add_device(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *first_id) {
+int mx_index_add_device(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *first_id) try {
     if (!idx || (!d_rows && n)) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     if (idx->composite()) {
@@ -1838,31 +1862,39 @@ int mx_index_add_device(mx_index *idx, const float *d_rows, uint64_t n, uint64_t
     }
     DeviceGuard g(idx->device);
     return add_device_locked(idx, d_rows, n, first_id);
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_add(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_id) {
+int mx_index_add(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_id) try {
     if (!idx || (!rows && n)) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     return add_host_locked(idx, rows, n, first_id);
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_clear(mx_index *idx) {
+int mx_index_clear(mx_index *idx) try {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
     return clear_locked(idx);
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_set_search_mode(mx_index *idx, int mode) {
+int mx_index_set_search_mode(mx_index *idx, int mode) try {
     if (!idx) return fail(MX_EINVAL, "null index");
     if (mode != MX_SEARCH_AUTO && mode != MX_SEARCH_EXACT) return fail(MX_EINVAL, "unknown search mode %d", mode);
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->mode = mode;
     for (mx_index *sh : idx->shards) sh->mode = mode;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 int mx_index_search_device(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids, float *d_scores,
-                           float *d_dists, int32_t *d_nfound) {
+                           float *d_dists, int32_t *d_nfound) try {
     if (!idx) return fail(MX_ESEARCH, "null index");
     if (B < 0 || k < 0) return fail(MX_EINVAL, "negative batch or k");
     if (B == 0) return MX_OK;
@@ -1877,6 +1909,8 @@ int mx_index_search_device(mx_index *idx, const float *d_q, int B, int k, uint64
         if (rc != MX_OK) return rc;
     }
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 namespace {
@@ -1931,7 +1965,7 @@ int run_combined(mx_index *idx, const std::vector<SearchReq *> &batch) {
 // own request is done, then hands over.  A lone caller runs immediately (no timer, no added
 // latency); under load the batch is whatever queued up while the previous pass was on the GPU.
 int mx_index_search(mx_index *idx, const float *q, int B, int k, uint64_t *ids, float *scores, float *dists,
-                    int32_t *n_found) {
+                    int32_t *n_found) try {
     if (!idx) return fail(MX_ESEARCH, "null index");
     if (B < 0 || k < 0) return fail(MX_EINVAL, "negative batch or k");
     if (B == 0) return MX_OK;
@@ -1974,7 +2008,12 @@ int mx_index_search(mx_index *idx, const float *q, int B, int k, uint64_t *ids, 
                 }
             }
             ql.unlock();
-            const int rc = run_combined(idx, batch);
+            int rc;
+            try {  // the leader answers for the others: an exception must reach them as an error code, not leave them waiting
+                rc = run_combined(idx, batch);
+            } catch (...) {
+                rc = guard_exception();
+            }
             const std::string err = rc == MX_OK ? std::string() : last_error_slot();
             ql.lock();
             for (SearchReq *r : batch) {
@@ -1990,9 +2029,11 @@ int mx_index_search(mx_index *idx, const float *q, int B, int k, uint64_t *ids, 
     ql.unlock();
     if (req.rc != MX_OK) last_error_slot() = req.err;  // the leader's message, in the caller's thread
     return req.rc;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_set_filter_copy(mx_index *idx, int on) {
+int mx_index_set_filter_copy(mx_index *idx, int on) try {
     if (!idx) return fail(MX_EINVAL, "null index");
     if (on < 0 || on > 3) return fail(MX_EINVAL, "filter copy: 0 = none, 1 = kind chosen by the library, 2 = int8, 3 = bf16 (got %d)", on);
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -2032,9 +2073,11 @@ int mx_index_set_filter_copy(mx_index *idx, int on) {
     for (double &w : idx->wait_ema_us) w = 0.0;
     if (idx->xh || idx->cap == 0 || idx->kc > kMaxKC16) return MX_OK;  // present, or built with the first rows
     return build_filter_copy(idx, i8);
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_set_corpus_mode(mx_index *idx, int mode) {
+int mx_index_set_corpus_mode(mx_index *idx, int mode) try {
     if (!idx) return fail(MX_EINVAL, "null index");
     if (mode != MX_CORPUS_F32 && mode != MX_CORPUS_BF16) return fail(MX_EINVAL, "unknown corpus mode %d", mode);
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -2060,9 +2103,11 @@ int mx_index_set_corpus_mode(mx_index *idx, int mode) {
     idx->compressed = mode == MX_CORPUS_BF16;
     idx->want_filter = true;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_get_rows(mx_index *idx, uint64_t first_row, uint64_t n, float *out) {
+int mx_index_get_rows(mx_index *idx, uint64_t first_row, uint64_t n, float *out) try {
     if (!idx || (!out && n)) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     if (first_row + n > rows_of(idx)) return fail(MX_EINVAL, "rows [%llu, %llu) outside the index", (unsigned long long)first_row,
@@ -2070,17 +2115,21 @@ int mx_index_get_rows(mx_index *idx, uint64_t first_row, uint64_t n, float *out)
     if (n == 0) return MX_OK;
     std::vector<float> tmp;
     return fetch_rows(idx, first_row, n, out, tmp);
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_set_profiling(mx_index *idx, int on) {
+int mx_index_set_profiling(mx_index *idx, int on) try {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->profiling = on != 0;
     for (mx_index *sh : idx->shards) sh->profiling = on != 0;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
+int mx_index_get_stats(mx_index *idx, mx_index_stats *out) try {
     if (!idx || !out) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     if (idx->composite()) {
@@ -2125,9 +2174,11 @@ int mx_index_get_stats(mx_index *idx, mx_index_stats *out) {
     idx->stats.filter_centred = idx->centred && idx->xh && !idx->filter_i8 ? 1u : 0u;
     *out = idx->stats;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_reset_stats(mx_index *idx) {
+int mx_index_reset_stats(mx_index *idx) try {
     if (!idx) return fail(MX_EINVAL, "null index");
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->stats = mx_index_stats{};
@@ -2137,6 +2188,8 @@ int mx_index_reset_stats(mx_index *idx) {
         (void)hipMemset(idx->s.max_err, 0, sizeof(float));
     }
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 // ---- persistence (replaces hnsw file_dump / load_hnsw, local.rs:115-165) ----------------------
@@ -2144,7 +2197,7 @@ int mx_index_reset_stats(mx_index *idx) {
 // order: the file does not depend on how many devices hold the index).  The reference saves after
 // EVERY insert (local.rs:67); to make that affordable a save into the directory this handle last
 // saved to / loaded from APPENDS the new rows and patches the header instead of rewriting the file.
-int mx_index_save(mx_index *idx, const char *dir) {
+int mx_index_save(mx_index *idx, const char *dir) try {
     if (!idx || !dir) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     if (mkdir_p(dir) != 0) return fail(MX_EIO, "cannot create directory %s", dir);
@@ -2191,9 +2244,11 @@ int mx_index_save(mx_index *idx, const char *dir) {
     }
     remember_disk(idx, dir, n);
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_load(mx_index *idx, const char *dir) {
+int mx_index_load(mx_index *idx, const char *dir) try {
     if (!idx || !dir) return fail(MX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     const std::string path = store_file(dir);
@@ -2298,16 +2353,20 @@ int mx_index_load(mx_index *idx, const char *dir) {
     }
     remember_disk(idx, dir, n);
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_has_store(const char *dir, int *exists) {
+int mx_index_has_store(const char *dir, int *exists) try {
     if (!dir || !exists) return fail(MX_EINVAL, "null argument");
     struct stat sb;
     *exists = stat(store_file(dir).c_str(), &sb) == 0 ? 1 : 0;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_store_info(const char *dir, int *dim, uint64_t *n_rows) {
+int mx_index_store_info(const char *dir, int *dim, uint64_t *n_rows) try {
     if (!dir || !dim || !n_rows) return fail(MX_EINVAL, "null argument");
     FILE *f = fopen(store_file(dir).c_str(), "rb");
     if (!f) return fail(MX_EIO, "cannot open %s", store_file(dir).c_str());
@@ -2321,18 +2380,22 @@ int mx_index_store_info(const char *dir, int *dim, uint64_t *n_rows) {
     *dim = (int)hdr[0];
     *n_rows = n;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_index_remove_files(const char *dir) {
+int mx_index_remove_files(const char *dir) try {
     if (!dir) return fail(MX_EINVAL, "null argument");
     const std::string p = store_file(dir);
     struct stat sb;
     if (stat(p.c_str(), &sb) == 0 && unlink(p.c_str()) != 0) return fail(MX_EIO, "cannot remove %s", p.c_str());
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 int mx_topk_merge_device(int device, const uint64_t *d_ids, const float *d_dists, int G, int B, int k,
-                         uint64_t *d_out_ids, float *d_out_dists, float *d_out_scores) {
+                         uint64_t *d_out_ids, float *d_out_dists, float *d_out_scores) try {
     if (G < 1 || B < 0 || k < 0) return fail(MX_EINVAL, "bad merge shape");
     if (B == 0 || k == 0) return MX_OK;
     if (!d_ids || !d_dists || !d_out_ids || !d_out_dists) return fail(MX_EINVAL, "null argument");
@@ -2342,10 +2405,12 @@ int mx_topk_merge_device(int device, const uint64_t *d_ids, const float *d_dists
                         G, B, k, d_out_ids, d_out_dists, d_out_scores));
     MX_HIP(hipStreamSynchronize(hipStreamPerThread));
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 int mx_topk_merge_packed_device(int device, const void *d_packed, int G, int B, int k, uint64_t *d_out_ids,
-                                float *d_out_dists, float *d_out_scores) {
+                                float *d_out_dists, float *d_out_scores) try {
     if (G < 1 || B < 0 || k < 0) return fail(MX_EINVAL, "bad merge shape");
     if (B == 0 || k == 0) return MX_OK;
     if (!d_packed || !d_out_ids || !d_out_dists) return fail(MX_EINVAL, "null argument");
@@ -2356,10 +2421,12 @@ int mx_topk_merge_packed_device(int device, const void *d_packed, int G, int B, 
                         d_out_ids, d_out_dists, d_out_scores));
     MX_HIP(hipStreamSynchronize(hipStreamPerThread));
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 int mx_topk_merge_packed_async(int device, void *hip_stream, const void *d_packed, int G, int B, int k, uint64_t *d_out_ids,
-                               float *d_out_dists, float *d_out_scores) {
+                               float *d_out_dists, float *d_out_scores) try {
     if (G < 1 || B < 0 || k < 0) return fail(MX_EINVAL, "bad merge shape");
     if (B == 0 || k == 0) return MX_OK;
     if (!d_packed || !d_out_ids || !d_out_dists) return fail(MX_EINVAL, "null argument");
@@ -2369,6 +2436,8 @@ int mx_topk_merge_packed_async(int device, void *hip_stream, const void *d_packe
     MX_HIP(launch_merge(static_cast<hipStream_t>(hip_stream), d_packed, blk, static_cast<const char *>(d_packed) + ids_bytes, blk, G,
                         B, k, d_out_ids, d_out_dists, d_out_scores));
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 }  // extern "C"

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
+#include <exception>
+#include <new>
 #include <string>
 
 #include "../../include/memex_hip.h"
@@ -25,6 +27,20 @@ inline int fail(int code, const char *fmt, ...) {
     va_end(ap);
     last_error_slot() = buf;
     return code;
+}
+
+// The C ABI never lets a C++ exception cross into the caller (a Rust or ctypes frame cannot unwind it): every `int mx_*`
+// entry point is a function-try-block that ends in `catch (...) { return guard_exception(); }`.
+inline int guard_exception() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail(MX_ENOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MX_EDEVICE, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(MX_EDEVICE, "internal error");
+    }
 }
 
 #define MX_HIP(call)                                                                              \

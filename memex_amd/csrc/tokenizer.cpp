@@ -27,6 +27,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -760,7 +761,7 @@ int parse_vocab(mx_tokenizer *t, std::istream &in) {
 
 extern "C" {
 
-int mx_tokenizer_create(const char *vocab_path, int lowercase, mx_tokenizer **out) {
+int mx_tokenizer_create(const char *vocab_path, int lowercase, mx_tokenizer **out) try {
     if (!vocab_path || !out) return fail(MX_EINVAL, "null argument");
     *out = nullptr;
     std::ifstream f(vocab_path);
@@ -771,9 +772,11 @@ int mx_tokenizer_create(const char *vocab_path, int lowercase, mx_tokenizer **ou
     if (rc != MX_OK) { delete t; return rc; }
     *out = t;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_tokenizer_create_from_memory(const char *vocab, size_t nbytes, int lowercase, mx_tokenizer **out) {
+int mx_tokenizer_create_from_memory(const char *vocab, size_t nbytes, int lowercase, mx_tokenizer **out) try {
     if (!vocab || !out) return fail(MX_EINVAL, "null argument");
     *out = nullptr;
     std::istringstream in(std::string(vocab, nbytes));
@@ -783,10 +786,12 @@ int mx_tokenizer_create_from_memory(const char *vocab, size_t nbytes, int lowerc
     if (rc != MX_OK) { delete t; return rc; }
     *out = t;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 // Byte-level BPE (RoBERTa family: all-distilroberta-v1, embedding.rs:29,159): vocab.json + merges.txt as the checkpoints ship them
-int mx_tokenizer_create_bpe_from_memory(const char *vocab_json, size_t n_vocab, const char *merges, size_t n_merges, mx_tokenizer **out) {
+int mx_tokenizer_create_bpe_from_memory(const char *vocab_json, size_t n_vocab, const char *merges, size_t n_merges, mx_tokenizer **out) try {
     if (!vocab_json || !merges || !out) return fail(MX_EINVAL, "null argument");
     *out = nullptr;
     mx_tokenizer *t = new mx_tokenizer();
@@ -798,9 +803,11 @@ int mx_tokenizer_create_bpe_from_memory(const char *vocab_json, size_t n_vocab, 
     if (rc != MX_OK) { delete t; return rc; }
     *out = t;
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_tokenizer_create_bpe(const char *vocab_json_path, const char *merges_path, mx_tokenizer **out) {
+int mx_tokenizer_create_bpe(const char *vocab_json_path, const char *merges_path, mx_tokenizer **out) try {
     if (!vocab_json_path || !merges_path || !out) return fail(MX_EINVAL, "null argument");
     *out = nullptr;
     std::ifstream fv(vocab_json_path, std::ios::binary), fm(merges_path, std::ios::binary);
@@ -811,17 +818,21 @@ int mx_tokenizer_create_bpe(const char *vocab_json_path, const char *merges_path
     sm << fm.rdbuf();
     const std::string v = sv.str(), m = sm.str();
     return mx_tokenizer_create_bpe_from_memory(v.data(), v.size(), m.data(), m.size(), out);
+} catch (...) {
+    return guard_exception();
 }
 
 void mx_tokenizer_destroy(mx_tokenizer *t) { delete t; }
 
-int mx_tokenizer_vocab_size(mx_tokenizer *t, int *n) {
+int mx_tokenizer_vocab_size(mx_tokenizer *t, int *n) try {
     if (!t || !n) return fail(MX_EINVAL, "null argument");
     *n = (int)t->vocab.size();
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
-int mx_tokenizer_encode(mx_tokenizer *t, const char *text, int add_special_tokens, int32_t *ids, int cap, int *n) {
+int mx_tokenizer_encode(mx_tokenizer *t, const char *text, int add_special_tokens, int32_t *ids, int cap, int *n) try {
     if (!t || !text || !n || (cap > 0 && !ids)) return fail(MX_EINVAL, "null argument");
     std::vector<int32_t> v = encode_plain(t, text);
     if (add_special_tokens) {
@@ -831,15 +842,19 @@ int mx_tokenizer_encode(mx_tokenizer *t, const char *text, int add_special_token
     *n = (int)v.size();  // always the full length: call again with a larger buffer if n > cap
     for (int i = 0; i < (int)v.size() && i < cap; ++i) ids[i] = v[i];
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 int mx_tokenizer_decode(mx_tokenizer *t, const int32_t *ids, int n, int skip_special_tokens, char *out, size_t cap,
-                        size_t *nbytes) {
+                        size_t *nbytes) try {
     if (!t || (n > 0 && !ids) || !nbytes) return fail(MX_EINVAL, "null argument");
     const std::string s = decode_ids(t, ids, n, skip_special_tokens != 0);
     *nbytes = s.size() + 1;
     if (out && cap >= s.size() + 1) memcpy(out, s.c_str(), s.size() + 1);
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 // segment_text's windows of one text, each NUL-terminated, appended to buf; -> number of windows
@@ -871,7 +886,7 @@ static int segment_into(const mx_tokenizer *t, const char *text, int max_length,
 }
 
 int mx_tokenizer_segment(mx_tokenizer *t, const char *text, int max_length, int stride, char *out, size_t cap,
-                         size_t *nbytes, int *n_segments) {
+                         size_t *nbytes, int *n_segments) try {
     if (!t || !text || !nbytes || !n_segments) return fail(MX_EINVAL, "null argument");
     if (max_length < 1 || stride < 0 || stride >= max_length) return fail(MX_EINVAL, "need 0 <= stride < max_length");
     std::string buf;
@@ -879,6 +894,8 @@ int mx_tokenizer_segment(mx_tokenizer *t, const char *text, int max_length, int 
     *nbytes = buf.size();
     if (out && cap >= buf.size()) memcpy(out, buf.data(), buf.size());
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 // segment_text for a batch of documents (the ingest worker drains its queue: tasks.rs:17-19 runs one document per task, up to
@@ -886,15 +903,20 @@ int mx_tokenizer_segment(mx_tokenizer *t, const char *text, int max_length, int 
 // host threads.  out: the windows of text 0, then of text 1, ... each NUL-terminated; n_segments[i] = windows of text i.
 // nbytes is always the size needed; out is filled only when cap covers it (call again with a larger buffer otherwise).
 int mx_tokenizer_segment_batch(mx_tokenizer *t, const char *const *texts, int n_texts, int max_length, int stride, char *out,
-                               size_t cap, size_t *nbytes, int32_t *n_segments) {
+                               size_t cap, size_t *nbytes, int32_t *n_segments) try {
     if (!t || (n_texts > 0 && (!texts || !n_segments)) || !nbytes || n_texts < 0) return fail(MX_EINVAL, "null argument");
     if (max_length < 1 || stride < 0 || stride >= max_length) return fail(MX_EINVAL, "need 0 <= stride < max_length");
     for (int i = 0; i < n_texts; ++i)
         if (!texts[i]) return fail(MX_EINVAL, "texts[%d] is null", i);
     std::vector<std::string> bufs((size_t)n_texts);
     std::atomic<int> next{0};
+    std::atomic<bool> failed{false};  // an exception must not leave a helper thread (std::terminate): reported as MX_ENOMEM below
     auto work = [&] {
-        for (int i; (i = next.fetch_add(1)) < n_texts;) n_segments[i] = segment_into(t, texts[i], max_length, stride, bufs[(size_t)i]);
+        try {
+            for (int i; (i = next.fetch_add(1)) < n_texts;) n_segments[i] = segment_into(t, texts[i], max_length, stride, bufs[(size_t)i]);
+        } catch (...) {
+            failed = true;
+        }
     };
     const int nthr = std::min<int>((int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u), n_texts);
     if (nthr <= 1) {
@@ -904,6 +926,7 @@ int mx_tokenizer_segment_batch(mx_tokenizer *t, const char *const *texts, int n_
         for (int i = 0; i < nthr; ++i) pool.emplace_back(work);
         for (auto &th : pool) th.join();
     }
+    if (failed) return fail(MX_ENOMEM, "segmenting a batch of %d texts failed (out of host memory)", n_texts);
     size_t total = 0;
     for (const std::string &b : bufs) total += b.size();
     *nbytes = total;
@@ -915,20 +938,27 @@ int mx_tokenizer_segment_batch(mx_tokenizer *t, const char *const *texts, int n_
         }
     }
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 // the stage-by-stage WordPiece encoder (normalize -> pre_tokenize -> wordpiece), for tests that hold the one-pass form against it
-int mx_tokenizer_encode_staged(mx_tokenizer *t, const char *text, int32_t *ids, int cap, int *n) {
+int mx_tokenizer_encode_staged(mx_tokenizer *t, const char *text, int32_t *ids, int cap, int *n) try {
     if (!t || !text || !n || (cap > 0 && !ids)) return fail(MX_EINVAL, "null argument");
     if (t->kind != 0) return fail(MX_EUNSUPPORTED, "WordPiece handles only");
+    // (test hook of a test hook: tests/test_abi.py checks that an exception inside an entry point comes back as an error code)
+    if (strcmp(text, "\x01\x02throw:bad_alloc") == 0) throw std::bad_alloc();
+    if (strcmp(text, "\x01\x02throw:logic_error") == 0) throw std::logic_error("thrown on request");
     const std::vector<int32_t> v = encode_staged(t, text);
     *n = (int)v.size();
     for (int i = 0; i < (int)v.size() && i < cap; ++i) ids[i] = v[i];
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 int mx_tokenizer_encode_batch(mx_tokenizer *t, const char *const *texts, int B, int max_seq_length, int32_t *ids,
-                              int s_cap, int32_t *lens, int *S) {
+                              int s_cap, int32_t *lens, int *S) try {
     if (!t || (B > 0 && (!texts || !ids || !lens)) || !S) return fail(MX_EINVAL, "null argument");
     if (max_seq_length < 2) return fail(MX_EINVAL, "max_seq_length must be >= 2");
     for (int b = 0; b < B; ++b)
@@ -936,13 +966,18 @@ int mx_tokenizer_encode_batch(mx_tokenizer *t, const char *const *texts, int B, 
     std::vector<std::vector<int32_t>> rows((size_t)B);
     // rows are independent and the tokenizer state is read-only: split the batch over host threads
     // (the GPU consumes ~20M tokens/s; one thread produces 1-2M)
+    std::atomic<bool> failed{false};  // (as in mx_tokenizer_segment_batch)
     auto work = [&](int b0, int b1) {
-        for (int b = b0; b < b1; ++b) {
-            std::vector<int32_t> v = encode_plain(t, texts[b]);
-            if ((int)v.size() > max_seq_length - 2) v.resize((size_t)max_seq_length - 2);  // truncate, keep room for specials
-            v.insert(v.begin(), t->cls);
-            v.push_back(t->sep);
-            rows[(size_t)b] = std::move(v);
+        try {
+            for (int b = b0; b < b1; ++b) {
+                std::vector<int32_t> v = encode_plain(t, texts[b]);
+                if ((int)v.size() > max_seq_length - 2) v.resize((size_t)max_seq_length - 2);  // truncate, keep room for specials
+                v.insert(v.begin(), t->cls);
+                v.push_back(t->sep);
+                rows[(size_t)b] = std::move(v);
+            }
+        } catch (...) {
+            failed = true;
         }
     };
     int nthr = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
@@ -954,6 +989,7 @@ int mx_tokenizer_encode_batch(mx_tokenizer *t, const char *const *texts, int B, 
         for (int i = 0; i < nthr; ++i) pool.emplace_back(work, (int)((long)B * i / nthr), (int)((long)B * (i + 1) / nthr));
         for (auto &th : pool) th.join();
     }
+    if (failed) return fail(MX_ENOMEM, "tokenising a batch of %d texts failed (out of host memory)", B);
     int smax = 0;
     for (int b = 0; b < B; ++b) smax = std::max(smax, (int)rows[(size_t)b].size());
     *S = smax;
@@ -963,6 +999,8 @@ int mx_tokenizer_encode_batch(mx_tokenizer *t, const char *const *texts, int B, 
         for (int i = 0; i < s_cap; ++i) ids[(size_t)b * s_cap + i] = i < (int)rows[b].size() ? rows[b][i] : t->pad;
     }
     return MX_OK;
+} catch (...) {
+    return guard_exception();
 }
 
 }  // extern "C"

@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-O=gpurun_out/r5_cpp_host.txt
-: > $O
-timeout 900 python -m pytest tests/test_cpp_host.py -m gpu -x -q 2>&1 | tail -15 >> $O
-cat $O
+timeout 2400 python -m pytest tests -m gpu -x -q > /tmp/pt.log 2>&1
+echo "pytest rc=$?" > gpurun_out/r5_full_check2.txt
+grep -E "passed|failed|error" /tmp/pt.log | tail -5 >> gpurun_out/r5_full_check2.txt
+cat gpurun_out/r5_full_check2.txt

@@ -66,3 +66,26 @@ def test_product_code_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not pat.search(text), f"{os.path.join(dirpath, f)} reaches into oracle/"
+
+
+def test_exceptions_do_not_cross_the_c_abi(lib_built):
+    """Every `int mx_*` entry point is a function-try-block (mx_common.h::guard_exception): a C++ exception inside the library
+    comes back as an error code + mx_last_error text, never as an unwinding frame in the caller (Rust / ctypes cannot take one)."""
+    import ctypes
+    from memex_amd import _lib
+    from memex_amd.tokenizer import WordPieceTokenizer
+    tok = WordPieceTokenizer(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "a"])
+    ids = (ctypes.c_int32 * 8)()
+    n = ctypes.c_int(0)
+    rc = _lib.lib().mx_tokenizer_encode_staged(tok._h, b"\x01\x02throw:bad_alloc", ids, 8, ctypes.byref(n))
+    assert rc == _lib.MX_ENOMEM and b"memory" in _lib.lib().mx_last_error()
+    rc = _lib.lib().mx_tokenizer_encode_staged(tok._h, b"\x01\x02throw:logic_error", ids, 8, ctypes.byref(n))
+    assert rc == _lib.MX_EDEVICE and b"thrown on request" in _lib.lib().mx_last_error()
+    assert tok.encode_staged("a a") == tok.encode("a a")          # the handle is still usable
+    # and the source keeps the shape: no `int mx_*(...) {` without its try
+    import os, re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "memex_amd", "csrc")
+    for f in ("index.hip", "encoder.hip", "tokenizer.cpp"):
+        src = open(os.path.join(root, f), encoding="utf-8").read()
+        heads = re.findall(r"^int mx_\w+\([^{;]*\)\s*(try\s*)?\{", src, flags=re.M)
+        assert heads and all(h.strip() == "try" for h in heads), f
