@@ -63,6 +63,14 @@ class JsonParser {
   private:
     const std::string &s_;
     size_t i_ = 0;
+    int depth_ = 0;
+    struct Nest {  // a hostile file must not turn nesting into stack depth
+        JsonParser &p;
+        explicit Nest(JsonParser &q) : p(q) {
+            if (++p.depth_ > 64) p.fail("nested too deeply");
+        }
+        ~Nest() { --p.depth_; }
+    };
     [[noreturn]] void fail(const char *m) const { throw EmbeddingError(EmbeddingError::SetupError, std::string("JSON: ") + m + " at byte " + std::to_string(i_)); }
     void ws() {
         while (i_ < s_.size() && (s_[i_] == ' ' || s_[i_] == '\n' || s_[i_] == '\t' || s_[i_] == '\r')) ++i_;
@@ -72,6 +80,7 @@ class JsonParser {
         if (i_ >= s_.size()) fail("unexpected end");
         const char c = s_[i_];
         Json v;
+        const Nest nest(*this);
         if (c == '{') {
             v.type = Json::Obj;
             ++i_;
@@ -143,7 +152,13 @@ class JsonParser {
                     case 'f': out += '\f'; break;
                     case 'u': {  // BMP code point -> UTF-8 (config files only use it for the odd special token)
                         if (i_ + 4 > s_.size()) fail("bad \\u escape");
-                        const unsigned cp = (unsigned)std::stoul(s_.substr(i_, 4), nullptr, 16);
+                        unsigned cp = 0;
+                        for (int h = 0; h < 4; ++h) {
+                            const char x = s_[i_ + h];
+                            const int d = x >= '0' && x <= '9' ? x - '0' : x >= 'a' && x <= 'f' ? x - 'a' + 10 : x >= 'A' && x <= 'F' ? x - 'A' + 10 : -1;
+                            if (d < 0) fail("bad \\u escape");
+                            cp = cp * 16 + (unsigned)d;
+                        }
                         i_ += 4;
                         if (cp < 0x80) out += (char)cp;
                         else if (cp < 0x800) out += (char)(0xC0 | (cp >> 6)), out += (char)(0x80 | (cp & 0x3F));
@@ -221,13 +236,17 @@ class SafeTensors {
             if (!sh || !off || off->arr.size() != 2) throw EmbeddingError(EmbeddingError::SetupError, "safetensors: malformed entry " + name);
             size_t n = 1;
             bool same = sh->arr.size() == shape.size();
-            for (size_t i = 0; i < sh->arr.size(); ++i) {
-                n *= (size_t)sh->arr[i].num;
-                same = same && i < shape.size() && (int64_t)sh->arr[i].num == shape[i];
+            for (size_t i = 0; i < sh->arr.size() && same; ++i) {
+                const double dnum = sh->arr[i].num;
+                same = sh->arr[i].type == Json::Num && dnum >= 0.0 && dnum < 1e12 && (int64_t)dnum == shape[i];
+                if (same) n *= (size_t)dnum;
             }
             if (!same) throw EmbeddingError(EmbeddingError::SetupError, name + ": shape differs from what config.json implies");
             const std::string dt = t->string("dtype", "");
-            const size_t b0 = base_ + (size_t)off->arr[0].num, b1 = base_ + (size_t)off->arr[1].num;
+            const double o0 = off->arr[0].num, o1 = off->arr[1].num;
+            if (off->arr[0].type != Json::Num || off->arr[1].type != Json::Num || !(o0 >= 0.0) || !(o1 >= o0) || !(o1 <= (double)data_.size()))
+                throw EmbeddingError(EmbeddingError::SetupError, name + ": data_offsets outside the file");
+            const size_t b0 = base_ + (size_t)o0, b1 = base_ + (size_t)o1;
             const size_t esz = dt == "F32" ? 4 : (dt == "F16" || dt == "BF16") ? 2 : 0;
             if (!esz) throw EmbeddingError(EmbeddingError::SetupError, name + ": dtype " + dt + " is not supported");
             if (b1 > data_.size() || b1 - b0 != n * esz) throw EmbeddingError(EmbeddingError::SetupError, name + ": data range does not match its shape");
@@ -267,7 +286,22 @@ struct PretrainedModel {
     std::vector<std::string> modules;  // module types of modules.json in order
 };
 
+inline PretrainedModel load_pretrained_dir_impl(const std::string &dir, int precision);
+
+// -> configuration, f32 weight blob and tokenizer files of a sentence-transformers directory.  Throws EmbeddingError(SetupError)
+// and nothing else: whatever a damaged file provokes underneath (a bad number, an allocation the header asked for) is reported
+// as "Unable to load model", like the reference's create_model() failing (embedding.rs:99-100).
 inline PretrainedModel load_pretrained_dir(const std::string &dir, int precision = MX_PREC_BF16) {
+    try {
+        return load_pretrained_dir_impl(dir, precision);
+    } catch (const EmbeddingError &) {
+        throw;
+    } catch (const std::exception &e) {
+        throw EmbeddingError(EmbeddingError::SetupError, "Unable to load model <" + dir + ">: " + e.what());
+    }
+}
+
+inline PretrainedModel load_pretrained_dir_impl(const std::string &dir, int precision) {
     using namespace pretrained_detail;
     auto unsupported = [&](const std::string &what) -> EmbeddingError {
         return EmbeddingError(EmbeddingError::SetupError, "Unable to load model <" + dir + ">: " + what);

@@ -62,7 +62,20 @@ def load_pretrained_dir(path: str, precision: str = "bf16") -> Tuple[EncoderConf
     """-> (EncoderConfig, tensors by HF name, path of vocab.txt or None, info).
 
     ``info``: ``do_lower_case``, ``model_type``, ``modules`` (the pipeline's module types in order), ``bpe_files``
-    (``(vocab.json, merges.txt)`` of a byte-level BPE tokenizer, or None)."""
+    (``(vocab.json, merges.txt)`` of a byte-level BPE tokenizer, or None).
+
+    Raises :class:`UnsupportedModel`, ``OSError``, ``KeyError`` or ``ValueError`` -- what ``from_pretrained_dir`` turns into
+    ``SetupError``; whatever a damaged file provokes underneath (a list where an object belongs, safetensors' own error type)
+    is re-raised as ``ValueError``."""
+    try:
+        return _load_pretrained_dir(path, precision)
+    except (UnsupportedModel, OSError, KeyError, ValueError):
+        raise
+    except Exception as e:  # noqa: BLE001
+        raise ValueError(f"{path}: damaged model directory ({type(e).__name__}: {e})") from e
+
+
+def _load_pretrained_dir(path: str, precision: str):
     if not os.path.isdir(path):
         raise FileNotFoundError(path)
     modules_path = os.path.join(path, "modules.json")

@@ -139,6 +139,60 @@ def test_cpp_loader_agrees_with_the_python_one(tmp_path, lib_built):
     assert r.returncode == 3 and "safetensors" in r.stdout
 
 
+def test_loaders_survive_damaged_files(tmp_path, lib_built):
+    """Bit flips, truncations and insertions in config.json / modules.json / 1_Pooling/config.json and in the safetensors header:
+    both loaders either load the directory or refuse it with their own error -- never a crash (C++: exit code 0 or 3, no
+    signal, no foreign exception) and never an exception type the callers do not catch (Python)."""
+    import shutil
+    import struct
+    import subprocess
+    from memex_amd.pretrained import UnsupportedModel, load_pretrained_dir
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_pretrained")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "test_pretrained.cpp"), "-o", exe, "-L", os.path.join(root, "memex_amd"),
+                           "-lmemex_hip", "-lpthread", "-Wl,-rpath," + os.path.join(root, "memex_amd")])
+    good = str(tmp_path / "good")
+    make_st_dir(good, hidden=32, heads=2, ffn=64, layers=1)
+    rng = np.random.default_rng(5)
+    outcomes = {"cpp": {0: 0, 3: 0}, "py": {"ok": 0, "refused": 0}}
+    for it in range(120):
+        d = str(tmp_path / f"m{it}")
+        shutil.copytree(good, d)
+        target = ["config.json", "modules.json", os.path.join("1_Pooling", "config.json"), "model.safetensors",
+                  "sentence_bert_config.json"][it % 5]
+        raw = bytearray(open(os.path.join(d, target), "rb").read())
+        if target == "model.safetensors":
+            hl = struct.unpack("<Q", raw[:8])[0]
+            lo, hi = (0, 8 + hl) if it % 10 != 3 else (0, 8)              # the header (sometimes its length word only)
+        else:
+            lo, hi = 0, len(raw)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:                                                      # flip a few bytes
+            for _ in range(int(rng.integers(1, 4))):
+                raw[int(rng.integers(lo, hi))] = int(rng.integers(0, 256))
+        elif kind == 1:                                                    # truncate
+            del raw[int(rng.integers(lo, hi)):]
+        elif kind == 2:                                                    # insert structural noise
+            at = int(rng.integers(lo, hi))
+            raw[at:at] = rng.choice([b"[[[[", b'"\\u12', b"{", b"}", b"-", b"1e999", b'"\\', b"[" * 300, b"null"])
+        else:                                                              # swap a digit (shapes, offsets, sizes)
+            digits = [i for i in range(lo, hi) if 48 <= raw[i] <= 57]
+            if digits:
+                raw[digits[int(rng.integers(0, len(digits)))]] = 48 + int(rng.integers(0, 10))
+        open(os.path.join(d, target), "wb").write(bytes(raw))
+        r = subprocess.run([exe, d], capture_output=True, text=True, timeout=60)
+        assert r.returncode in (0, 3), (it, target, kind, r.returncode, r.stdout[-300:], r.stderr[-300:])
+        outcomes["cpp"][r.returncode] += 1
+        try:
+            load_pretrained_dir(d)
+            outcomes["py"]["ok"] += 1
+        except (UnsupportedModel, OSError, KeyError, ValueError):          # what SentenceEmbedder.from_pretrained_dir turns into SetupError
+            outcomes["py"]["refused"] += 1
+        shutil.rmtree(d)
+    assert outcomes["cpp"][3] >= 20 and outcomes["cpp"][0] >= 5, outcomes   # the mutations bite, and harmless ones still load
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("hidden,heads,ffn,pooling", [(384, 12, 1536, "mean"), (768, 12, 3072, "cls")])
 def test_embedder_from_pretrained_dir_matches_the_oracle(tmp_path, lib_built, hidden, heads, ffn, pooling):
