@@ -2268,7 +2268,8 @@ int mx_index_load(mx_index *idx, const char *dir) try {
         return fail(MX_EIO, "%s holds dim %u, index has dim %d", path.c_str(), hdr[0], idx->dim);
     }
     // validate BEFORE touching the live contents: a truncated file must not destroy them
-    if ((uint64_t)sb.st_size < (uint64_t)kHeaderBytes + n * (uint64_t)idx->dim * 4) {
+    if (n > (UINT64_MAX - (uint64_t)kHeaderBytes) / ((uint64_t)idx->dim * 4) ||  // (a damaged row count must not wrap the product)
+        (uint64_t)sb.st_size < (uint64_t)kHeaderBytes + n * (uint64_t)idx->dim * 4) {
         fclose(f);
         return fail(MX_EIO, "%s: truncated (%lld bytes for %llu rows)", path.c_str(), (long long)sb.st_size, (unsigned long long)n);
     }

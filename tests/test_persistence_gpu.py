@@ -143,3 +143,69 @@ def test_cold_load_runs_at_read_speed(tmp_path, oracle, lib_built):
         with pytest.raises(_lib.MemexHipError):
             idx4.load(dirp)
         assert len(idx4) == 0
+
+
+def test_damaged_store_files_are_refused_not_fatal(tmp_path, oracle, lib_built):
+    """Header flips, absurd row counts, truncations of vectors.mxflat and a damaged vectors.meta.json: every load either
+    succeeds with exactly the stored rows or fails with an error -- the process survives, a resident index keeps its contents,
+    and the file on disk is never 'repaired' behind the caller's back (reference: load errors map to FileIOError / SerdeError,
+    storage/local.rs:115-141)."""
+    import shutil
+    import struct
+    from memex_amd import _lib
+    from memex_amd.index import FlatIndex
+    from memex_amd.storage import FileIOError, HipFlatStore, SerdeError, VectorData, VectorStoreError, evict_resident
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((3000, 48), dtype=np.float32)
+    Q = rng.standard_normal((3, 48), dtype=np.float32)
+    good = str(tmp_path / "good")
+    with FlatIndex(48) as idx:
+        idx.add(X)
+        idx.save(good)
+    oi, od, _, _ = oracle.search(X, Q, 5)
+    raw0 = open(os.path.join(good, "vectors.mxflat"), "rb").read()
+    cases = [("magic", lambda b: b"XXXXXXXX" + b[8:]),
+             ("dim", lambda b: b[:8] + struct.pack("<I", 49) + b[12:]),
+             ("rows+1", lambda b: b[:16] + struct.pack("<Q", 3001) + b[24:]),
+             ("rows huge", lambda b: b[:16] + struct.pack("<Q", 2 ** 62) + b[24:]),          # n * dim * 4 wraps 64 bits
+             ("rows max", lambda b: b[:16] + struct.pack("<Q", 2 ** 64 - 1) + b[24:]),
+             ("header only", lambda b: b[:24]),
+             ("half a header", lambda b: b[:11]),
+             ("empty", lambda b: b""),
+             ("cut mid row", lambda b: b[:24 + 1500 * 48 * 4 + 7]),
+             ("nan rows", lambda b: b[:24 + 100 * 48 * 4] + struct.pack("<f", float("nan")) * 48 + b[24 + 101 * 48 * 4:])]
+    for name, mut in cases:
+        d = str(tmp_path / "case")
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d)
+        open(os.path.join(d, "vectors.mxflat"), "wb").write(mut(raw0))
+        with FlatIndex(48) as idx:
+            idx.add(X[:7])                                          # live contents that a failed load must leave alone ...
+            with pytest.raises(_lib.MemexHipError) as ei:
+                idx.load(d)
+            assert ei.value.code in (_lib.MX_EIO, _lib.MX_ENOMEM, _lib.MX_EINVAL, _lib.MX_EINSERT), (name, ei.value.code)
+            if name != "nan rows":                                  # (... unless the file passed validation and died while streaming in)
+                assert len(idx) == 7, name
+            idx.clear()
+            idx.add(X)                                              # and the handle is as good as new
+            ids, _, di, _ = idx.search(Q, 5)
+            np.testing.assert_array_equal(ids, oi)
+            np.testing.assert_array_equal(bits(di), bits(od))
+    # the store level: vectors fine, id map damaged
+    sd = str(tmp_path / "store")
+    st = HipFlatStore.new(sd)
+    st.bulk_insert([VectorData(_id=f"id-{i}", document_id="d", text="", vector=X[i], segment_id=i) for i in range(50)])
+    evict_resident()
+    meta = os.path.join(sd, "vectors.meta.json")
+    good_meta = open(meta, "rb").read()
+    for name, blob, exc in (("not json", b"{\"1\": ", SerdeError), ("array", b"[1, 2]", SerdeError), ("short", good_meta[: len(good_meta) // 2], SerdeError),
+                            ("fewer ids", b"{\"1\": \"id-0\"}", FileIOError)):
+        open(meta, "wb").write(blob)
+        with pytest.raises(VectorStoreError) as ei:
+            HipFlatStore.load(sd)
+        assert isinstance(ei.value, exc), (name, type(ei.value))
+        evict_resident()
+    open(meta, "wb").write(good_meta)
+    st2 = HipFlatStore.load(sd)
+    assert st2.search(X[17], 1)[0][0] == "id-17"
+    evict_resident()
