@@ -17,8 +17,8 @@ from conftest import bits
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("d,cone", [(64, False), (384, True)])
-def test_searches_are_linearisable_under_appends(d, cone, oracle, lib_built, tmp_path):
+@pytest.mark.parametrize("d,cone,shards", [(64, False, 1), (384, True, 1), (96, False, 3)])
+def test_searches_are_linearisable_under_appends(d, cone, shards, oracle, lib_built, tmp_path):
     from memex_amd.index import FlatIndex
     soak = int(os.environ.get("MEMEX_TEST_SOAK", "0"))
     seconds = 3.0 * (1 + soak)
@@ -32,7 +32,9 @@ def test_searches_are_linearisable_under_appends(d, cone, oracle, lib_built, tmp
             X = axis + X * (0.8 / np.sqrt(d))
         return (X * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
 
-    idx = FlatIndex(d)
+    # shards > 1: the in-library sharded index (rows dealt to the shards in blocks; here all on device 0) -- an append spans
+    # several shards and must still be atomic for a concurrent search
+    idx = FlatIndex(d) if shards == 1 else FlatIndex(d, devices=[0] * shards, block_rows=512)
     first = make_rows(rng0, 3000)
     idx.add(first)
     batches = [first]                    # appended batches, in id order
