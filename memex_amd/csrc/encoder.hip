@@ -10,7 +10,7 @@
 //   embed+LN -> L x { QKV GEMM -> attention -> out-proj GEMM(+res+LN) -> FFN1 GEMM(+GELU)
 //                     -> FFN2 GEMM(+res+LN) } -> pool (+L2 normalise)
 // with bf16 activations/weights, f32 accumulation and f32 LayerNorm/softmax/GELU.  Three kernel sets serve that layer:
-// large passes (pgemm_kernel / the fused tail_kernel), passes of <= 512 rows of the hidden-384 models (encoder_small.hip:
+// large passes (pgemm_kernel / the fused tail_kernel), passes of <= 2048 rows of the hidden-384 models (encoder_small.hip:
 // query-time embedding, embedding.rs:146-151), and MX_PREC_BF16X3 (encoder_precise.hip: split bf16 operands, f32 hidden
 // state and attention) -- see include/memex_hip.h for what a caller can observe of the difference.
 #include <algorithm>
@@ -80,6 +80,7 @@ struct mx_encoder {
     bf16_t *sp_x1 = nullptr;
     float *sp_part = nullptr;
     bool small_pass = true;   // MEMEX_HIP_SMALL=0: small passes take the large-pass kernels (tests, A/B)
+    int small_rows = kSmallRows;  // passes of at most this many packed rows take the small-pass layer (MEMEX_HIP_SMALL_ROWS)
     char *h_io = nullptr;     // pinned, device-mapped page of a query-sized host call: ids | lens | embeddings (mx_encoder_encode)
     int32_t *cu = nullptr, *tok_seq = nullptr, *tok_pos = nullptr, *lens_dev = nullptr, *ids_dev = nullptr;
     void *attn_plan = nullptr;  // attention work list of the pass in flight (kAttnPlanBytesPerSeq per sequence)
@@ -299,7 +300,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         }
         return launch_gemm(st, EPI_BIAS_RES_LN, gp);
     };
-    const bool small = e->small_pass && t_pad <= kSmallRows;
+    const bool small = e->small_pass && t_pad <= e->small_rows;
     for (const Layer &L : e->layers) {
         if (small) {
             // query-time passes (encoder_small.hip): projections by one wave per 32 features, the MLP split over the ffn chunks
@@ -386,7 +387,7 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
     if (e->profiling) MX_HIP(hipEventRecord(e->ev1, e->stream));
     // results complete in d_out when the call returns.  The thread naps meanwhile -- except through a query-sized call (one
     // small pass: 0.2-0.4 ms), where a 50 us nap granularity would be a fifth of the latency: those are polled through
-    const bool query_sized = passes.size() == 1 && max_rows + 32 <= kSmallRows;
+    const bool query_sized = passes.size() == 1 && max_rows + 32 <= kQueryRows;
     MX_HIP(napping_sync(e->stream, e->ev_done, query_sized ? 1000 : 100));
     if (e->profiling) {
         float ms = 0.f;
@@ -534,8 +535,12 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     }
     if (e->small_pass) {
         void *px = nullptr, *pp = nullptr;
-        if (hipMalloc(&px, (size_t)kSmallRows * H * sizeof(uint16_t)) != hipSuccess ||
-            hipMalloc(&pp, (size_t)(F / 128) * kSmallRows * H * sizeof(float)) != hipSuccess) {
+        if (const char *sr = getenv("MEMEX_HIP_SMALL_ROWS")) {  // where the small-pass layer hands over to the bulk kernels (a multiple of 64)
+            const int v = atoi(sr);
+            if (v >= 64 && v <= 16384) e->small_rows = v / 64 * 64;
+        }
+        if (hipMalloc(&px, (size_t)e->small_rows * H * sizeof(uint16_t)) != hipSuccess ||
+            hipMalloc(&pp, (size_t)(F / 128) * e->small_rows * H * sizeof(float)) != hipSuccess) {
             if (px) (void)hipFree(px);
             return bail(fail(MX_ENOMEM, "hipMalloc(small-pass workspace) failed"));
         }

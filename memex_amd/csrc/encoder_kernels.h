@@ -119,7 +119,11 @@ hipError_t launch_pool(hipStream_t s, const bf16_t *x, const float *xf, const in
 
 // ---- small passes of the hidden-384 encoder (encoder_small.hip): query-time embedding.  m = padded packed rows (multiple
 // of 64), rows = the packed rows that can hold tokens (the rest of the pass is padding and is not computed)
-constexpr int kSmallRows = 512;  // passes of at most this many packed rows take the small-pass layer
+// passes of at most this many packed rows take the small-pass layer (encoder_small.hip).  Measured crossover against the bulk
+// kernels (scripts/gpu_small_rows_sweep.py, profiles/r5_small_rows_sweep.txt): L12 at 128 tokens 1024 rows 0.69 vs 0.96 ms, 2048 rows
+// 0.85 vs 0.97, 3072 rows 1.00 vs 1.06, 4096 rows 1.10 vs 1.07; L6 at 256 tokens 2048 rows 0.51 vs 0.59, 4096 rows 0.61 vs 0.59
+constexpr int kSmallRows = 2048;
+constexpr int kQueryRows = 512;   // a call of one pass up to this size is polled through by the host (0.2-0.5 ms: a nap would show)
 hipError_t small_setup();
 hipError_t launch_sp_qkv(hipStream_t s, const bf16_t *x, const bf16_t *wqkv, const float *bqkv, int m, int rows, float qscale, bf16_t *q,
                          bf16_t *k, bf16_t *vt, int ldvt);

@@ -88,7 +88,7 @@ def test_attention_stage_and_block_boundaries(hidden, ffn, lib_built, monkeypatc
 @pytest.mark.parametrize("small", ["1", "0"])
 def test_batch_composition_does_not_change_a_row(small, lib_built, monkeypatch):
     """Varlen packing: a sequence's embedding must not depend on its batch neighbours / padding ids.  Passes of the same
-    kind return the same bits; a small pass (<= 512 packed rows: encoder_small.hip sums the MLP's ffn chunks in another order)
+    kind return the same bits; a small pass (<= 2048 packed rows: encoder_small.hip sums the MLP's ffn chunks in another order)
     agrees with a large one to 1 - cos <= 1e-6, and bit for bit when MEMEX_HIP_SMALL=0 routes it through the large-pass kernels."""
     monkeypatch.setenv("MEMEX_HIP_SMALL", small)
     from memex_amd.encoder import Encoder
@@ -120,7 +120,7 @@ def test_batch_composition_does_not_change_a_row(small, lib_built, monkeypatch):
                                                  (2, 1, 1, 65, 1536), (3, 2, 40, 66, 768), (3, 3, 33, 67, 384), (2, 1, 480, 68, 384),
                                                  (2, 4, 120, 69, 1152)])
 def test_small_pass_matches_large_pass(layers, B, S, seed, ffn, lib_built, monkeypatch):
-    """Query-time passes (<= 512 packed rows, hidden 384) run encoder_small.hip -- one wave per 32 projection features, the MLP
+    """Query-time passes (<= 2048 packed rows, hidden 384) run encoder_small.hip -- one wave per 32 projection features, the MLP
     split over its ffn chunks -- with the operands, MFMA shape and rounding points of the large-pass kernels; only the f32
     summation order of the MLP's chunk products differs.  Both against the f64 oracle within the 1e-3 bar, and against each
     other far inside it."""
@@ -298,7 +298,7 @@ def test_large_passes_run_their_gemms_on_pgemm_kernel(lib_built, monkeypatch):
 
 def test_a_row_across_the_pass_size_regimes(lib_built):
     """A text's embedding depends (in its last bits) on how many packed rows share its pass -- three kernel sets, stated in
-    include/memex_hip.h: hidden 384: small passes (<= 512 rows: encoder_small.hip) / everything else; hidden 768: passes
+    include/memex_hip.h: hidden 384: small passes (<= 2048 rows: encoder_small.hip) / everything else; hidden 768: passes
     below / from 32768 rows (gemm_kernel with the fused Add&LayerNorm / pgemm_kernel + ln_rows_kernel).  Same rounding
     points, other f32 summation orders (and one more bf16 rounding of the pre-LayerNorm sum at >= 32768 rows): the same rows
     on either side of each threshold must agree far inside the 1e-3 bar."""
@@ -306,14 +306,14 @@ def test_a_row_across_the_pass_size_regimes(lib_built):
     from memex_amd.weights import EncoderConfig, synthetic_weights
     rng = np.random.default_rng(71)
     for kw, S, b_small, b_large in ((dict(layers=4, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 512, 63, 64),
-                                    (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000), 64, 7, 8)):
+                                    (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000), 64, 31, 32)):
         cfg = EncoderConfig(**kw)
         w = synthetic_weights(cfg, 71)
         ids = rng.integers(1000, cfg.vocab, size=(b_large, S)).astype(np.int32)
         lens = np.full(b_large, S, dtype=np.int32)
         with Encoder(cfg, w) as enc:
-            below = enc.encode(ids[:b_small], lens[:b_small])     # 63 x 512 = 32256 rows (+32 < 32768) / 7 x 64 = 448 (+32 <= 512)
-            above = enc.encode(ids, lens)                         # 64 x 512 = 32768 / 8 x 64 = 512 (+32 > 512)
+            below = enc.encode(ids[:b_small], lens[:b_small])     # 63 x 512 = 32256 rows (+32 < 32768) / 31 x 64 = 1984 (+32 <= 2048)
+            above = enc.encode(ids, lens)                         # 64 x 512 = 32768 / 32 x 64 = 2048 (+32 > 2048)
         d = (1.0 - _cos(below.astype(np.float64), above[:b_small].astype(np.float64))).max()
         print(f"hidden {cfg.hidden}: the same {b_small} rows in a pass below / above the threshold: 1 - cos = {d:.2e}")
         assert (below != above[:b_small]).any(), "both calls took the same kernels: the thresholds moved?"
