@@ -226,10 +226,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
         for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
 #endif
-    if constexpr (EPI == EPI_F32 || EPI == EPI_GELU_SPLIT) {
-        // ---- the bf16x3 encoder's epilogues, straight from the accumulators (a lane owns row m = its l31 and 4 consecutive
-        // columns per register group: 16-byte f32 / 8-byte bf16 stores; these GEMMs multiply three times the k of the bf16
-        // path, their stores are a few per cent of the launch)
+    if constexpr (EPI == EPI_F32) {
+        // ---- the bf16x3 encoder's f32 epilogue, straight from the accumulators (a lane owns row m = its l31 and 4 consecutive
+        // columns per register group: 16-byte stores; these GEMMs multiply three times the k of the bf16 path)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -242,23 +241,66 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + b4[e];
-                    if constexpr (EPI == EPI_F32) {
-                        *reinterpret_cast<f32x4 *>(p.out_f32 + grow * p.ldo + ncol) = v;
-                    } else {
-                        bf16x4 hi, lo;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float g = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));  // exact-erf GELU
-                            hi[e] = (__bf16)g;
-                            lo[e] = (__bf16)(g - (float)hi[e]);
-                        }
-                        bf16_t *o = p.out + grow * p.ldo + ncol;
-                        *reinterpret_cast<bf16x4 *>(o) = hi;
-                        *reinterpret_cast<bf16x4 *>(o + p.n) = lo;
-                        *reinterpret_cast<bf16x4 *>(o + 2 * p.n) = hi;
-                    }
+                    *reinterpret_cast<f32x4 *>(p.out_f32 + grow * p.ldo + ncol) = v;
                 }
             }
+        return;
+    }
+    if constexpr (EPI == EPI_GELU_SPLIT) {
+        // ---- bias + erf GELU (f32 accuracy, mx_gelu.h) + split into [hi | lo | hi] column blocks.  Through the LDS output tile like
+        // the bf16 epilogues below, one pass per half: 8-byte stores from the accumulators' layout (a lane = a row) left the
+        // 1.2 GB of this output to 150 M scattered stores -- as long again as the 3 x MFMA loop in front of them.
+        static_assert(G::NGROUP == 1, "the whole tile is one output group");
+        __syncthreads();  // all waves are done with the ring: its space becomes the output tile
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 96 + j * 32 + 8 * rg + 4 * h);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const gelu_f32x2 g = gelu_erf2_precise(gelu_f32x2{acc[i][j][rg * 4 + e] + b4[e], acc[i][j][rg * 4 + e + 1] + b4[e + 1]});
+                        acc[i][j][rg * 4 + e] = g[0];
+                        acc[i][j][rg * 4 + e + 1] = g[1];
+                    }
+            }
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {  // 0: hi = bf16(g), 1: lo = bf16(g - hi)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int nloc = wn * 96 + j * 32 + 8 * rg + 4 * h;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int mrow = wm * 32 * MI + i * 32 + l31;
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float g = acc[i][j][rg * 4 + e];
+                            const __bf16 hi = (__bf16)g;
+                            pk[e] = half == 0 ? hi : (__bf16)(g - (float)hi);
+                        }
+                        *reinterpret_cast<bf16x4 *>(smem + mrow * G::PO + nloc * 2) = pk;
+                    }
+                }
+            __syncthreads();
+            constexpr int CPO = G::BN / 8;  // 16-byte chunks per output row
+            for (int c = tid; c < G::GR * CPO; c += NT) {
+                const int row = c / CPO, cc = c % CPO;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(smem + row * G::PO + cc * 16);
+                bf16_t *o = p.out + (size_t)(m0 + row) * p.ldo + n0 + cc * 8;
+                if (half == 0) {
+                    *reinterpret_cast<u32x4 *>(o) = v;
+                    *reinterpret_cast<u32x4 *>(o + 2 * p.n) = v;
+                } else {
+                    *reinterpret_cast<u32x4 *>(o + p.n) = v;
+                }
+            }
+            __syncthreads();  // the tile is rewritten by the next half
+        }
         return;
     }
     __syncthreads();  // all waves are done with the ring: its space becomes the output tile

@@ -34,4 +34,37 @@ __device__ __forceinline__ gelu_f32x2 gelu_erf2(gelu_f32x2 x) {
     return x * phi;
 }
 
+// The same function to f32 accuracy, for MX_PREC_BF16X3 (encoder_precise.hip keeps 16 significant bits through every product:
+// the 1.2e-5 of the polynomial above would be its largest error).  erf in two pieces, both on PAIRS:
+//   |a| < 1:   erf a = a P5(a^2)                                      (|err| <= 1.1e-7)
+//   |a| >= 1:  erfc |a| = exp2(|a| Q6(|a|)),  |a| clamped to 4.2       (relative 4e-6 of erfc, i.e. <= 1.1e-7 of erf)
+// with a = x / sqrt 2, and Phi = 1/2 + erf(a)/2 resp. erfc(|a|)/2 or 1 - erfc(|a|)/2 -- the negative tail keeps its relative accuracy.
+// Coefficients: Chebyshev fits in f64, evaluated in f32 Horner against math.erf over [-9, 9] (scripts/gelu_precise_fit.py):
+// |gelu - exact| <= 3.9e-7 (at x = 4.9: one ulp), relative <= 4.1e-6 wherever |gelu| > 1e-6.  ocml's erff, which this replaces,
+// cost the W1 GEMM of the bf16x3 mode more than its 3 x MFMA loop; this one: 13 packed fma/mul, 2 v_exp_f32, a select.
+__device__ __forceinline__ gelu_f32x2 gelu_erf2_precise(gelu_f32x2 x) {
+    typedef gelu_f32x2 v2;
+    const v2 a = x * (v2)0.70710678118654752f;
+    const v2 t = {__builtin_fminf(__builtin_fabsf(a[0]), 4.2f), __builtin_fminf(__builtin_fabsf(a[1]), 4.2f)};
+    const v2 s = a * a;
+    v2 p = __builtin_elementwise_fma(s, (v2)-0.0005654105916619301f, (v2)0.004923277534544468f);
+    p = __builtin_elementwise_fma(p, s, (v2)-0.026716385036706924f);
+    p = __builtin_elementwise_fma(p, s, (v2)0.11280364543199539f);
+    p = __builtin_elementwise_fma(p, s, (v2)-0.37612348794937134f);
+    p = __builtin_elementwise_fma(p, s, (v2)1.1283791065216064f);
+    const v2 phi_small = __builtin_elementwise_fma(a * p, (v2)0.5f, (v2)0.5f);
+    v2 q = __builtin_elementwise_fma(t, (v2)-2.20783258555457e-05f, (v2)0.0005113601218909025f);
+    q = __builtin_elementwise_fma(q, t, (v2)-0.005364956334233284f);
+    q = __builtin_elementwise_fma(q, t, (v2)0.03429649397730827f);
+    q = __builtin_elementwise_fma(q, t, (v2)-0.15295468270778656f);
+    q = __builtin_elementwise_fma(q, t, (v2)-0.9167695045471191f);
+    q = __builtin_elementwise_fma(q, t, (v2)-1.62811279296875f);
+    const v2 r = t * q;
+    const v2 he = {0.5f * __builtin_amdgcn_exp2f(r[0]), 0.5f * __builtin_amdgcn_exp2f(r[1])};  // erfc(|a|) / 2
+    v2 phi;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) phi[i] = t[i] < 1.0f ? phi_small[i] : (a[i] < 0.0f ? he[i] : 1.0f - he[i]);
+    return x * phi;
+}
+
 }  // namespace mx

@@ -1,13 +1,21 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_encoder_gpu.py tests/test_pipeline_native_gpu.py tests/test_pretrained.py tests/test_cfg2_gpu.py -m gpu -x -q > /tmp/pt.log 2>&1
-echo "pytest rc=$?" > gpurun_out/r5_enc_tests.txt
-grep -E "passed|failed|Error|assert" /tmp/pt.log | tail -15 >> gpurun_out/r5_enc_tests.txt
-timeout 300 python scripts/gpu_doc_pass_prof.py 8 128 2>&1 | grep "per encode" >> gpurun_out/r5_enc_tests.txt
-timeout 300 python scripts/gpu_doc_pass_prof.py 16 128 2>&1 | grep "per encode" >> gpurun_out/r5_enc_tests.txt
-timeout 600 python -c "
-import json, bench
-for w in (1, 5):
-    r = bench.text_ingest_leg(200, workers=w, cpu_too=False); print(w, 'workers', json.dumps({k: r[k] for k in ('value','windows_per_s','text_MBps','seconds','errors','query_finds_its_window')}))
-" 2>&1 | grep workers >> gpurun_out/r5_enc_tests.txt
-cat gpurun_out/r5_enc_tests.txt
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r5_precise_kernels_v2.txt
+: > $O
+for m in l6 bge; do
+  rm -rf /tmp/prof_p
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_p -- python $R/scripts/gpu_encoder_prof.py $m bf16x3 > /tmp/prof.log 2>&1
+  f=$(find /tmp/prof_p -name "*kernel_stats.csv" | head -1)
+  echo "== $m bf16x3" >> $O
+  python - "$f" >> $O <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print(f"total kernel time {tot/1e6:.1f} ms")
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:6]:
+    print(f"  {r['Name'][:60]:60s} calls {int(r['Calls']):6d} avg {float(r['AverageNs'])/1e3:8.1f} us  {float(r['TotalDurationNs'])/tot*100:5.1f} %")
+PY
+done
+cat $O

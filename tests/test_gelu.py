@@ -83,3 +83,42 @@ def test_polynomial_gelu_moves_no_embedding():
             assert (1.0 - cos).max() <= 1e-9, (make.__name__, cos)
     finally:
         bert_oracle.gelu_erf = exact
+
+
+def test_precise_gelu_of_the_bf16x3_mode():
+    """mx_gelu.h::gelu_erf2_precise (MX_PREC_BF16X3's W1 epilogue): constants read out of the header, evaluated the way the
+    kernel does -- f32 Horner with fused multiply-adds, v_exp_f32 as exp2 -- against the exact erf form: |err| <= 4e-7 everywhere,
+    one part in 2^-18 relative wherever the value is not tiny (the mode keeps 16 significant bits per operand)."""
+    src = open(HDR).read()
+    body = src[src.index("gelu_f32x2 gelu_erf2_precise("):]
+    pfirst = re.search(r"v2 p = __builtin_elementwise_fma\(s, \(v2\)(-?[0-9.e+-]+)f, \(v2\)(-?[0-9.e+-]+)f\)", body)
+    P = [float(pfirst.group(1)), float(pfirst.group(2))] + [float(m) for m in re.findall(r"p = __builtin_elementwise_fma\(p, s, \(v2\)(-?[0-9.e+-]+)f\)", body)]
+    qfirst = re.search(r"v2 q = __builtin_elementwise_fma\(t, \(v2\)(-?[0-9.e+-]+)f, \(v2\)(-?[0-9.e+-]+)f\)", body)
+    Q = [float(qfirst.group(1)), float(qfirst.group(2))] + [float(m) for m in re.findall(r"q = __builtin_elementwise_fma\(q, t, \(v2\)(-?[0-9.e+-]+)f\)", body)]
+    tmax = float(re.search(r"fabsf\(a\[0\]\), ([0-9.]+)f\)", body).group(1))
+    assert len(P) == 6 and len(Q) == 7 and tmax == 4.2, (P, Q, tmax)
+    f32 = np.float32
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * np.float64(b) + np.float64(c)).astype(np.float32) if np.isscalar(b) else \
+            (a.astype(np.float64) * b.astype(np.float64) + np.float64(c)).astype(np.float32)
+    x = np.concatenate([np.linspace(-12.0, 12.0, 960001), np.random.default_rng(0).standard_normal(200000) * 3,
+                        np.array([0.0, -0.0, 1e-30, -1e-30, 1e4, -1e4, math.sqrt(2.0), -math.sqrt(2.0)])]).astype(np.float32)
+    a = (x * f32(0.70710678118654752)).astype(np.float32)
+    t = np.minimum(np.abs(a), f32(tmax)).astype(np.float32)
+    s = (a * a).astype(np.float32)
+    p = fma(s, f32(P[0]), f32(P[1]))
+    for c in P[2:]:
+        p = fma(p, s, f32(c))
+    phi_small = fma((a * p).astype(np.float32), f32(0.5), f32(0.5))
+    q = fma(t, f32(Q[0]), f32(Q[1]))
+    for c in Q[2:]:
+        q = fma(q, t, f32(c))
+    he = (f32(0.5) * np.exp2((t * q).astype(np.float32).astype(np.float64)).astype(np.float32)).astype(np.float32)
+    phi = np.where(t < f32(1.0), phi_small, np.where(a < 0, he, f32(1.0) - he)).astype(np.float32)
+    got = (x * phi).astype(np.float64)
+    ref = gelu_exact(x)
+    err = np.abs(got - ref)
+    assert np.isfinite(got).all() and err[np.abs(x) <= 64].max() <= 4e-7, (err.max(), x[err.argmax()])
+    big = np.abs(ref) > 1e-3
+    assert (err[big] / np.abs(ref[big])).max() <= 2.0 ** -18, (err[big] / np.abs(ref[big])).max()
