@@ -1,21 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5_precise_kernels_v2.txt
-: > $O
-for m in l6 bge; do
-  rm -rf /tmp/prof_p
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_p -- python $R/scripts/gpu_encoder_prof.py $m bf16x3 > /tmp/prof.log 2>&1
-  f=$(find /tmp/prof_p -name "*kernel_stats.csv" | head -1)
-  echo "== $m bf16x3" >> $O
-  python - "$f" >> $O <<'PY'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"total kernel time {tot/1e6:.1f} ms")
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:6]:
-    print(f"  {r['Name'][:60]:60s} calls {int(r['Calls']):6d} avg {float(r['AverageNs'])/1e3:8.1f} us  {float(r['TotalDurationNs'])/tot*100:5.1f} %")
-PY
-done
-cat $O
+timeout 2400 bash scripts/profile_search.sh r5 > gpurun_out/r5_profile_run.log 2>&1
+echo "rc=$?" >> gpurun_out/r5_profile_run.log
+tail -5 gpurun_out/r5_profile_run.log
+ls gpurun_out/prof_r5 | head -50

@@ -108,6 +108,8 @@ def main():
             rf = bench.get("cfg4_shard_10Mx768", {}).get("roofline", {})
             if ("scan8" in want) != ("scan8" in str(rf.get("kernel", ""))):
                 rf = {}
+        elif label == "f32":
+            rf = bench.get("f32_rows", {}).get("roofline", {})          # (its own leg: N*D*4 bytes per launch)
         else:
             rf = bench.get("roofline", {}) if bench.get("scan") == label else bench.get("other_scan", {}).get("roofline", {})
         algo = rf.get("bytes_per_launch")
