@@ -109,7 +109,10 @@ int mx_index_set_id_offset(mx_index *idx, uint64_t id_offset);
  * Append n rows ([n, dim] row-major f32).  Replaces HnswStore::insert / bulk_insert
  * (storage/local.rs:55-69): ids are dense, 1-based, in insertion order; *first_id receives the id
  * of rows[0] (later rows follow consecutively).  Non-finite values are rejected (MX_EINVAL) and
- * nothing is inserted.  Unlike the reference there is no save-per-insert (local.rs:67); call
+ * nothing is inserted.  (Finite values whose f32 products overflow -- elements beyond ~1.8e19 in a row or
+ * a query -- take DistCosine into inf / inf = NaN, where hnsw_rs asserts, i.e. the reference panics;
+ * here such a call returns, rows at a NaN distance are left out, everything that has a defined distance
+ * is ranked by it: tests/test_centred_gpu.py.)  Unlike the reference there is no save-per-insert (local.rs:67); call
  * mx_index_save.
  */
 int mx_index_add(mx_index *idx, const float *rows, uint64_t n, uint64_t *first_id);

@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 2400 bash scripts/profile_search.sh r5 > gpurun_out/r5_profile_run.log 2>&1
-echo "rc=$?" >> gpurun_out/r5_profile_run.log
-tail -5 gpurun_out/r5_profile_run.log
-ls gpurun_out/prof_r5 | head -50
+timeout 900 python -m pytest tests/test_centred_gpu.py -m gpu -x -q > /tmp/pt.log 2>&1
+echo "pytest rc=$?" > gpurun_out/r5_centred_wild.txt
+tail -30 /tmp/pt.log >> gpurun_out/r5_centred_wild.txt
+cat gpurun_out/r5_centred_wild.txt

@@ -139,3 +139,41 @@ def test_sharded_index_over_a_cone_corpus(oracle, lib_built):
         idx.search(Q, 10)
         st = idx.stats()
         assert st.fallback_queries == 0 and st.filter_centred == 1, (st.fallback_queries, st.filter_centred, st.filter_kind)
+
+
+def test_centred_copy_with_out_of_range_norms_and_queries_off_the_cone(oracle, lib_built):
+    """What rides on the side lists of the plain copies must ride on them under a centred copy too: rows whose norm is outside
+    the f32 stages' range (stored as zeros, evaluated in f64 for every query), zero rows, and queries that have nothing to do
+    with the cone (a_q ~ 0), are scaled by 1e-30 / 1e30, or are a row of the corpus."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(12)
+    d, n = 384, 30000
+    X = cone_rows(rng, n, d)
+    X[5] *= np.float32(1e-19)                      # norms far outside [1e-15, 1e15]: the wild list
+    X[6] *= np.float32(1e18)
+    X[7] *= np.float32(3e-16)
+    X[50] = 0.0
+    X[51] = 0.0
+    Q = cone_rows(rng, 40, d)
+    Q[1] = rng.standard_normal(d).astype(np.float32)                # off the cone
+    Q[2] = -Q[3]                                                      # opposite the cone: every cosine negative
+    Q[4] = Q[4] * np.float32(1e-30)
+    Q[5] = Q[5] * np.float32(1e15)                                   # (f32 self-products still finite: 1e30 would make DistCosine's norm inf)
+    Q[6] = X[6]                                                       # the huge row itself
+    Q[7] = X[5]                                                       # the tiny row itself
+    with FlatIndex(d) as idx:
+        idx.add(X)
+        idx.set_filter_copy("bf16")
+        assert idx.stats().filter_centred == 1
+        for k in (1, 10, 64):
+            _equal(idx, X, Q, k, oracle)
+        # a query whose f32 self-products overflow (|q_i| > 1.8e19): DistCosine's norm is inf, every non-zero row is at
+        # distance 1 - dot/inf = 1, and a row whose dot product overflows too makes 1 - inf/inf = NaN, where the reference
+        # asserts (panics).  Outside the arithmetic's domain the call still returns: zero-norm rows (distance 0) first.
+        Qinf = (Q[8:9] * np.float32(1e30)).astype(np.float32)
+        ids, sc, di, nf = idx.search(Qinf, 5)
+        assert nf[0] == 5 and sorted(ids[0, :2].tolist()) == [51, 52] and di[0, 0] == 0.0 and di[0, 2] == 1.0
+        # rows appended behind the centred copy, all of them with norms outside the range (up to the list's capacity)
+        extra = (cone_rows(np.random.default_rng(13), 900, d) * np.float32(1e-17)).astype(np.float32)
+        idx.add(extra)
+        _equal(idx, np.concatenate([X, extra]), Q, 10, oracle)
