@@ -80,6 +80,7 @@ struct mx_encoder {
     bf16_t *sp_x1 = nullptr;
     float *sp_part = nullptr;
     bool small_pass = true;   // MEMEX_HIP_SMALL=0: small passes take the large-pass kernels (tests, A/B)
+    bool attn_f32 = false;    // MEMEX_HIP_ATTN_F32=1: the bf16x3 mode's attention on the f32 MFMA instead of split bf16 products (tests)
     int small_rows = kSmallRows;  // passes of at most this many packed rows take the small-pass layer (MEMEX_HIP_SMALL_ROWS)
     char *h_io = nullptr;     // pinned, device-mapped page of a query-sized host call: ids | lens | embeddings (mx_encoder_encode)
     int32_t *cu = nullptr, *tok_seq = nullptr, *tok_pos = nullptr, *lens_dev = nullptr, *ids_dev = nullptr;
@@ -252,28 +253,34 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
     if ((size_t)attention_groups(heads, dh) * 16 > kAttnPlanBytesPerSeq) return fail(MX_EINVAL, "more than 16 head groups per sequence");
     MX_HIP(launch_token_map(st, d_lens, B, S, e->cu, e->tok_seq, e->tok_pos, t_pad, heads, dh, e->attn_plan));
     if (e->precise) {
-        // MX_PREC_BF16X3 (encoder_precise.hip): split operands through gemm_kernel with k tripled, f32 everywhere else
+        // MX_PREC_BF16X3 (encoder_precise.hip): split operands through the unchanged GEMM loops with k tripled (pgemm_kernel for
+        // the shapes it takes in large passes, gemm_kernel otherwise), f32 everywhere else
+        const bool pbig = e->pgemm && t_pad >= kPgemmRows;
+        auto pgemm_or_gemm = [&](int epi, const GemmParams &gp) -> hipError_t {
+            if (pbig && pgemm_supported(epi, gp)) return launch_pgemm(st, epi, gp);
+            return launch_gemm(st, epi, gp);
+        };
         MX_HIP(launch_embed_ln_precise(st, d_ids, S, e->tok_seq, e->tok_pos, t_pad, H, e->word, e->pos, e->type0, e->eg, e->eb,
                                        c.ln_eps, c.vocab, e->xf, e->xs));
         for (const Layer &L : e->layers) {
             GemmParams g{};
             g.a = e->xs; g.lda = 3 * H; g.w = L.wqkv3; g.w_rows = 3 * H; g.bias = L.bqkv; g.m = t_pad; g.n = 3 * H; g.k = 3 * H;
             g.out_f32 = e->qkvf; g.ldo = 3 * H;
-            MX_HIP(launch_gemm(st, EPI_F32, g));
-            MX_HIP(launch_attention_f32(st, e->qkvf, e->cu, d_lens, B, max_len, heads, dh, H, e->ctxs));
+            MX_HIP(pgemm_or_gemm(EPI_F32, g));
+            MX_HIP(launch_attention_f32(st, e->qkvf, e->cu, d_lens, B, max_len, heads, dh, H, e->ctxs, e->attn_f32));
             GemmParams o{};
             o.a = e->ctxs; o.lda = 3 * H; o.w = L.wo3; o.w_rows = H; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = 3 * H;
             o.out_f32 = e->af; o.ldo = H;
-            MX_HIP(launch_gemm(st, EPI_F32, o));
+            MX_HIP(pgemm_or_gemm(EPI_F32, o));
             MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, t_pad, H, L.ln1g, L.ln1b, c.ln_eps));
             GemmParams f1{};
             f1.a = e->xs; f1.lda = 3 * H; f1.w = L.wi3; f1.w_rows = F; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = 3 * H;
             f1.out = e->hs; f1.ldo = 3 * F;
-            MX_HIP(launch_gemm(st, EPI_GELU_SPLIT, f1));
+            MX_HIP(pgemm_or_gemm(EPI_GELU_SPLIT, f1));
             GemmParams f2{};
             f2.a = e->hs; f2.lda = 3 * F; f2.w = L.wo23; f2.w_rows = H; f2.bias = L.bo2; f2.m = t_pad; f2.n = H; f2.k = 3 * F;
             f2.out_f32 = e->af; f2.ldo = H;
-            MX_HIP(launch_gemm(st, EPI_F32, f2));
+            MX_HIP(pgemm_or_gemm(EPI_F32, f2));
             MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, t_pad, H, L.ln2g, L.ln2b, c.ln_eps));
         }
         MX_HIP(launch_pool(st, nullptr, e->xf, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
@@ -470,6 +477,8 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         e->pgemm = !(pv && pv[0] == '0');
         const char *sv = getenv("MEMEX_HIP_SMALL");
         e->small_pass = e->fused_tail && !(sv && sv[0] == '0');
+        const char *av = getenv("MEMEX_HIP_ATTN_F32");
+        e->attn_f32 = av && av[0] == '1';
     }
     auto bail = [&](int code) {
         destroy_impl(e);

@@ -234,6 +234,75 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
 #else
                     b4[j][rg] = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wc * 64 + j * 32 + 8 * rg + 4 * h);
 #endif
+            if constexpr (EPI == EPI_F32) {
+                // MX_PREC_BF16X3: bias + f32 out.  The wave's scratch holds 32 rows x 128 B = one 32-column block in f32: two
+                // passes per row block, 16-byte chunk (2 rg + h) of row l31 at chunk ^ (l31 & 7)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + b4[j][rg][e];
+                            *reinterpret_cast<f32x4 *>(sc + l31 * 128 + (((rg * 2 + h) ^ (l31 & 7)) << 4)) = v;
+                        }
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const int row = ps * 8 + (lane >> 3), pc = lane & 7, lc = pc ^ (row & 7);
+                            const u32x4 v = *reinterpret_cast<const u32x4 *>(sc + row * 128 + pc * 16);
+                            *reinterpret_cast<u32x4 *>(p.out_f32 + (size_t)(m0 + wr * 128 + i * 32 + row) * p.ldo + ncol0 + j * 32 + lc * 4) = v;
+                        }
+                    }
+            } else if constexpr (EPI == EPI_GELU_SPLIT) {
+                // MX_PREC_BF16X3: bias + erf GELU at f32 accuracy, split into the [hi | lo | hi] column blocks the next GEMM
+                // multiplies (blocks p.n apart): the hi pass and the lo pass go through the same scratch tile
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            // (the bias is fetched where it is used: 32 registers of it next to the GELU's temporaries spill)
+                            const f32x4 bb = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wc * 64 + j * 32 + 8 * rg + 4 * h);
+#pragma unroll
+                            for (int e = 0; e < 4; e += 2) {
+                                const gelu_f32x2 g = gelu_erf2_precise(gelu_f32x2{acc[i][j][rg * 4 + e] + bb[e], acc[i][j][rg * 4 + e + 1] + bb[e + 1]});
+                                acc[i][j][rg * 4 + e] = g[0];
+                                acc[i][j][rg * 4 + e + 1] = g[1];
+                            }
+                        }
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                bf16x4 pk;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float g = acc[i][j][rg * 4 + e];
+                                    const __bf16 hi = (__bf16)g;
+                                    pk[e] = half == 0 ? hi : (__bf16)(g - (float)hi);
+                                }
+                                *reinterpret_cast<bf16x4 *>(sc + l31 * 128 + (((j * 4 + rg) ^ (l31 & 7)) << 4) + h * 8) = pk;
+                            }
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const int row = ps * 8 + (lane >> 3), pc = lane & 7, lc = pc ^ (row & 7);
+                            const u32x4 v = *reinterpret_cast<const u32x4 *>(sc + row * 128 + pc * 16);
+                            bf16_t *o = dst + (size_t)(m0 + wr * 128 + i * 32 + row) * p.ldo + ncol0 + lc * 8;
+                            if (half == 0) {
+                                *reinterpret_cast<u32x4 *>(o) = v;
+                                *reinterpret_cast<u32x4 *>(o + 2 * p.n) = v;
+                            } else {
+                                *reinterpret_cast<u32x4 *>(o + p.n) = v;
+                            }
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // D^T[n][m]: lane owns row m = l31 of block i, 4 consecutive columns n per register group
@@ -501,6 +570,8 @@ hipError_t pgemm_setup() {
     if ((e = pgemm_attr<EPI_QKV>()) != hipSuccess) return e;
     if ((e = pgemm_attr<EPI_VT>()) != hipSuccess) return e;
     if ((e = pgemm_attr<EPI_BIAS_RES>()) != hipSuccess) return e;
+    if ((e = pgemm_attr<EPI_F32>()) != hipSuccess) return e;
+    if ((e = pgemm_attr<EPI_GELU_SPLIT>()) != hipSuccess) return e;
     int dev = 0;
     hipDeviceProp_t prop;
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
@@ -514,7 +585,9 @@ hipError_t pgemm_setup() {
 
 // shapes pgemm_kernel takes: whole 256 x 256 tiles, k-tiles of 64, 32-bit byte offsets, the q / k split on a wave edge
 bool pgemm_supported(int epi, const GemmParams &p) {
-    if (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_QKV && epi != EPI_VT && epi != EPI_BIAS_RES) return false;
+    if (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_QKV && epi != EPI_VT && epi != EPI_BIAS_RES && epi != EPI_F32 &&
+        epi != EPI_GELU_SPLIT)
+        return false;
     if (g_pgemm_cus < 8 || p.m % kPT || p.n % kPT || p.k % kPK || p.k < 2 * kPK) return false;
     if ((size_t)p.m * p.lda * 2 >= (1ull << 32) || (size_t)p.w_rows * p.k * 2 >= (1ull << 32)) return false;
     if (epi == EPI_QKV && (p.hidden % 64 || p.n != 2 * p.hidden)) return false;
@@ -529,6 +602,8 @@ hipError_t launch_pgemm(hipStream_t s, int epi, const GemmParams &p) {
         case EPI_QKV: return pgemm_go<EPI_QKV>(s, p);
         case EPI_VT: return pgemm_go<EPI_VT>(s, p);
         case EPI_BIAS_RES: return pgemm_go<EPI_BIAS_RES>(s, p);
+        case EPI_F32: return pgemm_go<EPI_F32>(s, p);
+        case EPI_GELU_SPLIT: return pgemm_go<EPI_GELU_SPLIT>(s, p);
         default: return hipErrorInvalidValue;
     }
 }

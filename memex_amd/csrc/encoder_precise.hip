@@ -286,11 +286,189 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restr
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same attention on the bf16 matrix cores, every product as three (hi hi + lo hi + hi lo, the GEMMs' split): the f32 MFMA
+// above has 1/16 of their rate.  Same workgroup shape, same key blocks, same lane-owns-a-query softmax; what changes:
+//   * a key block is staged as bf16 PAIRS -- K_hi / K_lo [key][d] (A operand of the transposed scores: 8 consecutive d per
+//     lane), V^T_hi / V^T_lo [d][slot] (A operand of O^T += V^T P^T: 8 consecutive key slots per lane) -- the same LDS bytes
+//     as the f32 tiles;
+//   * the scores' D layout gives lane (query, h) the keys (r & 3) + 8 (r >> 2) + 4 h; a 16-key k-step of the PV product wants
+//     that lane to supply key slots 8 h .. 8 h + 7, so slot s of a k-step holds key s with bits 2 and 3 swapped (V^T is
+//     staged in that order) and the lane's P registers 8 t .. 8 t + 7 ARE its B operand of k-step t, split hi / lo in place;
+//   * q is split once per lane (registers), scaled first.
+// Dropped: the lo x lo products (2^-18 relative), as in the GEMMs.  MEMEX_HIP_ATTN_F32=1 (read when an encoder is created) keeps the f32-MFMA kernel
+// (tests hold the two against each other).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8p;
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restrict__ qkv, int hidden, const int32_t *__restrict__ cu,
+                                                            const int32_t *__restrict__ lens, int S, float qscale,
+                                                            bf16_t *__restrict__ ctxs) {
+    constexpr int KP = DH + 8;   // K tile pitch (bf16): rows 16 bytes apart modulo 128 -> conflict-free ds_read_b128
+    constexpr int VP = 32 + 8;   // V^T tile pitch (bf16)
+    __shared__ __attribute__((aligned(16))) __bf16 Kh[32 * KP], Kl[32 * KP];
+    __shared__ __attribute__((aligned(16))) __bf16 Vh[DH * VP], Vl[DH * VP];
+    const int b = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+    int len = lens[b];
+    len = len < 1 ? 1 : (len > S ? S : len);
+    if (qb * 128 >= len) return;  // workgroup-uniform
+    const int tok0 = cu[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ld = 3 * hidden;
+    const int qi = qb * 128 + wave * 32 + l31;  // this lane's query
+    const bool q_ok = qi < len;
+    const float *qrow = qkv + (size_t)(tok0 + (q_ok ? qi : 0)) * ld + head * DH;
+    // B operand of the scores: lane (query, h) holds q[16 s + 8 h .. + 7] of k-step s, hi and lo
+    bf16x8p qh[DH / 16], ql[DH / 16];
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = q_ok ? qrow[16 * s + 8 * h + e] * qscale : 0.0f;
+            qh[s][e] = (__bf16)v;
+            ql[s][e] = (__bf16)(v - (float)qh[s][e]);
+        }
+    f32x16 o[DH / 32];
+#pragma unroll
+    for (int t = 0; t < DH / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+    float m_run = -1e30f, l_run = 0.0f;
+    const float *kbase = qkv + (size_t)tok0 * ld + hidden + head * DH;
+    const float *vbase = kbase + hidden;
+    const int nkb = (len + 31) / 32;
+    // this thread's float4s of a key block's K and V rows (zeros past the sequence's end); block kb + 1 is fetched while
+    // block kb is multiplied
+    constexpr int NP = 32 * DH / 4 / 256;
+    f32x4 kpre[NP], vpre[NP];
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = tid + 256 * u, r = i / (DH / 4), c4 = i % (DH / 4);
+            const int key = kb * 32 + r;
+            kpre[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            vpre[u] = kpre[u];
+            if (key < len) {
+                kpre[u] = *reinterpret_cast<const f32x4 *>(kbase + (size_t)key * ld + 4 * c4);
+                vpre[u] = *reinterpret_cast<const f32x4 *>(vbase + (size_t)key * ld + 4 * c4);
+            }
+        }
+    };
+    fetch(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();  // everybody is done with the previous block's tiles
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = tid + 256 * u, r = i / (DH / 4), c4 = i % (DH / 4);
+            const f32x4 kv = kpre[u], vv = vpre[u];
+            bf16x4 khi, klo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                khi[e] = (__bf16)kv[e];
+                klo[e] = (__bf16)(kv[e] - (float)khi[e]);
+            }
+            *reinterpret_cast<bf16x4 *>(Kh + r * KP + 4 * c4) = khi;
+            *reinterpret_cast<bf16x4 *>(Kl + r * KP + 4 * c4) = klo;
+            // key r of the block sits in slot (r with bits 2 and 3 swapped) of its 16-key k-step
+            const int slot = (r & 16) | (r & 3) | ((r & 8) >> 1) | ((r & 4) << 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 vh = (__bf16)vv[e];
+                Vh[(4 * c4 + e) * VP + slot] = vh;
+                Vl[(4 * c4 + e) * VP + slot] = (__bf16)(vv[e] - (float)vh);
+            }
+        }
+        if (kb + 1 < nkb) fetch(kb + 1);
+        __syncthreads();
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) {
+            const bf16x8p ah = *reinterpret_cast<const bf16x8p *>(Kh + l31 * KP + 16 * s + 8 * h);
+            const bf16x8p al = *reinterpret_cast<const bf16x8p *>(Kl + l31 * KP + 16 * s + 8 * h);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[s], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[s], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[s], sc, 0, 0, 0);
+        }
+        float bm = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            sc[r] = key < len ? sc[r] : -1e30f;
+            bm = fmaxf(bm, sc[r]);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float m_new = fmaxf(m_run, bm);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // (arguments <= 0: the raw v_exp_f32 is all there is to do)
+        const bool moved = m_new != m_run;
+        m_run = m_new;
+        float ps = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            sc[r] = key < len ? __builtin_amdgcn_exp2f(sc[r] - m_new) : 0.0f;
+            ps += sc[r];
+        }
+        l_run = l_run * alpha + ps;
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // after the first blocks a row's maximum rarely moves: alpha = 1 for the whole wave
+#pragma unroll
+            for (int t = 0; t < DH / 32; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
+        // k-step t of O^T += V^T P^T: keys 16 t .. 16 t + 15 in slot order; this lane's registers 8 t .. 8 t + 7 are the keys
+        // 16 t + {0..3, 8..11} + 4 h = the slots 8 h .. 8 h + 7
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            bf16x8p ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pv = sc[8 * t2 + e];
+                ph[e] = (__bf16)pv;
+                pl[e] = (__bf16)(pv - (float)ph[e]);
+            }
+#pragma unroll
+            for (int t = 0; t < DH / 32; ++t) {
+                const bf16x8p vh = *reinterpret_cast<const bf16x8p *>(Vh + (32 * t + l31) * VP + 16 * t2 + 8 * h);
+                const bf16x8p vl = *reinterpret_cast<const bf16x8p *>(Vl + (32 * t + l31) * VP + 16 * t2 + 8 * h);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[t], 0, 0, 0);
+            }
+        }
+    }
+    const float l_row = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_row;
+    if (!q_ok) return;
+    bf16_t *crow = ctxs + (size_t)(tok0 + qi) * ld + head * DH;
+#pragma unroll
+    for (int t = 0; t < DH / 32; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = o[t][rg * 4 + e] * inv;
+            store_split4(crow + 32 * t + 8 * rg + 4 * h, hidden, v);
+        }
+}
+
 hipError_t launch_attention_f32(hipStream_t s, const float *qkv, const int32_t *cu, const int32_t *lens, int B, int S, int heads,
-                                int d_head, int hidden, bf16_t *ctxs) {
+                                int d_head, int hidden, bf16_t *ctxs, bool f32_mfma) {
     if (B < 1 || S < 1 || S > 512 || heads * d_head != hidden) return hipErrorInvalidValue;
     const float qscale = (float)(1.4426950408889634 / sqrt((double)d_head));
     const dim3 grid((S + 127) / 128, heads, B);
+    if (!f32_mfma) {
+        if (d_head == 32)
+            hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
+        else if (d_head == 64)
+            hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
+        else
+            return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (d_head == 32)
         hipLaunchKernelGGL(attention_f32_kernel<32>, grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
     else if (d_head == 64)

@@ -43,6 +43,7 @@ __device__ __forceinline__ gelu_f32x2 gelu_erf2(gelu_f32x2 x) {
 // |gelu - exact| <= 3.9e-7 (at x = 4.9: one ulp), relative <= 4.1e-6 wherever |gelu| > 1e-6.  ocml's erff, which this replaces,
 // cost the W1 GEMM of the bf16x3 mode more than its 3 x MFMA loop; this one: 13 packed fma/mul, 2 v_exp_f32, a select.
 __device__ __forceinline__ gelu_f32x2 gelu_erf2_precise(gelu_f32x2 x) {
+#pragma clang fp contract(off)  // (1 - 0.5 e must not become an fma in one GEMM kernel and stay two operations in the other)
     typedef gelu_f32x2 v2;
     const v2 a = x * (v2)0.70710678118654752f;
     const v2 t = {__builtin_fminf(__builtin_fabsf(a[0]), 4.2f), __builtin_fminf(__builtin_fabsf(a[1]), 4.2f)};

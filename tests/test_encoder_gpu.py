@@ -490,3 +490,61 @@ def test_keyed_encoder_is_shared_and_refcounted(lib_built):
     with pytest.raises(_lib.MemexHipError):
         Encoder(other, synthetic_weights(other, 1), key="k2")      # same key, different configuration
     c.close()
+
+
+@pytest.mark.parametrize("kw,B,S", [(dict(layers=3, hidden=384, heads=12, ffn=1536, vocab=3000, precision="bf16x3"), 9, 300),
+                                    (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls", precision="bf16x3"), 5, 512),
+                                    (dict(layers=2, hidden=384, heads=6, ffn=768, vocab=3000, precision="bf16x3"), 6, 77)])
+def test_split_bf16_attention_matches_the_f32_mfma_attention(kw, B, S, lib_built, monkeypatch):
+    """MX_PREC_BF16X3's attention runs its two products as three bf16 MFMAs each (hi hi + lo hi + hi lo, keys of a k-step in
+    the slot order that makes a lane's P registers its B operand); MEMEX_HIP_ATTN_F32=1 keeps the f32-MFMA kernel it replaced.
+    Ragged lengths, key blocks cut by the sequence end, head dims 32 and 64: the two agree to the dropped lo x lo terms."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, checkpoint_like_weights
+    cfg = EncoderConfig(**kw)
+    w = checkpoint_like_weights(cfg, 5)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
+    lens = rng.integers(1, S + 1, size=B).astype(np.int32)
+    lens[0], lens[1] = S, 33
+    outs = []
+    for f32_attn in ("0", "1"):
+        monkeypatch.setenv("MEMEX_HIP_ATTN_F32", f32_attn)
+        with Encoder(cfg, w) as enc:
+            outs.append(enc.encode(ids, lens).astype(np.float64))
+    d = (1.0 - _cos(outs[0], outs[1])).max()
+    pair = np.abs(outs[0] @ outs[0].T - outs[1] @ outs[1].T).max() if cfg.normalize else 0.0
+    print(f"{kw['hidden']}/{kw['heads']}: split-bf16 vs f32-MFMA attention: 1 - cos = {d:.2e}, pairwise {pair:.2e}")
+    assert (outs[0] != outs[1]).any(), "both encoders ran the same attention kernel"
+    assert d <= 1e-7 and pair <= 1e-5, (d, pair)
+
+
+@pytest.mark.parametrize("kw,B,S,seed", [
+    (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls", precision="bf16x3"), 80, 512, 61),   # every GEMM on pgemm_kernel
+    (dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000, precision="bf16x3"), 96, 512, 62)])               # W1 (N = 1536) only: 1152 and 384 are no multiples of 256
+def test_split_operand_mode_on_pgemm_kernel(kw, B, S, seed, lib_built, monkeypatch):
+    """MX_PREC_BF16X3 in large passes: its GEMMs run on pgemm_kernel where the shape allows (EPI_F32 / EPI_GELU_SPLIT through the
+    wave-private scratch tile).  Same k order, same products, f32 sums in the same order as gemm_kernel: bit-identical
+    embeddings with MEMEX_HIP_PGEMM=0, and within the mode's bars of the f64 oracle."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, checkpoint_like_weights
+    from oracle import bert_oracle
+    cfg = EncoderConfig(**kw)
+    w = checkpoint_like_weights(cfg, seed)
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(1000, cfg.vocab, (B, S)).astype(np.int32)
+    lens = rng.integers(S // 2, S + 1, B).astype(np.int32)
+    outs = []
+    for pg in ("0", "1"):
+        monkeypatch.setenv("MEMEX_HIP_PGEMM", pg)
+        with Encoder(cfg, w) as enc:
+            outs.append(enc.encode(ids, lens))
+    print(f"hidden {cfg.hidden}: pgemm vs gemm max |diff| {np.abs(outs[0] - outs[1]).max():.3e}, rows differing {(outs[0] != outs[1]).any(axis=1).sum()} of {B}")
+    sub = np.arange(0, B, 9)
+    ref = bert_oracle.encode(w, cfg.as_dict(), ids[sub], lens[sub])
+    print(f"gemm_kernel path vs oracle: {(1.0 - _cos(outs[0][sub].astype(np.float64), ref)).max():.2e}")
+    d = (1.0 - _cos(outs[1][sub].astype(np.float64), ref)).max()
+    pair = np.abs(outs[1][sub].astype(np.float64) @ outs[1][sub].astype(np.float64).T - ref @ ref.T).max()
+    print(f"bf16x3 on pgemm_kernel, hidden {cfg.hidden}: 1 - cos = {d:.2e}, pairwise {pair:.2e}")
+    assert d <= 1e-6 and pair <= 1e-3, (d, pair)
+    np.testing.assert_array_equal(outs[0], outs[1])
