@@ -1,25 +1,20 @@
 #!/bin/bash
 mkdir -p gpurun_out
-O=gpurun_out/r5_precise_final.txt
-: > $O
-timeout 1500 python -m pytest tests/test_encoder_gpu.py tests/test_pretrained.py tests/test_pipeline_native_gpu.py -m gpu -x -q > /tmp/pt.log 2>&1
-echo "pytest rc=$?" >> $O
-grep -E "passed|failed|Error" /tmp/pt.log | tail -4 >> $O
-timeout 600 python scripts/gpu_encoder_precise.py 2>&1 | grep chunks >> $O
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-for m in l6 bge; do
-  rm -rf /tmp/prof_p
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_p -- python $R/scripts/gpu_encoder_prof.py $m bf16x3 > /tmp/prof.log 2>&1
-  f=$(find /tmp/prof_p -name "*kernel_stats.csv" | head -1)
-  echo "== $m bf16x3" >> $R/$O
-  python - "$f" >> $R/$O <<'PY'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"total kernel time {tot/1e6:.1f} ms")
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:7]:
-    print(f"  {r['Name'][:60]:60s} calls {int(r['Calls']):6d} avg {float(r['AverageNs'])/1e3:8.1f} us  {float(r['TotalDurationNs'])/tot*100:5.1f} %")
+S=$(date +%s)
+timeout 900 python bench.py > gpurun_out/r5_bench_final.json 2> gpurun_out/r5_bench_final.err
+echo "bench rc=$? wall $(( $(date +%s) - S )) s" > gpurun_out/r5_final_check.txt
+timeout 2400 python -m pytest tests -m gpu -x -q > /tmp/pt.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/r5_final_check.txt
+grep -E "passed|failed|Error" /tmp/pt.log | tail -4 >> gpurun_out/r5_final_check.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> gpurun_out/r5_final_check.txt
+python - >> gpurun_out/r5_final_check.txt <<'PY'
+import json
+d = json.load(open("gpurun_out/r5_bench_final.json"))
+print("value", d["value"], "ms", d["ms_per_step"], "frac", d["roofline"]["frac"], "outside", d["ms_outside_collect_launch"])
+print("enc_like", {k: d["enc_like_10M"].get(k) for k in ("value", "retry_queries", "fallback_queries", "ids_equal_exact_path")})
+print("text_ingest", {k: d["text_ingest"].get(k) for k in ("value", "windows_per_s", "errors", "query_finds_its_window", "error")})
+print("ingest", d["ingest"]["value"], d["ingest"]["roofline"]["frac"], "bge", d["ingest_bge_base"]["value"], d["ingest_bge_base"]["roofline"]["frac"])
+print("f32_rows", d["f32_rows"]["value"], d["f32_rows"]["roofline"]["frac"], "cfg2", d["cfg2"]["embed_segments_per_s"], d["cfg2"]["search_ms_per_step"])
+print("qlat", d["query_latency"]["all-MiniLM-L6-v2"]["encode_ms_p50"], d["query_latency"]["all-MiniLM-L12-v2"]["encode_ms_p50"])
 PY
-done
-cat $R/$O
+cat gpurun_out/r5_final_check.txt
