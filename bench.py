@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--ingest-chunks", type=int, default=262_144, help="512-token chunks per GPU for the ingest leg (0 = skip)")
     ap.add_argument("--bge-chunks", type=int, default=24_576, help="N=1 only: 512-token chunks of the bge-base-en ingest leg (0 = skip)")
     ap.add_argument("--cfg2-segments", type=int, default=100_000, help="N=1 only: segments of the configs[1] end-to-end leg (0 = skip)")
+    ap.add_argument("--precise-chunks", type=int, default=16384, help="N=1 only: 512-token chunks of the MX_PREC_BF16X3 ingest leg (a quarter of them for bge-base; 0 = skip)")
     ap.add_argument("--text-docs", type=int, default=200, help="N=1 only: documents of the text-ingest leg (segmenter + encoder + add; 0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=0.5,
                     help="untimed steps of the same work run in front of every timed region until this much time has passed: the "
@@ -343,6 +344,46 @@ def ingest_leg(chunks: int, dev: int, world: int, cpu_too: bool = True, model: s
         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / MFMA_PEAK_TFLOPS, "note": "GPU time of replica 0 by HIP events on the encoder stream"},
     }
+
+
+def precise_ingest_leg(chunks_l6: int, chunks_bge: int):
+    """The split-operand mode (mx_encoder_cfg.precision = MX_PREC_BF16X3: every GEMM / attention product as three bf16 MFMA
+    products, f32 hidden state; the mode whose search scores stay within north_star's 1e-3 under checkpoint-like weights,
+    DESIGN.md section 4.2) on the ingest shapes, device ids in -> device embeddings out.  `flops` are the algorithmic ones of the
+    model (one product per product): the MFMA work is three times that."""
+    import dataclasses
+    import torch
+    from memex_amd import weights as W
+    from memex_amd.encoder import Encoder
+    out = {}
+    for name, base, chunks in (("all-MiniLM-L6-v2", W.ALL_MINILM_L6_V2, chunks_l6), ("bge-base-en", W.BGE_BASE_EN, chunks_bge)):
+        if chunks <= 0:
+            continue
+        cfg = dataclasses.replace(base, precision="bf16x3")
+        enc = Encoder(cfg, W.pack_weights(W.synthetic_weights(cfg, 0), cfg))
+        g = torch.Generator(device="cuda")
+        g.manual_seed(3)
+        B = 256
+        ids = torch.randint(1000, cfg.vocab, (B, 512), device="cuda", dtype=torch.int32, generator=g)
+        lens = torch.full((B,), 512, device="cuda", dtype=torch.int32)
+        emb = torch.zeros((B, cfg.hidden), device="cuda")
+        enc.encode_device(ids, lens, emb)
+        enc.reset_stats()
+        enc.set_profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(1, chunks // B)):
+            enc.encode_device(ids, lens, emb)
+        dt = time.perf_counter() - t0
+        st = enc.stats()
+        enc.close()
+        tf = st.flops / (st.gpu_ms / 1e3) / 1e12 if st.gpu_ms > 0 else 0.0
+        out[name] = {"value": st.sequences / dt, "unit": "chunks/s", "chunks": int(st.sequences), "algorithmic_tflops": tf,
+                     "mfma_tflops": 3.0 * tf, "mfma_frac": 3.0 * tf / MFMA_PEAK_TFLOPS,
+                     "note": "512-token chunks, MX_PREC_BF16X3; mfma_* count the three bf16 products per product"}
+        del ids, lens, emb
+        torch.cuda.empty_cache()
+    return out
 
 
 def cfg2_leg(n_seg: int, batch: int, k: int, steps: int):
@@ -1008,6 +1049,11 @@ def run(a):
             sides["enc_like_10M"] = enc_like_leg(a.enc_like_rows, 100_000, a.batch, k, a.side_steps)
         if a.cfg2_segments > 0:
             sides["cfg2"] = cfg2_leg(a.cfg2_segments, a.batch, k, a.side_steps)
+        if a.precise_chunks > 0:
+            try:
+                sides["ingest_bf16x3"] = precise_ingest_leg(a.precise_chunks, a.precise_chunks // 4)
+            except Exception as e:  # noqa: BLE001 -- a side leg must not fail the bench
+                sides["ingest_bf16x3"] = {"error": repr(e)[:300]}
         if a.text_docs > 0:
             try:
                 sides["text_ingest"] = text_ingest_leg(a.text_docs, cpu_too=not a.no_cpu_baseline)

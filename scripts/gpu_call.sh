@@ -1,20 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-S=$(date +%s)
-timeout 900 python bench.py > gpurun_out/r5_bench_final.json 2> gpurun_out/r5_bench_final.err
-echo "bench rc=$? wall $(( $(date +%s) - S )) s" > gpurun_out/r5_final_check.txt
-timeout 2400 python -m pytest tests -m gpu -x -q > /tmp/pt.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/r5_final_check.txt
-grep -E "passed|failed|Error" /tmp/pt.log | tail -4 >> gpurun_out/r5_final_check.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> gpurun_out/r5_final_check.txt
-python - >> gpurun_out/r5_final_check.txt <<'PY'
-import json
-d = json.load(open("gpurun_out/r5_bench_final.json"))
-print("value", d["value"], "ms", d["ms_per_step"], "frac", d["roofline"]["frac"], "outside", d["ms_outside_collect_launch"])
-print("enc_like", {k: d["enc_like_10M"].get(k) for k in ("value", "retry_queries", "fallback_queries", "ids_equal_exact_path")})
-print("text_ingest", {k: d["text_ingest"].get(k) for k in ("value", "windows_per_s", "errors", "query_finds_its_window", "error")})
-print("ingest", d["ingest"]["value"], d["ingest"]["roofline"]["frac"], "bge", d["ingest_bge_base"]["value"], d["ingest_bge_base"]["roofline"]["frac"])
-print("f32_rows", d["f32_rows"]["value"], d["f32_rows"]["roofline"]["frac"], "cfg2", d["cfg2"]["embed_segments_per_s"], d["cfg2"]["search_ms_per_step"])
-print("qlat", d["query_latency"]["all-MiniLM-L6-v2"]["encode_ms_p50"], d["query_latency"]["all-MiniLM-L12-v2"]["encode_ms_p50"])
-PY
-cat gpurun_out/r5_final_check.txt
+timeout 300 python -c "
+import json, bench
+print(json.dumps(bench.precise_ingest_leg(16384, 4096), indent=1))
+" > gpurun_out/r5_precise_leg.txt 2>&1
+cat gpurun_out/r5_precise_leg.txt
