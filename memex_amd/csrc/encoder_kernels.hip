@@ -449,7 +449,7 @@ static hipError_t gemm_go(hipStream_t s, const GemmParams &p) {
 constexpr int kBigTileRows = 32768;
 
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
-    // MEMEX_HIP_GEMM_BIG: bit 0 = QK projection, bit 1 = V projection, bit 2 = bias / GELU GEMMs (A/B switch)
+    // MEMEX_HIP_GEMM_BIG: bit 0 = QK projection, bit 1 = V projection, bit 2 = bias / GELU GEMMs, bit 3 = the bf16x3 mode's f32-output GEMMs (A/B switch)
     static const int big_mask = [] {
         const char *e = getenv("MEMEX_HIP_GEMM_BIG");
         return e ? atoi(e) : -1;
@@ -462,7 +462,7 @@ hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
         case EPI_BIAS_GELU: return big_ff ? gemm_go<EPI_BIAS_GELU, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_BIAS_GELU, 2, 2, 2, 32, 4>(s, p);
         case EPI_QKV: return big_qk ? gemm_go<EPI_QKV, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_QKV, 2, 2, 2, 32, 4>(s, p);
         case EPI_VT: return big_vt ? gemm_go<EPI_VT, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_VT, 2, 2, 2, 32, 4>(s, p);
-        case EPI_F32: return gemm_go<EPI_F32, 2, 2, 2, 32, 4>(s, p);
+        case EPI_F32: return (fits && (mask & 8)) ? gemm_go<EPI_F32, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_F32, 2, 2, 2, 32, 4>(s, p);
         case EPI_GELU_SPLIT: return gemm_go<EPI_GELU_SPLIT, 2, 2, 2, 32, 4>(s, p);
         case EPI_BIAS_RES_LN:
             if (p.n == 384) return gemm_go<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>(s, p);
@@ -1153,6 +1153,7 @@ hipError_t encoder_kernels_setup() {
     if ((e = gemm_attr<EPI_BIAS_GELU, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_QKV, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_VT, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_F32, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>()) != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<32, 1>),

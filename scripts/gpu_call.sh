@@ -1,7 +1,13 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 300 python -c "
+O=gpurun_out/r5_precise_bigtile.txt
+: > $O
+for m in unset 8 9; do
+  if [ $m = unset ]; then unset MEMEX_HIP_GEMM_BIG; else export MEMEX_HIP_GEMM_BIG=$m; fi
+  echo "GEMM_BIG=$m" >> $O
+  timeout 300 python -c "
 import json, bench
-print(json.dumps(bench.precise_ingest_leg(16384, 4096), indent=1))
-" > gpurun_out/r5_precise_leg.txt 2>&1
-cat gpurun_out/r5_precise_leg.txt
+r = bench.precise_ingest_leg(16384, 0); print({k: round(v['value']) for k, v in r.items()})
+" 2>&1 | tail -1 >> $O
+done
+cat $O
