@@ -76,6 +76,7 @@ struct Scratch {
     uint32_t *dev_flags = nullptr;   // [kFlagWords]
     uint32_t *host_flags = nullptr;  // pinned mirror of dev_flags [kFlagWords] (D2H copy, rare)
     uint32_t *host_sum = nullptr;    // pinned, device-visible [kSumWords]: written by finish_kernel's last workgroup
+    bool out_on_host = false;        // this batch's output pointers are mapped host memory (run_combined)
     uint32_t *done_ctr = nullptr;    // finish_kernel's workgroup counter
     uint32_t flag_seq = 0;           // sequence number of the last finish launch
     uint32_t *overflow = nullptr, *cand_cnt = nullptr, *qflags = nullptr;  // views into dev_flags
@@ -410,8 +411,8 @@ int ensure_scratch(mx_index *idx) {
     MX_HIP(hipMalloc(&s.qb, kMaxBatch * sizeof(float)));
     MX_HIP(hipMalloc(&s.qmean, kMaxBatch * sizeof(float)));
     MX_HIP(hipMemsetAsync(s.qmean, 0, kMaxBatch * sizeof(float), idx->stream));
-    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_q), (size_t)kMaxBatch * idx->dim * sizeof(float), hipHostMallocDefault));
-    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_nf), kMaxBatch * sizeof(int32_t), hipHostMallocDefault));
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_q), (size_t)kMaxBatch * idx->dim * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_nf), kMaxBatch * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
     MX_HIP(hipMalloc(&s.max_err, sizeof(float)));
     MX_HIP(hipMemsetAsync(s.max_err, 0, sizeof(float), idx->stream));
     s.ready = true;
@@ -435,9 +436,9 @@ int ensure_out(mx_index *idx, int k) {
     MX_HIP(hipMalloc(&s.out_scores, (size_t)kMaxBatch * kc * sizeof(float)));
     MX_HIP(hipMalloc(&s.out_dists, (size_t)kMaxBatch * kc * sizeof(float)));
     MX_HIP(hipMalloc(&s.out_nfound, kMaxBatch * sizeof(int32_t)));
-    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_ids), (size_t)kMaxBatch * kc * sizeof(uint64_t), hipHostMallocDefault));
-    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_scores), (size_t)kMaxBatch * kc * sizeof(float), hipHostMallocDefault));
-    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_dists), (size_t)kMaxBatch * kc * sizeof(float), hipHostMallocDefault));
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_ids), (size_t)kMaxBatch * kc * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent));
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_scores), (size_t)kMaxBatch * kc * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    MX_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.h_dists), (size_t)kMaxBatch * kc * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
     s.kcap = kc;
     return MX_OK;
 }
@@ -897,6 +898,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     fp.dev_flags = s.dev_flags;
     fp.host_flags = s.host_sum;
     fp.n_queries = B;
+    fp.host_out = s.out_on_host ? 1 : 0;
     // finish + completion: the kernel's last workgroup writes the batch summary into pinned host memory and
     // stores the launch's sequence number behind it; the host spins on that word (no D2H copy command and no
     // memset between batches: the host gap between two batches drops from 45 to 22 us, the kernel grows by
@@ -1933,6 +1935,23 @@ int run_combined(mx_index *idx, const std::vector<SearchReq *> &batch) {
         memcpy(s.h_q + (size_t)nb * dim, r->q, (size_t)r->B * dim * sizeof(float));
         nb += r->B;
     }
+    // A plain index reads the queries from, and writes the answers into, the pinned staging buffers themselves (they are mapped
+    // into the device's address space): prep_queries_kernel is the only reader of the raw queries, finish_kernel (or the EXACT
+    // kernels) the only writers of the outputs, and every exit of search_batch is host-synchronised -- through the completion
+    // word, behind a system-scope fence per workgroup, on the fast path.  That is one H2D copy, four D2H copies and a stream
+    // synchronise less per call: 25-30 us of a single query's 95-115 us on a small collection (profiles/r5_small_corpus_latency.txt).
+    // MEMEX_HIP_HOST_COPIES=1 keeps the copies (A/B, tests).  A sharded index merges on the device and copies as before.
+    static const bool keep_copies = [] {
+        const char *e = getenv("MEMEX_HIP_HOST_COPIES");
+        return e && e[0] == '1';
+    }();
+    if (!idx->composite() && !keep_copies) {
+        s.out_on_host = true;
+        rc = any_batch(idx, s.h_q, nb, k, s.h_ids, s.h_scores, s.h_dists, s.h_nf);
+        s.out_on_host = false;
+        if (rc != MX_OK) return rc;
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
     MX_HIP(hipMemcpyAsync(s.qstage, s.h_q, (size_t)nb * dim * sizeof(float), hipMemcpyHostToDevice, t->stream));
     rc = any_batch(idx, s.qstage, nb, k, s.out_ids, s.out_scores, s.out_dists, s.out_nfound);
     if (rc != MX_OK) return rc;
@@ -1943,6 +1962,7 @@ int run_combined(mx_index *idx, const std::vector<SearchReq *> &batch) {
     }
     MX_HIP(hipMemcpyAsync(s.h_nf, s.out_nfound, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
     MX_HIP(hipStreamSynchronize(t->stream));
+    }
     int b0 = 0;
     for (SearchReq *r : batch) {
         if (k > 0) {

@@ -212,6 +212,7 @@ struct FinishParams {
     const uint32_t *dev_flags;
     uint32_t *host_flags;       // [5]: max overflow code, sum of cand_cnt, any bad query, e1[0], seq
     int n_queries;              // B
+    int host_out;               // ids / scores / dists / n_found are pinned host memory (mx_index_search): system-scope fence before the tick
     uint32_t seq;
 };
 hipError_t finish_setup();

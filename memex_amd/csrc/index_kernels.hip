@@ -980,7 +980,10 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(const FinishParams 
     __shared__ uint32_t s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();  // this workgroup's results and flag words before its tick
+        // this workgroup's results and flag words before its tick (results in mapped host memory: visible to the host, which
+        // reads them as soon as it sees the sequence number)
+        if (p.host_out) __threadfence_system();
+        else __threadfence();
         s_last = atomicAdd(p.done_ctr, 1u) == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
