@@ -314,8 +314,8 @@ int mx_encoder_wait_stream(mx_encoder *enc, void *hip_stream);
  * A row's embedding does not depend on its neighbours in a call, but it does depend, in its last bits, on
  * how many packed rows share its pass (calls are cut into passes of <= 1024 sequences / 131072 rows): three
  * kernel sets round at the same points and sum in f32 in different orders -- hidden 384: passes of <= 2048
- * rows (query-time and small documents: encoder_small.hip) / larger ones; hidden 768: passes below / from 32768 rows (the latter
- * round the pre-LayerNorm sum to bf16 once more).  The same text embedded alone and inside a bulk ingest call
+ * rows (query-time and small documents: encoder_small.hip) / larger ones; hidden 768: passes of <= 4096 rows (the two Add & LayerNorm
+ * GEMMs split over k) / below / from 32768 rows (the latter round the pre-LayerNorm sum to bf16 once more).  The same text embedded alone and inside a bulk ingest call
  * agrees to 1 - cos ~ 1e-7 .. 1e-5 (tests/test_encoder_gpu.py::test_a_row_across_the_pass_size_regimes),
  * not bit for bit; calls of the same shape are bit-reproducible.  MX_PREC_BF16X3 uses one kernel set.
  */

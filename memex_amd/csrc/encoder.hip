@@ -79,6 +79,11 @@ struct mx_encoder {
     // small passes (<= kSmallRows packed rows, fused-tail models): x1 of the layer in flight, the MLP's partial products
     bf16_t *sp_x1 = nullptr;
     float *sp_part = nullptr;
+    // small passes of the GEMM-by-GEMM models (hidden 768): the two Add & LayerNorm GEMMs run split over k with f32 partials and a
+    // reduce + LayerNorm kernel behind them (one 64 x 768 workgroup looping over k = 3072 is an 80 us latency chain)
+    bool split_small = true;  // MEMEX_HIP_SPLITK=0: keep the fused Add & LayerNorm GEMMs at every pass size (tests, A/B)
+    float *sk_part = nullptr; // [kSplitMax][kSplitRows][H] f32
+    float *sk_zero = nullptr; // [H] zeros: the partial GEMMs' bias (the reduce kernel adds the real one)
     bool small_pass = true;   // MEMEX_HIP_SMALL=0: small passes take the large-pass kernels (tests, A/B)
     bool attn_f32 = false;    // MEMEX_HIP_ATTN_F32=1: the bf16x3 mode's attention on the f32 MFMA instead of split bf16 products (tests)
     int small_rows = kSmallRows;  // passes of at most this many packed rows take the small-pass layer (MEMEX_HIP_SMALL_ROWS)
@@ -229,6 +234,8 @@ constexpr int kMaxRowsPerPass = 1 << 17;
 // passes of at least this many packed rows use pgemm_kernel: 128 row tiles of 256 = 16 per XCD, every CU busy for
 // the 768-wide outputs (3 column tiles); below, gemm_kernel's small tiles fill the chip better
 constexpr int kPgemmRows = 32768;
+constexpr int kSplitRows = 4096;  // passes up to this many packed rows split the Add & LayerNorm GEMMs of a hidden-768 layer over k
+constexpr int kSplitMax = 8;
 
 // one pass: sequences [0, B) with device ids [B,S] (row pitch S) and HOST lens; output d_out [B,H]
 int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const int32_t *d_lens, int B, int S,
@@ -339,6 +346,20 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         GemmParams o{};
         o.a = e->ctx; o.lda = H; o.w = L.wo; o.w_rows = H; o.w_row0 = 0; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = H;
         o.out = e->x1; o.ldo = H; o.res = e->x; o.ldres = H; o.gamma = L.ln1g; o.beta = L.ln1b; o.eps = c.ln_eps;
+        // small passes: product split over k into f32 partials (gemm_kernel<EPI_F32>, chunks of >= 384 columns), then
+        // reduce + bias + residual + LayerNorm -- the rounding points of the fused epilogue, another f32 summation order
+        auto split_res_ln = [&](GemmParams gp, int nsplit) -> hipError_t {
+            const float *bias = gp.bias;
+            bf16_t *out = gp.out;
+            gp.k /= nsplit; gp.ksplit = nsplit; gp.bias = e->sk_zero; gp.out = nullptr; gp.out_f32 = e->sk_part; gp.ldo = gp.n;
+            hipError_t he = launch_gemm(st, EPI_F32, gp);
+            if (he != hipSuccess) return he;
+            return launch_reduce_res_ln(st, e->sk_part, nsplit, t_pad, gp.n, bias, gp.res, gp.ldres, gp.gamma, gp.beta, gp.eps, out, gp.n);
+        };
+        const bool split = e->split_small && e->sk_part && t_pad <= kSplitRows && H == 768 && F % 384 == 0;  // (hidden 384 has its own small-pass layer)
+        const int ns_o = H / 384, ns_2 = std::min(kSplitMax, F / 384);
+        if (split && ns_o >= 2) MX_HIP(split_res_ln(o, ns_o));
+        else
         MX_HIP(gemm_res_ln(o));
         GemmParams f1{};
         f1.a = e->x1; f1.lda = H; f1.w = L.wi; f1.w_rows = F; f1.w_row0 = 0; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = H;
@@ -347,6 +368,8 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         GemmParams f2{};
         f2.a = e->hbuf; f2.lda = F; f2.w = L.wo2; f2.w_rows = H; f2.w_row0 = 0; f2.bias = L.bo2; f2.m = t_pad; f2.n = H; f2.k = F;
         f2.out = e->x; f2.ldo = H; f2.res = e->x1; f2.ldres = H; f2.gamma = L.ln2g; f2.beta = L.ln2b; f2.eps = c.ln_eps;
+        if (split && ns_2 >= 2 && F % ns_2 == 0 && (F / ns_2) % 32 == 0) MX_HIP(split_res_ln(f2, ns_2));
+        else
         MX_HIP(gemm_res_ln(f2));
     }
     MX_HIP(launch_pool(st, e->x, nullptr, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
@@ -541,6 +564,23 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         MX_TRY(upload_f32(e, b2_src, H, &L.bo2));
         MX_TRY(upload_f32(e, g2_src, H, &L.ln2g));
         MX_TRY(upload_f32(e, be2_src, H, &L.ln2b));
+    }
+    if (!e->fused_tail && !e->precise && H == 768) {
+        const char *sv = getenv("MEMEX_HIP_SPLITK"), *sm = getenv("MEMEX_HIP_SMALL");  // (MEMEX_HIP_SMALL=0: one kernel set at every pass size)
+        e->split_small = !(sv && sv[0] == '0') && !(sm && sm[0] == '0');
+        if (e->split_small) {
+            void *pp = nullptr, *pz = nullptr;
+            if (hipMalloc(&pp, (size_t)kSplitMax * kSplitRows * H * sizeof(float)) != hipSuccess || hipMalloc(&pz, (size_t)H * sizeof(float)) != hipSuccess ||
+                hipMemset(pz, 0, (size_t)H * sizeof(float)) != hipSuccess) {
+                if (pp) (void)hipFree(pp);
+                if (pz) (void)hipFree(pz);
+                return bail(fail(MX_ENOMEM, "hipMalloc(split-k workspace) failed"));
+            }
+            e->allocs.push_back(pp);
+            e->allocs.push_back(pz);
+            e->sk_part = static_cast<float *>(pp);
+            e->sk_zero = static_cast<float *>(pz);
+        }
     }
     if (e->small_pass) {
         void *px = nullptr, *pp = nullptr;

@@ -50,6 +50,8 @@ struct GemmParams {
     const float *beta;
     float eps;
     float *out_f32;       // EPI_F32
+    int ksplit;           // EPI_F32 only, 0 / 1 = off: the launch has `ksplit` k-chunks of p.k columns each (blockIdx.y = chunk): chunk z reads
+                          // a + z k and the weights' k-blocks from z k / 32 on, and writes its partial product to out_f32 + z m ldo
 };
 
 // the layer tail (encoder_tail.hip), hidden = 384:
@@ -93,6 +95,10 @@ hipError_t pgemm_setup();
 bool pgemm_supported(int epi, const GemmParams &p);
 hipError_t launch_pgemm(hipStream_t s, int epi, const GemmParams &p);
 // x[r] = LayerNorm(x[r]) * gamma + beta in place, rows of `hidden` (384 / 768) bf16, row pitch ld
+// out[r] = LayerNorm(bf16(sum_z part[z][r] + bias) + res[r]) for rows < m, hidden n in {384, 768}: closes a split-k GEMM (small passes of
+// the hidden-768 models: encoder.hip)
+hipError_t launch_reduce_res_ln(hipStream_t s, const float *part, int nsplit, int m, int n, const float *bias, const bf16_t *res, int ldres,
+                                const float *gamma, const float *beta, float eps, bf16_t *out, int ldo);
 hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden, const float *gamma, const float *beta, float eps);
 
 // token maps from sequence lengths: cu[b] (aligned starts), tok_seq / tok_pos for every packed row

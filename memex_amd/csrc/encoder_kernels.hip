@@ -119,8 +119,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         // activations: row-major [M][K]; weights: K-blocked [K/32][w_rows][32] so that a weight piece
         // (16 rows x 64 B) is one contiguous KiB of full cache lines
-        const bf16_t *base = row < G::BM ? p.a + (size_t)(m0 + row) * p.lda
-                                         : p.w + (size_t)(p.w_row0 + n0 + row - G::BM) * 32;
+        // (split-k launches, EPI_F32: chunk blockIdx.y starts p.k columns / p.k / 32 weight k-blocks further on)
+        const size_t kz = EPI == EPI_F32 ? (size_t)blockIdx.y : 0;
+        const bf16_t *base = row < G::BM ? p.a + (size_t)(m0 + row) * p.lda + kz * p.k
+                                         : p.w + (size_t)(p.w_row0 + n0 + row - G::BM) * 32 + kz * (p.k / 32) * p.w_rows * 32;
         src[i] = reinterpret_cast<const char *>(base + c * 8);
         kstep[i] = row < G::BM ? (size_t)(BK * 2) : (size_t)p.w_rows * (BK * 2);
         dst[i] = (uint32_t)piece * 1024u;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + b4[e];
-                    *reinterpret_cast<f32x4 *>(p.out_f32 + grow * p.ldo + ncol) = v;
+                    *reinterpret_cast<f32x4 *>(p.out_f32 + (size_t)blockIdx.y * p.m * p.ldo + grow * p.ldo + ncol) = v;
                 }
             }
         return;
@@ -427,7 +429,7 @@ static hipError_t gemm_go(hipStream_t s, const GemmParams &p) {
     using G = GemmGeom<WM, WN, MI, BK, S>;
     if (p.m % G::BM || p.n % G::BN || p.k % BK) return hipErrorInvalidValue;
     if (EPI == EPI_QKV && (p.hidden % G::BN || p.n != 2 * p.hidden)) return hipErrorInvalidValue;
-    dim3 grid((p.m / G::BM) * (p.n / G::BN));
+    dim3 grid((p.m / G::BM) * (p.n / G::BN), EPI == EPI_F32 && p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL((gemm_kernel<EPI, WM, WN, MI, BK, S>), grid, dim3(G::NT), G::LDS, s, p);
     return hipGetLastError();
 }
@@ -668,6 +670,77 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(bf16_t *__restrict__ x, in
         }
         *reinterpret_cast<bf16x8 *>(xr + col) = o;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// closes a split-k GEMM: out[r] = LayerNorm(bf16(sum_z part[z][r] + bias) + res[r]).  TPR lanes per row, 24 columns per lane (hidden
+// 384: 16 lanes, 768: 32); all chunks' loads in flight together, summed in chunk order; the rounding points of the fused
+// Add & LayerNorm epilogue (bf16 of product + bias, then + residual in f32).
+// ---------------------------------------------------------------------------------------------
+template <int TPR>
+__global__ __launch_bounds__(256) void reduce_res_ln_kernel(const float *__restrict__ part, int nsplit, int m, const float *__restrict__ bias,
+                                                             const bf16_t *__restrict__ res, int ldres, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, float eps, bf16_t *__restrict__ out, int ldo) {
+    constexpr int N = TPR * 24, kMaxSplit = 8;
+    const int l = threadIdx.x % TPR;
+    const int row = (int)(blockIdx.x * (256 / TPR) + threadIdx.x / TPR);
+    if (row >= m) return;
+    float y[24];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        const int col = (cc * TPR + l) * 8;
+        f32x4 pa[kMaxSplit], pb[kMaxSplit];
+#pragma unroll
+        for (int z = 0; z < kMaxSplit; ++z) {
+            const float *pp = part + ((size_t)(z < nsplit ? z : 0) * m + row) * N + col;
+            pa[z] = *reinterpret_cast<const f32x4 *>(pp);
+            pb[z] = *reinterpret_cast<const f32x4 *>(pp + 4);
+        }
+        f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
+#pragma unroll
+        for (int z = 0; z < kMaxSplit; ++z)
+            if (z < nsplit) {
+                s0 += pa[z];
+                s1 += pb[z];
+            }
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias + col);
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias + col + 4);
+        const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(res + (size_t)row * ldres + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[cc * 8 + e] = (float)(__bf16)(s0[e] + b0[e]) + (float)rs[e];
+            y[cc * 8 + 4 + e] = (float)(__bf16)(s1[e] + b1[e]) + (float)rs[4 + e];
+        }
+    }
+    float mean, rstd;
+    ln_row_stats<TPR, 24>(y, eps, mean, rstd);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        const int col = (cc * TPR + l) * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4 *>(gamma + col);
+        const f32x4 g1 = *reinterpret_cast<const f32x4 *>(gamma + col + 4);
+        const f32x4 e0 = *reinterpret_cast<const f32x4 *>(beta + col);
+        const f32x4 e1 = *reinterpret_cast<const f32x4 *>(beta + col + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (__bf16)ln_affine(y[cc * 8 + e], mean, rstd, g0[e], e0[e]);
+            o[4 + e] = (__bf16)ln_affine(y[cc * 8 + 4 + e], mean, rstd, g1[e], e1[e]);
+        }
+        *reinterpret_cast<bf16x8 *>(out + (size_t)row * ldo + col) = o;
+    }
+}
+
+hipError_t launch_reduce_res_ln(hipStream_t s, const float *part, int nsplit, int m, int n, const float *bias, const bf16_t *res, int ldres,
+                                const float *gamma, const float *beta, float eps, bf16_t *out, int ldo) {
+    if (nsplit < 1 || nsplit > 8 || m < 1) return hipErrorInvalidValue;
+    if (n == 768)
+        hipLaunchKernelGGL(reduce_res_ln_kernel<32>, dim3((m + 7) / 8), dim3(256), 0, s, part, nsplit, m, bias, res, ldres, gamma, beta, eps, out, ldo);
+    else if (n == 384)
+        hipLaunchKernelGGL(reduce_res_ln_kernel<16>, dim3((m + 15) / 16), dim3(256), 0, s, part, nsplit, m, bias, res, ldres, gamma, beta, eps, out, ldo);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden, const float *gamma, const float *beta, float eps) {

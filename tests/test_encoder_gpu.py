@@ -548,3 +548,36 @@ def test_split_operand_mode_on_pgemm_kernel(kw, B, S, seed, lib_built, monkeypat
     print(f"bf16x3 on pgemm_kernel, hidden {cfg.hidden}: 1 - cos = {d:.2e}, pairwise {pair:.2e}")
     assert d <= 1e-6 and pair <= 1e-3, (d, pair)
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("kw,B,S,seed", [
+    (dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 1, 16, 81),          # bge-base: one short query
+    (dict(layers=6, hidden=768, heads=12, ffn=3072, vocab=3000, max_pos=514, type_vocab=1, ln_eps=1e-5, pos_offset=2), 5, 90, 82),   # all-distilroberta-v1
+    (dict(layers=3, hidden=768, heads=12, ffn=3072, vocab=3000), 14, 128, 83),                         # 1792 rows: just below the threshold
+    (dict(layers=2, hidden=768, heads=12, ffn=1536, vocab=3000), 3, 200, 84)])                         # another ffn width (4 k-chunks)
+def test_hidden_768_small_passes_split_k(kw, B, S, seed, lib_built, monkeypatch):
+    """Passes of <= 2048 rows of a hidden-768 model run their two Add & LayerNorm GEMMs split over k (f32 partials from
+    gemm_kernel<EPI_F32>, reduce_res_ln_kernel behind them) instead of one 64 x 768 workgroup per row tile looping over all of k
+    (80 us per layer for one query).  Same rounding points, another f32 summation order: within 1e-5 of the fused form
+    (MEMEX_HIP_SPLITK=0), and within the usual bar of the f64 oracle."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, checkpoint_like_weights
+    from oracle import bert_oracle
+    cfg = EncoderConfig(**kw)
+    w = checkpoint_like_weights(cfg, seed)
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
+    lens = rng.integers(1, S + 1, size=B).astype(np.int32)
+    lens[0] = S
+    outs = []
+    for sk in ("1", "0"):
+        monkeypatch.setenv("MEMEX_HIP_SPLITK", sk)
+        with Encoder(cfg, w) as enc:
+            outs.append(enc.encode(ids, lens))
+            np.testing.assert_array_equal(outs[-1], enc.encode(ids, lens))
+    ref = bert_oracle.encode(w, cfg.as_dict(), ids, lens)
+    d_ref = (1.0 - _cos(outs[0].astype(np.float64), ref)).max()
+    d_pair = (1.0 - _cos(outs[0].astype(np.float64), outs[1].astype(np.float64))).max()
+    print(f"split-k small pass: vs fused {d_pair:.2e}, vs oracle {d_ref:.2e} (fused vs oracle {(1.0 - _cos(outs[1].astype(np.float64), ref)).max():.2e})")
+    assert (outs[0] != outs[1]).any(), "both encoders ran the same kernels"
+    assert d_ref <= TOL and d_pair <= 1e-4, (d_ref, d_pair)
