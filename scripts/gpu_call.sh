@@ -1,8 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-O=gpurun_out/r5_splitk_768_sweep.txt
-: > $O
-timeout 300 python scripts/gpu_query_latency.py bge 16x128,24x128,31x128,40x128 >> $O 2>&1
-echo "-- MEMEX_HIP_SPLITK=0" >> $O
-MEMEX_HIP_SPLITK=0 timeout 300 python scripts/gpu_query_latency.py bge 16x128,24x128,31x128,40x128 >> $O 2>&1
-cat $O
+timeout 2400 python -m pytest tests -m gpu -x -q > /tmp/pt.log 2>&1
+echo "pytest rc=$?" > gpurun_out/r5_final_check2.txt
+grep -E "passed|failed|Error" /tmp/pt.log | tail -4 >> gpurun_out/r5_final_check2.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> gpurun_out/r5_final_check2.txt
+cat gpurun_out/r5_final_check2.txt
