@@ -358,9 +358,11 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         };
         const bool split = e->split_small && e->sk_part && t_pad <= kSplitRows && H == 768 && F % 384 == 0;  // (hidden 384 has its own small-pass layer)
         const int ns_o = H / 384, ns_2 = std::min(kSplitMax, F / 384);
-        if (split && ns_o >= 2) MX_HIP(split_res_ln(o, ns_o));
-        else
-        MX_HIP(gemm_res_ln(o));
+        auto res_ln = [&](const GemmParams &gp, int nsplit) -> hipError_t {  // k must divide into chunks of whole k-tiles
+            const bool ok = split && nsplit >= 2 && gp.k % nsplit == 0 && (gp.k / nsplit) % 32 == 0;
+            return ok ? split_res_ln(gp, nsplit) : gemm_res_ln(gp);
+        };
+        MX_HIP(res_ln(o, ns_o));
         GemmParams f1{};
         f1.a = e->x1; f1.lda = H; f1.w = L.wi; f1.w_rows = F; f1.w_row0 = 0; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = H;
         f1.out = e->hbuf; f1.ldo = F;
@@ -368,9 +370,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         GemmParams f2{};
         f2.a = e->hbuf; f2.lda = F; f2.w = L.wo2; f2.w_rows = H; f2.w_row0 = 0; f2.bias = L.bo2; f2.m = t_pad; f2.n = H; f2.k = F;
         f2.out = e->x; f2.ldo = H; f2.res = e->x1; f2.ldres = H; f2.gamma = L.ln2g; f2.beta = L.ln2b; f2.eps = c.ln_eps;
-        if (split && ns_2 >= 2 && F % ns_2 == 0 && (F / ns_2) % 32 == 0) MX_HIP(split_res_ln(f2, ns_2));
-        else
-        MX_HIP(gemm_res_ln(f2));
+        MX_HIP(res_ln(f2, ns_2));
     }
     MX_HIP(launch_pool(st, e->x, nullptr, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
     // no synchronisation here: the passes of one call queue up on the stream (same workspace, stream order)
