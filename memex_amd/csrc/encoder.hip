@@ -83,7 +83,7 @@ struct mx_encoder {
     // reduce + LayerNorm kernel behind them (one 64 x 768 workgroup looping over k = 3072 is an 80 us latency chain)
     bool split_small = true;  // MEMEX_HIP_SPLITK=0: keep the fused Add & LayerNorm GEMMs at every pass size (tests, A/B)
     float *sk_part = nullptr; // [kSplitMax][kSplitRows][H] f32
-    float *sk_zero = nullptr; // [H] zeros: the partial GEMMs' bias (the reduce kernel adds the real one)
+    float *sk_zero = nullptr; // [3H] zeros: the partial GEMMs' bias (the reduce kernel adds the real one)
     bool small_pass = true;   // MEMEX_HIP_SMALL=0: small passes take the large-pass kernels (tests, A/B)
     bool attn_f32 = false;    // MEMEX_HIP_ATTN_F32=1: the bf16x3 mode's attention on the f32 MFMA instead of split bf16 products (tests)
     int small_rows = kSmallRows;  // passes of at most this many packed rows take the small-pass layer (MEMEX_HIP_SMALL_ROWS)
@@ -325,14 +325,26 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             MX_HIP(launch_sp_reduce_ln(st, e->sp_part, F, t_pad, (int)rows, L.bo2, e->sp_x1, L.ln2g, L.ln2b, c.ln_eps, e->x));
             continue;
         }
-        GemmParams g{};
-        g.a = e->x; g.lda = H; g.w = L.wqkv; g.w_rows = 3 * H; g.w_row0 = 0; g.bias = L.bqkv; g.m = t_pad; g.n = 2 * H; g.k = H;
-        g.out = e->q; g.out_k = e->k; g.ldo = H; g.hidden = H; g.qscale = qscale;
-        MX_HIP(gemm(EPI_QKV, g));
-        GemmParams gv{};  // V third of the concatenated projection, written feature-major
-        gv.a = e->x; gv.lda = H; gv.w = L.wqkv; gv.w_rows = 3 * H; gv.w_row0 = 2 * H; gv.bias = L.bqkv + 2 * H; gv.m = t_pad; gv.n = H;
-        gv.k = H; gv.out_vt = e->vt; gv.ldvt = t_pad; gv.hidden = H;
-        MX_HIP(gemm(EPI_VT, gv));
+        // small passes of the hidden-768 models (no fused tail, no small-pass layer of their own): k is split, see below
+        const bool split = e->split_small && e->sk_part && t_pad <= kSplitRows && H == 768 && F % 384 == 0;
+        if (split && t_pad <= kQueryRows) {  // (beyond a few row tiles the partials and the transposed V stores cost more than the launch saved)
+            // Q, K and V in ONE product over the concatenated weights, two k-chunks of f32 partials, then reduce_qkv_kernel
+            // (bias, q scale, the V third transposed): two 24-k-tile latency chains become one of 12 on 3 x the workgroups
+            GemmParams g3{};
+            g3.a = e->x; g3.lda = H; g3.w = L.wqkv; g3.w_rows = 3 * H; g3.w_row0 = 0; g3.bias = e->sk_zero; g3.m = t_pad; g3.n = 3 * H;
+            g3.k = H / 2; g3.ksplit = 2; g3.out_f32 = e->sk_part; g3.ldo = 3 * H;
+            MX_HIP(launch_gemm(st, EPI_F32, g3));
+            MX_HIP(launch_reduce_qkv(st, e->sk_part, 2, t_pad, H, L.bqkv, qscale, e->q, e->k, e->vt, t_pad));
+        } else {
+            GemmParams g{};
+            g.a = e->x; g.lda = H; g.w = L.wqkv; g.w_rows = 3 * H; g.w_row0 = 0; g.bias = L.bqkv; g.m = t_pad; g.n = 2 * H; g.k = H;
+            g.out = e->q; g.out_k = e->k; g.ldo = H; g.hidden = H; g.qscale = qscale;
+            MX_HIP(gemm(EPI_QKV, g));
+            GemmParams gv{};  // V third of the concatenated projection, written feature-major
+            gv.a = e->x; gv.lda = H; gv.w = L.wqkv; gv.w_rows = 3 * H; gv.w_row0 = 2 * H; gv.bias = L.bqkv + 2 * H; gv.m = t_pad; gv.n = H;
+            gv.k = H; gv.out_vt = e->vt; gv.ldvt = t_pad; gv.hidden = H;
+            MX_HIP(gemm(EPI_VT, gv));
+        }
         MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->attn_plan, B, heads, dh, H, e->ctx));
         if (e->fused_tail) {
             // out-projection + Add&Norm + MLP + Add&Norm in one kernel, in place on e->x
@@ -356,7 +368,6 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             if (he != hipSuccess) return he;
             return launch_reduce_res_ln(st, e->sk_part, nsplit, t_pad, gp.n, bias, gp.res, gp.ldres, gp.gamma, gp.beta, gp.eps, out, gp.n);
         };
-        const bool split = e->split_small && e->sk_part && t_pad <= kSplitRows && H == 768 && F % 384 == 0;  // (hidden 384 has its own small-pass layer)
         const int ns_o = H / 384, ns_2 = std::min(kSplitMax, F / 384);
         auto res_ln = [&](const GemmParams &gp, int nsplit) -> hipError_t {  // k must divide into chunks of whole k-tiles
             const bool ok = split && nsplit >= 2 && gp.k % nsplit == 0 && (gp.k / nsplit) % 32 == 0;
@@ -570,8 +581,8 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         e->split_small = !(sv && sv[0] == '0') && !(sm && sm[0] == '0');
         if (e->split_small) {
             void *pp = nullptr, *pz = nullptr;
-            if (hipMalloc(&pp, (size_t)kSplitMax * kSplitRows * H * sizeof(float)) != hipSuccess || hipMalloc(&pz, (size_t)H * sizeof(float)) != hipSuccess ||
-                hipMemset(pz, 0, (size_t)H * sizeof(float)) != hipSuccess) {
+            if (hipMalloc(&pp, (size_t)kSplitMax * kSplitRows * H * sizeof(float)) != hipSuccess || hipMalloc(&pz, (size_t)3 * H * sizeof(float)) != hipSuccess ||
+                hipMemset(pz, 0, (size_t)3 * H * sizeof(float)) != hipSuccess) {
                 if (pp) (void)hipFree(pp);
                 if (pz) (void)hipFree(pz);
                 return bail(fail(MX_ENOMEM, "hipMalloc(split-k workspace) failed"));

@@ -99,6 +99,10 @@ hipError_t launch_pgemm(hipStream_t s, int epi, const GemmParams &p);
 // the hidden-768 models: encoder.hip)
 hipError_t launch_reduce_res_ln(hipStream_t s, const float *part, int nsplit, int m, int n, const float *bias, const bf16_t *res, int ldres,
                                 const float *gamma, const float *beta, float eps, bf16_t *out, int ldo);
+// q | k | v^T from the f32 partials of a split-k QKV product [nsplit][m][3 hidden]: q = bf16((sum + b) qscale), k = bf16(sum + b) token-major,
+// v^T = bf16(sum + b) feature-major [hidden][ldvt] -- the roundings of gemm_kernel's EPI_QKV / EPI_VT epilogues
+hipError_t launch_reduce_qkv(hipStream_t s, const float *part, int nsplit, int m, int hidden, const float *bias, float qscale, bf16_t *q,
+                             bf16_t *k, bf16_t *vt, int ldvt);
 hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden, const float *gamma, const float *beta, float eps);
 
 // token maps from sequence lengths: cu[b] (aligned starts), tok_seq / tok_pos for every packed row

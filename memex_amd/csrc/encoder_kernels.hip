@@ -743,6 +743,48 @@ hipError_t launch_reduce_res_ln(hipStream_t s, const float *part, int nsplit, in
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// closes a split-k QKV product (small passes of the hidden-768 models): one thread per 8 columns of a row
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_qkv_kernel(const float *__restrict__ part, int nsplit, int m, int hidden, const float *__restrict__ bias,
+                                                          float qscale, bf16_t *__restrict__ q, bf16_t *__restrict__ k, bf16_t *__restrict__ vt,
+                                                          int ldvt) {
+    const int cpr = 3 * hidden / 8;  // 8-column chunks per row
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= m * cpr) return;
+    // consecutive threads take consecutive ROWS of one chunk: the v^T stores of a wave are then 64 consecutive tokens of a feature
+    const int row = i % m, col = (i / m) * 8;
+    f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
+    for (int z = 0; z < nsplit; ++z) {
+        const float *pp = part + ((size_t)z * m + row) * (3 * hidden) + col;
+        s0 += *reinterpret_cast<const f32x4 *>(pp);
+        s1 += *reinterpret_cast<const f32x4 *>(pp + 4);
+    }
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias + col), b1 = *reinterpret_cast<const f32x4 *>(bias + col + 4);
+    const int part_id = col / hidden;  // 0 = q, 1 = k, 2 = v (8 divides hidden)
+    const float sc = part_id == 0 ? qscale : 1.0f;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] = (__bf16)((s0[e] + b0[e]) * sc);
+        o[4 + e] = (__bf16)((s1[e] + b1[e]) * sc);
+    }
+    if (part_id < 2) {
+        *reinterpret_cast<bf16x8 *>((part_id == 0 ? q : k) + (size_t)row * hidden + (col - part_id * hidden)) = o;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vt[(size_t)(col - 2 * hidden + e) * ldvt + row] = o[e];
+    }
+}
+
+hipError_t launch_reduce_qkv(hipStream_t s, const float *part, int nsplit, int m, int hidden, const float *bias, float qscale, bf16_t *q,
+                             bf16_t *k, bf16_t *vt, int ldvt) {
+    if (nsplit < 1 || m < 1 || hidden % 8) return hipErrorInvalidValue;
+    const long n = (long)m * (3 * hidden / 8);
+    hipLaunchKernelGGL(reduce_qkv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nsplit, m, hidden, bias, qscale, q, k, vt, ldvt);
+    return hipGetLastError();
+}
+
 hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden, const float *gamma, const float *beta, float eps) {
     static const int rev = [] {
         const char *ev = getenv("MEMEX_HIP_LN_REV");
