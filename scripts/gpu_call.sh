@@ -1,8 +1,7 @@
 #!/bin/bash
-# the GPU call of the moment (see scripts/README.md): full GPU suite + smoke
+# the GPU call of the moment (see scripts/README.md): soak of the random-operation and concurrency tests
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -x -q > /tmp/pt.log 2>&1
-echo "pytest rc=$?" > gpurun_out/r5_final_check3.txt
-grep -E "passed|failed|Error" /tmp/pt.log | tail -4 >> gpurun_out/r5_final_check3.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> gpurun_out/r5_final_check3.txt
-cat gpurun_out/r5_final_check3.txt
+MEMEX_TEST_SOAK=4 timeout 2400 python -m pytest tests/test_random_ops_gpu.py -m gpu -q > /tmp/pt.log 2>&1
+echo "pytest rc=$?" > gpurun_out/r5_soak_final.txt
+grep -E "passed|failed|^E |FAILED" /tmp/pt.log | tail -12 >> gpurun_out/r5_soak_final.txt
+cat gpurun_out/r5_soak_final.txt
