@@ -185,6 +185,8 @@ struct mx_index {
     bool filter_auto = true;     // the library picks the kind (by row width) and may demote int8 to bf16 when a batch overflows
     bool pooled = false;         // counted in its device's lane-buffer pool (open_plain)
     uint32_t i8_batches = 0, i8_retry_batches = 0;  // since the int8 copy was built: batches served, batches that needed the retry pass
+    uint64_t plain_bf16_rows = 0;  // rows the index held when its bf16 copy was last built WITHOUT centring (0: no such copy): a collection
+                                   // that started small, or off a cone, is looked at again once it has doubled (add_device_locked)
     uint64_t demoted_at_rows = 0;  // rows the index held when an automatic int8 copy was demoted to bf16 (0: never); the
                                    // int8 copy gets another try once the collection has doubled (add_device_locked)
     float *tsc = nullptr;
@@ -687,6 +689,18 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
             last_error_slot() = keep;
         }
     }
+    // ... and a bf16 copy that was built plain (fewer than 256 rows at the time, or rows that did not sit in a cone) is rebuilt once the
+    // collection has doubled: should the rows sit in a cone by now, it comes back centred (section 3.2c) -- one pass over the rows per
+    // doubling.  (An automatic copy gets there through the promotion above; this is for a pinned bf16 copy.)
+    // (plain_bf16_rows == 0: the copy grew with the index from empty and was never built in one piece: first look at 256 rows)
+    if (idx->xh && !idx->filter_i8 && !idx->compressed && !idx->centred && idx->kc <= kMaxKC && idx->n >= 256 &&
+        idx->n >= 2 * std::max<uint64_t>(idx->plain_bf16_rows, 128) && !(idx->filter_auto && idx->demoted_at_rows)) {
+        const std::string keep = last_error_slot();
+        if (build_filter_copy(idx, false) != MX_OK) {
+            idx->plain_bf16_rows = idx->n;  // no room now: ask again after the next doubling
+            last_error_slot() = keep;
+        }
+    }
     return MX_OK;
 }
 
@@ -792,6 +806,7 @@ int build_filter_copy(mx_index *idx, bool i8) {
     idx->amean = static_cast<float *>(nam.release());
     idx->centred = centre;
     idx->filter_i8 = i8;
+    idx->plain_bf16_rows = (!i8 && !centre) ? std::max<uint64_t>(idx->n, 1) : 0;
     idx->i8_batches = idx->i8_retry_batches = 0;
     for (double &w : idx->wait_ema_us) w = 0.0;
     return MX_OK;
@@ -1498,6 +1513,7 @@ int clear_locked(mx_index *idx) {
     } else {
         idx->n = 0;  // ids restart at 1 (local.rs:50,63); HBM is kept for reuse
         idx->centred = false;  // (the centre belonged to the rows that are gone: appends refill the copy uncentred)
+        idx->plain_bf16_rows = 0;
         idx->wild_rows = 0;
         idx->n_zero = 0;
         idx->n_wild = 0;

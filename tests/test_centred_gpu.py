@@ -177,3 +177,33 @@ def test_centred_copy_with_out_of_range_norms_and_queries_off_the_cone(oracle, l
         extra = (cone_rows(np.random.default_rng(13), 900, d) * np.float32(1e-17)).astype(np.float32)
         idx.add(extra)
         _equal(idx, np.concatenate([X, extra]), Q, 10, oracle)
+
+
+def test_a_pinned_bf16_copy_that_started_small_is_centred_once_the_collection_has_grown(oracle, lib_built):
+    """A bf16 copy that grew with its index from empty (or was built when the collection held < 256 rows) is plain.  Once
+    the collection has doubled it is rebuilt -- and comes back centred if the rows sit in a cone by then; rows without a cone
+    are looked at again at every doubling and stay plain.  Answers bit-identical throughout."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(21)
+    d = 384
+    X = cone_rows(rng, 1500, d)
+    Q = cone_rows(rng, 20, d)
+    with FlatIndex(d) as idx:
+        idx.set_filter_copy("bf16")                    # pinned, on an empty index
+        idx.add(X[:100])
+        idx.add(X[100:200])
+        assert idx.stats().filter_centred == 0         # 200 rows: too few to judge
+        _equal(idx, X[:200], Q, 5, oracle)
+        idx.add(X[200:300])                            # 300 rows >= 256: rebuilt, and these rows sit in a cone
+        assert idx.stats().filter_centred == 1
+        _equal(idx, X[:300], Q, 10, oracle)
+        idx.add(X[300:])                               # appended behind the centred copy
+        assert idx.stats().filter_centred == 1
+        _equal(idx, X, Q, 10, oracle)
+        idx.clear()
+        G = rng.standard_normal((900, d), dtype=np.float32)
+        idx.add(G[:300])
+        assert idx.stats().filter_centred == 0         # looked at (>= 256 rows since the clear), no cone: plain
+        idx.add(G[300:])                               # doubled: looked at again, still plain
+        assert idx.stats().filter_centred == 0 and idx.stats().filter_kind == 3
+        _equal(idx, G, rng.standard_normal((9, d), dtype=np.float32), 10, oracle)
