@@ -351,6 +351,13 @@ int mx_tokenizer_create_from_memory(const char *vocab, size_t nbytes, int lowerc
 int mx_tokenizer_create_bpe(const char *vocab_json_path, const char *merges_path, mx_tokenizer **out);
 int mx_tokenizer_create_bpe_from_memory(const char *vocab_json, size_t n_vocab, const char *merges, size_t n_merges,
                                         mx_tokenizer **out);
+/* tokenizer.json -- the file Tokenizer::from_pretrained itself reads (embedding.rs:163): model.vocab (+ model.merges) and the
+ * normalizer's lowercase flag select one of the two kinds above.  The stacks of the reference's three models are accepted
+ * (BertNormalizer / BertPreTokenizer / WordPiece "##" / WordPiece decoder; ByteLevel / BPE / ByteLevel decoder); any other
+ * component -> MX_EUNSUPPORTED.  The file's truncation / padding blocks are ignored (segment_text overrides the first,
+ * embedding.rs:172-176, and decodes with skip_special_tokens, :182,189). */
+int mx_tokenizer_create_from_json(const char *tokenizer_json_path, mx_tokenizer **out);
+int mx_tokenizer_create_from_json_memory(const char *json, size_t nbytes, mx_tokenizer **out);
 void mx_tokenizer_destroy(mx_tokenizer *tok);
 int mx_tokenizer_vocab_size(mx_tokenizer *tok, int *n);
 

@@ -540,6 +540,13 @@ class Tokenizer {
             throw EmbeddingError(EmbeddingError::SetupError, mx_last_error());
         return std::shared_ptr<Tokenizer>(new Tokenizer(h));
     }
+    // tokenizer.json, the file Tokenizer::from_pretrained itself reads (embedding.rs:163): either kind, chosen by its "model"
+    static std::shared_ptr<Tokenizer> from_file(const std::string &tokenizer_json) {
+        mx_tokenizer *h = nullptr;
+        if (mx_tokenizer_create_from_json(tokenizer_json.c_str(), &h) != MX_OK)
+            throw EmbeddingError(EmbeddingError::SetupError, mx_last_error());
+        return std::shared_ptr<Tokenizer>(new Tokenizer(h));
+    }
     ~Tokenizer() { mx_tokenizer_destroy(h_); }
     Tokenizer(const Tokenizer &) = delete;
     Tokenizer &operator=(const Tokenizer &) = delete;

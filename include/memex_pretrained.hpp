@@ -281,6 +281,7 @@ struct PretrainedModel {
     std::vector<float> weights;   // the blob mx_encoder_create takes (include/memex_hip.h)
     std::string vocab_path;       // vocab.txt of a WordPiece model ("" otherwise): mx_tokenizer_create
     std::string vocab_json_path, merges_path;  // byte-level BPE files of a RoBERTa-family model ("" otherwise): mx_tokenizer_create_bpe
+    std::string tokenizer_json_path;  // tokenizer.json ("" when absent): the fallback when neither of the above is there
     size_t max_seq_length = 0;    // sentence_bert_config.json
     bool do_lower_case = true;    // tokenizer_config.json (default: BERT uncased)
     std::vector<std::string> modules;  // module types of modules.json in order
@@ -375,6 +376,11 @@ inline PretrainedModel load_pretrained_dir_impl(const std::string &dir, int prec
             pm.merges_path = d2 + "/merges.txt";
             break;
         }
+    for (const std::string &d2 : {dir, tdir})
+        if (file_exists(d2 + "/tokenizer.json")) {
+            pm.tokenizer_json_path = d2 + "/tokenizer.json";
+            break;
+        }
     if (!file_exists(tdir + "/model.safetensors"))
         throw unsupported(file_exists(tdir + "/pytorch_model.bin") || file_exists(tdir + "/rust_model.ot")
                               ? "only a pickled checkpoint is present (pytorch_model.bin / rust_model.ot): convert it to model.safetensors"
@@ -418,11 +424,12 @@ inline PretrainedModel load_pretrained_dir_impl(const std::string &dir, int prec
     return pm;
 }
 
-// The model's own tokenizer: WordPiece over vocab.txt, or byte-level BPE over vocab.json + merges.txt
+// The model's own tokenizer: WordPiece over vocab.txt, byte-level BPE over vocab.json + merges.txt, or what tokenizer.json describes
 inline std::shared_ptr<Tokenizer> pretrained_tokenizer(const PretrainedModel &pm) {
     if (!pm.vocab_path.empty()) return Tokenizer::wordpiece(pm.vocab_path, pm.do_lower_case);
     if (!pm.vocab_json_path.empty() && !pm.merges_path.empty()) return Tokenizer::bpe(pm.vocab_json_path, pm.merges_path);
-    throw EmbeddingError(EmbeddingError::SetupError, "Unable to load model: neither vocab.txt nor vocab.json + merges.txt");
+    if (!pm.tokenizer_json_path.empty()) return Tokenizer::from_file(pm.tokenizer_json_path);
+    throw EmbeddingError(EmbeddingError::SetupError, "Unable to load model: neither vocab.txt, vocab.json + merges.txt nor tokenizer.json");
 }
 
 // SentenceEmbedder::spawn(&ModelConfig) with create_model() reading a LOCAL sentence-transformers directory

@@ -33,6 +33,7 @@ EXPORTS = [
     "mx_encoder_encode_device", "mx_encoder_set_profiling", "mx_encoder_get_stats",
     "mx_encoder_reset_stats",
     "mx_tokenizer_create", "mx_tokenizer_create_from_memory", "mx_tokenizer_create_bpe", "mx_tokenizer_create_bpe_from_memory",
+    "mx_tokenizer_create_from_json", "mx_tokenizer_create_from_json_memory",
     "mx_tokenizer_destroy", "mx_tokenizer_vocab_size",
     "mx_tokenizer_encode", "mx_tokenizer_decode", "mx_tokenizer_segment", "mx_tokenizer_encode_batch",
     "mx_tokenizer_segment_batch", "mx_tokenizer_encode_staged",
@@ -137,6 +138,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "mx_tokenizer_create_from_memory": [cp, ctypes.c_size_t, i32, P(vp)],
         "mx_tokenizer_create_bpe": [cp, cp, P(vp)],
         "mx_tokenizer_create_bpe_from_memory": [cp, ctypes.c_size_t, cp, ctypes.c_size_t, P(vp)],
+        "mx_tokenizer_create_from_json": [cp, P(vp)],
+        "mx_tokenizer_create_from_json_memory": [cp, ctypes.c_size_t, P(vp)],
         "mx_tokenizer_vocab_size": [vp, P(i32)],
         "mx_tokenizer_encode": [vp, cp, i32, vp, i32, P(i32)],
         "mx_tokenizer_decode": [vp, vp, i32, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)],

@@ -757,9 +757,237 @@ int parse_vocab(mx_tokenizer *t, std::istream &in) {
     return finish_vocab(t);
 }
 
+// ---- tokenizer.json (what Tokenizer::from_pretrained fetches, embedding.rs:163): a span scanner, no tree --------------------
+// A value is the byte range [b, e) of the source text.  Only what the loader reads is interpreted; everything else is skipped
+// with bracket / string matching (depth-limited like the model-directory loaders).
+struct JSpan { size_t b = 0, e = 0; bool ok() const { return e > b; } };
+
+struct JScan {
+    const std::string &s;
+    explicit JScan(const std::string &src) : s(src) {}
+    void ws(size_t &i) const { while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\r' || s[i] == '\t')) ++i; }
+    // i at the opening quote -> one past the closing quote (false: unterminated)
+    bool skip_string(size_t &i) const {
+        for (++i; i < s.size(); ++i) {
+            if (s[i] == '\\') { ++i; continue; }
+            if (s[i] == '"') { ++i; return true; }
+        }
+        return false;
+    }
+    bool skip_value(size_t &i, int depth = 0) const {
+        ws(i);
+        if (i >= s.size() || depth > 64) return false;
+        if (s[i] == '"') return skip_string(i);
+        if (s[i] == '{' || s[i] == '[') {
+            const char close = s[i] == '{' ? '}' : ']';
+            const bool obj = s[i] == '{';
+            ++i;
+            ws(i);
+            if (i < s.size() && s[i] == close) { ++i; return true; }
+            for (;;) {
+                if (obj) {
+                    ws(i);
+                    if (i >= s.size() || s[i] != '"' || !skip_string(i)) return false;
+                    ws(i);
+                    if (i >= s.size() || s[i] != ':') return false;
+                    ++i;
+                }
+                if (!skip_value(i, depth + 1)) return false;
+                ws(i);
+                if (i < s.size() && s[i] == ',') { ++i; continue; }
+                if (i < s.size() && s[i] == close) { ++i; return true; }
+                return false;
+            }
+        }
+        const size_t b = i;  // number / true / false / null
+        while (i < s.size() && s[i] != ',' && s[i] != '}' && s[i] != ']' && s[i] != ' ' && s[i] != '\n' && s[i] != '\r' && s[i] != '\t') ++i;
+        return i > b;
+    }
+    // the value of `key` in the object `o` (span of "{...}"); empty span when absent or o is not an object
+    JSpan find(JSpan o, const char *key) const {
+        size_t i = o.b;
+        ws(i);
+        if (i >= o.e || s[i] != '{') return {};
+        ++i;
+        const size_t klen = strlen(key);
+        for (;;) {
+            ws(i);
+            if (i >= o.e || s[i] != '"') return {};
+            const size_t kb = i + 1;
+            if (!skip_string(i)) return {};
+            const bool hit = i - 1 - kb == klen && s.compare(kb, klen, key) == 0;
+            ws(i);
+            if (i >= o.e || s[i] != ':') return {};
+            ++i;
+            ws(i);
+            JSpan v;
+            v.b = i;
+            if (!skip_value(i)) return {};
+            v.e = i;
+            if (hit) return v;
+            ws(i);
+            if (i < o.e && s[i] == ',') { ++i; continue; }
+            return {};
+        }
+    }
+    bool is_null(JSpan v) const { return !v.ok() || s.compare(v.b, v.e - v.b, "null") == 0; }
+    bool is_true(JSpan v) const { return v.ok() && s.compare(v.b, v.e - v.b, "true") == 0; }
+    bool is_false(JSpan v) const { return v.ok() && s.compare(v.b, v.e - v.b, "false") == 0; }
+    // a JSON string value, unescaped ("" for anything else)
+    std::string str(JSpan v) const {
+        std::string out;
+        if (!v.ok() || s[v.b] != '"') return out;
+        for (size_t i = v.b + 1; i + 1 < v.e; ++i) {
+            if (s[i] != '\\') { out += s[i]; continue; }
+            const char e = s[++i];
+            if (e == 'u' && i + 4 < v.e) {
+                uint32_t c = (uint32_t)strtoul(s.substr(i + 1, 4).c_str(), nullptr, 16);
+                i += 4;
+                if (c >= 0xd800 && c <= 0xdbff && i + 6 < v.e && s[i + 1] == '\\' && s[i + 2] == 'u') {
+                    const uint32_t lo = (uint32_t)strtoul(s.substr(i + 3, 4).c_str(), nullptr, 16);
+                    if (lo >= 0xdc00 && lo <= 0xdfff) { c = 0x10000 + ((c - 0xd800) << 10) + (lo - 0xdc00); i += 6; }
+                }
+                append_utf8(out, c);
+            } else {
+                out += e == 'n' ? '\n' : e == 't' ? '\t' : e == 'r' ? '\r' : e == 'b' ? '\b' : e == 'f' ? '\f' : e;
+            }
+        }
+        return out;
+    }
+    // the elements of an array value
+    bool elements(JSpan a, std::vector<JSpan> &out) const {
+        size_t i = a.b;
+        ws(i);
+        if (i >= a.e || s[i] != '[') return false;
+        ++i;
+        ws(i);
+        if (i < a.e && s[i] == ']') return true;
+        for (;;) {
+            ws(i);
+            JSpan v;
+            v.b = i;
+            if (!skip_value(i)) return false;
+            v.e = i;
+            out.push_back(v);
+            ws(i);
+            if (i < a.e && s[i] == ',') { ++i; continue; }
+            return i < a.e && s[i] == ']';
+        }
+    }
+};
+
+// tokenizer.json -> a WordPiece or byte-level BPE handle.  The stacks the two native tokenizers implement are the ones the
+// reference's three models ship (BertNormalizer + BertPreTokenizer + WordPiece("##") + WordPiece decoder; ByteLevel + BPE +
+// ByteLevel decoder); any other component is refused with MX_EUNSUPPORTED, never approximated.  The file's own truncation /
+// padding blocks are ignored, as segment_text overrides the first (with_truncation, embedding.rs:172-176) and its decode calls
+// skip the pad tokens of the second (skip_special_tokens = true, :182,189).
+int build_from_tokenizer_json(mx_tokenizer *t, const std::string &js) {
+    JScan J(js);
+    JSpan root;
+    root.b = 0;
+    {
+        size_t i = 0;
+        if (!J.skip_value(i)) return fail(MX_EINVAL, "tokenizer.json: not a JSON document");
+        root.e = i;
+    }
+    const JSpan model = J.find(root, "model");
+    if (!model.ok()) return fail(MX_EINVAL, "tokenizer.json: no \"model\" object");
+    const JSpan vocab = J.find(model, "vocab"), merges = J.find(model, "merges");
+    if (!vocab.ok()) return fail(MX_EINVAL, "tokenizer.json: model has no vocab");
+    std::string type = J.str(J.find(model, "type"));
+    if (type.empty()) type = merges.ok() ? "BPE" : "WordPiece";  // files written before the tag existed
+    auto type_of = [&](const char *key) { const JSpan v = J.find(root, key); return J.is_null(v) ? std::string() : J.str(J.find(v, "type")); };
+    const std::string norm = type_of("normalizer"), pre = type_of("pre_tokenizer"), dec = type_of("decoder");
+    if (type == "WordPiece") {
+        if (norm != "BertNormalizer") return fail(MX_EUNSUPPORTED, "tokenizer.json: normalizer '%s' (BertNormalizer only)", norm.c_str());
+        if (pre != "BertPreTokenizer") return fail(MX_EUNSUPPORTED, "tokenizer.json: pre_tokenizer '%s' (BertPreTokenizer only)", pre.c_str());
+        if (!dec.empty() && dec != "WordPiece") return fail(MX_EUNSUPPORTED, "tokenizer.json: decoder '%s'", dec.c_str());
+        const JSpan nz = J.find(root, "normalizer");
+        const bool lower = !J.is_false(J.find(nz, "lowercase"));
+        // the native normaliser is BertNormalizer with its defaults: clean_text, handle_chinese_chars, accents stripped iff lowercase
+        const JSpan sa = J.find(nz, "strip_accents");
+        if (J.is_false(J.find(nz, "clean_text")) || J.is_false(J.find(nz, "handle_chinese_chars")) ||
+            (!J.is_null(sa) && J.is_true(sa) != lower))
+            return fail(MX_EUNSUPPORTED, "tokenizer.json: BertNormalizer options other than the defaults");
+        const JSpan pfx = J.find(model, "continuing_subword_prefix"), unk = J.find(model, "unk_token");
+        if (!J.is_null(pfx) && J.str(pfx) != "##") return fail(MX_EUNSUPPORTED, "tokenizer.json: continuing_subword_prefix '%s'", J.str(pfx).c_str());
+        if (!J.is_null(unk) && J.str(unk) != "[UNK]") return fail(MX_EUNSUPPORTED, "tokenizer.json: unk_token '%s'", J.str(unk).c_str());
+        const JSpan mc = J.find(model, "max_input_chars_per_word");
+        if (mc.ok() && !J.is_null(mc) && strtol(js.c_str() + mc.b, nullptr, 10) != 100)
+            return fail(MX_EUNSUPPORTED, "tokenizer.json: max_input_chars_per_word != 100");
+        t->lowercase = lower;
+        int rc = parse_vocab_json(t, js.substr(vocab.b, vocab.e - vocab.b));
+        if (rc != MX_OK) return rc;
+        return finish_vocab(t);
+    }
+    if (type == "BPE") {
+        if (!norm.empty()) return fail(MX_EUNSUPPORTED, "tokenizer.json: normalizer '%s' in front of a byte-level BPE", norm.c_str());
+        if (pre != "ByteLevel") return fail(MX_EUNSUPPORTED, "tokenizer.json: pre_tokenizer '%s' (ByteLevel only)", pre.c_str());
+        if (!dec.empty() && dec != "ByteLevel") return fail(MX_EUNSUPPORTED, "tokenizer.json: decoder '%s'", dec.c_str());
+        const JSpan pt = J.find(root, "pre_tokenizer");
+        if (J.is_true(J.find(pt, "add_prefix_space")) || J.is_false(J.find(pt, "use_regex")))
+            return fail(MX_EUNSUPPORTED, "tokenizer.json: ByteLevel options other than add_prefix_space = false, use_regex = true");
+        for (const char *k : {"continuing_subword_prefix", "end_of_word_suffix"}) {
+            const JSpan v = J.find(model, k);
+            if (!J.is_null(v) && !J.str(v).empty()) return fail(MX_EUNSUPPORTED, "tokenizer.json: BPE option %s", k);
+        }
+        {
+            const JSpan v = J.find(model, "dropout");
+            if (!J.is_null(v) && strtod(js.c_str() + v.b, nullptr) != 0.0) return fail(MX_EUNSUPPORTED, "tokenizer.json: BPE dropout");
+        }
+        if (J.is_true(J.find(model, "byte_fallback")) || J.is_true(J.find(model, "ignore_merges")))
+            return fail(MX_EUNSUPPORTED, "tokenizer.json: BPE byte_fallback / ignore_merges");
+        if (!merges.ok()) return fail(MX_EINVAL, "tokenizer.json: BPE model has no merges");
+        std::vector<JSpan> ms;
+        if (!J.elements(merges, ms)) return fail(MX_EINVAL, "tokenizer.json: merges is not an array");
+        std::string lines;  // the merges.txt the same tokenizer would ship
+        for (const JSpan &m : ms) {
+            if (js[m.b] == '"') {  // "a b"
+                lines += J.str(m);
+            } else {  // ["a", "b"] (tokenizers >= 0.20)
+                std::vector<JSpan> ab;
+                if (!J.elements(m, ab) || ab.size() != 2) return fail(MX_EINVAL, "tokenizer.json: a merge that is not a pair");
+                lines += J.str(ab[0]) + " " + J.str(ab[1]);
+            }
+            lines += '\n';
+        }
+        int rc = parse_vocab_json(t, js.substr(vocab.b, vocab.e - vocab.b));
+        if (rc != MX_OK) return rc;
+        std::istringstream in(lines);
+        return finish_bpe(t, in);
+    }
+    return fail(MX_EUNSUPPORTED, "tokenizer.json: model type '%s' (WordPiece / byte-level BPE only)", type.c_str());
+}
+
 }  // namespace
 
 extern "C" {
+
+// tokenizer.json, the file Tokenizer::from_pretrained reads (embedding.rs:163)
+int mx_tokenizer_create_from_json_memory(const char *json, size_t nbytes, mx_tokenizer **out) try {
+    if (!json || !out) return fail(MX_EINVAL, "null argument");
+    *out = nullptr;
+    mx_tokenizer *t = new mx_tokenizer();
+    int rc = build_from_tokenizer_json(t, std::string(json, nbytes));
+    if (rc != MX_OK) { delete t; return rc; }
+    *out = t;
+    return MX_OK;
+} catch (...) {
+    return guard_exception();
+}
+
+int mx_tokenizer_create_from_json(const char *tokenizer_json_path, mx_tokenizer **out) try {
+    if (!tokenizer_json_path || !out) return fail(MX_EINVAL, "null argument");
+    *out = nullptr;
+    std::ifstream f(tokenizer_json_path, std::ios::binary);
+    if (!f) return fail(MX_EIO, "Unable to load model <%s>", tokenizer_json_path);  // embedding.rs:166-169 wording
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    const std::string js = ss.str();
+    return mx_tokenizer_create_from_json_memory(js.data(), js.size(), out);
+} catch (...) {
+    return guard_exception();
+}
 
 int mx_tokenizer_create(const char *vocab_path, int lowercase, mx_tokenizer **out) try {
     if (!vocab_path || !out) return fail(MX_EINVAL, "null argument");

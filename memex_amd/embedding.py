@@ -162,7 +162,14 @@ def _as_tokenizer(tokenizer, vocab: int):
             return WordPieceTokenizer(tokenizer, lowercase=True)
         except Exception as e:
             raise SetupError(f"Unable to load model <{tokenizer}>") from e
-    if isinstance(tokenizer, str):
+    if isinstance(tokenizer, str):                           # tokenizer.json: native when it is one of the two stacks the
+        from ._lib import MX_EUNSUPPORTED, MemexHipError    # library implements, the `tokenizers` package for anything else
+        from .tokenizer import JsonTokenizer
+        try:
+            return JsonTokenizer(tokenizer)
+        except MemexHipError as e:
+            if e.code != MX_EUNSUPPORTED:
+                raise SetupError(f"Unable to load model <{tokenizer}>") from e
         try:
             from tokenizers import Tokenizer
             return HFTokenizerAdapter(Tokenizer.from_file(tokenizer))
@@ -234,12 +241,14 @@ class SentenceEmbedder:
             cfg, tensors, vocab, info = load_pretrained_dir(path, precision)
         except (UnsupportedModel, OSError, KeyError, ValueError) as e:
             raise SetupError(f"Unable to load model <{path}>: {e}") from e
-        if vocab is None and info["bpe_files"] is None:
-            raise SetupError(f"Unable to load model <{path}>: neither vocab.txt (WordPiece) nor vocab.json + merges.txt (byte-level BPE)")
-        from .tokenizer import ByteLevelBpeTokenizer, WordPieceTokenizer
+        if vocab is None and info["bpe_files"] is None and info.get("tokenizer_json") is None:
+            raise SetupError(f"Unable to load model <{path}>: neither vocab.txt (WordPiece), vocab.json + merges.txt "
+                             "(byte-level BPE) nor tokenizer.json")
+        from .tokenizer import ByteLevelBpeTokenizer, JsonTokenizer, WordPieceTokenizer
         try:
             tok = (WordPieceTokenizer(vocab, lowercase=info["do_lower_case"]) if vocab is not None
-                   else ByteLevelBpeTokenizer(*info["bpe_files"]))
+                   else ByteLevelBpeTokenizer(*info["bpe_files"]) if info["bpe_files"] is not None
+                   else JsonTokenizer(info["tokenizer_json"]))
         except Exception as e:
             raise SetupError(f"Unable to load model <{path}>: {e}") from e
         return cls.spawn(model_config, weights=tensors, tokenizer=tok, device=device, encoder_config=cfg,

@@ -10,6 +10,9 @@ lib/libmemex/src/llm/embedding.rs:99-100; rust-bert 0.21.0) 
     model.safetensors | pytorch_model.bin | rust_model.ot      weights
     vocab.txt (+ tokenizer_config.json)                        WordPiece vocabulary   (BERT family)
     vocab.json + merges.txt                                    byte-level BPE         (RoBERTa family: all-distilroberta-v1)
+    tokenizer.json                                             either kind in one file (what ``Tokenizer::from_pretrained``
+                                                               reads in segment_text, embedding.rs:163); used when the
+                                                               files above are absent
 
 and builds the model from them.  :func:`load_pretrained_dir` reads the same files from a LOCAL directory (this build has no
 network: the day a checkpoint is reachable the path is pointed at its directory) into an :class:`EncoderConfig`, the tensor
@@ -62,7 +65,8 @@ def load_pretrained_dir(path: str, precision: str = "bf16") -> Tuple[EncoderConf
     """-> (EncoderConfig, tensors by HF name, path of vocab.txt or None, info).
 
     ``info``: ``do_lower_case``, ``model_type``, ``modules`` (the pipeline's module types in order), ``bpe_files``
-    (``(vocab.json, merges.txt)`` of a byte-level BPE tokenizer, or None).
+    (``(vocab.json, merges.txt)`` of a byte-level BPE tokenizer, or None), ``tokenizer_json`` (path of ``tokenizer.json``, or
+    None: the fallback when neither ``vocab.txt`` nor the BPE pair is there).
 
     Raises :class:`UnsupportedModel`, ``OSError``, ``KeyError`` or ``ValueError`` -- what ``from_pretrained_dir`` turns into
     ``SetupError``; whatever a damaged file provokes underneath (a list where an object belongs, safetensors' own error type)
@@ -154,6 +158,7 @@ def _load_pretrained_dir(path: str, precision: str):
     tc_path = os.path.join(path, "tokenizer_config.json")
     if os.path.exists(tc_path):
         lower = _read_json(tc_path).get("do_lower_case", lower)
+    tj = next((p for p in (os.path.join(path, "tokenizer.json"), os.path.join(tdir, "tokenizer.json")) if os.path.exists(p)), None)
     info = {"do_lower_case": True if lower is None else bool(lower), "model_type": mtype, "modules": module_types,
-            "bpe_files": bpe}
+            "bpe_files": bpe, "tokenizer_json": tj}
     return cfg, tensors, vocab, info

@@ -117,3 +117,19 @@ class ByteLevelBpeTokenizer(_NativeTokenizer):
         h = ctypes.c_void_p()
         check(lib().mx_tokenizer_create_bpe(vocab_json.encode(), merges.encode(), ctypes.byref(h)))
         self._finish(h)
+
+
+class JsonTokenizer(_NativeTokenizer):
+    """A native tokenizer built from ``tokenizer.json`` -- the file ``Tokenizer::from_pretrained`` itself reads
+    (embedding.rs:163): WordPiece or byte-level BPE, whichever the file's ``model`` describes.  A component the native
+    code does not implement raises :class:`memex_amd._lib.MemexHipError` with ``MX_EUNSUPPORTED``."""
+
+    def __init__(self, tokenizer_json):
+        """``tokenizer_json``: a path, or the document itself as ``bytes``."""
+        h = ctypes.c_void_p()
+        if isinstance(tokenizer_json, (bytes, bytearray)):
+            blob = bytes(tokenizer_json)
+            check(lib().mx_tokenizer_create_from_json_memory(blob, len(blob), ctypes.byref(h)))
+        else:
+            check(lib().mx_tokenizer_create_from_json(str(tokenizer_json).encode(), ctypes.byref(h)))
+        self._finish(h)

@@ -1,7 +1,8 @@
 #!/bin/bash
-# the GPU call of the moment (see scripts/README.md)
+# full check at HEAD: GPU tests, smoke, default bench line
+cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_centred_gpu.py tests/test_random_ops_gpu.py tests/test_search_gpu.py tests/test_persistence_gpu.py tests/test_compressed_gpu.py -m gpu -x -q > /tmp/pt.log 2>&1
-echo "pytest rc=$?" > gpurun_out/r5_recentre.txt
-grep -E "passed|failed|^E |FAILED" /tmp/pt.log | tail -10 >> gpurun_out/r5_recentre.txt
-cat gpurun_out/r5_recentre.txt
+( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5; echo "pytest rc=${PIPESTATUS[0]}" ) > gpurun_out/r5c_check.txt 2>&1
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/r5c_check.txt 2>&1
+timeout 600 python bench.py > gpurun_out/r5c_bench.json 2> gpurun_out/r5c_bench.err
+tail -3 gpurun_out/r5c_check.txt; head -c 600 gpurun_out/r5c_bench.json
