@@ -16,7 +16,9 @@ static unsigned long long fnv(const std::string &s) {
 int main(int argc, char **argv) {
     if (argc < 3) return 2;
     try {
-        auto tok = memex::Tokenizer::wordpiece(argv[1], true);
+        const std::string src = argv[1];  // vocab.txt, or tokenizer.json (what Tokenizer::from_pretrained reads, embedding.rs:163)
+        const bool json = src.size() > 5 && src.compare(src.size() - 5, 5, ".json") == 0;
+        auto tok = json ? memex::Tokenizer::from_file(src) : memex::Tokenizer::wordpiece(src, true);
         std::vector<std::string> docs;
         std::ifstream f(argv[2]);
         for (std::string line; std::getline(f, line);) docs.push_back(line);

@@ -60,6 +60,10 @@ def test_cpp_tokenizer_class_matches_the_tokenizers_package(tmp_path, lib_built)
     (tmp_path / "docs.txt").write_text("\n".join(docs) + "\n", encoding="utf-8")
     r = subprocess.run([exe, str(vocab), str(tmp_path / "docs.txt")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "OK tokenizer host" in r.stdout, r.stdout + r.stderr
+    # the same tokenizer from the one-file form, tokenizer.json (Tokenizer::from_file): the same output, line for line
+    BertWordPieceTokenizer(str(vocab), lowercase=True).save(str(tmp_path / "tokenizer.json"))
+    rj = subprocess.run([exe, str(tmp_path / "tokenizer.json"), str(tmp_path / "docs.txt")], capture_output=True, text=True, timeout=120)
+    assert rj.returncode == 0 and rj.stdout == r.stdout, rj.stdout + rj.stderr
 
     def fnv(b: bytes) -> int:
         h = 1469598103934665603
