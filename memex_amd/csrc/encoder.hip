@@ -254,6 +254,15 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         attn_flops += 4.0 * (double)l * (double)l * H;
     }
     const int t_pad = (int)round_up((uint64_t)rows + 32, kRowPad);
+    // t_pad rows are ALLOCATED (leading dimensions, the token map, the 32 rows a key block may read past the last sequence);
+    // m_c rows are COMPUTED by the GEMMs, the layer tail and the LayerNorm passes.  They differ by one 256-row tile exactly
+    // when a pass is full (131072 packed rows: 256 chunks of 512 tokens), and that 513th tile cost a whole extra round of
+    // workgroups in every kernel whose grid the other 512 fill exactly (pgemm_kernel: 7 tiles on three CUs of XCD 0 where
+    // every other CU has 6; tail_kernel / gemm_kernel: 2052 workgroups on 512 slots) -- 8-17 % of those launches.  Rows
+    // past m_c keep whatever the buffers held (zeros, or finite activations of an earlier pass): nothing reads them
+    // unmasked.
+    static const bool pad_tile = [] { const char *ev = getenv("MEMEX_HIP_PAD_TILE"); return ev && ev[0] == '1'; }();  // A/B: the old extent
+    const int m_c = pad_tile ? t_pad : (int)round_up((uint64_t)rows, kRowPad);
     int rc = ensure_ws(e, t_pad, B, 0);
     if (rc != MX_OK) return rc;
     hipStream_t st = e->stream;
@@ -271,24 +280,24 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
                                        c.ln_eps, c.vocab, e->xf, e->xs));
         for (const Layer &L : e->layers) {
             GemmParams g{};
-            g.a = e->xs; g.lda = 3 * H; g.w = L.wqkv3; g.w_rows = 3 * H; g.bias = L.bqkv; g.m = t_pad; g.n = 3 * H; g.k = 3 * H;
+            g.a = e->xs; g.lda = 3 * H; g.w = L.wqkv3; g.w_rows = 3 * H; g.bias = L.bqkv; g.m = m_c; g.n = 3 * H; g.k = 3 * H;
             g.out_f32 = e->qkvf; g.ldo = 3 * H;
             MX_HIP(pgemm_or_gemm(EPI_F32, g));
             MX_HIP(launch_attention_f32(st, e->qkvf, e->cu, d_lens, B, max_len, heads, dh, H, e->ctxs, e->attn_f32));
             GemmParams o{};
-            o.a = e->ctxs; o.lda = 3 * H; o.w = L.wo3; o.w_rows = H; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = 3 * H;
+            o.a = e->ctxs; o.lda = 3 * H; o.w = L.wo3; o.w_rows = H; o.bias = L.bo; o.m = m_c; o.n = H; o.k = 3 * H;
             o.out_f32 = e->af; o.ldo = H;
             MX_HIP(pgemm_or_gemm(EPI_F32, o));
-            MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, t_pad, H, L.ln1g, L.ln1b, c.ln_eps));
+            MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, m_c, H, L.ln1g, L.ln1b, c.ln_eps));
             GemmParams f1{};
-            f1.a = e->xs; f1.lda = 3 * H; f1.w = L.wi3; f1.w_rows = F; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = 3 * H;
+            f1.a = e->xs; f1.lda = 3 * H; f1.w = L.wi3; f1.w_rows = F; f1.bias = L.bi; f1.m = m_c; f1.n = F; f1.k = 3 * H;
             f1.out = e->hs; f1.ldo = 3 * F;
             MX_HIP(pgemm_or_gemm(EPI_GELU_SPLIT, f1));
             GemmParams f2{};
-            f2.a = e->hs; f2.lda = 3 * F; f2.w = L.wo23; f2.w_rows = H; f2.bias = L.bo2; f2.m = t_pad; f2.n = H; f2.k = 3 * F;
+            f2.a = e->hs; f2.lda = 3 * F; f2.w = L.wo23; f2.w_rows = H; f2.bias = L.bo2; f2.m = m_c; f2.n = H; f2.k = 3 * F;
             f2.out_f32 = e->af; f2.ldo = H;
             MX_HIP(pgemm_or_gemm(EPI_F32, f2));
-            MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, t_pad, H, L.ln2g, L.ln2b, c.ln_eps));
+            MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, m_c, H, L.ln2g, L.ln2b, c.ln_eps));
         }
         MX_HIP(launch_pool(st, nullptr, e->xf, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
         e->stats.sequences += (uint64_t)B;
@@ -331,17 +340,17 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             // Q, K and V in ONE product over the concatenated weights, two k-chunks of f32 partials, then reduce_qkv_kernel
             // (bias, q scale, the V third transposed): two 24-k-tile latency chains become one of 12 on 3 x the workgroups
             GemmParams g3{};
-            g3.a = e->x; g3.lda = H; g3.w = L.wqkv; g3.w_rows = 3 * H; g3.w_row0 = 0; g3.bias = e->sk_zero; g3.m = t_pad; g3.n = 3 * H;
+            g3.a = e->x; g3.lda = H; g3.w = L.wqkv; g3.w_rows = 3 * H; g3.w_row0 = 0; g3.bias = e->sk_zero; g3.m = m_c; g3.n = 3 * H;
             g3.k = H / 2; g3.ksplit = 2; g3.out_f32 = e->sk_part; g3.ldo = 3 * H;
             MX_HIP(launch_gemm(st, EPI_F32, g3));
-            MX_HIP(launch_reduce_qkv(st, e->sk_part, 2, t_pad, H, L.bqkv, qscale, e->q, e->k, e->vt, t_pad));
+            MX_HIP(launch_reduce_qkv(st, e->sk_part, 2, m_c, H, L.bqkv, qscale, e->q, e->k, e->vt, t_pad));
         } else {
             GemmParams g{};
-            g.a = e->x; g.lda = H; g.w = L.wqkv; g.w_rows = 3 * H; g.w_row0 = 0; g.bias = L.bqkv; g.m = t_pad; g.n = 2 * H; g.k = H;
+            g.a = e->x; g.lda = H; g.w = L.wqkv; g.w_rows = 3 * H; g.w_row0 = 0; g.bias = L.bqkv; g.m = m_c; g.n = 2 * H; g.k = H;
             g.out = e->q; g.out_k = e->k; g.ldo = H; g.hidden = H; g.qscale = qscale;
             MX_HIP(gemm(EPI_QKV, g));
             GemmParams gv{};  // V third of the concatenated projection, written feature-major
-            gv.a = e->x; gv.lda = H; gv.w = L.wqkv; gv.w_rows = 3 * H; gv.w_row0 = 2 * H; gv.bias = L.bqkv + 2 * H; gv.m = t_pad; gv.n = H;
+            gv.a = e->x; gv.lda = H; gv.w = L.wqkv; gv.w_rows = 3 * H; gv.w_row0 = 2 * H; gv.bias = L.bqkv + 2 * H; gv.m = m_c; gv.n = H;
             gv.k = H; gv.out_vt = e->vt; gv.ldvt = t_pad; gv.hidden = H;
             MX_HIP(gemm(EPI_VT, gv));
         }
@@ -350,13 +359,13 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             // out-projection + Add&Norm + MLP + Add&Norm in one kernel, in place on e->x
             TailParams tp{};
             tp.ctx = e->ctx; tp.ldc = H; tp.x = e->x; tp.ldx = H; tp.wf = L.wf; tp.bo = L.bo; tp.ln1g = L.ln1g; tp.ln1b = L.ln1b;
-            tp.b1 = L.bi; tp.b2 = L.bo2; tp.f = F; tp.m = t_pad; tp.out = e->x; tp.ldo = H; tp.gamma = L.ln2g; tp.beta = L.ln2b;
+            tp.b1 = L.bi; tp.b2 = L.bo2; tp.f = F; tp.m = m_c; tp.out = e->x; tp.ldo = H; tp.gamma = L.ln2g; tp.beta = L.ln2b;
             tp.eps = c.ln_eps;
             MX_HIP(launch_tail(st, tp));
             continue;
         }
         GemmParams o{};
-        o.a = e->ctx; o.lda = H; o.w = L.wo; o.w_rows = H; o.w_row0 = 0; o.bias = L.bo; o.m = t_pad; o.n = H; o.k = H;
+        o.a = e->ctx; o.lda = H; o.w = L.wo; o.w_rows = H; o.w_row0 = 0; o.bias = L.bo; o.m = m_c; o.n = H; o.k = H;
         o.out = e->x1; o.ldo = H; o.res = e->x; o.ldres = H; o.gamma = L.ln1g; o.beta = L.ln1b; o.eps = c.ln_eps;
         // small passes: product split over k into f32 partials (gemm_kernel<EPI_F32>, chunks of >= 384 columns), then
         // reduce + bias + residual + LayerNorm -- the rounding points of the fused epilogue, another f32 summation order
@@ -366,7 +375,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             gp.k /= nsplit; gp.ksplit = nsplit; gp.bias = e->sk_zero; gp.out = nullptr; gp.out_f32 = e->sk_part; gp.ldo = gp.n;
             hipError_t he = launch_gemm(st, EPI_F32, gp);
             if (he != hipSuccess) return he;
-            return launch_reduce_res_ln(st, e->sk_part, nsplit, t_pad, gp.n, bias, gp.res, gp.ldres, gp.gamma, gp.beta, gp.eps, out, gp.n);
+            return launch_reduce_res_ln(st, e->sk_part, nsplit, m_c, gp.n, bias, gp.res, gp.ldres, gp.gamma, gp.beta, gp.eps, out, gp.n);
         };
         const int ns_o = H / 384, ns_2 = std::min(kSplitMax, F / 384);
         auto res_ln = [&](const GemmParams &gp, int nsplit) -> hipError_t {  // k must divide into chunks of whole k-tiles
@@ -375,11 +384,11 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         };
         MX_HIP(res_ln(o, ns_o));
         GemmParams f1{};
-        f1.a = e->x1; f1.lda = H; f1.w = L.wi; f1.w_rows = F; f1.w_row0 = 0; f1.bias = L.bi; f1.m = t_pad; f1.n = F; f1.k = H;
+        f1.a = e->x1; f1.lda = H; f1.w = L.wi; f1.w_rows = F; f1.w_row0 = 0; f1.bias = L.bi; f1.m = m_c; f1.n = F; f1.k = H;
         f1.out = e->hbuf; f1.ldo = F;
         MX_HIP(gemm(EPI_BIAS_GELU, f1));
         GemmParams f2{};
-        f2.a = e->hbuf; f2.lda = F; f2.w = L.wo2; f2.w_rows = H; f2.w_row0 = 0; f2.bias = L.bo2; f2.m = t_pad; f2.n = H; f2.k = F;
+        f2.a = e->hbuf; f2.lda = F; f2.w = L.wo2; f2.w_rows = H; f2.w_row0 = 0; f2.bias = L.bo2; f2.m = m_c; f2.n = H; f2.k = F;
         f2.out = e->x; f2.ldo = H; f2.res = e->x1; f2.ldres = H; f2.gamma = L.ln2g; f2.beta = L.ln2b; f2.eps = c.ln_eps;
         MX_HIP(res_ln(f2, ns_2));
     }

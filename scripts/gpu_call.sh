@@ -1,8 +1,5 @@
 #!/bin/bash
-# full check at HEAD: GPU tests, smoke, default bench line
-cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
-( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5; echo "pytest rc=${PIPESTATUS[0]}" ) > gpurun_out/r5c_check.txt 2>&1
-timeout 120 python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/r5c_check.txt 2>&1
-timeout 600 python bench.py > gpurun_out/r5c_bench.json 2> gpurun_out/r5c_bench.err
-tail -3 gpurun_out/r5c_check.txt; head -c 600 gpurun_out/r5c_bench.json
+# A/B on one box: computed rows = round_up(rows, 256) (default) against round_up(rows + 32, 256) (MEMEX_HIP_PAD_TILE=1)
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+for rep in 1 2; do for v in 0 1; do echo "== MEMEX_HIP_PAD_TILE=$v (run $rep)"; MEMEX_HIP_PAD_TILE=$v timeout 300 python scripts/gpu_encoder_perf.py 2>&1 | grep chunks; done; done > gpurun_out/r5f_pad_tile_ab.txt
+cat gpurun_out/r5f_pad_tile_ab.txt

@@ -581,3 +581,42 @@ def test_hidden_768_small_passes_split_k(kw, B, S, seed, lib_built, monkeypatch)
     print(f"split-k small pass: vs fused {d_pair:.2e}, vs oracle {d_ref:.2e} (fused vs oracle {(1.0 - _cos(outs[1].astype(np.float64), ref)).max():.2e})")
     assert (outs[0] != outs[1]).any(), "both encoders ran the same kernels"
     assert d_ref <= TOL and d_pair <= 1e-4, (d_ref, d_pair)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,seed", [
+    (dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000), 81),                       # tail_kernel / gemm_kernel / pgemm QK
+    (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 82),        # pgemm_kernel + ln_rows_kernel
+    (dict(layers=1, hidden=384, heads=12, ffn=1536, vocab=3000, precision="bf16x3"), 83),   # the split-operand layer
+])
+def test_full_passes_compute_whole_tiles_only(kw, seed, lib_built):
+    """The GEMMs, the layer tail and the LayerNorm passes run over round_up(rows, 256) rows, the workspace (and the rows a key
+    block reads past the last sequence) over round_up(rows + 32, 256): a pass whose packed rows fill their last 256-row tile --
+    the ingest shape, 256 chunks x 512 tokens -- no longer multiplies a 513th tile of padding.  Rows between the two are then
+    never written; run such passes on a workspace a LARGER pass has left dirty and hold every sequence against the oracle,
+    the last ones (whose key blocks reach into the unwritten rows) in particular."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    from oracle import bert_oracle
+    cfg = EncoderConfig(**kw)
+    w = synthetic_weights(cfg, seed)
+    rng = np.random.default_rng(seed)
+    S = 512
+    precise = cfg.precision == "bf16x3"
+    tol = 1e-7 if precise else TOL
+    with Encoder(cfg, w) as enc:
+        big_ids = rng.integers(1000, cfg.vocab, size=(80, S)).astype(np.int32)
+        enc.encode(big_ids, np.full(80, S, dtype=np.int32))                       # 40960 rows: dirties the workspace
+        for lens in (np.full(64, S), np.full(8, S),                                # 32768 / 4096 rows: a multiple of 256 exactly
+                     np.r_[np.full(63, S), [S - 16]],                              # 32752: 240 of the last tile (rows + 32 spills over)
+                     np.r_[np.full(7, S), [250], [5]],                             # 3848 = 15 * 256 + 8
+                     np.r_[np.full(3, S), [505]]):                                 # 2048 exactly through a length that is not 8-aligned
+            lens = lens.astype(np.int32)
+            B = len(lens)
+            ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
+            out = enc.encode(ids, lens)
+            assert np.isfinite(out).all()
+            sub = np.r_[0:min(4, B), max(4, B - 4):B]
+            ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub])
+            assert (1.0 - _cos(out[sub].astype(np.float64), ref)).max() <= tol, (kw, lens[-3:])
+            np.testing.assert_array_equal(out, enc.encode(ids, lens))
