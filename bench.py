@@ -729,6 +729,48 @@ class SearchBuffers:
         self.nf = torch.zeros((batch,), device="cuda", dtype=torch.int32)
 
 
+def concurrent_callers_leg(idx, q, k: int, dim: int, data: str, calls: int, threads: int = 4):
+    """Several request threads, each issuing 256-query mx_index_search calls (host pointers) against the headline corpus --
+    the reference's API handlers run on a multi-threaded runtime (handlers.rs:55-109).  While one combined batch is on
+    the GPU the other callers queue up and the next batch takes up to 512 queries, which the int8 scan serves in one pass:
+    two batches' worth of queries share one sample / theta / collect / finish sequence and the host turn-around hides under
+    the next callers' queueing.  Reported: aggregate queries/s, scan passes per call (0.5 = every pass carried two calls),
+    and that every caller got its own single-caller answers."""
+    import threading
+    import torch
+    qs = [q.cpu().numpy()] + [make_queries(256, dim, data, seed=7000 + t).cpu().numpy() for t in range(1, threads)]
+    want = [idx.search(x, k)[0] for x in qs]                      # single-caller answers
+    ok = [True] * threads
+    start = threading.Barrier(threads + 1)
+
+    def worker(t):
+        start.wait()
+        for _ in range(calls):
+            ids = idx.search(qs[t], k)[0]
+            ok[t] = ok[t] and bool((ids == want[t]).all())
+
+    for _ in range(3):
+        idx.search(qs[0], k)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    for x in th:
+        x.start()
+    idx.reset_stats()
+    idx.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    start.wait()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    st = idx.stats()
+    idx.set_profiling(False)
+    total_calls = threads * calls
+    return {"workload": f"{threads} caller threads x {calls} calls of 256 queries, mx_index_search (host pointers), top-{k}",
+            "value": 256 * total_calls / dt, "unit": "queries/s", "ms_per_call": dt / total_calls * 1e3,
+            "scan_passes_per_call": st.scan_launches / max(1, total_calls), "retry_queries": int(st.retry_queries),
+            "fallback_queries": int(st.fallback_queries), "answers_equal_single_caller": all(ok)}
+
+
 def roofline_of(st, scan: str, dim: int, batch: int, rows_total: int, world: int):
     scan_s = st.scan_ms / 1e3
     achieved = (st.scan_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
@@ -868,6 +910,12 @@ def run(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    laps, t_lap = {}, [time.perf_counter()]
+
+    def lap(name):  # wall seconds per stage of this script (corpus builds and CPU baselines included): `wall_s` in the line
+        now = time.perf_counter()
+        laps[name] = round(laps.get(name, 0.0) + now - t_lap[0], 2)
+        t_lap[0] = now
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     # one plain process and N > 1: the in-library sharded index drives all N GPUs (the form the single-process
@@ -938,6 +986,7 @@ def run(a):
             torch.cuda.synchronize(d)
 
     dt, st = timed_steps(idx, step, fence, a.warmup, a.steps, world)
+    lap("headline (build + timed steps)")
     settle_steps = getattr(timed_steps, "last_settle", 0)
     ids_main = bufs.ids.clone()
     exchange = idx.exchange
@@ -958,6 +1007,7 @@ def run(a):
         alt = next(iter(legs.values()), None)
         idx.set_filter_copy({"f32": False, "bf16": "bf16", "i8": "i8"}[a.scan])
         step()
+    lap("other_scan + f32_rows")
     host_api = None
     if single and a.side_steps > 0:
         # the entry point the Rust shim binds: host pointers in and out (queries H2D, results D2H inside the step)
@@ -965,6 +1015,11 @@ def run(a):
         dt3, st3 = timed_steps(idx, lambda: idx.search(qh, k), fence, 3, a.side_steps, world)
         host_api = leg_report(st3, dt3, a.side_steps, f"{rows_total}x{a.dim} f32 corpus ({a.data}), query batch {a.batch}, "
                               f"top-{k}, mx_index_search (host pointers)", a.dim, a.batch, rows_total)
+
+    callers = None
+    if single and a.side_steps > 0 and a.batch == 256:
+        callers = concurrent_callers_leg(idx, q, k, a.dim, a.data, a.side_steps)
+        lap("host_api + concurrent_callers")
 
     small = None
     small_steps = a.side_steps if a.small_steps is None else a.small_steps
@@ -996,6 +1051,7 @@ def run(a):
     qlat = None
     if single and small_steps > 0:
         qlat = query_latency_leg(idx, k)
+        lap("small_batches + query_latency")
 
     # ---- recall@10 against the all-f64 EXACT path on a few queries (oracle-level parity at smaller
     # sizes and the oracle-based 10M check live in tests/; the EXACT path is itself oracle-checked there)
@@ -1026,6 +1082,7 @@ def run(a):
     sides = {}
     if single and a.side_steps > 0:
         sides["host_api"] = host_api
+        sides["concurrent_callers"] = callers
         sides["small_batches"] = small
         sides["query_latency"] = qlat
         other_data = "clustered" if a.data == "gaussian" else "gaussian"
@@ -1033,6 +1090,7 @@ def run(a):
         if a.data == "gaussian":  # embedding-like rows (decaying spectrum + common mean direction), the library's own choice of copy
             sides["anisotropic"] = side_leg(rows_total, a.dim, a.batch, k, a.side_steps, "anisotropic")
         sides["cfg4_shard_10Mx768"] = side_leg(10_000_000, 768, a.batch, k, a.side_steps, "gaussian")
+        lap("clustered + anisotropic + cfg4 shard")
         if a.shard_legs:
             # what each of 8 GPUs runs per step when configs[2] / a 10M x 768 corpus is sharded 8 ways: the whole per-step fixed
             # cost (prep, sample, theta, finish) against 1/8 of the scan -- a one-GPU proxy for strong scaling (no exchange)
@@ -1059,25 +1117,31 @@ def run(a):
                 except Exception as e:  # noqa: BLE001 -- a side leg must not fail the bench
                     leg["exchange_and_merge_error"] = repr(e)[:300]
                 sides[nm] = leg
+            lap("shard legs")
         if a.enc_like_rows > 0:
             sides["enc_like_10M"] = enc_like_leg(a.enc_like_rows, 100_000, a.batch, k, a.side_steps)
+            lap("enc_like_10M")
         if a.cfg2_segments > 0:
             sides["cfg2"] = cfg2_leg(a.cfg2_segments, a.batch, k, a.side_steps)
+            lap("cfg2")
         if a.precise_chunks > 0:
             try:
                 sides["ingest_bf16x3"] = precise_ingest_leg(a.precise_chunks, a.precise_chunks // 4)
             except Exception as e:  # noqa: BLE001 -- a side leg must not fail the bench
                 sides["ingest_bf16x3"] = {"error": repr(e)[:300]}
+            lap("ingest_bf16x3")
         if a.text_docs > 0:
             try:
                 sides["text_ingest"] = text_ingest_leg(a.text_docs, cpu_too=not a.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001 -- a side leg must not fail the bench
                 sides["text_ingest"] = {"error": repr(e)[:300]}
+            lap("text_ingest (incl. its CPU baseline)")
     ingest = None
     if a.ingest_chunks > 0:
         ingest = ingest_leg(a.ingest_chunks, dev, world, not a.no_cpu_baseline, devices=shard_devs if in_library and not one_device else None)
     if single and a.bge_chunks > 0:
         sides["ingest_bge_base"] = ingest_leg(a.bge_chunks, dev, 1, not a.no_cpu_baseline, model="bge-base-en")
+    lap("ingest + ingest_bge_base (incl. their CPU baselines)")
 
     if rank == 0:
         n_gpus = world * shards
@@ -1133,6 +1197,8 @@ def run(a):
                 except Exception as e:  # the baseline must never fail the bench
                     cb["hnsw"] = {"error": repr(e)}
             out["cpu_baseline"] = cb
+            lap("cpu_baseline (brute force + HNSW)")
+        out["wall_s"] = laps
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -409,6 +409,11 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
     // passes queue on the stream without synchronisation, so a later pass must never reallocate buffers an
     // earlier one is still using)
     std::vector<std::pair<int, int>> passes;  // (first sequence, count)
+    static const long pass_rows = [] {  // MEMEX_HIP_PASS_ROWS: A/B of the pass size (multiple of 256 in [4096, 2^19])
+        const char *ev = getenv("MEMEX_HIP_PASS_ROWS");
+        const long v = ev ? atol(ev) / 256 * 256 : 0;
+        return v >= 4096 && v <= (1L << 19) ? v : (long)kMaxRowsPerPass;
+    }();
     long max_rows = 0;
     int max_nb = 0;
     for (int b0 = 0; b0 < B;) {
@@ -417,7 +422,7 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
         while (b0 + nb < B && nb < kMaxSeqsPerPass) {
             const int l = std::min(std::max(h_lens[b0 + nb], 1), S);
             const long r = (l + kSeqAlign - 1) / kSeqAlign * kSeqAlign;
-            if (nb > 0 && rows + r > kMaxRowsPerPass) break;
+            if (nb > 0 && rows + r > pass_rows) break;
             rows += r;
             ++nb;
         }

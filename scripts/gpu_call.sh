@@ -1,5 +1,8 @@
 #!/bin/bash
-# A/B on one box: computed rows = round_up(rows, 256) (default) against round_up(rows + 32, 256) (MEMEX_HIP_PAD_TILE=1)
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-for rep in 1 2; do for v in 0 1; do echo "== MEMEX_HIP_PAD_TILE=$v (run $rep)"; MEMEX_HIP_PAD_TILE=$v timeout 300 python scripts/gpu_encoder_perf.py 2>&1 | grep chunks; done; done > gpurun_out/r5f_pad_tile_ab.txt
-cat gpurun_out/r5f_pad_tile_ab.txt
+# full check: GPU tests, smoke, default bench line
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+( timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -5; echo "pytest rc=${PIPESTATUS[0]}" ) > gpurun_out/r5h_check.txt 2>&1
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids >> gpurun_out/r5h_check.txt
+timeout 900 python bench.py > gpurun_out/r5h_bench.json 2> gpurun_out/r5h_bench.err
+cat gpurun_out/r5h_check.txt; head -c 300 gpurun_out/r5h_bench.json; tail -3 gpurun_out/r5h_bench.err
