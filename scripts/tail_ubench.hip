@@ -69,6 +69,21 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) CK(launch_tail(0, p2)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
   printf("tail po=%d ablate=%d skew=%d(bit %d, < %d) m=%d f=%d: %.1f us  %.0f TFLOP/s (%.1f%% of 2.5 PF)\n", po, MX_TAIL_ABLATE, skew_iters, skew_shift, skew_hi, m, f, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
+  if (argc > 9 && atoi(argv[9]) > 0) {
+    // argv[9] = MB: the same launches with COLD inputs -- between two launches a kernel streams that many MB through the
+    // caches (in the encoder the tail's x was written three kernels and ~400 MB of q / k / v / ctx traffic earlier); each
+    // launch timed by its own event pair.  argv[10] = 1: the flush touches x and ctx themselves last (warm inputs, same gaps)
+    const size_t fb = (size_t)atoi(argv[9]) << 20; const int rewarm = argc > 10 ? atoi(argv[10]) : 0; unsigned short* junk; CK(hipMalloc(&junk, fb)); CK(hipMemset(junk, 0, fb));
+    const int n2 = reps < 200 ? reps : 200; double tot = 0.0;
+    for (int i = 0; i < n2 + 3; ++i) {
+      fill16<<<4096, 256>>>(junk, fb / 2, 11 + i, 0x3f00);
+      if (rewarm) { fill16<<<4096, 256>>>((unsigned short*)x, (size_t)m * 384, 1, 0x3f00); fill16<<<4096, 256>>>((unsigned short*)ctx, (size_t)m * 384, 7, 0x3f00); }
+      CK(hipEventRecord(e0)); CK(launch_tail(0, p2)); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float t1; CK(hipEventElapsedTime(&t1, e0, e1)); if (i >= 3) tot += t1;
+    }
+    printf("tail with %d MB streamed between launches (rewarm %d): %.1f us per launch\n", atoi(argv[9]), rewarm, tot / n2 * 1e3);
+    CK(hipFree(junk));
+  }
 #if MX_TAIL_TRACE
   { // one traced launch in steady state: phase durations per dispatch round, and who shares a CU
     const int nb = m / 64; unsigned long long* tr; CK(hipMalloc(&tr, (size_t)nb * 64)); CK(hipMemset(tr, 0, (size_t)nb * 64));
