@@ -78,7 +78,9 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
     // ---- this workgroup's tiles.  Workgroup b runs on XCD b % 8 (observed dispatch rule, speed only): XCD x owns the
     // m-tiles x, x+8, ...; its entries e = (m-tile index, n-tile) are dealt round-robin to its G workgroups, so the G
     // tiles in flight on an XCD share 2-3 activation m-tiles and the weights in that XCD's L2.
-    const int n_tiles = p.n / kPT, m_tiles = p.m / kPT;
+    // (EPI_F32 also takes n = 256 t + 128: the last column tile is half valid -- its weight rows past w_rows alias into the next
+    // k-block or fall outside the descriptor, and the two wave columns that own them skip their epilogue)
+    const int n_tiles = (p.n + kPT - 1) / kPT, m_tiles = p.m / kPT;
     const int xcd = blockIdx.x & 7, G = gridDim.x >> 3;
     const int cnt_x = (m_tiles - xcd + 7) >> 3;
     const int total_e = cnt_x * n_tiles;
@@ -185,7 +187,9 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
 #endif
         const int mq = e_done / n_tiles, nt = e_done - mq * n_tiles;
         const int m0 = (xcd + 8 * mq) * kPT, n0 = nt * kPT;
-        if (FM) {
+        if ((EPI == EPI_F32 || EPI == EPI_VT) && n0 + wc * 64 >= p.n) {
+            // wave-uniform: this wave's 64 columns lie past the matrix -- nothing to write (the accumulators are cleared below)
+        } else if (FM) {
             // D[m][n]: lane owns column n = l31 of block j, 4 consecutive rows m per register group
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -588,7 +592,12 @@ bool pgemm_supported(int epi, const GemmParams &p) {
     if (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_QKV && epi != EPI_VT && epi != EPI_BIAS_RES && epi != EPI_F32 &&
         epi != EPI_GELU_SPLIT)
         return false;
-    if (g_pgemm_cus < 8 || p.m % kPT || p.n % kPT || p.k % kPK || p.k < 2 * kPK) return false;
+    // whole column tiles, or for the f32-output epilogue a last tile of 128 columns (MX_PREC_BF16X3 at hidden 384: N = 1152 / 384;
+    // MEMEX_HIP_PGEMM_PART=0 sends those back to gemm_kernel: A/B)
+    static const bool part_ok = [] { const char *ev = getenv("MEMEX_HIP_PGEMM_PART"); return !(ev && ev[0] == '0'); }();
+    static const bool part_vt = [] { const char *ev = getenv("MEMEX_HIP_PGEMM_PART_VT"); return ev && ev[0] == '1'; }();
+    const bool n_ok = p.n % kPT == 0 || ((epi == EPI_F32 || (epi == EPI_VT && part_vt)) && part_ok && p.n % kPT == kPT / 2 && p.n > kPT / 2);
+    if (g_pgemm_cus < 8 || p.m % kPT || !n_ok || p.k % kPK || p.k < 2 * kPK) return false;
     if ((size_t)p.m * p.lda * 2 >= (1ull << 32) || (size_t)p.w_rows * p.k * 2 >= (1ull << 32)) return false;
     if (epi == EPI_QKV && (p.hidden % 64 || p.n != 2 * p.hidden)) return false;
     return true;
