@@ -107,8 +107,9 @@ hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden
 
 // token maps from sequence lengths: cu[b] (aligned starts), tok_seq / tok_pos for every packed row
 // (+ the attention work list of the pass, see launch_attention)
+// `max_len`: the longest sequence of the pass (host side); it decides the head grouping of the attention work list
 hipError_t launch_token_map(hipStream_t s, const int32_t *lens, int B, int S, int32_t *cu, int32_t *tok_seq,
-                            int32_t *tok_pos, int t_pad, int heads, int d_head, void *attn_plan);
+                            int32_t *tok_pos, int t_pad, int heads, int d_head, int max_len, void *attn_plan);
 
 // x[t] = LayerNorm(word[id] + pos[p] + type[0])
 hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32_t *tok_seq, const int32_t *tok_pos,
@@ -119,9 +120,9 @@ hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32
 // `plan`: kAttnPlanBytesPerSeq bytes per sequence, written by launch_token_map once per pass (the work list: one
 // item per (sequence, head group), longest sequences first) and read by every layer's launch_attention
 constexpr size_t kAttnPlanBytesPerSeq = 16 * 16;
-int attention_groups(int heads, int d_head);
+int attention_groups(int heads, int d_head, int max_len);
 hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt, const void *plan, int B,
-                            int heads, int d_head, int hidden, bf16_t *ctx);
+                            int heads, int d_head, int hidden, int max_len, bf16_t *ctx);
 
 // masked mean (or CLS) over tokens + optional L2 normalise -> out [B, H] f32; xf != nullptr: the f32 hidden state instead of x
 hipError_t launch_pool(hipStream_t s, const bf16_t *x, const float *xf, const int32_t *cu, const int32_t *lens, int B, int hidden,

@@ -540,13 +540,13 @@ __global__ __launch_bounds__(1024) void token_map_kernel(const int32_t *__restri
     }
 }
 
-static bool attn_pair(int heads, int d_head);
+static bool attn_pair(int heads, int d_head, int max_len);
 hipError_t launch_token_map(hipStream_t s, const int32_t *lens, int B, int S, int32_t *cu, int32_t *tok_seq,
-                            int32_t *tok_pos, int t_pad, int heads, int d_head, void *attn_plan) {
+                            int32_t *tok_pos, int t_pad, int heads, int d_head, int max_len, void *attn_plan) {
     if (B > 1024) return hipErrorInvalidValue;
     const int blocks = t_pad / 1024 < 1 ? 1 : (t_pad / 1024 > 256 ? 256 : t_pad / 1024);
     hipLaunchKernelGGL(token_map_kernel, dim3(blocks), dim3(1024), 0, s, lens, B, S, cu, tok_seq, tok_pos, t_pad,
-                       attention_groups(heads, d_head), reinterpret_cast<AttnItem *>(attn_plan));
+                       attention_groups(heads, d_head, max_len), reinterpret_cast<AttnItem *>(attn_plan));
     return hipGetLastError();
 }
 
@@ -1143,17 +1143,24 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
 
 static size_t attn_lds(int d) { return (size_t)2 * 2 * kAttnStage * d * 2 + 16; }
 
-// head groups of a stage: one head, or (MEMEX_HIP_ATTN_PAIR=1, d = 32) two adjacent heads -- q / k / ctx rows in 128-byte pieces
-// instead of 64: 403 MB per pass of 131k tokens take 87-93 us alone instead of 111-118, but the launch is bound by its exp2
-// and the paired form keeps one more register than it has (166 against 173 us): off by default
-static bool attn_pair(int heads, int d_head) {
-    const char *ev = getenv("MEMEX_HIP_ATTN_PAIR");
-    return d_head == 32 && heads % 2 == 0 && ev && ev[0] == '1';
+// head groups of a stage: one head, or (d = 32) two adjacent heads -- q / k / ctx rows in 128-byte pieces instead of 64, half as
+// many work items, each with the same fixed cost (a DMA stage, its barrier and wait).  At 512-token sequences the launch is
+// bound by its exp2 and the paired form keeps one more register than it has (166 against 173 us per 131k tokens): one head.
+// Short sequences are bound by the per-item cost instead -- 134 us per 131k tokens at 128-token sequences, 208 at 64, against
+// 164 at 512 (profiles/r5_encoder_short_windows.txt) -- and pairs win: +0.8 % per pass at 256 tokens, +3.2 % at 128, +4.5 % at
+// ragged U[32, 128], +7 % at 64 (profiles/r5_attention_pairs_short_windows.txt).  So the pass decides: pairs when its longest
+// sequence has <= 256 tokens.  MEMEX_HIP_ATTN_PAIR=1 / 0: always / never (tests, A/B).  Same arithmetic per head either way.
+constexpr int kAttnPairMaxLen = 256;
+static bool attn_pair(int heads, int d_head, int max_len) {
+    const char *ev = getenv("MEMEX_HIP_ATTN_PAIR");  // (read per pass: tests switch it inside one process)
+    const int env = !ev || !ev[0] ? -1 : (ev[0] == '1' ? 1 : 0);
+    if (d_head != 32 || heads % 2) return false;
+    return env >= 0 ? env == 1 : max_len <= kAttnPairMaxLen;
 }
-int attention_groups(int heads, int d_head) { return attn_pair(heads, d_head) ? heads / 2 : heads; }
+int attention_groups(int heads, int d_head, int max_len) { return attn_pair(heads, d_head, max_len) ? heads / 2 : heads; }
 
 hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt, const void *plan, int B,
-                            int heads, int d_head, int hidden, bf16_t *ctx) {
+                            int heads, int d_head, int hidden, int max_len, bf16_t *ctx) {
     if (B < 1 || B > 1024 || (d_head != 32 && d_head != 64) || heads * d_head != hidden) return hipErrorInvalidValue;
     if ((size_t)d_head * 2 * ldvt * 2 > 0xFFFFFFF0ull || (size_t)kAttnQ * hidden * 2 > 0x7FFFFFFFull) return hipErrorInvalidValue;  // 32-bit buffer offsets
     static const int n_cu = [] {
@@ -1161,8 +1168,8 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
         hipDeviceProp_t prop;
         return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
     }();
-    const bool pair = attn_pair(heads, d_head);
-    const int n_items = B * attention_groups(heads, d_head);
+    const bool pair = attn_pair(heads, d_head, max_len);
+    const int n_items = B * attention_groups(heads, d_head, max_len);
     const size_t lds = attn_lds(pair ? 64 : d_head);
     // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path); 2 .. 6: measurement modes
     // (no key loop / no loads / no stores: wrong results)

@@ -1,6 +1,7 @@
 #!/bin/bash
-# bf16 MiniLM: the V projection (EPI_VT, N = 384) on pgemm_kernel with a half-valid second column tile (MEMEX_HIP_PGEMM_PART_VT=1)
+# attention: head pairs chosen per pass (longest sequence <= 256 tokens, >= 1024 items) -- tests, throughput, query latency
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-( MEMEX_HIP_PGEMM_PART_VT=1 timeout 900 python -m pytest tests/test_encoder_gpu.py -m gpu -x -q -k "pgemm_kernel or full_passes or vs_oracle" 2>&1 | grep -E "passed|failed|rror|assert" | tail -6 ) > gpurun_out/r5l_tests.txt
-for v in 1 0 1 0; do echo "== MEMEX_HIP_PGEMM_PART_VT=$v"; MEMEX_HIP_PGEMM_PART_VT=$v timeout 300 python scripts/gpu_encoder_perf.py 2>&1 | grep -E "B=2048 S=512 ragged=False" ; done > gpurun_out/r5l_part_vt_ab.txt
-cat gpurun_out/r5l_tests.txt gpurun_out/r5l_part_vt_ab.txt
+( timeout 1200 python -m pytest tests/test_encoder_gpu.py tests/test_pipeline_native_gpu.py tests/test_cfg2_gpu.py tests/test_pretrained.py -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -6 ) > gpurun_out/r5p_tests.txt
+timeout 600 python scripts/gpu_encoder_perf.py short 2>&1 | grep chunks > gpurun_out/r5p_perf.txt
+timeout 300 python scripts/gpu_query_latency.py > gpurun_out/r5p_query_latency.txt 2>&1
+cat gpurun_out/r5p_tests.txt gpurun_out/r5p_perf.txt; tail -12 gpurun_out/r5p_query_latency.txt

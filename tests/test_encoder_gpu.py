@@ -619,3 +619,36 @@ def test_full_passes_compute_whole_tiles_only(kw, seed, lib_built):
             ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub])
             assert (1.0 - _cos(out[sub].astype(np.float64), ref)).max() <= tol, (kw, lens[-3:])
             np.testing.assert_array_equal(out, enc.encode(ids, lens))
+
+
+@pytest.mark.gpu
+def test_short_sequence_passes_pair_heads(lib_built, monkeypatch):
+    """Passes whose longest sequence has <= 256 tokens (and that hold enough (sequence, head) items to fill the chip) stage two
+    adjacent heads per attention item (d = 32; the per-item fixed cost bounds short sequences: DESIGN.md 4.1).  The same
+    arithmetic per head: the automatic choice must equal MEMEX_HIP_ATTN_PAIR=0 (one head per item) bit for bit under ordinary
+    weights, and the oracle within the usual bar; MEMEX_HIP_ATTN_PAIR=1 on a pass the automatic rule leaves unpaired (a
+    300-token sequence in it) as well."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, synthetic_weights
+    from oracle import bert_oracle
+    cfg = EncoderConfig(layers=3, hidden=384, heads=12, ffn=1536, vocab=3000)
+    w = synthetic_weights(cfg, 91)
+    rng = np.random.default_rng(91)
+    for B, S, lo in ((128, 128, 1), (96, 256, 200), (90, 300, 40), (40, 64, 1)):   # the last one: too few items, never paired
+        ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
+        lens = rng.integers(lo, S + 1, size=B).astype(np.int32)
+        lens[0] = S
+        outs = {}
+        for mode in (None, "0", "1"):
+            if mode is None:
+                monkeypatch.delenv("MEMEX_HIP_ATTN_PAIR", raising=False)
+            else:
+                monkeypatch.setenv("MEMEX_HIP_ATTN_PAIR", mode)
+            with Encoder(cfg, w) as enc:
+                outs[mode] = enc.encode(ids, lens)
+        monkeypatch.delenv("MEMEX_HIP_ATTN_PAIR", raising=False)
+        np.testing.assert_array_equal(outs[None], outs["0"])
+        np.testing.assert_array_equal(outs["1"], outs["0"])
+        sub = np.r_[0:3, B - 3:B]
+        ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub])
+        assert (1.0 - _cos(outs[None][sub].astype(np.float64), ref)).max() <= TOL, (B, S)
