@@ -511,13 +511,31 @@ __global__ __launch_bounds__(1024) void token_map_kernel(const int32_t *__restri
         __syncthreads();
     }
     if (blockIdx.x == 0 && tid <= B) cu[tid] = s_cu[tid];
-    if (blockIdx.x == gridDim.x - 1 && tid < B && plan) {
-        int rank = 0;  // sequences that come first: longer ones, and equally long ones with a smaller index
-        for (int j = 0; j < B; ++j) {
-            const int o = s_len[j];
-            rank += (o > l || (o == l && j < tid)) ? 1 : 0;
+    if (plan && B <= 128) {  // few sequences: one thread per sequence counts for itself (no barriers: query-sized passes)
+        if (blockIdx.x == gridDim.x - 1 && tid < B) {
+            int rank = 0;
+            for (int j = 0; j < B; ++j) {
+                const int o = s_len[j];
+                rank += (o > l || (o == l && j < tid)) ? 1 : 0;
+            }
+            for (int g = 0; g < groups; ++g) plan[(size_t)rank * groups + g] = AttnItem{s_cu[tid], l, g, 0};
         }
-        for (int g = 0; g < groups; ++g) plan[(size_t)rank * groups + g] = AttnItem{s_cu[tid], l, g, 0};
+    } else if (plan) {
+        // rank of sequence b = how many come first: longer ones, and equally long ones with a smaller index.  Block j ranks the
+        // sequences j, j + gridDim.x, ...: every thread compares ITS sequence with b, the block counts (one thread per sequence
+        // looping over all the others in the last block alone took 48 us per pass of 1024 sequences)
+        __shared__ int s_rank;
+        for (int b = blockIdx.x; b < B; b += gridDim.x) {
+            const int lb = s_len[b];
+            if (tid == 0) s_rank = 0;
+            __syncthreads();
+            const bool first = tid < B && (l > lb || (l == lb && tid < b));
+            const unsigned long long m = __ballot(first);
+            if ((tid & 63) == 0 && m) atomicAdd(&s_rank, __popcll(m));
+            __syncthreads();
+            if (tid < groups) plan[(size_t)s_rank * groups + tid] = AttnItem{s_cu[b], lb, tid, 0};
+            __syncthreads();
+        }
     }
     const int total = s_cu[B];
     for (int t = blockIdx.x * 1024 + tid; t < t_pad; t += gridDim.x * 1024) {
