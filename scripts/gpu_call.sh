@@ -1,6 +1,8 @@
 #!/bin/bash
-# token_map: ranks of the attention work list counted by the whole grid -- encoder tests, throughput at short windows
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-( timeout 1200 python -m pytest tests/test_encoder_gpu.py tests/test_pipeline_native_gpu.py tests/test_cfg2_gpu.py -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -6 ) > gpurun_out/r5q_tests.txt
-timeout 600 python scripts/gpu_encoder_perf.py short 2>&1 | grep chunks > gpurun_out/r5q_perf.txt
-cat gpurun_out/r5q_tests.txt gpurun_out/r5q_perf.txt
+# full check at the end of the session: GPU tests, smoke, default bench line (+ its kernel trace summary)
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -5; echo "pytest rc=${PIPESTATUS[0]}" ) > gpurun_out/r5r_check.txt 2>&1
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids >> gpurun_out/r5r_check.txt
+timeout 900 python bench.py > gpurun_out/r5r_bench.json 2> gpurun_out/r5r_bench.err
+cat gpurun_out/r5r_check.txt; head -c 300 gpurun_out/r5r_bench.json
