@@ -318,10 +318,10 @@ int mx_encoder_wait_stream(mx_encoder *enc, void *hip_stream);
  * GEMMs split over k) / below / from 32768 rows (the latter round the pre-LayerNorm sum to bf16 once more).  The same text embedded alone and inside a bulk ingest call
  * agrees to 1 - cos ~ 1e-7 .. 1e-5 (tests/test_encoder_gpu.py::test_a_row_across_the_pass_size_regimes),
  * not bit for bit; calls of the same shape are bit-reproducible.  MX_PREC_BF16X3 uses one kernel set.
- * (The attention of a head-dim-32 model stages one head per work item, or two when the longest sequence of a pass has
- * <= 256 tokens and the pass holds >= 1024 (sequence, head) items: the same arithmetic per head and the same bits, except
- * that a head whose exp2 row sums leave the fast path's range -- logits of several hundred -- takes its pair partner
- * through the running-maximum loop with it.)
+ * (The attention of a head-dim-32 model comes in three forms chosen per pass from its longest sequence and its size -- one
+ * head per work item, two, or a kernel of its own for short sequences: the same arithmetic per head and the same bits, except
+ * that in the two-head form a head whose exp2 row sums leave the fast path's range -- logits of several hundred -- takes
+ * its pair partner through the running-maximum loop with it.)
  */
 int mx_encoder_encode(mx_encoder *enc, const int32_t *ids, const int32_t *lens, int B, int S, float *out);
 int mx_encoder_encode_device(mx_encoder *enc, const int32_t *d_ids, const int32_t *d_lens, int B, int S,

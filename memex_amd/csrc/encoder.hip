@@ -253,10 +253,6 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         tokens += (uint64_t)l;
         attn_flops += 4.0 * (double)l * (double)l * H;
     }
-    // what the attention's head grouping is decided on (encoder_kernels.hip, attn_pair): the longest sequence of the pass -- but
-    // a pass with too few (sequence, head) items to fill the chip keeps one head per item whatever its lengths (a query-sized
-    // pass is a latency chain: more, smaller items)
-    const int attn_len = (long)B * heads >= 1024 ? max_len : (1 << 30);
     const int t_pad = (int)round_up((uint64_t)rows + 32, kRowPad);
     // t_pad rows are ALLOCATED (leading dimensions, the token map, the 32 rows a key block may read past the last sequence);
     // m_c rows are COMPUTED by the GEMMs, the layer tail and the LayerNorm passes.  They differ by one 256-row tile exactly
@@ -270,8 +266,8 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
     int rc = ensure_ws(e, t_pad, B, 0);
     if (rc != MX_OK) return rc;
     hipStream_t st = e->stream;
-    if ((size_t)attention_groups(heads, dh, attn_len) * 16 > kAttnPlanBytesPerSeq) return fail(MX_EINVAL, "more than 16 head groups per sequence");
-    MX_HIP(launch_token_map(st, d_lens, B, S, e->cu, e->tok_seq, e->tok_pos, t_pad, heads, dh, attn_len, e->attn_plan));
+    if ((size_t)attention_groups(heads, dh, max_len, B) * 16 > kAttnPlanBytesPerSeq) return fail(MX_EINVAL, "more than 16 head groups per sequence");
+    MX_HIP(launch_token_map(st, d_lens, B, S, e->cu, e->tok_seq, e->tok_pos, t_pad, heads, dh, max_len, e->attn_plan));
     if (e->precise) {
         // MX_PREC_BF16X3 (encoder_precise.hip): split operands through the unchanged GEMM loops with k tripled (pgemm_kernel for
         // the shapes it takes in large passes, gemm_kernel otherwise), f32 everywhere else
@@ -332,7 +328,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
         if (small) {
             // query-time passes (encoder_small.hip): projections by one wave per 32 features, the MLP split over the ffn chunks
             MX_HIP(launch_sp_qkv(st, e->x, L.wqkv, L.bqkv, t_pad, (int)rows, qscale, e->q, e->k, e->vt, t_pad));
-            MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->attn_plan, B, heads, dh, H, attn_len, e->ctx));
+            MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->attn_plan, B, heads, dh, H, max_len, e->ctx));
             MX_HIP(launch_sp_out_ln(st, e->ctx, e->x, L.wo, L.bo, L.ln1g, L.ln1b, c.ln_eps, t_pad, (int)rows, e->sp_x1));
             MX_HIP(launch_sp_ffn(st, e->sp_x1, L.wf, L.bi, F, t_pad, (int)rows, e->sp_part));
             MX_HIP(launch_sp_reduce_ln(st, e->sp_part, F, t_pad, (int)rows, L.bo2, e->sp_x1, L.ln2g, L.ln2b, c.ln_eps, e->x));
@@ -358,7 +354,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             gv.k = H; gv.out_vt = e->vt; gv.ldvt = t_pad; gv.hidden = H;
             MX_HIP(gemm(EPI_VT, gv));
         }
-        MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->attn_plan, B, heads, dh, H, attn_len, e->ctx));
+        MX_HIP(launch_attention(st, e->q, e->k, e->vt, t_pad, e->attn_plan, B, heads, dh, H, max_len, e->ctx));
         if (e->fused_tail) {
             // out-projection + Add&Norm + MLP + Add&Norm in one kernel, in place on e->x
             TailParams tp{};

@@ -120,7 +120,7 @@ hipError_t launch_embed_ln(hipStream_t s, const int32_t *ids, int S, const int32
 // `plan`: kAttnPlanBytesPerSeq bytes per sequence, written by launch_token_map once per pass (the work list: one
 // item per (sequence, head group), longest sequences first) and read by every layer's launch_attention
 constexpr size_t kAttnPlanBytesPerSeq = 16 * 16;
-int attention_groups(int heads, int d_head, int max_len);
+int attention_groups(int heads, int d_head, int max_len, int B);
 hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt, const void *plan, int B,
                             int heads, int d_head, int hidden, int max_len, bf16_t *ctx);
 

@@ -558,13 +558,12 @@ __global__ __launch_bounds__(1024) void token_map_kernel(const int32_t *__restri
     }
 }
 
-static bool attn_pair(int heads, int d_head, int max_len);
 hipError_t launch_token_map(hipStream_t s, const int32_t *lens, int B, int S, int32_t *cu, int32_t *tok_seq,
                             int32_t *tok_pos, int t_pad, int heads, int d_head, int max_len, void *attn_plan) {
     if (B > 1024) return hipErrorInvalidValue;
     const int blocks = t_pad / 1024 < 1 ? 1 : (t_pad / 1024 > 256 ? 256 : t_pad / 1024);
     hipLaunchKernelGGL(token_map_kernel, dim3(blocks), dim3(1024), 0, s, lens, B, S, cu, tok_seq, tok_pos, t_pad,
-                       attention_groups(heads, d_head, max_len), reinterpret_cast<AttnItem *>(attn_plan));
+                       attention_groups(heads, d_head, max_len, B), reinterpret_cast<AttnItem *>(attn_plan));
     return hipGetLastError();
 }
 
@@ -1159,6 +1158,195 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
     pass(std::true_type{}, redo_u, my_redo);
 }
 
+// ---------------------------------------------------------------------------------------------
+// attention_short_kernel: passes whose longest sequence has <= 128 tokens (head dim 32) -- the window of the reference's default
+// model.  attention_kernel above is built around 512-query sequences: 16 waves per item, keys streamed through LDS in
+// 256-key stages behind a barrier; a 128-token sequence fills 4 of its waves and an item costs ~1.5-2 us of stage latency
+// whatever its length (134 us per 131k rows at 128 tokens, 208 at 64, against 164 at 512).  Here an item (sequence, head) is
+// one workgroup of up to four waves (32 queries each) in a plain grid: the item's K rows and V^T rows (8 KiB each at 128
+// tokens) are copied to LDS once, behind ONE barrier, every wave then holds all of its fragments in registers and runs to its
+// ctx stores without another synchronisation (SHARE = false: each wave fetches them itself in the MFMA's operand layouts, no
+// LDS and no barrier at all -- four times the global loads, slower wherever it was measured); with 112-144 VGPRs a SIMD holds
+// 3-4 such waves of different items, which is what hides the latency.  The ARITHMETIC is
+// attention_kernel's, instruction for instruction (same MFMA sequences, no softmax shift on the fast path, the same row-sum
+// range check with the same running-maximum redo, the same summation order and store conversion): bit-identical results
+// (tests/test_encoder_gpu.py::test_short_sequence_passes_pair_heads).
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool SHARE>  // NB: key blocks of 32 an item can have: 2 (sequences of <= 64 tokens) or 4; SHARE: K / V^T through LDS
+__global__ __launch_bounds__(256) void attention_short_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k,
+                                                              const bf16_t *__restrict__ vt, int ldvt,
+                                                              const AttnItem *__restrict__ plan, int hidden,
+                                                              bf16_t *__restrict__ ctx, int mode) {
+    constexpr int D = 32, RB = D * 2;
+    const AttnItem it = plan[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int len = it.len;
+    if (!SHARE && wave * 32 >= len) return;  // (no barrier in this form: waves without queries simply leave)
+    const int l31 = lane & 31, h = lane >> 5;
+    const int pitch = hidden * 2;
+    const uint32_t nrec = (uint32_t)((len - 1) * pitch + RB);  // rows >= len of q / k read as zero, their ctx stores are dropped
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void *)(q + (size_t)it.tok0 * hidden + it.group * D), 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void *)(k + (size_t)it.tok0 * hidden + it.group * D), 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void *)(vt + (size_t)it.group * D * ldvt + it.tok0), 0,
+                                                                           (uint32_t)(((size_t)D * ldvt - it.tok0) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void *)(ctx + (size_t)it.tok0 * hidden + it.group * D), 0, nrec, 0x00020000);
+    const int vo_q = (wave * 32 + l31) * pitch + h * 16;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_q, vo_q + s * 32, 0, 0));
+    const int pr = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);  // pi(l31): A-row j of a score tile holds key pi(j)
+    const int vo_k = pr * pitch + h * 16;
+    const int vo_v = (l31 * ldvt + 8 * h) * 2;
+    const int nkb = (len + 31) / 32, full_blocks = len / 32;
+    // every K and V^T fragment of the item is requested before the first MFMA: one memory round trip per wave instead of one
+    // per key block (block by block, a 128-token pass ran 7 % behind the staged kernel with head pairs)
+    bf16x8 kfr[NB][2], vfr[NB][2];
+    if (SHARE) {
+        // the item's K rows (64 B each, pitch 80 B in LDS) and V^T rows (NB * 64 B each, pitch + 16 B): one cooperative copy,
+        // ONE barrier, then every wave reads its fragments from LDS (the padded pitches keep 16 lanes' 16-byte reads on
+        // distinct banks) -- a quarter of the global loads of the form above, which fetches a head's K / V^T once per wave
+        constexpr int KP = 80, VP = NB * 64 + 16, NT = NB * 64;  // NT threads = NB waves
+        __shared__ __attribute__((aligned(16))) char sk[NB * 32 * KP + 32 * VP];
+        char *sv = sk + NB * 32 * KP;
+        u32x4 kg[2], vg[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * NT;                       // K: chunk c = row * 4 + part; V^T: chunk c = row * (NB * 4) + part
+            kg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, (c >> 2) * pitch + (c & 3) * 16, 0, 0);
+            const int vr = c / (NB * 4), vc = c % (NB * 4);
+            vg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, (vr * ldvt + vc * 8) * 2, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * NT;
+            *reinterpret_cast<u32x4 *>(sk + (c >> 2) * KP + (c & 3) * 16) = kg[i];
+            const int vr = c / (NB * 4), vc = c % (NB * 4);
+            *reinterpret_cast<u32x4 *>(sv + vr * VP + vc * 16) = vg[i];
+        }
+        __syncthreads();
+        if (wave * 32 >= len) return;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+            if (kb < nkb) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    kfr[kb][s] = *reinterpret_cast<const bf16x8 *>(sk + (kb * 32 + pr) * KP + h * 16 + s * 32);
+                    vfr[kb][s] = *reinterpret_cast<const bf16x8 *>(sv + l31 * VP + (kb * 32 + 16 * s + 8 * h) * 2);
+                }
+            }
+    } else {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+        if (kb < nkb) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) kfr[kb][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_k, vo_k + kb * 32 * pitch + s * 32, 0, 0));
+        }
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+        if (kb < nkb) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) vfr[kb][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo_v + (kb * 32 + 16 * s) * 2, 0, 0));
+        }
+    }
+
+    auto run = [&](auto safe_tag) __attribute__((always_inline)) -> bool {  // -> true: the row sums left the fast path's range
+        constexpr bool SAFE = decltype(safe_tag)::value;
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+        float m_run = -1e30f, l_run = 0.0f;
+        auto key_block = [&](const int kb, auto tail_tag) __attribute__((always_inline)) {
+            constexpr bool TAIL = decltype(tail_tag)::value;
+            const int rem = len - kb * 32 - 8 * h;  // this lane's keys 16 (r>>3) + (r&7) < rem are real
+            const bf16x8(&kf)[2] = kfr[kb], (&vf)[2] = vfr[kb];
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sc, 0, 0, 0);
+            if (TAIL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = 16 * (r >> 3) + (r & 7) < rem ? sc[r] : -1e30f;
+            }
+            if (SAFE) {
+                float bm = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) bm = fmaxf(fmaxf(bm, sc[r]), sc[r + 1]);
+                bm = fmaxf(bm, sc[15]);
+                bm = fmaxf(bm, __shfl_xor(bm, 32));
+                if (__builtin_amdgcn_ballot_w64(bm > m_run) != 0) {
+                    const float m_new = fmaxf(m_run, bm);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    l_run *= alpha;
+                    m_run = m_new;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+                }
+            }
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            const f32x2 mm = {m_run, m_run};
+            f32x2 ps2 = {0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 t = {sc[r], sc[r + 1]};
+                if (SAFE) t -= mm;
+                const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                sc[r] = e[0];
+                sc[r + 1] = e[1];
+                ps2 += e;
+            }
+            l_run += ps2[0] + ps2[1];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s + e];
+                bf16x8 v = vf[s];
+                if (TAIL) {  // 0 * (another token's value, possibly not finite) must stay 0
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (16 * s + e >= rem) v[e] = (__bf16)0.0f;
+                }
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, pf, o, 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {  // (unrolled: the fragments are register arrays)
+            if (kb < full_blocks) key_block(kb, std::false_type{});
+            else if (kb < nkb) key_block(kb, std::true_type{});
+        }
+        const float l_row = l_run + __shfl_xor(l_run, 32);
+        const bool bad = __builtin_amdgcn_ballot_w64(!(l_row > 1.0e-30f && l_row < 1.0e30f)) != 0;
+        if (!SAFE && bad) return true;
+        const float inv = 1.0f / l_row;
+#pragma unroll
+        for (int rgp = 0; rgp < 2; ++rgp) {  // (attention_kernel's store: the wave halves trade groups, 16-byte stores)
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+            u32x2 pa, pb;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                const bf16x2 a2 = {(__bf16)(o[rgp * 8 + 2 * e] * inv), (__bf16)(o[rgp * 8 + 2 * e + 1] * inv)};
+                const bf16x2 b2 = {(__bf16)(o[rgp * 8 + 4 + 2 * e] * inv), (__bf16)(o[rgp * 8 + 4 + 2 * e + 1] * inv)};
+                pa[e] = __builtin_bit_cast(unsigned int, a2);
+                pb[e] = __builtin_bit_cast(unsigned int, b2);
+            }
+            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(pa[0], pb[0], false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pa[1], pb[1], false, false);
+            const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, vo_q + (16 * rgp) * 2, 0, 0);
+        }
+        return false;
+    };
+    if (mode == 1) {
+        (void)run(std::true_type{});
+    } else if (run(std::false_type{})) {
+        (void)run(std::true_type{});
+    }
+}
+
 static size_t attn_lds(int d) { return (size_t)2 * 2 * kAttnStage * d * 2 + 16; }
 
 // head groups of a stage: one head, or (d = 32) two adjacent heads -- q / k / ctx rows in 128-byte pieces instead of 64, half as
@@ -1169,13 +1357,28 @@ static size_t attn_lds(int d) { return (size_t)2 * 2 * kAttnStage * d * 2 + 16; 
 // ragged U[32, 128], +7 % at 64 (profiles/r5_attention_pairs_short_windows.txt).  So the pass decides: pairs when its longest
 // sequence has <= 256 tokens.  MEMEX_HIP_ATTN_PAIR=1 / 0: always / never (tests, A/B).  Same arithmetic per head either way.
 constexpr int kAttnPairMaxLen = 256;
-static bool attn_pair(int heads, int d_head, int max_len) {
-    const char *ev = getenv("MEMEX_HIP_ATTN_PAIR");  // (read per pass: tests switch it inside one process)
+// ... and attention_short_kernel (above) takes the passes it measures faster on (same box, profiles/r5_attention_short_kernel_ab.txt):
+//   * longest sequence <= 64 tokens: 447k -> 490k sequences/s on full passes (+9.5 % against head pairs);
+//   * passes of < 1024 items with sequences of <= 128 tokens -- a query, a batch of queries, one document's windows -- where a
+//     plain grid of one workgroup per item beats sixteen-wave workgroups walking a list: one 16-token query 0.255 -> 0.240 ms
+//     (all-MiniLM-L6-v2), 0.486 -> 0.453 (L12).
+// Full passes of 65 .. 128-token sequences stay on the head pairs (126.4k against 125.5k sequences/s at 128 tokens).
+// MEMEX_HIP_ATTN_SHORT=0 / 1: never / for every pass of <= 128-token sequences; MEMEX_HIP_ATTN_SHORT_LDS=0: its form that
+// fetches K / V^T per wave instead of sharing them through LDS (faster only nowhere: 477k at 64 tokens, 117.8k at 128).
+constexpr int kAttnShortMaxLen = 128, kAttnShortAlwaysLen = 64;
+enum { ATTN_ONE = 0, ATTN_PAIR = 1, ATTN_SHORT = 2 };
+static int attn_form(int heads, int d_head, int max_len, int B) {
+    if (d_head != 32) return ATTN_ONE;
+    const bool many = (long)B * heads >= 1024;
+    const char *es = getenv("MEMEX_HIP_ATTN_SHORT");  // (read per pass: tests switch these inside one process)
+    const int env_s = !es || !es[0] ? -1 : (es[0] == '1' ? 1 : 0);
+    if (max_len <= kAttnShortMaxLen && (env_s == 1 || (env_s < 0 && (!many || max_len <= kAttnShortAlwaysLen)))) return ATTN_SHORT;
+    if (heads % 2) return ATTN_ONE;
+    const char *ev = getenv("MEMEX_HIP_ATTN_PAIR");
     const int env = !ev || !ev[0] ? -1 : (ev[0] == '1' ? 1 : 0);
-    if (d_head != 32 || heads % 2) return false;
-    return env >= 0 ? env == 1 : max_len <= kAttnPairMaxLen;
+    return (env >= 0 ? env == 1 : (many && max_len <= kAttnPairMaxLen)) ? ATTN_PAIR : ATTN_ONE;
 }
-int attention_groups(int heads, int d_head, int max_len) { return attn_pair(heads, d_head, max_len) ? heads / 2 : heads; }
+int attention_groups(int heads, int d_head, int max_len, int B) { return attn_form(heads, d_head, max_len, B) == ATTN_PAIR ? heads / 2 : heads; }
 
 hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, const bf16_t *vt, int ldvt, const void *plan, int B,
                             int heads, int d_head, int hidden, int max_len, bf16_t *ctx) {
@@ -1186,8 +1389,9 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
         hipDeviceProp_t prop;
         return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
     }();
-    const bool pair = attn_pair(heads, d_head, max_len);
-    const int n_items = B * attention_groups(heads, d_head, max_len);
+    const int form = attn_form(heads, d_head, max_len, B);
+    const bool pair = form == ATTN_PAIR;
+    const int n_items = B * attention_groups(heads, d_head, max_len, B);
     const size_t lds = attn_lds(pair ? 64 : d_head);
     // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path); 2 .. 6: measurement modes
     // (no key loop / no loads / no stores: wrong results)
@@ -1204,6 +1408,15 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
     }();
     const int G = cus_env > 0 ? cus_env : n_cu;
     const AttnItem *items = reinterpret_cast<const AttnItem *>(plan);
+    if (form == ATTN_SHORT && mode <= 1) {  // (the measurement modes 2 .. 6 belong to the staged kernel)
+        const char *eh = getenv("MEMEX_HIP_ATTN_SHORT_LDS");  // A/B: K / V^T of an item through LDS (default) or per wave from global memory (0)
+        const bool share = !(eh && eh[0] == '0');
+        if (max_len <= 64 && share) hipLaunchKernelGGL((attention_short_kernel<2, true>), dim3(n_items), dim3(128), 0, s, q, k, vt, ldvt, items, hidden, ctx, mode);
+        else if (max_len <= 64) hipLaunchKernelGGL((attention_short_kernel<2, false>), dim3(n_items), dim3(128), 0, s, q, k, vt, ldvt, items, hidden, ctx, mode);
+        else if (share) hipLaunchKernelGGL((attention_short_kernel<4, true>), dim3(n_items), dim3(256), 0, s, q, k, vt, ldvt, items, hidden, ctx, mode);
+        else hipLaunchKernelGGL((attention_short_kernel<4, false>), dim3(n_items), dim3(256), 0, s, q, k, vt, ldvt, items, hidden, ctx, mode);
+        return hipGetLastError();
+    }
     for (int off = 0; off < n_items; off += 64 * G) {
         const int n = n_items - off < 64 * G ? n_items - off : 64 * G;
         const dim3 grid(n < G ? n : G);

@@ -623,32 +623,54 @@ def test_full_passes_compute_whole_tiles_only(kw, seed, lib_built):
 
 @pytest.mark.gpu
 def test_short_sequence_passes_pair_heads(lib_built, monkeypatch):
-    """Passes whose longest sequence has <= 256 tokens (and that hold enough (sequence, head) items to fill the chip) stage two
-    adjacent heads per attention item (d = 32; the per-item fixed cost bounds short sequences: DESIGN.md 4.1).  The same
-    arithmetic per head: the automatic choice must equal MEMEX_HIP_ATTN_PAIR=0 (one head per item) bit for bit under ordinary
-    weights, and the oracle within the usual bar; MEMEX_HIP_ATTN_PAIR=1 on a pass the automatic rule leaves unpaired (a
-    300-token sequence in it) as well."""
+    """Head dim 32, passes of short sequences: the attention's per-item fixed cost, not exp2, bounds them.
+    attention_short_kernel (a plain grid, one workgroup of up to four waves per item, K / V^T shared through LDS behind one
+    barrier) takes the passes whose longest sequence has <= 64 tokens and the small passes (< 1024 items) of <= 128-token
+    sequences; full passes up to 256 tokens stage two heads per item of the staged kernel.  Both
+    forms repeat attention_kernel's arithmetic instruction for instruction: whatever the automatic rule picks must equal the
+    one-head staged kernel (MEMEX_HIP_ATTN_SHORT=0, MEMEX_HIP_ATTN_PAIR=0) bit for bit, and so must each form when forced --
+    under ordinary weights, on the running-maximum path (MEMEX_HIP_ATTN_SAFE=1), and with scores of several hundred, where
+    every row leaves the fast path and is redone."""
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, synthetic_weights
     from oracle import bert_oracle
     cfg = EncoderConfig(layers=3, hidden=384, heads=12, ffn=1536, vocab=3000)
-    w = synthetic_weights(cfg, 91)
     rng = np.random.default_rng(91)
-    for B, S, lo in ((128, 128, 1), (96, 256, 200), (90, 300, 40), (40, 64, 1)):   # the last one: too few items, never paired
-        ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
-        lens = rng.integers(lo, S + 1, size=B).astype(np.int32)
-        lens[0] = S
-        outs = {}
-        for mode in (None, "0", "1"):
-            if mode is None:
-                monkeypatch.delenv("MEMEX_HIP_ATTN_PAIR", raising=False)
-            else:
-                monkeypatch.setenv("MEMEX_HIP_ATTN_PAIR", mode)
-            with Encoder(cfg, w) as enc:
-                outs[mode] = enc.encode(ids, lens)
-        monkeypatch.delenv("MEMEX_HIP_ATTN_PAIR", raising=False)
-        np.testing.assert_array_equal(outs[None], outs["0"])
-        np.testing.assert_array_equal(outs["1"], outs["0"])
-        sub = np.r_[0:3, B - 3:B]
-        ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub])
-        assert (1.0 - _cos(outs[None][sub].astype(np.float64), ref)).max() <= TOL, (B, S)
+
+    def encode(w, ids, lens, **env):
+        for kname in ("MEMEX_HIP_ATTN_SHORT", "MEMEX_HIP_ATTN_SHORT_LDS", "MEMEX_HIP_ATTN_PAIR", "MEMEX_HIP_ATTN_SAFE"):
+            monkeypatch.delenv(kname, raising=False)
+        for kname, v in env.items():
+            monkeypatch.setenv(kname, v)
+        with Encoder(cfg, w) as enc:
+            out = enc.encode(ids, lens)
+        for kname in env:
+            monkeypatch.delenv(kname, raising=False)
+        return out
+
+    for scale in (1.0, 24.0):
+        w = synthetic_weights(cfg, 91)
+        for name in list(w):
+            if scale != 1.0 and (name.endswith("attention.self.query.weight") or name.endswith("attention.self.key.weight")):
+                w[name] = (w[name] * scale).astype(np.float32)
+        # (B, S, shortest length); the last two: too few items for the automatic rule, forced forms only
+        for B, S, lo in ((128, 128, 1), (100, 97, 30), (96, 256, 200), (90, 300, 40), (40, 64, 1), (3, 128, 100)):
+            ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
+            lens = rng.integers(lo, S + 1, size=B).astype(np.int32)
+            lens[0] = S
+            base = encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="0", MEMEX_HIP_ATTN_PAIR="0")
+            assert np.isfinite(base).all()
+            np.testing.assert_array_equal(encode(w, ids, lens), base, err_msg=f"automatic choice, {B} x {S}, scale {scale}")
+            np.testing.assert_array_equal(encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="1"), base, err_msg=f"short kernel, {B} x {S}, scale {scale}")
+            np.testing.assert_array_equal(encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="1", MEMEX_HIP_ATTN_SHORT_LDS="0"), base,
+                                          err_msg=f"short kernel, fragments from global memory, {B} x {S}, scale {scale}")
+            if scale == 1.0:  # (a redo takes a pair partner along through the running-maximum loop: last-bit differences, see the header)
+                np.testing.assert_array_equal(encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="0", MEMEX_HIP_ATTN_PAIR="1"), base,
+                                              err_msg=f"head pairs, {B} x {S}")
+            safe = encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="0", MEMEX_HIP_ATTN_PAIR="0", MEMEX_HIP_ATTN_SAFE="1")
+            np.testing.assert_array_equal(encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="1", MEMEX_HIP_ATTN_SAFE="1"), safe,
+                                          err_msg=f"short kernel, running maximum, {B} x {S}, scale {scale}")
+            if scale == 1.0:
+                sub = np.r_[0:min(3, B), max(3, B - 3):B]
+                ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub])
+                assert (1.0 - _cos(base[sub].astype(np.float64), ref)).max() <= TOL, (B, S)
