@@ -660,7 +660,11 @@ def test_short_sequence_passes_pair_heads(lib_built, monkeypatch):
             lens[0] = S
             base = encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="0", MEMEX_HIP_ATTN_PAIR="0")
             assert np.isfinite(base).all()
-            np.testing.assert_array_equal(encode(w, ids, lens), base, err_msg=f"automatic choice, {B} x {S}, scale {scale}")
+            auto = encode(w, ids, lens)
+            if scale == 1.0:
+                np.testing.assert_array_equal(auto, base, err_msg=f"automatic choice, {B} x {S}")
+            else:  # (the automatic choice may be the head pairs: a redo takes the pair partner along, last-bit differences)
+                assert (1.0 - _cos(auto.astype(np.float64), base.astype(np.float64))).max() <= 1e-4, (B, S, scale)
             np.testing.assert_array_equal(encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="1"), base, err_msg=f"short kernel, {B} x {S}, scale {scale}")
             np.testing.assert_array_equal(encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="1", MEMEX_HIP_ATTN_SHORT_LDS="0"), base,
                                           err_msg=f"short kernel, fragments from global memory, {B} x {S}, scale {scale}")
