@@ -1164,10 +1164,10 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
 // 256-key stages behind a barrier; a 128-token sequence fills 4 of its waves and an item costs ~1.5-2 us of stage latency
 // whatever its length (134 us per 131k rows at 128 tokens, 208 at 64, against 164 at 512).  Here an item (sequence, head) is
 // one workgroup of up to four waves (32 queries each) in a plain grid: the item's K rows and V^T rows (8 KiB each at 128
-// tokens) are copied to LDS once, behind ONE barrier, every wave then holds all of its fragments in registers and runs to its
-// ctx stores without another synchronisation (SHARE = false: each wave fetches them itself in the MFMA's operand layouts, no
-// LDS and no barrier at all -- four times the global loads, slower wherever it was measured); with 112-144 VGPRs a SIMD holds
-// 3-4 such waves of different items, which is what hides the latency.  The ARITHMETIC is
+// tokens) are copied to LDS once, behind ONE barrier, and every wave reads its fragments from there block by block and runs
+// to its ctx stores without another synchronisation (SHARE = false: each wave fetches all of them itself in the MFMA's operand
+// layouts, no LDS and no barrier at all -- four times the global loads and 144 VGPRs, slower wherever it was measured); at 109
+// VGPRs a SIMD holds four such waves of different items, which is what hides the latency.  The ARITHMETIC is
 // attention_kernel's, instruction for instruction (same MFMA sequences, no softmax shift on the fast path, the same row-sum
 // range check with the same running-maximum redo, the same summation order and store conversion): bit-identical results
 // (tests/test_encoder_gpu.py::test_short_sequence_passes_pair_heads).
@@ -1203,13 +1203,14 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const bf16_t *__re
     // every K and V^T fragment of the item is requested before the first MFMA: one memory round trip per wave instead of one
     // per key block (block by block, a 128-token pass ran 7 % behind the staged kernel with head pairs)
     bf16x8 kfr[NB][2], vfr[NB][2];
+    constexpr int KP = 80, VP = NB * 64 + 16, NT = NB * 64;  // LDS pitches of a K row / a V^T row; NT threads = NB waves
+    __shared__ __attribute__((aligned(16))) char sk[SHARE ? NB * 32 * KP + 32 * VP : 16];
+    char *sv = sk + NB * 32 * KP;
     if (SHARE) {
         // the item's K rows (64 B each, pitch 80 B in LDS) and V^T rows (NB * 64 B each, pitch + 16 B): one cooperative copy,
-        // ONE barrier, then every wave reads its fragments from LDS (the padded pitches keep 16 lanes' 16-byte reads on
-        // distinct banks) -- a quarter of the global loads of the form above, which fetches a head's K / V^T once per wave
-        constexpr int KP = 80, VP = NB * 64 + 16, NT = NB * 64;  // NT threads = NB waves
-        __shared__ __attribute__((aligned(16))) char sk[NB * 32 * KP + 32 * VP];
-        char *sv = sk + NB * 32 * KP;
+        // ONE barrier, then every wave reads its fragments from LDS where it needs them (the padded pitches keep 16 lanes'
+        // 16-byte reads on distinct banks) -- a quarter of the global loads of the form below, which fetches a head's K / V^T
+        // once per wave, and no fragment held in registers across the key blocks
         u32x4 kg[2], vg[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1227,15 +1228,6 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const bf16_t *__re
         }
         __syncthreads();
         if (wave * 32 >= len) return;
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb)
-            if (kb < nkb) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    kfr[kb][s] = *reinterpret_cast<const bf16x8 *>(sk + (kb * 32 + pr) * KP + h * 16 + s * 32);
-                    vfr[kb][s] = *reinterpret_cast<const bf16x8 *>(sv + l31 * VP + (kb * 32 + 16 * s + 8 * h) * 2);
-                }
-            }
     } else {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb)
@@ -1260,7 +1252,17 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const bf16_t *__re
         auto key_block = [&](const int kb, auto tail_tag) __attribute__((always_inline)) {
             constexpr bool TAIL = decltype(tail_tag)::value;
             const int rem = len - kb * 32 - 8 * h;  // this lane's keys 16 (r>>3) + (r&7) < rem are real
-            const bf16x8(&kf)[2] = kfr[kb], (&vf)[2] = vfr[kb];
+            bf16x8 kf[2], vf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if constexpr (SHARE) {
+                    kf[s] = *reinterpret_cast<const bf16x8 *>(sk + (kb * 32 + pr) * KP + h * 16 + s * 32);
+                    vf[s] = *reinterpret_cast<const bf16x8 *>(sv + l31 * VP + (kb * 32 + 16 * s + 8 * h) * 2);
+                } else {
+                    kf[s] = kfr[kb][s];
+                    vf[s] = vfr[kb][s];
+                }
+            }
             f32x16 sc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
@@ -1357,23 +1359,21 @@ static size_t attn_lds(int d) { return (size_t)2 * 2 * kAttnStage * d * 2 + 16; 
 // ragged U[32, 128], +7 % at 64 (profiles/r5_attention_pairs_short_windows.txt).  So the pass decides: pairs when its longest
 // sequence has <= 256 tokens.  MEMEX_HIP_ATTN_PAIR=1 / 0: always / never (tests, A/B).  Same arithmetic per head either way.
 constexpr int kAttnPairMaxLen = 256;
-// ... and attention_short_kernel (above) takes the passes it measures faster on (same box, profiles/r5_attention_short_kernel_ab.txt):
-//   * longest sequence <= 64 tokens: 447k -> 490k sequences/s on full passes (+9.5 % against head pairs);
-//   * passes of < 1024 items with sequences of <= 128 tokens -- a query, a batch of queries, one document's windows -- where a
-//     plain grid of one workgroup per item beats sixteen-wave workgroups walking a list: one 16-token query 0.255 -> 0.240 ms
-//     (all-MiniLM-L6-v2), 0.486 -> 0.453 (L12).
-// Full passes of 65 .. 128-token sequences stay on the head pairs (126.4k against 125.5k sequences/s at 128 tokens).
-// MEMEX_HIP_ATTN_SHORT=0 / 1: never / for every pass of <= 128-token sequences; MEMEX_HIP_ATTN_SHORT_LDS=0: its form that
-// fetches K / V^T per wave instead of sharing them through LDS (faster only nowhere: 477k at 64 tokens, 117.8k at 128).
-constexpr int kAttnShortMaxLen = 128, kAttnShortAlwaysLen = 64;
+// ... and attention_short_kernel (above) takes every pass whose longest sequence has <= 128 tokens (same box, full passes,
+// profiles/r5_attention_short_kernel_ab.txt): 126.6k -> 130.4k sequences/s at 128 tokens, 170.7k -> 181.9k at U[32, 128],
+// 449k -> 499k at 64 -- against the head pairs, which had been +3 .. +7 % on the one-head items themselves -- and one 16-token
+// query 0.255 -> 0.240 ms (all-MiniLM-L6-v2), 0.486 -> 0.453 (L12): a plain grid of one workgroup per item beats sixteen-wave
+// workgroups walking a list at every size.  (Its first two forms did not: fragments fetched per wave from global memory,
+// 117.8k at 128 tokens; all fragments read from LDS up front and held in registers, 144 VGPRs, 125.5k.)
+// MEMEX_HIP_ATTN_SHORT=0 / 1: never / as the rule says (tests, A/B); MEMEX_HIP_ATTN_SHORT_LDS=0: the per-wave global form.
+constexpr int kAttnShortMaxLen = 128;
 enum { ATTN_ONE = 0, ATTN_PAIR = 1, ATTN_SHORT = 2 };
 static int attn_form(int heads, int d_head, int max_len, int B) {
     if (d_head != 32) return ATTN_ONE;
-    const bool many = (long)B * heads >= 1024;
     const char *es = getenv("MEMEX_HIP_ATTN_SHORT");  // (read per pass: tests switch these inside one process)
-    const int env_s = !es || !es[0] ? -1 : (es[0] == '1' ? 1 : 0);
-    if (max_len <= kAttnShortMaxLen && (env_s == 1 || (env_s < 0 && (!many || max_len <= kAttnShortAlwaysLen)))) return ATTN_SHORT;
+    if (max_len <= kAttnShortMaxLen && !(es && es[0] == '0')) return ATTN_SHORT;
     if (heads % 2) return ATTN_ONE;
+    const bool many = (long)B * heads >= 1024;  // a pass too small to fill the chip keeps more, smaller items
     const char *ev = getenv("MEMEX_HIP_ATTN_PAIR");
     const int env = !ev || !ev[0] ? -1 : (ev[0] == '1' ? 1 : 0);
     return (env >= 0 ? env == 1 : (many && max_len <= kAttnPairMaxLen)) ? ATTN_PAIR : ATTN_ONE;

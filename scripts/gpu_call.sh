@@ -1,5 +1,6 @@
 #!/bin/bash
-# one document at a time (72 windows of <= 128 tokens: a small pass): the encoder step with / without attention_short_kernel
+# encoder tests with the final attention rule (<= 128 tokens: attention_short_kernel), pipeline tests, throughput probe
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-for v in 0 1 0 1; do echo "== MEMEX_HIP_ATTN_SHORT=$v"; if [ $v = 0 ]; then export MEMEX_HIP_ATTN_SHORT=0; else unset MEMEX_HIP_ATTN_SHORT; fi; timeout 300 python scripts/gpu_text_ingest_profile.py 100 2>&1 | grep -iE "encoder|total|per doc"; done > gpurun_out/r5x_doc_pass_ab.txt
-cat gpurun_out/r5x_doc_pass_ab.txt
+( timeout 1200 python -m pytest tests/test_encoder_gpu.py tests/test_pipeline_native_gpu.py tests/test_cfg2_gpu.py tests/test_pretrained.py -m gpu -q 2>&1 | grep -E "passed|failed|rror|FAILED" | tail -8 ) > gpurun_out/r5z_tests.txt
+timeout 600 python scripts/gpu_encoder_perf.py short 2>&1 | grep chunks > gpurun_out/r5z_perf.txt
+cat gpurun_out/r5z_tests.txt gpurun_out/r5z_perf.txt

@@ -625,8 +625,8 @@ def test_full_passes_compute_whole_tiles_only(kw, seed, lib_built):
 def test_short_sequence_passes_pair_heads(lib_built, monkeypatch):
     """Head dim 32, passes of short sequences: the attention's per-item fixed cost, not exp2, bounds them.
     attention_short_kernel (a plain grid, one workgroup of up to four waves per item, K / V^T shared through LDS behind one
-    barrier) takes the passes whose longest sequence has <= 64 tokens and the small passes (< 1024 items) of <= 128-token
-    sequences; full passes up to 256 tokens stage two heads per item of the staged kernel.  Both
+    barrier) takes the passes whose longest sequence has <= 128 tokens; full passes (>= 1024 items) up to 256 tokens stage two
+    heads per item of the staged kernel.  Both
     forms repeat attention_kernel's arithmetic instruction for instruction: whatever the automatic rule picks must equal the
     one-head staged kernel (MEMEX_HIP_ATTN_SHORT=0, MEMEX_HIP_ATTN_PAIR=0) bit for bit, and so must each form when forced --
     under ordinary weights, on the running-maximum path (MEMEX_HIP_ATTN_SAFE=1), and with scores of several hundred, where
