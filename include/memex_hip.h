@@ -18,6 +18,19 @@
  *   - handles are safe to use from several threads; calls on one handle are serialised inside.
  *   - "_device" variants take pointers into the HBM of the handle's device (for callers that keep
  *     data resident: the encoder output feeding mx_index_add_device, benchmarks, multi-GPU merge).
+ *
+ * Environment (everything the library reads; there is no fault-injection switch -- the two hooks the
+ * tests need exist only in libmemex_hip_testing.so, built with -DMEMEX_TESTING):
+ *   MEMEX_HIP_SPIN=1            host waits poll the completion word from the start (a benchmark owns its
+ *                               core); default: sleep for most of the expected batch time, then poll
+ *   MEMEX_HIP_EXCHANGE=rccl|p2p sharded index: insist on the RCCL all-gather / force peer copies
+ *                               (default: RCCL when every shard has its own device)
+ *   MEMEX_HIP_RCCL_TIMEOUT=s    deadline of ncclCommInitAll and of the communicator self-test (30)
+ *   MEMEX_HIP_SHARD_THREADS=0|1 per-shard helper threads never / also for logical shards on one device
+ *   MEMEX_HIP_FILTER=i8|bf16    pins the filter copy of every index opened afterwards (mx_index_set_filter_copy)
+ *   MEMEX_HIP_DEBUG=key=v,...   which of two equivalent kernel forms runs (parity tests; keys in
+ *                               memex_amd/csrc/mx_debug.h).  Results do not depend on it beyond the bounds
+ *                               stated there (bit-identical forms, or different f32 summation orders).
  */
 #ifndef MEMEX_HIP_H
 #define MEMEX_HIP_H
@@ -274,6 +287,10 @@ typedef struct mx_encoder_cfg {
                            the bf16 path moves them by up to 1e-2; about 6x slower        */
 } mx_encoder_cfg;
 enum { MX_PREC_BF16 = 0, MX_PREC_BF16X3 = 1 };
+/* sizeof(mx_encoder_cfg) of the library that is loaded: the struct grew a trailing field (`precision`) and may again; a shim
+ * built against an older header compares this with its own sizeof at start-up instead of letting the library read past
+ * its struct (same handshake as mx_index_stats_size). */
+size_t mx_encoder_cfg_size(void);
 
 /*
  * Weight blob: f32, little-endian, tensors concatenated in this order (HF BertModel names,

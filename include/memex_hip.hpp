@@ -689,6 +689,10 @@ class SentenceEmbedder {
     void runner(const ModelConfig &mc, const mx_encoder_cfg &cfg, const std::vector<float> &w, size_t max_seq_length, int device,
                 const std::shared_ptr<Tokenizer> &native, std::promise<std::string> &ready) {
         mx_encoder *enc = nullptr;
+        if (mx_encoder_cfg_size() != sizeof(mx_encoder_cfg)) {  // this header and the loaded library disagree about the struct
+            ready.set_value("mx_encoder_cfg size mismatch: header and libmemex_hip.so are different releases");
+            return;
+        }
         int rc = mx_encoder_create(&cfg, w.data(), w.size() * sizeof(float), device, &enc);  // create_model(), :99-100
         if (rc != MX_OK) {
             ready.set_value(mx_last_error());

@@ -12,6 +12,9 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmemex_hip.so")
+# the same sources built with -DMEMEX_TESTING: two fault-injection hooks (the first RCCL all-gather of a process fails;
+# mx_tokenizer_encode_staged throws on request).  Only tests load it -- testing_lib() / use_testing_library() below.
+TESTING_LIB_PATH = os.path.join(_HERE, "libmemex_hip_testing.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 MX_OK = 0
@@ -29,7 +32,7 @@ EXPORTS = [
     "mx_index_search", "mx_index_search_device", "mx_index_set_search_mode", "mx_index_set_filter_copy", "mx_index_set_corpus_mode", "mx_index_get_rows",
     "mx_index_save", "mx_index_load", "mx_index_has_store", "mx_index_store_info", "mx_index_remove_files",
     "mx_index_set_profiling", "mx_index_get_stats", "mx_index_reset_stats", "mx_topk_merge_device", "mx_topk_merge_packed_device", "mx_topk_merge_packed_async",
-    "mx_encoder_weight_bytes", "mx_encoder_create", "mx_encoder_open", "mx_encoder_wait_stream", "mx_encoder_destroy", "mx_encoder_encode",
+    "mx_encoder_cfg_size", "mx_encoder_weight_bytes", "mx_encoder_create", "mx_encoder_open", "mx_encoder_wait_stream", "mx_encoder_destroy", "mx_encoder_encode",
     "mx_encoder_encode_device", "mx_encoder_set_profiling", "mx_encoder_get_stats",
     "mx_encoder_reset_stats",
     "mx_tokenizer_create", "mx_tokenizer_create_from_memory", "mx_tokenizer_create_bpe", "mx_tokenizer_create_bpe_from_memory",
@@ -162,6 +165,8 @@ def _declare(L: ctypes.CDLL) -> None:
     L.mx_encoder_weight_bytes.argtypes = [P(EncoderCfg)]
     L.mx_index_stats_size.restype = ctypes.c_size_t
     L.mx_index_stats_size.argtypes = []
+    L.mx_encoder_cfg_size.restype = ctypes.c_size_t
+    L.mx_encoder_cfg_size.argtypes = []
 
 
 def _load_torch_runtime_first() -> None:
@@ -180,22 +185,45 @@ def _load_torch_runtime_first() -> None:
             pass
 
 
+_path = LIB_PATH
+
+
+def use_testing_library() -> None:
+    """Tests only, before the first lib() of the process: bind the package to libmemex_hip_testing.so."""
+    global _path
+    with _lock:
+        if _lib is not None:
+            raise RuntimeError("the library is already loaded")
+        _path = TESTING_LIB_PATH
+
+
+def testing_lib() -> ctypes.CDLL:
+    """Tests only: libmemex_hip_testing.so as a second, separately loaded library (own globals), declared like lib()."""
+    _load_torch_runtime_first()
+    L = ctypes.CDLL(TESTING_LIB_PATH)
+    _declare(L)
+    return L
+
+
 def lib() -> ctypes.CDLL:
     """The loaded library.  Raises (never falls back) when it is absent."""
     global _lib
     with _lock:
         if _lib is None:
             _load_torch_runtime_first()
-            if not os.path.exists(LIB_PATH):
-                raise MemexHipError(MX_EDEVICE, f"{LIB_PATH} is missing: run memex_amd.build() "
+            if not os.path.exists(_path):
+                raise MemexHipError(MX_EDEVICE, f"{_path} is missing: run memex_amd.build() "
                                                 "(python -c 'import __graft_entry__ as g; g.build()')")
-            L = ctypes.CDLL(LIB_PATH)
+            L = ctypes.CDLL(_path)
             _declare(L)
             # ABI handshake: mx_index_stats grows at the end from release to release; a binding older or newer than the
             # library must not read past / short of what the library writes
             if L.mx_index_stats_size() != ctypes.sizeof(IndexStats):
                 raise MemexHipError(MX_EINVAL, f"{LIB_PATH}: mx_index_stats is {L.mx_index_stats_size()} bytes, this binding "
                                                f"declares {ctypes.sizeof(IndexStats)} (library / binding version mismatch)")
+            if L.mx_encoder_cfg_size() != ctypes.sizeof(EncoderCfg):
+                raise MemexHipError(MX_EINVAL, f"{_path}: mx_encoder_cfg is {L.mx_encoder_cfg_size()} bytes, this binding "
+                                               f"declares {ctypes.sizeof(EncoderCfg)} (library / binding version mismatch)")
             _lib = L
         return _lib
 

@@ -25,6 +25,7 @@
 
 #include "encoder_kernels.h"
 #include "mx_common.h"
+#include "mx_debug.h"
 
 using namespace mx;
 
@@ -261,8 +262,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
     // every other CU has 6; tail_kernel / gemm_kernel: 2052 workgroups on 512 slots) -- 8-17 % of those launches.  Rows
     // past m_c keep whatever the buffers held (zeros, or finite activations of an earlier pass): nothing reads them
     // unmasked.
-    static const bool pad_tile = [] { const char *ev = getenv("MEMEX_HIP_PAD_TILE"); return ev && ev[0] == '1'; }();  // A/B: the old extent
-    const int m_c = pad_tile ? t_pad : (int)round_up((uint64_t)rows, kRowPad);
+    const int m_c = (int)round_up((uint64_t)rows, kRowPad);  // (A/B against the old extent: profiles/r5_whole_tile_passes_ab.txt)
     int rc = ensure_ws(e, t_pad, B, 0);
     if (rc != MX_OK) return rc;
     hipStream_t st = e->stream;
@@ -409,11 +409,7 @@ int encode_all(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, const
     // passes queue on the stream without synchronisation, so a later pass must never reallocate buffers an
     // earlier one is still using)
     std::vector<std::pair<int, int>> passes;  // (first sequence, count)
-    static const long pass_rows = [] {  // MEMEX_HIP_PASS_ROWS: A/B of the pass size (multiple of 256 in [4096, 2^19])
-        const char *ev = getenv("MEMEX_HIP_PASS_ROWS");
-        const long v = ev ? atol(ev) / 256 * 256 : 0;
-        return v >= 4096 && v <= (1L << 19) ? v : (long)kMaxRowsPerPass;
-    }();
+    const long pass_rows = kMaxRowsPerPass;  // (2^18 / 2^19 rows per pass: +0.3 ... +1.2 %, profiles/r5_pass_rows_ab.txt)
     long max_rows = 0;
     int max_nb = 0;
     for (int b0 = 0; b0 < B;) {
@@ -478,6 +474,8 @@ static void destroy_impl(mx_encoder *e);
 
 extern "C" {
 
+size_t mx_encoder_cfg_size(void) { return sizeof(mx_encoder_cfg); }
+
 size_t mx_encoder_weight_bytes(const mx_encoder_cfg *c) {
     if (!c) return 0;
     const size_t H = (size_t)c->hidden, F = (size_t)c->ffn;
@@ -518,15 +516,12 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     e->cfg = *cfg;
     e->device = device;
     {
-        const char *ev = getenv("MEMEX_HIP_UNFUSED_TAIL");
+        // kernel-variant keys of MEMEX_HIP_DEBUG (mx_debug.h), fixed per encoder handle
         e->precise = cfg->precision == MX_PREC_BF16X3;
-        e->fused_tail = !e->precise && tail_supported(cfg->hidden, cfg->ffn) && !(ev && ev[0] == '1');
-        const char *pv = getenv("MEMEX_HIP_PGEMM");
-        e->pgemm = !(pv && pv[0] == '0');
-        const char *sv = getenv("MEMEX_HIP_SMALL");
-        e->small_pass = e->fused_tail && !(sv && sv[0] == '0');
-        const char *av = getenv("MEMEX_HIP_ATTN_F32");
-        e->attn_f32 = av && av[0] == '1';
+        e->fused_tail = !e->precise && tail_supported(cfg->hidden, cfg->ffn) && debug_flag("unfused_tail", 0) != 1;
+        e->pgemm = debug_flag("pgemm", 1) != 0;
+        e->small_pass = e->fused_tail && debug_flag("small", 1) != 0;
+        e->attn_f32 = debug_flag("attn_f32", 0) == 1;
     }
     auto bail = [&](int code) {
         destroy_impl(e);
@@ -591,8 +586,7 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         MX_TRY(upload_f32(e, be2_src, H, &L.ln2b));
     }
     if (!e->fused_tail && !e->precise && H == 768) {
-        const char *sv = getenv("MEMEX_HIP_SPLITK"), *sm = getenv("MEMEX_HIP_SMALL");  // (MEMEX_HIP_SMALL=0: one kernel set at every pass size)
-        e->split_small = !(sv && sv[0] == '0') && !(sm && sm[0] == '0');
+        e->split_small = debug_flag("splitk", 1) != 0 && debug_flag("small", 1) != 0;  // (small=0: one kernel set at every pass size)
         if (e->split_small) {
             void *pp = nullptr, *pz = nullptr;
             if (hipMalloc(&pp, (size_t)kSplitMax * kSplitRows * H * sizeof(float)) != hipSuccess || hipMalloc(&pz, (size_t)3 * H * sizeof(float)) != hipSuccess ||
@@ -609,8 +603,8 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     }
     if (e->small_pass) {
         void *px = nullptr, *pp = nullptr;
-        if (const char *sr = getenv("MEMEX_HIP_SMALL_ROWS")) {  // where the small-pass layer hands over to the bulk kernels (a multiple of 64)
-            const int v = atoi(sr);
+        {   // where the small-pass layer hands over to the bulk kernels (a multiple of 64)
+            const int v = debug_flag("small_rows", 0);
             if (v >= 64 && v <= 16384) e->small_rows = v / 64 * 64;
         }
         if (hipMalloc(&px, (size_t)e->small_rows * H * sizeof(uint16_t)) != hipSuccess ||

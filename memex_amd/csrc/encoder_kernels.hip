@@ -16,6 +16,7 @@
 #include "encoder_kernels.h"
 #include "mx_gelu.h"
 #include "mx_layernorm.h"
+#include "mx_debug.h"
 
 #include <cmath>
 
@@ -451,13 +452,9 @@ static hipError_t gemm_go(hipStream_t s, const GemmParams &p) {
 constexpr int kBigTileRows = 32768;
 
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
-    // MEMEX_HIP_GEMM_BIG: bit 0 = QK projection, bit 1 = V projection, bit 2 = bias / GELU GEMMs, bit 3 = the bf16x3 mode's f32-output GEMMs (A/B switch)
-    static const int big_mask = [] {
-        const char *e = getenv("MEMEX_HIP_GEMM_BIG");
-        return e ? atoi(e) : -1;
-    }();
+    // mask: bit 0 = QK projection, bit 1 = V projection, bit 2 = bias / GELU GEMMs on the 256 x 384 tiles
     const bool fits = p.m >= kBigTileRows && p.n % 384 == 0;
-    const int mask = big_mask >= 0 ? big_mask : (p.k >= 768 ? 1 : 0);
+    const int mask = p.k >= 768 ? 1 : 0;
     const bool big_qk = fits && (mask & 1), big_vt = fits && (mask & 2), big_ff = fits && (mask & 4);
     switch (epi) {
         case EPI_BIAS: return big_ff ? gemm_go<EPI_BIAS, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_BIAS, 2, 2, 2, 32, 4>(s, p);
@@ -803,10 +800,7 @@ hipError_t launch_reduce_qkv(hipStream_t s, const float *part, int nsplit, int m
 }
 
 hipError_t launch_ln_rows(hipStream_t s, bf16_t *x, int ld, int rows, int hidden, const float *gamma, const float *beta, float eps) {
-    static const int rev = [] {
-        const char *ev = getenv("MEMEX_HIP_LN_REV");
-        return ev ? atoi(ev) : 1;
-    }();
+    const int rev = 1;  // last rows first (profiles/r4_ln_rows_order.txt)
     if (hidden == 768)
         hipLaunchKernelGGL(ln_rows_kernel<32>, dim3((rows + 7) / 8), dim3(256), 0, s, x, ld, rows, gamma, beta, eps, rev);
     else if (hidden == 384)
@@ -1370,12 +1364,10 @@ constexpr int kAttnShortMaxLen = 128;
 enum { ATTN_ONE = 0, ATTN_PAIR = 1, ATTN_SHORT = 2 };
 static int attn_form(int heads, int d_head, int max_len, int B) {
     if (d_head != 32) return ATTN_ONE;
-    const char *es = getenv("MEMEX_HIP_ATTN_SHORT");  // (read per pass: tests switch these inside one process)
-    if (max_len <= kAttnShortMaxLen && !(es && es[0] == '0')) return ATTN_SHORT;
+    if (max_len <= kAttnShortMaxLen && debug_flag("attn_short", 1) != 0) return ATTN_SHORT;  // (read per pass: tests switch these inside one process)
     if (heads % 2) return ATTN_ONE;
     const bool many = (long)B * heads >= 1024;  // a pass too small to fill the chip keeps more, smaller items
-    const char *ev = getenv("MEMEX_HIP_ATTN_PAIR");
-    const int env = !ev || !ev[0] ? -1 : (ev[0] == '1' ? 1 : 0);
+    const int env = debug_flag("attn_pair", -1);
     return (env >= 0 ? env == 1 : (many && max_len <= kAttnPairMaxLen)) ? ATTN_PAIR : ATTN_ONE;
 }
 int attention_groups(int heads, int d_head, int max_len, int B) { return attn_form(heads, d_head, max_len, B) == ATTN_PAIR ? heads / 2 : heads; }
@@ -1396,21 +1388,15 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
     // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path); 2 .. 6: measurement modes
     // (no key loop / no loads / no stores: wrong results)
     const int mode = [] {
-        const char *ev = getenv("MEMEX_HIP_ATTN_SAFE");
-        const int m = ev ? atoi(ev) : 0;
+        const int m = debug_flag("attn_safe", 0);
         return m >= 0 && m <= 6 ? m : 0;
     }();
     // a persistent grid: one 16-wave workgroup per CU (LDS: one at d = 64, register file: one at d = 32), each walks up to 64
-    // items (its redo masks are 64 bits); MEMEX_HIP_ATTN_CUS: fewer workgroups (measurement)
-    static const int cus_env = [] {
-        const char *ev = getenv("MEMEX_HIP_ATTN_CUS");
-        return ev ? atoi(ev) : 0;
-    }();
-    const int G = cus_env > 0 ? cus_env : n_cu;
+    // items (its redo masks are 64 bits)
+    const int G = n_cu;
     const AttnItem *items = reinterpret_cast<const AttnItem *>(plan);
     if (form == ATTN_SHORT && mode <= 1) {  // (the measurement modes 2 .. 6 belong to the staged kernel)
-        const char *eh = getenv("MEMEX_HIP_ATTN_SHORT_LDS");  // A/B: K / V^T of an item through LDS (default) or per wave from global memory (0)
-        const bool share = !(eh && eh[0] == '0');
+        const bool share = debug_flag("attn_short_lds", 1) != 0;  // K / V^T of an item through LDS (default) or per wave from global memory (0)
         if (max_len <= 64 && share) hipLaunchKernelGGL((attention_short_kernel<2, true>), dim3(n_items), dim3(128), 0, s, q, k, vt, ldvt, items, hidden, ctx, mode);
         else if (max_len <= 64) hipLaunchKernelGGL((attention_short_kernel<2, false>), dim3(n_items), dim3(128), 0, s, q, k, vt, ldvt, items, hidden, ctx, mode);
         else if (share) hipLaunchKernelGGL((attention_short_kernel<4, true>), dim3(n_items), dim3(256), 0, s, q, k, vt, ldvt, items, hidden, ctx, mode);

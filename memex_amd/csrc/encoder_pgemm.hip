@@ -557,7 +557,7 @@ hipError_t pgemm_attr() {
 }
 
 int g_pgemm_cus = 0;
-int g_pgemm_skew = 0;  // MEMEX_HIP_PGEMM_SKEW: measured 0 .. 8, 0 is the fastest (profiles/r4_pgemm_skew.txt)
+int g_pgemm_skew = 0;  // start-up skew, a measurement knob of scripts/gemm_ubench.hip: 0 .. 8 measured, 0 is the fastest (profiles/r4_pgemm_skew.txt)
 
 template <int EPI>
 hipError_t pgemm_go(hipStream_t s, const GemmParams &p) {
@@ -581,8 +581,6 @@ hipError_t pgemm_setup() {
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
     if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
     g_pgemm_cus = prop.multiProcessorCount / 8 * 8;  // one workgroup per CU, a multiple of the XCD count
-    if (const char *ev = getenv("MEMEX_HIP_PGEMM_SKEW")) g_pgemm_skew = atoi(ev);
-    if (const char *ev = getenv("MEMEX_HIP_PGEMM_CUS")) g_pgemm_cus = atoi(ev) / 8 * 8;
     if (g_pgemm_cus < 8) g_pgemm_cus = 0;  // pgemm is optional: pgemm_supported() then says no and gemm_kernel runs every pass
     return hipSuccess;
 }
@@ -593,10 +591,8 @@ bool pgemm_supported(int epi, const GemmParams &p) {
         epi != EPI_GELU_SPLIT)
         return false;
     // whole column tiles, or for the f32-output epilogue a last tile of 128 columns (MX_PREC_BF16X3 at hidden 384: N = 1152 / 384;
-    // MEMEX_HIP_PGEMM_PART=0 sends those back to gemm_kernel: A/B)
-    static const bool part_ok = [] { const char *ev = getenv("MEMEX_HIP_PGEMM_PART"); return !(ev && ev[0] == '0'); }();
-    static const bool part_vt = [] { const char *ev = getenv("MEMEX_HIP_PGEMM_PART_VT"); return ev && ev[0] == '1'; }();
-    const bool n_ok = p.n % kPT == 0 || ((epi == EPI_F32 || (epi == EPI_VT && part_vt)) && part_ok && p.n % kPT == kPT / 2 && p.n > kPT / 2);
+    // A/B against gemm_kernel: profiles/r5_precise_partial_tile_ab.txt; the same for EPI_VT is worth +0.3 %: r5_vt_partial_tile_ab.txt)
+    const bool n_ok = p.n % kPT == 0 || (epi == EPI_F32 && p.n % kPT == kPT / 2 && p.n > kPT / 2);
     if (g_pgemm_cus < 8 || p.m % kPT || !n_ok || p.k % kPK || p.k < 2 * kPK) return false;
     if ((size_t)p.m * p.lda * 2 >= (1ull << 32) || (size_t)p.w_rows * p.k * 2 >= (1ull << 32)) return false;
     if (epi == EPI_QKV && (p.hidden % 64 || p.n != 2 * p.hidden)) return false;

@@ -715,13 +715,8 @@ uint32_t sample_stride(uint64_t full_tiles, int nwg, int k, bool filt8, int ds) 
     // fastest end to end.  The int8 copy's certificate is four to five times wider, so a weak threshold costs it far
     // more rows: 1/16 of the tiles up to 512 dims, 1/8 at 768, 1/4 at 1024 (a smaller sample makes lanes overflow
     // their 64 records and the retry pass costs a whole scan: scripts/r3_i8_sample.sh, r3_dims.sh).
-    // MEMEX_HIP_SAMPLE_DIV overrides both (a tuning knob: results do not depend on it).
-    static const double env_div = [] {
-        const char *e = getenv("MEMEX_HIP_SAMPLE_DIV");
-        const double v = e ? atof(e) : 0.0;
-        return v >= 2.0 && v <= 4096.0 ? v : 0.0;
-    }();
-    const double div = env_div > 0.0 ? env_div : !filt8 ? 64.0 : ds <= 512 ? 16.0 : ds <= 768 ? 8.0 : 4.0;
+    // (A tuning constant: results do not depend on it.)
+    const double div = !filt8 ? 64.0 : ds <= 512 ? 16.0 : ds <= 768 ? 8.0 : 4.0;
     // larger k: the sample grows like k / 640 for every copy (int8 at k = 30 / 100: 1.33 / 1.56 ms per step with
     // 1/16 / 0.16 of the tiles against 1.93 / 1.77 with three and ten times the k = 10 sample)
     const double f = std::min(0.5, std::max(1.0 / div, (double)k / 640.0));
@@ -769,11 +764,8 @@ int build_filter_copy(mx_index *idx, bool i8) {
     // A bf16 copy rebuilt from a populated index is CENTRED on the rows' mean direction (launch_shadow): a corpus that an
     // int8 certificate could not resolve is a dense one, and embedding corpora are dense because they sit in a cone -- what
     // is left of a row after its component along the cone's axis is removed is several times shorter, and so is the
-    // rounding error the scan's certificate has to cover (MEMEX_HIP_CENTRE=0: never).
-    static const bool centre_ok = [] {
-        const char *e = getenv("MEMEX_HIP_CENTRE");
-        return !(e && e[0] == '0');
-    }();
+    // rounding error the scan's certificate has to cover.
+    const bool centre_ok = true;
     bool centre = false;
     if (!i8 && idx->kc <= kMaxKC && hipMalloc(&nam.p, (size_t)idx->cap * sizeof(float)) == hipSuccess) {
         MX_HIP(hipMemsetAsync(nam.p, 0, (size_t)idx->cap * sizeof(float), idx->stream));
@@ -904,11 +896,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     fp.dists = d_dists;
     fp.n_found = d_nfound;
     fp.max_err = idx->profiling ? s.max_err : nullptr;
-    static const int dbg_stop = [] {
-        const char *e = getenv("MEMEX_HIP_FINISH_STOP");
-        return e ? atoi(e) : 0;
-    }();
-    fp.debug_stop = dbg_stop;
+    fp.debug_stop = 0;  // (stage timing of finish_kernel: scripts/r2_finish_probe.sh set it from the environment)
     fp.done_ctr = s.done_ctr;
     fp.dev_flags = s.dev_flags;
     fp.host_flags = s.host_sum;
@@ -927,11 +915,9 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         // poll with the default scheduling policy -- 100 % of a core in all three forms (scripts/gpu_wait_modes.py) --
         // and hipSetDeviceFlags(BlockingSync) is not this library's to set in a host process.  So: sleep for most of
         // what the last batches took (clock_nanosleep), then poll the completion word; the estimate follows the
-        // workload (an EMA of the wait just observed).  MEMEX_HIP_SPIN=1 (bench.py sets it) polls from the start;
-        // MEMEX_HIP_NO_SPIN=1 is the older spelling of the default.
+        // workload (an EMA of the wait just observed).  MEMEX_HIP_SPIN=1 (bench.py sets it) polls from the start.
         static const bool no_spin = [] {
-            const char *sp = getenv("MEMEX_HIP_SPIN"), *ns = getenv("MEMEX_HIP_NO_SPIN");
-            if (ns && ns[0] == '1') return true;
+            const char *sp = getenv("MEMEX_HIP_SPIN");
             return !(sp && sp[0] == '1');
         }();
         const auto t0 = std::chrono::steady_clock::now();
@@ -1300,15 +1286,14 @@ int composite_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_i
         if (idx->use_rccl) {
             // ONE all-gather of B*k*12 bytes per shard over xGMI; every device receives all
             // blocks, device 0 merges
-            static const bool inject = [] {  // tests: the first all-gather of the process reports an error
-                const char *e = getenv("MEMEX_HIP_TEST_RCCL_FAIL");
-                return e && e[0] == '1';
-            }();
-            static std::atomic<bool> injected{false};
             int e = 0, e2 = 0;
-            if (inject && !injected.exchange(true)) {
+#ifdef MEMEX_TESTING  // libmemex_hip_testing.so only: the first all-gather of the process reports an error
+            static std::atomic<bool> injected{false};
+            if (!injected.exchange(true)) {
                 e = 1;
-            } else {
+            } else
+#endif
+            {
                 e = g_rccl.GroupStart();
                 for (int g = 0; g < G && e == 0; ++g)
                     e = g_rccl.AllGather(idx->sh_block[g], idx->sh_gather[g], blk, 1 /*ncclUint8*/, idx->comms[g], idx->shards[g]->stream);
@@ -1956,12 +1941,8 @@ int run_combined(mx_index *idx, const std::vector<SearchReq *> &batch) {
     // kernels) the only writers of the outputs, and every exit of search_batch is host-synchronised -- through the completion
     // word, behind a system-scope fence per workgroup, on the fast path.  That is one H2D copy, four D2H copies and a stream
     // synchronise less per call: 25-30 us of a single query's 95-115 us on a small collection (profiles/r5_small_corpus_latency.txt).
-    // MEMEX_HIP_HOST_COPIES=1 keeps the copies (A/B, tests).  A sharded index merges on the device and copies as before.
-    static const bool keep_copies = [] {
-        const char *e = getenv("MEMEX_HIP_HOST_COPIES");
-        return e && e[0] == '1';
-    }();
-    if (!idx->composite() && !keep_copies) {
+    // A sharded index merges on the device and copies as before.
+    if (!idx->composite()) {
         s.out_on_host = true;
         rc = any_batch(idx, s.h_q, nb, k, s.h_ids, s.h_scores, s.h_dists, s.h_nf);
         s.out_on_host = false;

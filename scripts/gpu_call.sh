@@ -1,14 +1,13 @@
 #!/bin/bash
+# r6a: this round's baseline of the GEMM / tail microbenchmarks (512-register tail2_kernel next to tail_kernel)
 cd /tmp && export TMPDIR=/tmp
-ROOT="$GRAFT_REPO_ROOT"; OUT=$ROOT/gpurun_out/r5ac; mkdir -p $OUT
-for cfgs in "8192 128" "8192 128 ragged" "16384 64" "4096 256"; do
-  tag=$(echo $cfgs | tr ' ' '_')
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$tag" -- python $ROOT/scripts/gpu_enc_short_prof.py $cfgs > /dev/null 2> "$OUT/$tag.log"
-  f=$(find $OUT/$tag -name "*kernel_stats.csv" | head -1); echo "== all-MiniLM-L12-v2 shape, B S = $cfgs"
-  python - "$f" <<'P'
-import csv, sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:7]:
-    print(f"  {r['Name'].split('(')[0][-44:]:44s} calls {int(r['Calls']):5d}  avg {float(r['AverageNs'])/1e3:8.1f} us  {float(r['Percentage']):5.1f} %")
-P
-done > $ROOT/gpurun_out/r5ac_short_window_kernels_after.txt
-cat $ROOT/gpurun_out/r5ac_short_window_kernels_after.txt; rm -rf $OUT
+ROOT="$GRAFT_REPO_ROOT"; O=$ROOT/gpurun_out
+{
+  echo "== tail_ub (tail_kernel: 2 waves/SIMD, 64 rows per workgroup | tail2_kernel: 1 wave/SIMD, 512 registers, 128 rows per workgroup)"
+  timeout 300 $ROOT/build_ub/tail_ub 131072 1536 3000 1 | grep -E "^tail|checksum|max err"
+  echo "== gemm_ub hidden 768"
+  timeout 300 $ROOT/build_ub/gemm_ub 131072 768 3072 200
+  echo "== gemm_ub hidden 384"
+  timeout 300 $ROOT/build_ub/gemm_ub 131072 384 1536 400
+} > $O/r6a_ubench_baseline.txt 2>&1
+cat $O/r6a_ubench_baseline.txt

@@ -8,6 +8,31 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
+class _DebugKeys:
+    """MEMEX_HIP_DEBUG="key=value,key=value" (memex_amd/csrc/mx_debug.h: which of two kernel forms runs) as a dict bound to a
+    test's monkeypatch: the library reads the string on every use, so a test may switch inside one process."""
+
+    def __init__(self, monkeypatch):
+        self.mp, self.kv = monkeypatch, {}
+
+    def _flush(self):
+        self.mp.setenv("MEMEX_HIP_DEBUG", ",".join(f"{k}={v}" for k, v in self.kv.items()))
+
+    def set(self, key, value):
+        self.kv[key] = str(value)
+        self._flush()
+
+    def unset(self, key):
+        self.kv.pop(key, None)
+        self._flush()
+
+
+def _dbg(monkeypatch):
+    if not hasattr(monkeypatch, "_mx_debug_keys"):
+        monkeypatch._mx_debug_keys = _DebugKeys(monkeypatch)
+    return monkeypatch._mx_debug_keys
+
+
 def _cos(a, b):
     return (a * b).sum(1) / np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1)
 
@@ -69,7 +94,7 @@ def test_attention_stage_and_block_boundaries(hidden, ffn, lib_built, monkeypatc
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, synthetic_weights
     from oracle import bert_oracle
-    monkeypatch.setenv("MEMEX_HIP_SMALL", "0")   # one sequence alone and in the batch through the same kernels: same bits
+    _dbg(monkeypatch).set("small", "0")   # one sequence alone and in the batch through the same kernels: same bits
     cfg = EncoderConfig(layers=2, hidden=hidden, heads=12, ffn=ffn, vocab=3000)
     w = synthetic_weights(cfg, 31)
     rng = np.random.default_rng(31)
@@ -89,8 +114,8 @@ def test_attention_stage_and_block_boundaries(hidden, ffn, lib_built, monkeypatc
 def test_batch_composition_does_not_change_a_row(small, lib_built, monkeypatch):
     """Varlen packing: a sequence's embedding must not depend on its batch neighbours / padding ids.  Passes of the same
     kind return the same bits; a small pass (<= 2048 packed rows: encoder_small.hip sums the MLP's ffn chunks in another order)
-    agrees with a large one to 1 - cos <= 1e-6, and bit for bit when MEMEX_HIP_SMALL=0 routes it through the large-pass kernels."""
-    monkeypatch.setenv("MEMEX_HIP_SMALL", small)
+    agrees with a large one to 1 - cos <= 1e-6, and bit for bit when MEMEX_HIP_DEBUG=small=0 routes it through the large-pass kernels."""
+    _dbg(monkeypatch).set("small", small)
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, synthetic_weights
     cfg = EncoderConfig(layers=3, hidden=384, heads=12, ffn=1536, vocab=3000)
@@ -134,7 +159,7 @@ def test_small_pass_matches_large_pass(layers, B, S, seed, ffn, lib_built, monke
     lens = rng.integers(max(1, S // 2), S + 1, size=B).astype(np.int32)
     outs = []
     for small in ("1", "0"):
-        monkeypatch.setenv("MEMEX_HIP_SMALL", small)
+        _dbg(monkeypatch).set("small", small)
         with Encoder(cfg, w) as enc:
             outs.append(enc.encode(ids, lens))
             np.testing.assert_array_equal(outs[-1], enc.encode(ids, lens))
@@ -233,7 +258,7 @@ def test_embed_then_search_pipeline_matches_cpu_path(oracle, lib_built, tmp_path
 
 def test_fused_layer_tail_equals_gemm_by_gemm_path(lib_built, monkeypatch):
     """tail_kernel (attention out-projection + Add&Norm + MLP + Add&Norm in one launch) rounds at the same
-    points and accumulates in the same k order as the three GEMMs it replaces (MEMEX_HIP_UNFUSED_TAIL=1):
+    points and accumulates in the same k order as the three GEMMs it replaces (MEMEX_HIP_DEBUG=unfused_tail=1):
     outputs must be bit-identical -- full passes, ragged lengths, a single short query and a non-default ffn
     width included."""
     from memex_amd.encoder import Encoder
@@ -248,9 +273,9 @@ def test_fused_layer_tail_equals_gemm_by_gemm_path(lib_built, monkeypatch):
         ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
         lens = rng.integers(S // 2 + S // 4, S + 1, B).astype(np.int32)
         outs = []
-        monkeypatch.setenv("MEMEX_HIP_SMALL", "0")   # (small passes have kernels of their own: test_small_pass_matches_large_pass)
+        _dbg(monkeypatch).set("small", "0")   # (small passes have kernels of their own: test_small_pass_matches_large_pass)
         for unfused in ("1", "0"):
-            monkeypatch.setenv("MEMEX_HIP_UNFUSED_TAIL", unfused)
+            _dbg(monkeypatch).set("unfused_tail", unfused)
             with Encoder(cfg, w) as enc:
                 outs.append(enc.encode(ids, lens))
         np.testing.assert_array_equal(outs[0], outs[1])
@@ -258,7 +283,7 @@ def test_fused_layer_tail_equals_gemm_by_gemm_path(lib_built, monkeypatch):
 
 def test_large_passes_run_their_gemms_on_pgemm_kernel(lib_built, monkeypatch):
     """Passes of >= 32768 packed rows run the projections and MLP GEMMs on pgemm_kernel (encoder_pgemm.hip: persistent
-    256 x 256 tiles, two wave rows half a phase apart) instead of gemm_kernel (MEMEX_HIP_PGEMM=0).  Same k order and
+    256 x 256 tiles, two wave rows half a phase apart) instead of gemm_kernel (MEMEX_HIP_DEBUG=pgemm=0).  Same k order and
     epilogue arithmetic: where only the schedule changes (hidden 384, GEMM-by-GEMM tail) the embeddings are
     bit-identical; the hidden-768 layer also moves its two LayerNorms behind the GEMM (y rounded to bf16 first,
     ln_rows_kernel), which must stay far inside the 1e-3 bar -- against the other path and against the f64 oracle."""
@@ -276,15 +301,15 @@ def test_large_passes_run_their_gemms_on_pgemm_kernel(lib_built, monkeypatch):
         ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
         lens = rng.integers(S // 2 + S // 4, S + 1, B).astype(np.int32)
         if cfg.hidden == 384:
-            monkeypatch.setenv("MEMEX_HIP_UNFUSED_TAIL", "1")
+            _dbg(monkeypatch).set("unfused_tail", "1")
         outs = []
         for pg in ("0", "1"):
-            monkeypatch.setenv("MEMEX_HIP_PGEMM", pg)
+            _dbg(monkeypatch).set("pgemm", pg)
             with Encoder(cfg, w) as enc:
                 outs.append(enc.encode(ids, lens))
                 np.testing.assert_array_equal(outs[-1], enc.encode(ids, lens))        # deterministic
-        monkeypatch.delenv("MEMEX_HIP_UNFUSED_TAIL", raising=False)
-        monkeypatch.delenv("MEMEX_HIP_PGEMM", raising=False)
+        _dbg(monkeypatch).unset("unfused_tail")
+        _dbg(monkeypatch).unset("pgemm")
         assert np.isfinite(outs[1]).all(), kw
         if identical or identical is None:
             np.testing.assert_array_equal(outs[0], outs[1])
@@ -376,7 +401,7 @@ def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, precision
 def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
     """attention_kernel's fast path applies no softmax shift (P = exp2(score)) and only falls back to the
     running maximum when a row sum says an exp2 may have overflowed or a row underflowed.  (a) ordinary
-    weights: fast path == running-maximum loop (MEMEX_HIP_ATTN_SAFE=1) up to bf16 rounding of P, both within
+    weights: fast path == running-maximum loop (MEMEX_HIP_DEBUG=attn_safe=1) up to bf16 rounding of P, both within
     tolerance of the oracle; (b) query / key projections scaled so that scores reach several hundred either
     side of 0: every row of the fast path overflows or underflows there, so finite outputs that agree with
     the running-maximum loop mean the fallback ran and is right."""
@@ -395,7 +420,7 @@ def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
                 w[name] = (w[name] * scale).astype(np.float32)
         outs = []
         for safe in ("0", "1"):
-            monkeypatch.setenv("MEMEX_HIP_ATTN_SAFE", safe)
+            _dbg(monkeypatch).set("attn_safe", safe)
             with Encoder(cfg, w) as enc:
                 outs.append(enc.encode(ids, lens))
         for o in outs:
@@ -407,11 +432,11 @@ def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
                 assert (1.0 - cos).max() <= TOL, cos
         cos = (outs[0] * outs[1]).sum(1) / np.linalg.norm(outs[0], axis=1) / np.linalg.norm(outs[1], axis=1)
         assert (1.0 - cos).max() <= 1e-4, (scale, cos)
-        # d = 32 can stage two adjacent heads together (MEMEX_HIP_ATTN_PAIR=1): the same arithmetic per head, the same bits --
+        # d = 32 can stage two adjacent heads together (MEMEX_HIP_DEBUG=attn_pair=1): the same arithmetic per head, the same bits --
         # except that a redo takes both heads of a pair through the running-maximum loop (scale 4)
-        monkeypatch.setenv("MEMEX_HIP_ATTN_PAIR", "1")
+        _dbg(monkeypatch).set("attn_pair", "1")
         for i, safe in enumerate(("0", "1")):
-            monkeypatch.setenv("MEMEX_HIP_ATTN_SAFE", safe)
+            _dbg(monkeypatch).set("attn_safe", safe)
             with Encoder(cfg, w) as enc:
                 o = enc.encode(ids, lens)
             if scale == 4.0 and safe == "0":
@@ -419,7 +444,7 @@ def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
                 assert (1.0 - cos).max() <= 1e-4, (scale, cos)
             else:
                 assert np.array_equal(o, outs[i]), (scale, safe)
-        monkeypatch.delenv("MEMEX_HIP_ATTN_PAIR")
+        _dbg(monkeypatch).unset("attn_pair")
 
 
 def test_embedder_batches_concurrent_requests(lib_built):
@@ -497,7 +522,7 @@ def test_keyed_encoder_is_shared_and_refcounted(lib_built):
                                     (dict(layers=2, hidden=384, heads=6, ffn=768, vocab=3000, precision="bf16x3"), 6, 77)])
 def test_split_bf16_attention_matches_the_f32_mfma_attention(kw, B, S, lib_built, monkeypatch):
     """MX_PREC_BF16X3's attention runs its two products as three bf16 MFMAs each (hi hi + lo hi + hi lo, keys of a k-step in
-    the slot order that makes a lane's P registers its B operand); MEMEX_HIP_ATTN_F32=1 keeps the f32-MFMA kernel it replaced.
+    the slot order that makes a lane's P registers its B operand); MEMEX_HIP_DEBUG=attn_f32=1 keeps the f32-MFMA kernel it replaced.
     Ragged lengths, key blocks cut by the sequence end, head dims 32 and 64: the two agree to the dropped lo x lo terms."""
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, checkpoint_like_weights
@@ -509,7 +534,7 @@ def test_split_bf16_attention_matches_the_f32_mfma_attention(kw, B, S, lib_built
     lens[0], lens[1] = S, 33
     outs = []
     for f32_attn in ("0", "1"):
-        monkeypatch.setenv("MEMEX_HIP_ATTN_F32", f32_attn)
+        _dbg(monkeypatch).set("attn_f32", f32_attn)
         with Encoder(cfg, w) as enc:
             outs.append(enc.encode(ids, lens).astype(np.float64))
     d = (1.0 - _cos(outs[0], outs[1])).max()
@@ -525,7 +550,7 @@ def test_split_bf16_attention_matches_the_f32_mfma_attention(kw, B, S, lib_built
 def test_split_operand_mode_on_pgemm_kernel(kw, B, S, seed, lib_built, monkeypatch):
     """MX_PREC_BF16X3 in large passes: its GEMMs run on pgemm_kernel where the shape allows (EPI_F32 / EPI_GELU_SPLIT through the
     wave-private scratch tile).  Same k order, same products, f32 sums in the same order as gemm_kernel: bit-identical
-    embeddings with MEMEX_HIP_PGEMM=0, and within the mode's bars of the f64 oracle."""
+    embeddings with MEMEX_HIP_DEBUG=pgemm=0, and within the mode's bars of the f64 oracle."""
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, checkpoint_like_weights
     from oracle import bert_oracle
@@ -536,7 +561,7 @@ def test_split_operand_mode_on_pgemm_kernel(kw, B, S, seed, lib_built, monkeypat
     lens = rng.integers(S // 2, S + 1, B).astype(np.int32)
     outs = []
     for pg in ("0", "1"):
-        monkeypatch.setenv("MEMEX_HIP_PGEMM", pg)
+        _dbg(monkeypatch).set("pgemm", pg)
         with Encoder(cfg, w) as enc:
             outs.append(enc.encode(ids, lens))
     print(f"hidden {cfg.hidden}: pgemm vs gemm max |diff| {np.abs(outs[0] - outs[1]).max():.3e}, rows differing {(outs[0] != outs[1]).any(axis=1).sum()} of {B}")
@@ -559,7 +584,7 @@ def test_hidden_768_small_passes_split_k(kw, B, S, seed, lib_built, monkeypatch)
     """Passes of <= 2048 rows of a hidden-768 model run their two Add & LayerNorm GEMMs split over k (f32 partials from
     gemm_kernel<EPI_F32>, reduce_res_ln_kernel behind them) instead of one 64 x 768 workgroup per row tile looping over all of k
     (80 us per layer for one query).  Same rounding points, another f32 summation order: within 1e-5 of the fused form
-    (MEMEX_HIP_SPLITK=0), and within the usual bar of the f64 oracle."""
+    (MEMEX_HIP_DEBUG=splitk=0), and within the usual bar of the f64 oracle."""
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, checkpoint_like_weights
     from oracle import bert_oracle
@@ -571,7 +596,7 @@ def test_hidden_768_small_passes_split_k(kw, B, S, seed, lib_built, monkeypatch)
     lens[0] = S
     outs = []
     for sk in ("1", "0"):
-        monkeypatch.setenv("MEMEX_HIP_SPLITK", sk)
+        _dbg(monkeypatch).set("splitk", sk)
         with Encoder(cfg, w) as enc:
             outs.append(enc.encode(ids, lens))
             np.testing.assert_array_equal(outs[-1], enc.encode(ids, lens))
@@ -628,8 +653,8 @@ def test_short_sequence_passes_pair_heads(lib_built, monkeypatch):
     barrier) takes the passes whose longest sequence has <= 128 tokens; full passes (>= 1024 items) up to 256 tokens stage two
     heads per item of the staged kernel.  Both
     forms repeat attention_kernel's arithmetic instruction for instruction: whatever the automatic rule picks must equal the
-    one-head staged kernel (MEMEX_HIP_ATTN_SHORT=0, MEMEX_HIP_ATTN_PAIR=0) bit for bit, and so must each form when forced --
-    under ordinary weights, on the running-maximum path (MEMEX_HIP_ATTN_SAFE=1), and with scores of several hundred, where
+    one-head staged kernel (MEMEX_HIP_DEBUG=attn_short=0, MEMEX_HIP_DEBUG=attn_pair=0) bit for bit, and so must each form when forced --
+    under ordinary weights, on the running-maximum path (MEMEX_HIP_DEBUG=attn_safe=1), and with scores of several hundred, where
     every row leaves the fast path and is redone."""
     from memex_amd.encoder import Encoder
     from memex_amd.weights import EncoderConfig, synthetic_weights
@@ -638,14 +663,14 @@ def test_short_sequence_passes_pair_heads(lib_built, monkeypatch):
     rng = np.random.default_rng(91)
 
     def encode(w, ids, lens, **env):
-        for kname in ("MEMEX_HIP_ATTN_SHORT", "MEMEX_HIP_ATTN_SHORT_LDS", "MEMEX_HIP_ATTN_PAIR", "MEMEX_HIP_ATTN_SAFE"):
-            monkeypatch.delenv(kname, raising=False)
+        for kname in ("attn_short", "attn_short_lds", "attn_pair", "attn_safe"):
+            _dbg(monkeypatch).unset(kname)
         for kname, v in env.items():
-            monkeypatch.setenv(kname, v)
+            _dbg(monkeypatch).set(kname, v)
         with Encoder(cfg, w) as enc:
             out = enc.encode(ids, lens)
         for kname in env:
-            monkeypatch.delenv(kname, raising=False)
+            _dbg(monkeypatch).unset(kname)
         return out
 
     for scale in (1.0, 24.0):
@@ -658,21 +683,21 @@ def test_short_sequence_passes_pair_heads(lib_built, monkeypatch):
             ids = rng.integers(1000, cfg.vocab, size=(B, S)).astype(np.int32)
             lens = rng.integers(lo, S + 1, size=B).astype(np.int32)
             lens[0] = S
-            base = encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="0", MEMEX_HIP_ATTN_PAIR="0")
+            base = encode(w, ids, lens, attn_short="0", attn_pair="0")
             assert np.isfinite(base).all()
             auto = encode(w, ids, lens)
             if scale == 1.0:
                 np.testing.assert_array_equal(auto, base, err_msg=f"automatic choice, {B} x {S}")
             else:  # (the automatic choice may be the head pairs: a redo takes the pair partner along, last-bit differences)
                 assert (1.0 - _cos(auto.astype(np.float64), base.astype(np.float64))).max() <= 1e-4, (B, S, scale)
-            np.testing.assert_array_equal(encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="1"), base, err_msg=f"short kernel, {B} x {S}, scale {scale}")
-            np.testing.assert_array_equal(encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="1", MEMEX_HIP_ATTN_SHORT_LDS="0"), base,
+            np.testing.assert_array_equal(encode(w, ids, lens, attn_short="1"), base, err_msg=f"short kernel, {B} x {S}, scale {scale}")
+            np.testing.assert_array_equal(encode(w, ids, lens, attn_short="1", attn_short_lds="0"), base,
                                           err_msg=f"short kernel, fragments from global memory, {B} x {S}, scale {scale}")
             if scale == 1.0:  # (a redo takes a pair partner along through the running-maximum loop: last-bit differences, see the header)
-                np.testing.assert_array_equal(encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="0", MEMEX_HIP_ATTN_PAIR="1"), base,
+                np.testing.assert_array_equal(encode(w, ids, lens, attn_short="0", attn_pair="1"), base,
                                               err_msg=f"head pairs, {B} x {S}")
-            safe = encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="0", MEMEX_HIP_ATTN_PAIR="0", MEMEX_HIP_ATTN_SAFE="1")
-            np.testing.assert_array_equal(encode(w, ids, lens, MEMEX_HIP_ATTN_SHORT="1", MEMEX_HIP_ATTN_SAFE="1"), safe,
+            safe = encode(w, ids, lens, attn_short="0", attn_pair="0", attn_safe="1")
+            np.testing.assert_array_equal(encode(w, ids, lens, attn_short="1", attn_safe="1"), safe,
                                           err_msg=f"short kernel, running maximum, {B} x {S}, scale {scale}")
             if scale == 1.0:
                 sub = np.r_[0:min(3, B), max(3, B - 3):B]

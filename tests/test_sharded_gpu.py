@@ -98,13 +98,15 @@ def test_rccl_exchange_single_rank(oracle, lib_built):
 def test_rccl_failure_at_search_time_falls_back_to_copies(oracle, lib_built):
     """A first multi-GPU run must not be lost to its collective: the communicator is self-tested when the index opens
     (one tiny all-gather under a deadline), and an all-gather that reports an error at search time
-    (MEMEX_HIP_TEST_RCCL_FAIL=1 injects one) switches the index to peer copies for that batch and every later one --
-    same answers, `exchange` says so, the stats count it.  Run in a child process: the injection is once per process."""
+    (libmemex_hip_testing.so, the -DMEMEX_TESTING build, injects one) switches the index to peer copies for that batch and every
+    later one -- same answers, `exchange` says so, the stats count it.  Run in a child process: the injection is once per process."""
     import subprocess
     import sys
     code = r'''
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd())
+from memex_amd import _lib
+_lib.use_testing_library()
 from memex_amd.index import FlatIndex
 from oracle.search_oracle import COracle
 rng = np.random.default_rng(8)
@@ -121,7 +123,7 @@ with FlatIndex(384, devices=[0]) as idx:
     assert idx.stats().exchange_fallbacks == 1
 print("FALLBACK_OK")
 '''
-    env = dict(os.environ, MEMEX_HIP_EXCHANGE="rccl", MEMEX_HIP_TEST_RCCL_FAIL="1")
+    env = dict(os.environ, MEMEX_HIP_EXCHANGE="rccl")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
