@@ -28,6 +28,7 @@
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -967,10 +968,10 @@ extern "C" {
 int mx_tokenizer_create_from_json_memory(const char *json, size_t nbytes, mx_tokenizer **out) try {
     if (!json || !out) return fail(MX_EINVAL, "null argument");
     *out = nullptr;
-    mx_tokenizer *t = new mx_tokenizer();
-    int rc = build_from_tokenizer_json(t, std::string(json, nbytes));
-    if (rc != MX_OK) { delete t; return rc; }
-    *out = t;
+    std::unique_ptr<mx_tokenizer> t(new mx_tokenizer());  // (the builders may throw: nothing leaks)
+    int rc = build_from_tokenizer_json(t.get(), std::string(json, nbytes));
+    if (rc != MX_OK) return rc;
+    *out = t.release();
     return MX_OK;
 } catch (...) {
     return guard_exception();
@@ -994,11 +995,11 @@ int mx_tokenizer_create(const char *vocab_path, int lowercase, mx_tokenizer **ou
     *out = nullptr;
     std::ifstream f(vocab_path);
     if (!f) return fail(MX_EIO, "Unable to load model <%s>", vocab_path);  // embedding.rs:166-169 wording
-    mx_tokenizer *t = new mx_tokenizer();
+    std::unique_ptr<mx_tokenizer> t(new mx_tokenizer());
     t->lowercase = lowercase != 0;
-    int rc = parse_vocab(t, f);
-    if (rc != MX_OK) { delete t; return rc; }
-    *out = t;
+    int rc = parse_vocab(t.get(), f);
+    if (rc != MX_OK) return rc;
+    *out = t.release();
     return MX_OK;
 } catch (...) {
     return guard_exception();
@@ -1008,11 +1009,11 @@ int mx_tokenizer_create_from_memory(const char *vocab, size_t nbytes, int lowerc
     if (!vocab || !out) return fail(MX_EINVAL, "null argument");
     *out = nullptr;
     std::istringstream in(std::string(vocab, nbytes));
-    mx_tokenizer *t = new mx_tokenizer();
+    std::unique_ptr<mx_tokenizer> t(new mx_tokenizer());
     t->lowercase = lowercase != 0;
-    int rc = parse_vocab(t, in);
-    if (rc != MX_OK) { delete t; return rc; }
-    *out = t;
+    int rc = parse_vocab(t.get(), in);
+    if (rc != MX_OK) return rc;
+    *out = t.release();
     return MX_OK;
 } catch (...) {
     return guard_exception();
@@ -1022,14 +1023,14 @@ int mx_tokenizer_create_from_memory(const char *vocab, size_t nbytes, int lowerc
 int mx_tokenizer_create_bpe_from_memory(const char *vocab_json, size_t n_vocab, const char *merges, size_t n_merges, mx_tokenizer **out) try {
     if (!vocab_json || !merges || !out) return fail(MX_EINVAL, "null argument");
     *out = nullptr;
-    mx_tokenizer *t = new mx_tokenizer();
-    int rc = parse_vocab_json(t, std::string(vocab_json, n_vocab));
+    std::unique_ptr<mx_tokenizer> t(new mx_tokenizer());
+    int rc = parse_vocab_json(t.get(), std::string(vocab_json, n_vocab));
     if (rc == MX_OK) {
         std::istringstream m(std::string(merges, n_merges));
-        rc = finish_bpe(t, m);
+        rc = finish_bpe(t.get(), m);
     }
-    if (rc != MX_OK) { delete t; return rc; }
-    *out = t;
+    if (rc != MX_OK) return rc;
+    *out = t.release();
     return MX_OK;
 } catch (...) {
     return guard_exception();
@@ -1150,8 +1151,15 @@ int mx_tokenizer_segment_batch(mx_tokenizer *t, const char *const *texts, int n_
     if (nthr <= 1) {
         work();
     } else {
+        // (a std::system_error from thread creation must not unwind past joinable threads: std::terminate.  The threads
+        // that did start share the queue; this thread takes the rest)
         std::vector<std::thread> pool;
-        for (int i = 0; i < nthr; ++i) pool.emplace_back(work);
+        pool.reserve((size_t)nthr);
+        try {
+            for (int i = 0; i < nthr; ++i) pool.emplace_back(work);
+        } catch (...) {
+            work();
+        }
         for (auto &th : pool) th.join();
     }
     if (failed) return fail(MX_ENOMEM, "segmenting a batch of %d texts failed (out of host memory)", n_texts);
@@ -1215,7 +1223,13 @@ int mx_tokenizer_encode_batch(mx_tokenizer *t, const char *const *texts, int B, 
         work(0, B);
     } else {
         std::vector<std::thread> pool;
-        for (int i = 0; i < nthr; ++i) pool.emplace_back(work, (int)((long)B * i / nthr), (int)((long)B * (i + 1) / nthr));
+        pool.reserve((size_t)nthr);
+        int started = 0;  // (thread creation may fail: the slices of the threads that did not start run here)
+        try {
+            for (; started < nthr; ++started) pool.emplace_back(work, (int)((long)B * started / nthr), (int)((long)B * (started + 1) / nthr));
+        } catch (...) {
+            work((int)((long)B * started / nthr), B);
+        }
         for (auto &th : pool) th.join();
     }
     if (failed) return fail(MX_ENOMEM, "tokenising a batch of %d texts failed (out of host memory)", B);

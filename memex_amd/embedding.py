@@ -52,7 +52,9 @@ class SetupError(EmbeddingError):
 @dataclass
 class EmbeddingResult:
     """embedding.rs:18-22.  ``vector``: the reference's ``Vec<f32>`` -- here one float32 row (``numpy.ndarray``, indexable and
-    iterable like a list; a Python list of 384 floats per window was a third of a document's ingest time)."""
+    iterable like a list, its own copy -- not a view of the batch; a Python list of 384 floats per window was a third of a
+    document's ingest time).  NOT a list where it matters: `if r.vector` raises, `==` is elementwise, `json.dumps` needs
+    `r.vector.tolist()` (`VectorData.to_json()` does that at the serialisation boundary)."""
     content: str
     vector: Sequence[float]
 
@@ -288,7 +290,8 @@ class SentenceEmbedder:
                         raise EncodingFailure("# of embeddings doesn't match # of segments")
                     o = 0
                     for reply, segs in work:
-                        reply.put([EmbeddingResult(content=s_, vector=v)
+                        # (a copy per row: a view would keep the whole batch's [N, H] array alive behind every result)
+                        reply.put([EmbeddingResult(content=s_, vector=v.copy())
                                    for s_, v in zip(segs, vecs[o:o + len(segs)])])
                         o += len(segs)
                 except Exception as e:

@@ -45,6 +45,12 @@ class VectorData:
     vector: Sequence[float]
     segment_id: int = 0
 
+    def to_json(self) -> dict:
+        """The serialisation boundary (the reference writes the vector as JSON into the `embeddings` table:
+        `vector.into()`, worker/tasks.rs:42-48): `vector` may be a numpy float32 row, which `json.dumps` refuses."""
+        return {"_id": self._id, "document_id": self.document_id, "text": self.text,
+                "vector": [float(x) for x in self.vector], "segment_id": int(self.segment_id)}
+
 
 class VectorStoreError(Exception):
     """mod.rs:31-48; subclasses below are the enum variants."""

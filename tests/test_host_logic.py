@@ -18,6 +18,18 @@ def test_vector_data_fields_match_reference():
     assert (v._id, v.document_id, v.text, v.segment_id) == ("a", "d", "t", 3)   # mod.rs:17-28
 
 
+def test_vector_data_serialises_with_a_numpy_row():
+    """The embedder hands out numpy float32 rows (embedding.py::EmbeddingResult); the reference serialises the vector as JSON
+    (`vector.into()`, worker/tasks.rs:42-48): `to_json()` is that boundary."""
+    import json
+    import numpy as np
+    from memex_amd.storage import VectorData
+    v = np.arange(6, dtype=np.float32) / 3
+    d = VectorData(_id="a", document_id="d", text="t", vector=v, segment_id=np.int64(2))
+    back = json.loads(json.dumps(d.to_json()))
+    assert back["segment_id"] == 2 and np.array_equal(np.array(back["vector"], dtype=np.float32), v)
+
+
 def test_store_without_rows_needs_no_device(tmp_path):
     s = storage.HipFlatStore.new(str(tmp_path))
     assert s.search([0.1, 0.2], 3) == []                 # empty store: nothing to search, no GPU touched
