@@ -49,6 +49,9 @@ def report(name, o, ref):
 def r16(x):  # hi + lo bf16 split: 16 significant bits
     x = np.asarray(x, np.float32); hi = bf(x); return hi + bf(x - hi)
 
+def r22(x):  # fp16 hi + fp16 lo split: 22 significant bits (inside fp16's exponent range)
+    x = np.asarray(x, np.float32); hi = hf(x); return hi + hf(x - hi)
+
 def run(w, cfg, ids, lens, R):
     """R: dict of rounding fns: res, gout, x_qk (x into q/k proj), w_qk, qk (q,k stored), x_v, w_v, v, p, ctx, w_o, x_f, w_1, h, w_2, final"""
     g = lambda k: R.get(k, bf)
@@ -64,8 +67,8 @@ def run(w, cfg, ids, lens, R):
             return (t.reshape(-1, t.shape[-1]).astype(np.float32) @ rw(W[p+name+".weight"]).T + W[p+name+".bias"]).reshape(t.shape[:-1]+(-1,))
         def heads(t): return t.reshape(B, S, nh, dh).transpose(0, 2, 1, 3)
         xr = g('res')(x)
-        q = heads(g('qk')(lin(g('x_qk')(x), "attention.self.query", g('w_qk'))/math.sqrt(dh)))
-        k = heads(g('qk')(lin(g('x_qk')(x), "attention.self.key", g('w_qk'))))
+        q = heads(R.get('q', g('qk'))(lin(g('x_qk')(x), "attention.self.query", g('w_qk'))/math.sqrt(dh)))
+        k = heads(R.get('k', g('qk'))(lin(g('x_qk')(x), "attention.self.key", g('w_qk'))))
         v = heads(g('v')(lin(g('x_v')(x), "attention.self.value", g('w_v'))))
         s = (q.astype(np.float64) @ k.transpose(0, 1, 3, 2).astype(np.float64))
         s = np.where(mask[:, None, None, :], s, -1e30)
@@ -112,3 +115,19 @@ if __name__ == "__main__":
     report("all fp16", run(w, cfg, ids, lens, allof(hf)), ref)
     report("fp16 ops, f32 residual / gemm out / final", run(w, cfg, ids, lens, allof(hf, res=ident, gout=ident, final=ident)), ref)
     report("all f32 (numpy f32 products)", run(w, cfg, ids, lens, allof(ident)), ref)
+    # ---- round 6: the TWO-product candidates: one operand of every product carried as a 16-bit pair, the other as
+    # ONE 16-bit value; hidden state / GEMM results / output in f32 throughout
+    F32 = dict(res=ident, gout=ident, final=ident)
+    WEIGHTS = ['w_qk', 'w_v', 'w_o', 'w_1', 'w_2']
+    ACTS = ['x_qk', 'x_v', 'ctx', 'x_f', 'h']
+    def mode(wfn, afn, **attn):
+        d = dict(F32); d.update({k: wfn for k in WEIGHTS}); d.update({k: afn for k in ACTS}); d.update(attn); return d
+    report("r6 fp16 w x split-fp16 a; attention 16-bit x3", run(w, cfg, ids, lens, mode(hf, r22, qk=r16, p=r16, v=r16)), ref)
+    report("r6 fp16 w x split-fp16 a; attention q split-fp16, k/v/p fp16", run(w, cfg, ids, lens, mode(hf, r22, q=r22, k=hf, p=hf, v=hf)), ref)
+    report("r6 fp16 w x split-fp16 a; attention all fp16", run(w, cfg, ids, lens, mode(hf, r22, qk=hf, p=hf, v=hf)), ref)
+    report("r6 bf16-hi/lo w x fp16 a; attention 16-bit x3", run(w, cfg, ids, lens, mode(r16, hf, qk=r16, p=r16, v=r16)), ref)
+    report("r6 bf16-hi/lo w x fp16 a; attention all fp16", run(w, cfg, ids, lens, mode(r16, hf, qk=hf, p=hf, v=hf)), ref)
+    report("r6 bf16 w x bf16-hi/lo a; attention 16-bit x3", run(w, cfg, ids, lens, mode(bf, r16, qk=r16, p=r16, v=r16)), ref)
+    report("r6 x3 everywhere but 2 products (fp16 w) in W1/W2", run(w, cfg, ids, lens, mode(r16, r16, qk=r16, p=r16, v=r16, w_1=hf, w_2=hf, x_f=r22, h=r22)), ref)
+    report("r6 x3 on the logit path + attention, fp16 w x split-fp16 a elsewhere", run(w, cfg, ids, lens, mode(hf, r22, w_qk=r16, x_qk=r16, qk=r16, p=r16, v=r16)), ref)
+    report("r6 fp16 w x fp16 a (ONE product), f32 state; attention 16-bit x3", run(w, cfg, ids, lens, mode(hf, hf, qk=r16, p=r16, v=r16)), ref)
