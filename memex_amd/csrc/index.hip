@@ -204,7 +204,8 @@ struct mx_index {
     uint64_t xs_rows = 0;
     uint64_t n = 0, cap = 0;
     IdMap idmap{0, 0, 1, 0};
-    uint32_t *flags = nullptr;  // device: [0] non-finite rows, [1] out-of-range-norm rows (last add), [2] ec_max (float bits), [3] zero-norm rows, [4] listed out-of-range-norm rows
+    uint32_t *flags = nullptr;  // device: [0] non-finite rows, [1] out-of-range-norm rows (last add), [2] ec_max (float bits), [3] zero-norm rows, [4] listed out-of-range-norm rows,
+                                // [5] rc_max (float bits): max |r_c| of a centred int8 copy
     uint64_t wild_rows = 0;         // rows with a norm outside [1e-15, 1e15] (a compressed corpus answers on the EXACT path then)
     uint32_t *zero_rows = nullptr;  // device: [kZeroCap] local rows with zero norm, ascending (finish_kernel adds them to every query)
     uint64_t n_zero = 0;            // zero-norm rows in the index; more than kZeroCap -> EXACT path
@@ -523,7 +524,7 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
         // the filter copy is an accelerator, not a requirement: without HBM for it the index
         // keeps working on the f32 scan
         const size_t eb = idx->filter_i8 ? 1 : 2;  // bytes per stored element
-        const size_t hb = (size_t)want * idx->ds * eb, tb = (size_t)(want / kTile8Rows) * 4 * sizeof(float);
+        const size_t hb = (size_t)want * idx->ds * eb, tb = (size_t)(want / kTile8Rows) * kTscaleFloats * sizeof(float);
         if (hipMalloc(&nh.p, hb) != hipSuccess || (idx->filter_i8 && hipMalloc(&nts.p, tb) != hipSuccess)) {
             (void)hipGetLastError();
             if (nh.p) (void)hipFree(nh.release());
@@ -534,9 +535,23 @@ int ensure_capacity(mx_index *idx, uint64_t rows) {
             if (used) MX_HIP(hipMemcpyAsync(nh.p, idx->xh, used, hipMemcpyDeviceToDevice, idx->stream));
             MX_HIP(hipMemsetAsync(static_cast<char *>(nh.p) + used, 0, hb - used, idx->stream));
             if (idx->filter_i8) {
-                const size_t tused = (size_t)(used_rows / kTile8Rows) * 4 * sizeof(float);
+                const size_t tused = (size_t)(used_rows / kTile8Rows) * kTscaleFloats * sizeof(float);
                 if (tused) MX_HIP(hipMemcpyAsync(nts.p, idx->tsc, tused, hipMemcpyDeviceToDevice, idx->stream));
                 MX_HIP(hipMemsetAsync(static_cast<char *>(nts.p) + tused, 0, tb - tused, idx->stream));
+                if (idx->centred && idx->xh && idx->amean) {
+                    // the a_c array of a CENTRED int8 copy grows with it; without room for it the copy is rewritten plain from the rows
+                    if (hipMalloc(&nam.p, want * sizeof(float)) == hipSuccess) {
+                        const size_t aused = (size_t)used_rows * sizeof(float);
+                        MX_HIP(hipMemcpyAsync(nam.p, idx->amean, std::min(aused, (size_t)idx->cap * sizeof(float)), hipMemcpyDeviceToDevice, idx->stream));
+                        if (want * sizeof(float) > aused) MX_HIP(hipMemsetAsync(static_cast<char *>(nam.p) + aused, 0, want * sizeof(float) - aused, idx->stream));
+                    } else {
+                        (void)hipGetLastError();
+                        if (idx->n) {
+                            const uint32_t t1c = (uint32_t)((idx->n + kTileRows - 1) / kTileRows);
+                            MX_HIP(launch_shadow8(idx->stream, fx, fsc, idx->ds, 0, (uint32_t)round_up(t1c, 2), idx->n, nh.p, static_cast<float *>(nts.p), idx->flags + 2));
+                        }
+                    }
+                }
             } else if (idx->kc <= kMaxKC && hipMalloc(&nam.p, want * sizeof(float)) == hipSuccess) {
                 // the a_c array of a (possibly centred) bf16 copy grows with it
                 const size_t aused = idx->amean && idx->xh ? (size_t)idx->n * sizeof(float) : 0;
@@ -654,9 +669,10 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
     // as a whole: its step depends on all of its rows)
     auto refilter = [&](uint64_t row_lo, uint64_t row_hi) -> hipError_t {
         const uint32_t h0 = (uint32_t)(row_lo / kTileRows), h1 = (uint32_t)((row_hi + kTileRows - 1) / kTileRows);
-        if (idx->filter_i8)  // both halves of the last 64-row scan tile: the one past row_hi becomes zeros with step 0
-            return launch_shadow8(idx->stream, idx->x, idx->scale, idx->ds, h0, (uint32_t)round_up(std::max(h1, h0 + 1), 2), row_hi, idx->xh, idx->tsc, idx->flags + 2);
         const bool ctr = idx->centred && idx->amean && idx->mean;
+        if (idx->filter_i8)  // both halves of the last 64-row scan tile: the one past row_hi becomes zeros with step 0
+            return launch_shadow8(idx->stream, idx->x, idx->scale, idx->ds, h0, (uint32_t)round_up(std::max(h1, h0 + 1), 2), row_hi, idx->xh, idx->tsc, idx->flags + 2,
+                                  ctr ? idx->mean : nullptr, ctr ? idx->amean : nullptr, ctr ? idx->flags + 5 : nullptr);
         return launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, h0, std::max(h1, h0 + 1), idx->xh, idx->flags + 2, 0, 0, ~0ull,
                              ctr ? idx->mean : nullptr, ctr ? idx->amean : nullptr);
     };
@@ -748,10 +764,10 @@ int run_exact(mx_index *idx, const std::vector<int> &qs, int k, uint64_t *d_ids,
 // builds the filter copy of kind (i8 ? int8 : bf16) from the f32 rows, complete before it replaces whatever copy is resident
 int build_filter_copy(mx_index *idx, bool i8) {
     DevBuf nh, nts, nec, nam;
-    const size_t hb = (size_t)idx->cap * idx->ds * (i8 ? 1 : 2), tb = (size_t)(idx->cap / kTile8Rows) * 4 * sizeof(float);
+    const size_t hb = (size_t)idx->cap * idx->ds * (i8 ? 1 : 2), tb = (size_t)(idx->cap / kTile8Rows) * kTscaleFloats * sizeof(float);
     hipError_t e = hipMalloc(&nh.p, hb);
     if (e == hipSuccess && i8) e = hipMalloc(&nts.p, tb);
-    if (e == hipSuccess) e = hipMalloc(&nec.p, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&nec.p, 2 * sizeof(uint32_t));  // [0] largest residual, [1] longest centred row (int8)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail(MX_ENOMEM, "hipMalloc(filter copy, %zu bytes): %s", hb, hipGetErrorString(e));
@@ -759,15 +775,15 @@ int build_filter_copy(mx_index *idx, bool i8) {
     uint32_t *ec = static_cast<uint32_t *>(nec.p);
     MX_HIP(hipMemsetAsync(nh.p, 0, hb, idx->stream));
     if (i8) MX_HIP(hipMemsetAsync(nts.p, 0, tb, idx->stream));
-    MX_HIP(hipMemsetAsync(ec, 0, sizeof(uint32_t), idx->stream));
+    MX_HIP(hipMemsetAsync(ec, 0, 2 * sizeof(uint32_t), idx->stream));
     const uint32_t t1 = (uint32_t)((idx->n + kTileRows - 1) / kTileRows);
-    // A bf16 copy rebuilt from a populated index is CENTRED on the rows' mean direction (launch_shadow): a corpus that an
-    // int8 certificate could not resolve is a dense one, and embedding corpora are dense because they sit in a cone -- what
-    // is left of a row after its component along the cone's axis is removed is several times shorter, and so is the
-    // rounding error the scan's certificate has to cover.
+    // A copy rebuilt from a populated index is CENTRED on the rows' mean direction (launch_shadow / launch_shadow8): a corpus
+    // that a plain int8 certificate could not resolve is a dense one, and embedding corpora are dense because they sit in a
+    // cone -- what is left of a row after its component along the cone's axis is removed is several times shorter, and so is
+    // the rounding (bf16) or quantisation (int8: round 6) error the scan's certificate has to cover.
     const bool centre_ok = true;
     bool centre = false;
-    if (!i8 && idx->kc <= kMaxKC && hipMalloc(&nam.p, (size_t)idx->cap * sizeof(float)) == hipSuccess) {
+    if (idx->kc <= kMaxKC && !idx->compressed && hipMalloc(&nam.p, (size_t)idx->cap * sizeof(float)) == hipSuccess) {
         MX_HIP(hipMemsetAsync(nam.p, 0, (size_t)idx->cap * sizeof(float), idx->stream));
         if (centre_ok && idx->n >= 256) {
             if (!idx->mean) MX_HIP(hipMalloc(reinterpret_cast<void **>(&idx->mean), (size_t)idx->ds * sizeof(float)));
@@ -780,15 +796,18 @@ int build_filter_copy(mx_index *idx, bool i8) {
             MX_HIP(hipStreamSynchronize(idx->stream));
             centre = std::isfinite(msq) && msq / (float)idx->n >= 0.3f;
         }
-    } else if (!i8) {
+    } else {
         (void)hipGetLastError();
     }
+    if (i8 && !centre && nam.p) (void)hipFree(nam.release());  // (a plain int8 copy has no use for the a_c array)
     if (i8)
-        MX_HIP(launch_shadow8(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)round_up(t1, 2), idx->n, nh.p, static_cast<float *>(nts.p), ec));
+        MX_HIP(launch_shadow8(idx->stream, idx->x, idx->scale, idx->ds, 0, (uint32_t)round_up(t1, 2), idx->n, nh.p, static_cast<float *>(nts.p), ec,
+                              centre ? idx->mean : nullptr, centre ? static_cast<float *>(nam.p) : nullptr, centre ? ec + 1 : nullptr));
     else
         MX_HIP(launch_shadow(idx->stream, idx->x, idx->scale, idx->ds, 0, t1, nh.p, ec, 0, 0, ~0ull, centre ? idx->mean : nullptr,
                              centre ? static_cast<float *>(nam.p) : nullptr));
     MX_HIP(hipMemcpyAsync(idx->flags + 2, ec, sizeof(uint32_t), hipMemcpyDeviceToDevice, idx->stream));
+    MX_HIP(hipMemcpyAsync(idx->flags + 5, ec + 1, sizeof(uint32_t), hipMemcpyDeviceToDevice, idx->stream));
     MX_HIP(hipStreamSynchronize(idx->stream));
     if (idx->xh) (void)hipFree(idx->xh);
     if (idx->tsc) (void)hipFree(idx->tsc);
@@ -833,7 +852,9 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                       idx->n_wild <= (uint64_t)kWildCap;
     // a batch of more than 256 queries is one pass of the int8 scan with two query groups per wave (up to 512 dims),
     // otherwise two passes
-    const bool x2 = fast && filt8 && idx->kc <= kMaxKC8x2 && B > kPassBatch;
+    // (a centred int8 copy runs passes of 256: the two-group variant has no register left for the per-row epilogue)
+    const bool centred8 = idx->centred && filt8 && idx->amean && idx->mean && idx->kc <= kMaxKC;
+    const bool x2 = fast && filt8 && !centred8 && idx->kc <= kMaxKC8x2 && B > kPassBatch;
     if (B > kPassBatch && !x2 && !(fast && wide)) {
         rc = search_batch(idx, d_q, kPassBatch, k, d_ids, d_scores, d_dists, d_nfound);
         if (rc != MX_OK) return rc;
@@ -849,12 +870,12 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                             d_dists ? d_dists + o : nullptr, d_nfound + kWideBatch);
     }
     // the bf16 copy of this index is centred on its rows' mean direction (build_filter_copy): queries are split the same way
-    const bool centred = idx->centred && idx->xh && !filt8 && !wide && !idx->compressed && idx->amean && idx->mean && idx->kc <= kMaxKC;
+    const bool centred = centred8 || (idx->centred && idx->xh && !filt8 && !wide && !idx->compressed && idx->amean && idx->mean && idx->kc <= kMaxKC);
     LaneLease lease;  // every return below is host-synchronised with the kernels that used the lane buffers
     if ((rc = lease.take(idx, x2 ? 2 : 1)) != MX_OK) return rc;
     MX_HIP(launch_prep_queries(st, d_q, B, idx->dim, idx->ds, s.qfrag, s.qpad, s.qnorm2, s.theta, s.e1,
                                idx->xh ? idx->flags + 2 : nullptr, s.overflow, s.qflags, s.qa, s.qb, filt8, s.qscale,
-                               centred ? idx->mean : nullptr, s.qmean));
+                               centred ? idx->mean : nullptr, s.qmean, centred8 ? idx->flags + 5 : nullptr));
     const uint32_t *h_ovf = s.host_flags, *h_qfl = s.host_flags + 3 * kMaxBatch;
     auto any_bad_query = [&] {
         uint32_t bad = 0;
@@ -1042,6 +1063,17 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
                 // More than 1/16 of the batch (and more than one query) did not fit the int8 pass: this corpus is too dense for the int8
                 // certificate (neighbourhoods narrower than ~0.05 in cosine).  Rebuild the copy as bf16 (one pass
                 // over the f32 rows) and answer the batch on it; the index stays on bf16.
+                // Round 6: first the same copy CENTRED on the rows' mean direction (section 3.2c carried over to int8: what an encoder
+                // produces sits in a cone, and the quantisation error of the short residual vectors is several times smaller); only
+                // a corpus without a cone, or one that overflows the centred copy as well, goes to bf16.
+                if (!idx->centred && idx->kc <= kMaxKC && idx->n >= 256) {
+                    const std::string keep = last_error_slot();
+                    if (build_filter_copy(idx, true) == MX_OK && idx->centred) {
+                        lease.drop();
+                        return search_batch(idx, d_q, B, k, d_ids, d_scores, d_dists, d_nfound);
+                    }
+                    last_error_slot() = keep;
+                }
                 const int drc = demote_filter(idx);
                 if (drc == MX_OK) {
                     idx->stats.filter_demotions += 1;
@@ -1505,7 +1537,7 @@ int clear_locked(mx_index *idx) {
         for (double &w : idx->wait_ema_us) w = 0.0;
         if (idx->flags) {
             DeviceGuard dg(idx->device);
-            (void)hipMemsetAsync(idx->flags + 2, 0, 3 * sizeof(uint32_t), idx->stream);  // ec_max, zero-row count, listed-row count
+            (void)hipMemsetAsync(idx->flags + 2, 0, 4 * sizeof(uint32_t), idx->stream);  // ec_max, zero-row count, listed-row count, rc_max
         }
     }
     idx->disk_dir.clear();
@@ -1583,8 +1615,8 @@ int open_plain(const std::string &k, int dim, int device, mx_index **out) {
     MX_HIP(hipEventCreate(&idx->ev0));
     MX_HIP(hipEventCreate(&idx->ev1));
     MX_HIP(hipEventCreateWithFlags(&idx->ev_wait, hipEventDisableTiming));
-    MX_HIP(hipMalloc(&idx->flags, 5 * sizeof(uint32_t)));
-    MX_HIP(hipMemset(idx->flags, 0, 5 * sizeof(uint32_t)));
+    MX_HIP(hipMalloc(&idx->flags, 6 * sizeof(uint32_t)));
+    MX_HIP(hipMemset(idx->flags, 0, 6 * sizeof(uint32_t)));
     MX_HIP(hipMalloc(&idx->zero_rows, kZeroCap * sizeof(uint32_t)));
     MX_HIP(hipMalloc(&idx->wild_list, kWildCap * sizeof(uint32_t)));
     if (device < kMaxDevices) {
@@ -2188,7 +2220,7 @@ int mx_index_get_stats(mx_index *idx, mx_index_stats *out) try {
     idx->stats.filter_kind = !idx->xh ? 0u : (idx->filter_i8 && !idx->compressed ? 2u : 3u);
     idx->stats.filter_copy_bytes = idx->xh ? (uint64_t)idx->cap * idx->ds * (idx->filter_i8 && !idx->compressed ? 1ull : 2ull) : 0;
     idx->stats.listed_rows = idx->n_zero + idx->n_wild;
-    idx->stats.filter_centred = idx->centred && idx->xh && !idx->filter_i8 ? 1u : 0u;
+    idx->stats.filter_centred = idx->centred && idx->xh ? 1u : 0u;
     *out = idx->stats;
     return MX_OK;
 } catch (...) {

@@ -91,7 +91,7 @@ struct ScanParams {
     float *lane_max;         // [512][nwg] sample mode: running maximum of each lane
     uint32_t *overflow;      // [256]
     // 8-bit filter copy (scan8_kernel): xh holds int8 fragments, tiles are 64 rows
-    const float *tscale = nullptr;  // [cap_rows / 64][4]: quantisation steps of a tile's two halves, then their residual bounds
+    const float *tscale = nullptr;  // [cap_rows / 64][kTscaleFloats]: quantisation steps of a tile's two halves, their residual bounds, max / min a_c
     const float *qscale = nullptr;  // [256] quantisation step of each query
     const float *qa = nullptr, *qb = nullptr;  // [256] a row's bound is qa + qb * residual (launch_prep_queries)
     // centred bf16 copy (scan16_kernel, launch_shadow): the copy holds r_c = c/|c| - a_c m for a fixed unit direction m (the
@@ -109,16 +109,23 @@ hipError_t launch_scan(hipStream_t s, int kc, bool collect, int nwg, const ScanP
 hipError_t launch_scan16(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
 // scan over the 8-bit filter copy: kc = ds / 128 in 1 .. 12, tile_begin / tile_end / tile_stride count 64-row tiles
 constexpr int kTile8Rows = 64;
+constexpr int kTscaleFloats = 8;  // per 64-row tile: steps of its two halves | residual bounds | largest a_c | smallest a_c (centred copy, else 0)
 constexpr int kScaleRing8 = 32;  // tiles whose scales can be in flight (15 slots ahead at one slot per tile, + the tile being multiplied)
-constexpr int kScan8LdsBytes = kRing16 * kSlot16Bytes + kScaleRing8 * 256;
+constexpr int kScale8Entry = 512;  // per tile: [0, 16) the steps and residual bounds of its halves | [256, 512) a_c of its 64 rows (centred copy)
+constexpr int kScan8LdsBytes = kRing16 * kSlot16Bytes + kScaleRing8 * kScale8Entry + 256;  // ... | 256 B that absorb the empty a_c operations
 hipError_t scan8_setup();
 hipError_t launch_scan8(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p, bool two_groups = false);
 // (re)build half tiles [half0, half1) (32 rows each) of the 8-bit filter copy from the padded f32 store: per half
 // tile one quantisation step = max |c_i/|c|| / 127 over its rows below row_hi (rows at or above row_hi, and zero-norm
 // rows, are stored as zeros) and one residual bound = 1.01 * max_rows |c/|c| - step * c8| + 1e-6; both go to
-// tscale[4 * (h / 2) + (h & 1)] and [.. + 2]: the 16 bytes of a 64-row scan tile; ec_max as launch_shadow
+// tscale[kTscaleFloats * (h / 2) + (h & 1)] and [.. + 2] (then the half tiles' largest / smallest a_c): the 32 bytes of a 64-row scan tile;
+// ec_max as launch_shadow.
+// Centred form (mean != nullptr, f32 corpora up to kMaxKC slots): the quantiser sees r_c = c/|c| - a_c mean, amean[row] = a_c
+// (f32; zero for the zero rows), steps and residual bounds are those of the shorter vectors, rc_max (device word, atomicMax'ed
+// float bits) = max |r_c|
 hipError_t launch_shadow8(hipStream_t s, const float *x, const float *scale, int ds, uint32_t half0, uint32_t half1,
-                          uint64_t row_hi, void *x8, float *tscale, uint32_t *ec_max);
+                          uint64_t row_hi, void *x8, float *tscale, uint32_t *ec_max, const float *mean = nullptr,
+                          float *amean = nullptr, uint32_t *rc_max = nullptr);
 hipError_t scan16w_setup();
 hipError_t launch_scan16w(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);  // kc in {8, 10, 12}, <= 128 queries
 
@@ -158,8 +165,10 @@ hipError_t launch_ingest(hipStream_t s, const float *src, uint64_t n, int d, flo
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag,
                                float *qpad, double *qnorm2, float *theta, float *e1, const uint32_t *ec_max,
                                uint32_t *overflow, uint32_t *flags, float *qa, float *qb, bool filt8 = false,
-                               float *qscale = nullptr, const float *mean = nullptr, float *qmean = nullptr);
-// mean / qmean: the centred bf16 copy (ScanParams::amean): fragments of q/|q| - a_q mean, qmean[q] = a_q
+                               float *qscale = nullptr, const float *mean = nullptr, float *qmean = nullptr,
+                               const uint32_t *rc_max = nullptr);
+// mean / qmean: the centred copy (ScanParams::amean; bf16 or int8): fragments of q/|q| - a_q mean, qmean[q] = a_q;
+// rc_max (int8 copy): device word with max |r_c| over the rows as float bits (launch_shadow8)
 // qa / qb [256]: the bound of one row's filter score is qa + qb * (residual of the row's half tile); scans that know
 // one residual for all rows get qa = e1, qb = 0
 // filt8: fragments for the 8-bit filter copy (scan8.hip: int8 [8 waves][ds/32][64 lanes][16]) and qscale[256] = the
@@ -185,7 +194,7 @@ struct FinishParams {
     const double *qnorm2;       // [256]
     const float *e1;            // [256]
     const float *qa, *qb;       // [256] bound of a row's filter score: qa + qb * residual(row)
-    const float *terr;          // the 8-bit copy's tscale array (residual of row r: [4 * (r / 64) + 2 + (r / 32 & 1)]); null: 0
+    const float *terr;          // the 8-bit copy's tscale array (residual of row r: [kTscaleFloats * (r / 64) + 2 + (r / 32 & 1)]); null: 0
     float e2;                   // bound on |f32 rescoring - cosine|
     const float *lane_rec;      // records of the collect launch (ScanParams)
     const uint32_t *lane_tile;

@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
                                                            uint32_t *__restrict__ overflow, uint32_t *__restrict__ flags,
                                                            int filt8, float *__restrict__ qscale,
                                                            float *__restrict__ qa, float *__restrict__ qb,
-                                                           const float *__restrict__ mean, float *__restrict__ qmean) {
+                                                           const float *__restrict__ mean, float *__restrict__ qmean,
+                                                           const uint32_t *__restrict__ rc_max) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
     float *s_row = reinterpret_cast<float *>(psm);  // [d] this query (coalesced load; the chain reads LDS)
     __shared__ float s_inv;
@@ -247,7 +248,29 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
         // 8-bit filter copy (scan8.hip): the normalised query goes through the same rotation as the rows
         // (mx_rotate.h), then q8 = rint(rotated / s_q), s_q = max |rotated_i| / 127
         float *rin = s_row + d, *rot = rin + ds, *mixq = rot + ds;  // behind the query: [ds] | [ds] | [144]
-        for (int dim = tid; dim < ds; dim += 256) rin[dim] = dim < d ? s_row[dim] * inv : 0.0f;
+        // centred copy: a_q = (q/|q|) . mean in f64, the quantiser sees r_q = q/|q| - a_q mean (as the rows' builder, shadow8_kernel)
+        float aq8 = 0.0f, rq2 = 0.0f;
+        if (mean) {
+            double dp = 0.0;
+            for (int dim = tid; dim < d; dim += 256) dp += (double)(s_row[dim] * inv) * (double)mean[dim];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dp += __shfl_xor(dp, o);
+            if ((tid & 63) == 0) s_dot[tid >> 6] = dp;
+            __syncthreads();
+            aq8 = (float)(s_dot[0] + s_dot[1] + s_dot[2] + s_dot[3]);
+            if (tid == 0) qmean[b] = aq8;
+        }
+        for (int dim = tid; dim < ds; dim += 256) {
+            float vn = dim < d ? s_row[dim] * inv : 0.0f;
+            if (mean && dim < d) vn = __builtin_fmaf(-aq8, mean[dim], vn);
+            rin[dim] = vn;
+            rq2 += vn * vn;
+        }
+        if (mean) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rq2 += __shfl_xor(rq2, o);
+            if ((tid & 63) == 0) s_rq[tid >> 6] = rq2;
+        }
         rot_fill_mix(mixq, ds >> 7, tid, 256);
         __syncthreads();
         if (tid < 64) rot_wave(rin, rot, ds >> 7, tid, mixq);
@@ -340,23 +363,34 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
                 e = fminf(e, rq * ec + eq * 1.0001f + ec * eq + kAccSlack);
             }
         }
-        e1[b] = e;
         // the bound of ONE row is a + b * (its residual): with a residual per half tile (8-bit copy, scan8.hip) the
         // rows of a well-conditioned half tile get a tighter bound than e1, which is the bound of the worst one;
         // the other scans know one residual for all rows: a = e1, b = 0
-        qa[b] = filt8 ? eq + kAccSlack : e;
-        qb[b] = filt8 ? 1.0f + eq : 0.0f;
+        float a8 = eq + kAccSlack, b8 = 1.0f + eq;
+        if (mean && filt8) {
+            // centred int8 copy: cos = a_q a_c + r_q . r_c exactly; |r^_q . r^_c - r_q . r_c| <= |r_q| e_h + (|r_c| + e_h) Eq
+            //   = Eq |r_c| + (|r_q| + Eq) e_h,  |r_c| <= rc_max (measured by the builder; 1 + 1e-6 without it)
+            const float rq = sqrtf(s_rq[0] + s_rq[1] + s_rq[2] + s_rq[3]) * 1.001f + 1e-6f;
+            const float rc = rc_max ? fminf(__uint_as_float(*rc_max) * 1.001f + 1e-6f, 1.0f + 1e-6f) : 1.0f + 1e-6f;
+            a8 = eq * rc * 1.0001f + kAccSlack;
+            b8 = rq + eq;
+            if (ec_max) e = a8 + b8 * (__uint_as_float(*ec_max) * 1.01f + 1e-6f);  // the bound of a row of the worst half tile
+        }
+        e1[b] = e;
+        qa[b] = filt8 ? a8 : e;
+        qb[b] = filt8 ? b8 : 0.0f;
     }
 }
 
 hipError_t launch_prep_queries(hipStream_t s, const float *q, int B, int d, int ds, void *qfrag, float *qpad,
                                double *qnorm2, float *theta, float *e1, const uint32_t *ec_max, uint32_t *overflow,
-                               uint32_t *flags, float *qa, float *qb, bool filt8, float *qscale, const float *mean, float *qmean) {
-    if (filt8 || !qmean) mean = nullptr;
+                               uint32_t *flags, float *qa, float *qb, bool filt8, float *qscale, const float *mean, float *qmean,
+                               const uint32_t *rc_max) {
+    if (!qmean) mean = nullptr;
     // one block per query slot: 256 slots (a pass computes all of them), 512 for a batch of more than 256
     hipLaunchKernelGGL(prep_queries_kernel, dim3(B > kPassBatch ? kMaxBatch : kPassBatch), dim3(256),
                        sizeof(float) * ((size_t)d + (filt8 ? 2 * (size_t)ds + kRotMaxBlocks * kRotMaxBlocks : 0)), s, q, B, d, ds,
-                       (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags, filt8 ? 1 : 0, qscale, qa, qb, mean, qmean);
+                       (__bf16 *)qfrag, qpad, qnorm2, theta, e1, ec_max, overflow, flags, filt8 ? 1 : 0, qscale, qa, qb, mean, qmean, rc_max);
     return hipGetLastError();
 }
 
@@ -598,7 +632,7 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     const uint32_t lane_ovf = p.overflow[q];
     // bound of a row's filter score: qa + qb * (residual of its half tile); one residual for all rows: qb = 0, qa = e1
     const float qa = p.qa[q], qb = p.qb[q];
-    auto resid = [&](uint32_t row) { return p.terr ? p.terr[4 * (size_t)(row >> 6) + 2 + ((row >> 5) & 1u)] : 0.0f; };
+    auto resid = [&](uint32_t row) { return p.terr ? p.terr[kTscaleFloats * (size_t)(row >> 6) + 2 + ((row >> 5) & 1u)] : 0.0f; };
     for (int i = tid; i < ds; i += kFinThreads) qv[i] = p.qpad[(size_t)q * ds + i];
 
     // ---- gather.  Scan workgroup w kept this query's records in lanes L0 and L0+32 of wave q/32

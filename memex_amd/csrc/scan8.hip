@@ -68,17 +68,18 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 // DMA operations a wave has issued after the one of slot j+1 when it waits for that slot at position kc of a
-// tile: the 13 slots j+2 .. j+14, plus one scale operation per tile that starts among them
+// tile: the 13 slots j+2 .. j+14, plus the TWO per-tile operations (scales; a_c of the centred copy, issued with
+// num_records = 0 for a plain one: the kernel has one wait schedule) of every tile that starts among them
 template <int KC>
 constexpr int ops_after(int lo, int hi) {  // slots lo .. hi relative to the tile start
     int n = 0;
-    for (int i = lo; i <= hi; ++i) n += 1 + (i % KC == 0 ? 1 : 0);
+    for (int i = lo; i <= hi; ++i) n += 1 + (i % KC == 0 ? 2 : 0);
     return n;
 }
-// 384 dims (3 slots per tile): after slot j+1 come 13 slots and the scale operations of the tiles that start at
-// relative slots 3, 6, 9, 12 (position 0 and 2) or 3 .. 15 (position 1); before the loop, after slot 0: 14 + 4.
-static_assert(ops_after<3>(2, 14) == 17 && ops_after<3>(3, 15) == 18 && ops_after<3>(4, 16) == 17 && ops_after<3>(1, 14) == 18, "");
-static_assert(ops_after<1>(2, 14) == 26 && ops_after<12>(2, 14) == 14 && ops_after<12>(13, 25) == 14 && ops_after<6>(5, 17) == 15, "");
+// 384 dims (3 slots per tile): after slot j+1 come 13 slots and the per-tile operations of the tiles that start at
+// relative slots 3, 6, 9, 12 (position 0 and 2) or 3 .. 15 (position 1); before the loop, after slot 0: 14 + 2 x 4.
+static_assert(ops_after<3>(2, 14) == 21 && ops_after<3>(3, 15) == 23 && ops_after<3>(4, 16) == 21 && ops_after<3>(1, 14) == 22, "");
+static_assert(ops_after<1>(2, 14) == 39 && ops_after<12>(2, 14) == 15 && ops_after<12>(13, 25) == 15 && ops_after<6>(5, 17) == 17, "");
 }  // namespace
 
 // QG = query groups (of 32) per wave: 1 = a pass of 256 queries (the kernel every batch size up to 256 runs);
@@ -87,7 +88,12 @@ static_assert(ops_after<1>(2, 14) == 26 && ops_after<12>(2, 14) == 14 && ops_aft
 template <int KC, int MODE, int QG>
 __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams p) {
     constexpr int R = QG == 2 ? (KC <= 3 ? 8 : 4) : KC <= 8 ? 8 : KC <= 10 ? 4 : 2;  // fragment ring: what the 256 VGPRs leave next to qf
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // slot ring | scale ring [kScaleRing8] x 256 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // slot ring | per-tile ring [kScaleRing8] x kScale8Entry B
+    // Centred copy (ScanParams::amean, section 3.2c of DESIGN.md carried over to int8; up to kMaxKC slots, one query group): the
+    // copy holds the quantised r_c = c/|c| - a_c m, amean[row] = a_c, the query fragments the quantised r_q, qmean[q] = a_q;
+    // a row's score is a_q a_c + s_h s_q sum, evaluated per row in the tile epilogue
+    constexpr bool CEN_OK = KC <= kMaxKC && QG == 1;
+    const bool centred = CEN_OK && p.amean != nullptr;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -103,6 +109,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
     // MODE 1: a half tile with residual bound e passes when a score reaches theta - qb * e (theta_kernel);
     // MODE 0: the lane keeps the best LOWER bound of a cosine, score - (qa + qb * e)
     float theta[QG], qa[QG], qb[QG], sq[QG];
+    float aq = 0.0f;
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int vw = wave * QG + g;  // wave index in the lane numbering of theta_kernel / finish_kernel
@@ -110,6 +117,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
 #pragma unroll
         for (int i = 0; i < KC * 4; ++i) qf[g * KC * 4 + i] = src[(size_t)i * 64];
         theta[g] = MODE == 1 ? p.theta[vw * 32 + m] : 0.0f;
+        if (CEN_OK && g == 0) aq = centred ? p.qmean[vw * 32 + m] : 0.0f;
         qa[g] = MODE == 0 ? p.qa[vw * 32 + m] : 0.0f;
         qb[g] = p.qb[vw * 32 + m];
         sq[g] = p.qscale[vw * 32 + m];  // 0 for an unusable (zero / padded) query
@@ -135,9 +143,17 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
     auto open_tile = [&]() {
         const uint32_t tile = t0 + is_ti * tstep;
         const bool live_tile = is_ti < nT;
-        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.tscale + 4 * (size_t)tile), 0, live_tile ? 16u : 0u, 0x00020000);
-        char *sdst = smem + __builtin_amdgcn_readfirstlane(kRing16 * kSlot16Bytes + (is_ti & (kScaleRing8 - 1)) * 256);
+        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.tscale + kTscaleFloats * (size_t)tile), 0, live_tile ? (uint32_t)(kTscaleFloats * 4) : 0u, 0x00020000);
+        char *sdst = smem + __builtin_amdgcn_readfirstlane(kRing16 * kSlot16Bytes + (is_ti & (kScaleRing8 - 1)) * kScale8Entry);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void *)sdst, 4, lane4, 0, 0, 0);
+        // a_c of the tile's 64 rows: 256 bytes behind the scales, fetched by ONE wave of the eight.  The others, and every wave of a
+        // plain copy, issue the same operation on an empty descriptor (one wait schedule, no memory read) -- into a dump area of
+        // their own: an out-of-range LDS-DMA lane still WRITES (zeros), and must not land on the values another wave fetched
+        const float *abase = centred ? p.amean + (size_t)kTile8Rows * tile : p.tscale;
+        const bool mine = live_tile && centred && (int)(is_ti & 7u) == wave;
+        __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)abase, 0, mine ? (uint32_t)(kTile8Rows * 4) : 0u, 0x00020000);
+        char *adst = mine ? sdst + 256 : smem + kRing16 * kSlot16Bytes + kScaleRing8 * kScale8Entry;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_void *)adst, 4, lane4, 0, 0, 0);
         const char *base = reinterpret_cast<const char *>(p.xh) + (size_t)tile * tilebytes;
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live_tile ? tilebytes : 0u, 0x00020000);
         ++is_ti;
@@ -202,12 +218,16 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
         // (read with inline asm: hipcc puts s_waitcnt vmcnt(0) in front of a plain LDS load that it thinks an LDS-DMA
         // may have written, which would drain the ring once per tile; the scales landed with the tile's first slot)
         f32x4 shs;  // steps of the two halves, residual bounds of the two halves
+        f32x4 amm = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // centred copy: largest a_c of the two halves, smallest a_c of the two halves
 #if MX_SCAN8_ABLATE == 1  /* scripts/scan8_ubench.hip: no scale read */
         shs = f32x4{1.0f, 1.0f, 0.0f, 0.0f};
 #else
         {
-            const uint32_t sa = kRing16 * kSlot16Bytes + (ti & (kScaleRing8 - 1)) * 256;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(shs) : "v"(sa) : "memory");
+            const uint32_t sa = kRing16 * kSlot16Bytes + (ti & (kScaleRing8 - 1)) * kScale8Entry;
+            if (CEN_OK && centred)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(shs), "=&v"(amm) : "v"(sa) : "memory");
+            else
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(shs) : "v"(sa) : "memory");
         }
 #endif
 #pragma unroll
@@ -216,6 +236,57 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
             for (int u = 0; u < 2; ++u) {
                 const i32x16 &ac = acc[g * 2 + u];
                 const float sh = u ? shs[1] : shs[0], er = u ? shs[3] : shs[2];
+                if constexpr (CEN_OK) {
+                    if (centred) {
+                        const float ss = sh * sq[g];
+                        const float thr = fmaf(-qb[g], er, theta[g]);
+                        if (MODE == 1) {
+                            // collect pass: an upper bound of the lane's 16 scores first -- the largest sum with the half tile's
+                            // largest a_q a_c (+ 1e-6: the per-row evaluation below rounds differently); in a cone the a_c of a half
+                            // tile differ by ~0.01, so nine half tiles in ten stop here and cost what a plain copy's do
+                            int mxq = max(max(ac[0], ac[1]), ac[2]);
+#pragma unroll
+                            for (int r = 3; r < 15; r += 2) mxq = max(max(mxq, ac[r]), ac[r + 1]);
+                            mxq = max(mxq, ac[15]);
+                            const float ub = fmaf((float)mxq, ss, fmaxf(aq * (u ? amm[1] : amm[0]), aq * (u ? amm[3] : amm[2]))) + 1e-6f;
+                            if (__builtin_amdgcn_ballot_w64(ub >= thr) == 0) continue;
+                        }
+                        // score of row r = a_q a_c[r] + sum_r (s_h s_q); this lane's rows: (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of half u
+                        f32x4 a4[4];
+                        const uint32_t aa = kRing16 * kSlot16Bytes + (ti & (kScaleRing8 - 1)) * kScale8Entry + 256 + u * 128 + (lane >> 5) * 16;
+                        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96\n\t"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "=&v"(a4[0]), "=&v"(a4[1]), "=&v"(a4[2]), "=&v"(a4[3])
+                                     : "v"(aa)
+                                     : "memory");
+                        float v[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(aq, a4[r >> 2][r & 3], (float)ac[r] * ss);
+                        float mxc = fmaxf(fmaxf(v[0], v[1]), v[2]);
+#pragma unroll
+                        for (int r = 3; r < 15; r += 2) mxc = fmaxf(fmaxf(mxc, v[r]), v[r + 1]);
+                        mxc = fmaxf(mxc, v[15]);
+                        // (an unusable query -- s_q = 0: zero or padded -- has theta = +inf in the collect pass; in the sample pass its
+                        // maxima are never read)
+                        if (MODE == 0) {
+                            best[g] = fmaxf(best[g], mxc - fmaf(qb[g], er, qa[g]));
+                        } else if (__builtin_amdgcn_ballot_w64(mxc >= thr) != 0) {
+                            if (mxc >= thr) {
+                                if ((cnt[g] & 0x7fffffffu) < (uint32_t)kRecCap) {
+                                    const size_t at = (size_t)mylane(g) * kRecCap + (cnt[g] & 0x7fffffffu);
+                                    f32x4 *dst = reinterpret_cast<f32x4 *>(p.lane_rec + at * 16);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) dst[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                                    p.lane_tile[at] = 2 * tile + u;
+                                    ++cnt[g];
+                                } else {
+                                    cnt[g] |= 0x80000000u;
+                                }
+                            }
+                        }
+                        continue;
+                    }
+                }
                 int mxi = max(max(ac[0], ac[1]), ac[2]);
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) mxi = max(max(mxi, ac[r]), ac[r + 1]);
@@ -266,10 +337,14 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
 // needs the largest rotated element of all 32 rows, so the rows are rotated twice: once for the maximum, once to
 // quantise (the arithmetic is nothing next to the row reads).  The int8 rows are staged in LDS row-major and copied
 // out in fragment order by the whole workgroup.
+// Centred form (mean != nullptr): with a_c = (c/|c|) . mean (f64 sum, stored as f32 in amean[row]) the quantiser sees
+// r_c = c/|c| - a_c mean, several times shorter than the unit row for a corpus that sits in a cone -- and so are its step and
+// its residual; rc_max tracks max |r_c| (the factor of the QUERY's residual in the row bound, prep_queries_kernel).
 __global__ __launch_bounds__(256) void shadow8_kernel(const float *__restrict__ x, const float *__restrict__ scale, int ds,
                                                       uint32_t half0, uint32_t half1, uint64_t row_hi,
                                                       i32x4 *__restrict__ x8, float *__restrict__ tscale,
-                                                      uint32_t *__restrict__ ec_max) {
+                                                      uint32_t *__restrict__ ec_max, const float *__restrict__ mean,
+                                                      float *__restrict__ amean, uint32_t *__restrict__ rc_max) {
     extern __shared__ __attribute__((aligned(16))) char s8[];
     // [4 waves][2][ds] f32 rotation buffers | [32][ds] int8 staged rows | mix [144] | per-row residuals, reductions
     float *rbuf = reinterpret_cast<float *>(s8);
@@ -277,21 +352,42 @@ __global__ __launch_bounds__(256) void shadow8_kernel(const float *__restrict__ 
     float *mix = reinterpret_cast<float *>(s8 + (size_t)8 * ds * sizeof(float) + (size_t)kTileRows * ds);
     float *s_r2 = mix + kRotMaxBlocks * kRotMaxBlocks;  // [32]
     float *s_red = s_r2 + kTileRows;                    // [4]
+    float *s_ac = s_red + 4;                            // [32] a_c of the half tile's rows (centred form)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kc = ds >> 7;
     const uint32_t frags = (uint32_t)(ds >> 5) * 64u;  // 16-byte fragments per half tile
     float *in = rbuf + (size_t)wave * 2 * ds, *out = in + ds;
     rot_fill_mix(mix, kc, tid, 256);
     __syncthreads();
-    float worst = 0.0f;
+    float worst = 0.0f, longest = 0.0f;
     for (uint32_t h = half0 + blockIdx.x; h < half1; h += gridDim.x) {
         const float *xt = x + (size_t)h * kTileRows * ds;
-        // a row of the half tile, normalised and rotated, in `out` (zeros for a zero-norm row and for rows >= row_hi)
+        // a row of the half tile, normalised (centred) and rotated, in `out` (zeros for a zero-norm row and for rows >= row_hi)
         auto rotated_row = [&](int r) -> bool {
             const uint64_t grow = (uint64_t)h * kTileRows + (uint64_t)r;
             const float sc = grow < row_hi ? scale[grow] : 0.0f;
-            if (sc == 0.0f) return false;
+            if (sc == 0.0f) {
+                if (mean && lane == 0) amean[grow] = 0.0f, s_ac[r] = 0.0f;
+                return false;
+            }
             for (int i = lane; i < ds; i += 64) in[i] = xt[(size_t)r * ds + i] * sc;
+            if (mean) {
+                double dp = 0.0;
+                for (int i = lane; i < ds; i += 64) dp += (double)in[i] * (double)mean[i];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) dp += __shfl_xor(dp, o);
+                const float ac = (float)dp;  // the f32 value the scan will use: r_c is what is left after THIS a_c
+                float l2 = 0.0f;
+                for (int i = lane; i < ds; i += 64) {
+                    const float v = __builtin_fmaf(-ac, mean[i], in[i]);
+                    in[i] = v;
+                    l2 += v * v;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) l2 += __shfl_xor(l2, o);
+                longest = fmaxf(longest, sqrtf(l2));
+                if (lane == 0) amean[grow] = ac, s_ac[r] = ac;
+            }
             rot_wave(in, out, kc, lane, mix);
             return true;
         };
@@ -336,9 +432,15 @@ __global__ __launch_bounds__(256) void shadow8_kernel(const float *__restrict__ 
         float hw = tid < kTileRows ? sqrtf(s_r2[tid]) : 0.0f;  // worst residual of THIS half tile (waves 1-3 hold zeros)
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) hw = fmaxf(hw, __shfl_xor(hw, o));
+        // centred form: the largest and smallest a_c of the half tile (the scan's quick upper bound of a lane's 16 scores)
+        float amx = mean && tid < kTileRows ? s_ac[tid] : 0.0f, amn = amx;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o)), amn = fminf(amn, __shfl_xor(amn, o));
         if (tid == 0) {
-            tscale[4 * (size_t)T + u] = sh;
-            tscale[4 * (size_t)T + 2 + u] = hw * 1.01f + 1e-6f;
+            tscale[kTscaleFloats * (size_t)T + u] = sh;
+            tscale[kTscaleFloats * (size_t)T + 2 + u] = hw * 1.01f + 1e-6f;
+            tscale[kTscaleFloats * (size_t)T + 4 + u] = amx;
+            tscale[kTscaleFloats * (size_t)T + 6 + u] = amn;
         }
         if (tid < kTileRows) worst = fmaxf(worst, hw);
         __syncthreads();
@@ -348,18 +450,21 @@ __global__ __launch_bounds__(256) void shadow8_kernel(const float *__restrict__ 
         for (int o = 16; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
         if (tid == 0 && worst > 0.0f) atomicMax(ec_max, __float_as_uint(worst));
     }
+    if (mean && rc_max && lane == 0 && longest > 0.0f) atomicMax(rc_max, __float_as_uint(longest));  // (every lane of a wave holds its wave's maximum)
 }
 
 static size_t shadow8_lds(int ds) {
-    return (size_t)8 * ds * sizeof(float) + (size_t)kTileRows * ds + (kRotMaxBlocks * kRotMaxBlocks + kTileRows + 4) * sizeof(float);
+    return (size_t)8 * ds * sizeof(float) + (size_t)kTileRows * ds + (kRotMaxBlocks * kRotMaxBlocks + 2 * kTileRows + 4) * sizeof(float);
 }
 
 hipError_t launch_shadow8(hipStream_t s, const float *x, const float *scale, int ds, uint32_t half0, uint32_t half1,
-                          uint64_t row_hi, void *x8, float *tscale, uint32_t *ec_max) {
+                          uint64_t row_hi, void *x8, float *tscale, uint32_t *ec_max, const float *mean, float *amean,
+                          uint32_t *rc_max) {
     if (half1 <= half0) return hipSuccess;
+    if (mean && (!amean || !rc_max)) return hipErrorInvalidValue;
     const uint32_t blocks = half1 - half0 < 16384u ? half1 - half0 : 16384u;
     hipLaunchKernelGGL(shadow8_kernel, dim3(blocks), dim3(256), shadow8_lds(ds), s, x, scale, ds, half0, half1, row_hi,
-                       reinterpret_cast<i32x4 *>(x8), tscale, ec_max);
+                       reinterpret_cast<i32x4 *>(x8), tscale, ec_max, mean, amean, rc_max);
     return hipGetLastError();
 }
 

@@ -735,29 +735,49 @@ def test_int8_filter_copy_appends_rejects_and_certificate(oracle, lib_built):
 
 
 def test_int8_copy_is_demoted_on_a_dense_corpus(oracle, lib_built):
-    """Automatic filter choice: a 384-d index starts on the int8 copy; when the rows sit in a cone narrower than the
-    int8 certificate (~0.05 in cosine -- here 60k rows whose cosines to a query spread by 0.012: the int8 band holds 46k of them per query, the bf16 band 250) a batch overflows it, the copy is
-    rebuilt as bf16 once, the batch is answered on it (no EXACT fallback), and the index stays on bf16.  A pinned
-    int8 copy is left alone and still answers exactly (through the retry / EXACT path)."""
+    """Automatic filter choice: a 384-d index starts on the (plain) int8 copy.  Rows in a cone narrower than its certificate
+    (~0.05 in cosine) overflow it on the first batch; round 6: the copy is then rebuilt CENTRED on the rows' mean direction,
+    still int8 (test_centred_gpu.py), and only a corpus that overflows that one as well is demoted to bf16 -- here 60k rows
+    within 0.01 / sqrt(d) per dimension of one direction: the residual vectors are 0.01 long, their mutual cosines spread by
+    ~5e-6, less than ANY of the certificates (a cone of 0.1 / sqrt(d) is still resolved by the centred int8 copy).  The batch is answered whichever copy it ends on (ids / dists equal the oracle's),
+    a pinned copy is left alone, and a demotion is not for life."""
     from memex_amd.index import FlatIndex
     rng = np.random.default_rng(43)
     n, d = 60_000, 384
     centre = rng.standard_normal(d).astype(np.float32)
+    # (a) the cone of round 3's test (cosines to a query spread by 0.012: 46k rows inside the plain int8 band): centred int8 resolves it
     X = (centre[None, :] + 0.45 * rng.standard_normal((n, d))).astype(np.float32) * rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
     Q = (centre[None, :] + 0.45 * rng.standard_normal((64, d))).astype(np.float32)
     oi, od, os_, _ = oracle.search(X, Q, 10)
     with FlatIndex(d) as idx:
         idx.add(X)
-        assert idx.stats().filter_kind == 2                       # int8 by default at 384 dims
+        assert idx.stats().filter_kind == 2 and idx.stats().filter_centred == 0      # int8 by default at 384 dims, built plain
         ids, sc, di, _ = idx.search(Q, 10)
         np.testing.assert_array_equal(ids, oi)
         np.testing.assert_array_equal(bits(di), bits(od))
         st = idx.stats()
-        assert st.filter_kind == 3 and st.filter_demotions == 1 and st.fallback_queries == 0
-        ids, sc, _, _ = idx.search(Q, 10)                          # stays there
+        assert st.filter_kind == 2 and st.filter_centred == 1 and st.filter_demotions == 0 and st.fallback_queries == 0
+        idx.reset_stats()
+        ids, sc, _, _ = idx.search(Q, 10)                          # stays there, first pass only
+        np.testing.assert_array_equal(ids, oi)
+        np.testing.assert_array_equal(bits(sc), bits(os_))
+        st = idx.stats()
+        assert st.filter_kind == 2 and st.retry_queries == 0 and st.fallback_queries == 0
+    # (b) a cone that no certificate resolves: centred int8 is tried, then the copy is demoted to (centred) bf16, once
+    X = (centre[None, :] * np.float32(1.0 / np.linalg.norm(centre)) + (0.01 / np.sqrt(d)) * rng.standard_normal((n, d))).astype(np.float32)
+    Q = (centre[None, :] * np.float32(1.0 / np.linalg.norm(centre)) + (0.01 / np.sqrt(d)) * rng.standard_normal((64, d))).astype(np.float32)
+    oi, od, os_, _ = oracle.search(X, Q, 10)
+    with FlatIndex(d) as idx:
+        idx.add(X)
+        ids, sc, di, _ = idx.search(Q, 10)
+        np.testing.assert_array_equal(ids, oi)
+        np.testing.assert_array_equal(bits(di), bits(od))
+        st = idx.stats()
+        assert st.filter_kind == 3 and st.filter_demotions == 1, (st.filter_kind, st.filter_demotions, st.filter_centred)
+        ids, _, _, _ = idx.search(Q, 10)                           # stays there
         np.testing.assert_array_equal(ids, oi)
         assert idx.stats().filter_demotions == 1
-        idx.set_filter_copy("i8")                                  # pinned: no demotion, same answers
+        idx.set_filter_copy("i8")                                  # pinned: no demotion, same answers (retry / EXACT path)
         ids, sc, _, _ = idx.search(Q, 10)
         np.testing.assert_array_equal(ids, oi)
         np.testing.assert_array_equal(bits(sc), bits(os_))
