@@ -52,7 +52,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 static_assert(kRing16 == 16, "waits below assume a 16-slot ring with 15 slots in flight");
 
-// Ablation switch for scripts/scan8_ubench.hip only (0 = production kernel): 1 = tile scales are constants (no LDS read)
+// Ablation switch for scripts/scan8_ubench.hip only (0 = production kernel): 1 = tile scales are constants (no LDS read),
+// 2 = every second fragment read dropped
 #ifndef MX_SCAN8_ABLATE
 #define MX_SCAN8_ABLATE 0
 #endif
@@ -203,6 +204,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
 #pragma unroll
                     for (int g = 0; g < QG; ++g)
                         acc[g * 2 + (f & 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[g * KC * 4 + kc * 4 + (f >> 1)], acc[g * 2 + (f & 1)], 0, 0, 0);
+#if MX_SCAN8_ABLATE == 2  /* scripts/scan8_ubench.hip: what would HALF the fragment reads buy (every read feeding two MFMAs; results meaningless) */
+                    if ((f & 1) == 0)
+#endif
                     a[f % R] = *reinterpret_cast<const i32x4 *>(smem + (f + R < 8 ? fb0 : fb1) + ((f + R) & 7) * 1024);
                     if (f == 1) issue((kc + kRing16 - 1) % KC, rpi);
                     __builtin_amdgcn_sched_barrier(0);
@@ -219,14 +223,25 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
         // may have written, which would drain the ring once per tile; the scales landed with the tile's first slot)
         f32x4 shs;  // steps of the two halves, residual bounds of the two halves
         f32x4 amm = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // centred copy: largest a_c of the two halves, smallest a_c of the two halves
+        f32x4 acv[CEN_OK ? 8 : 1];                  // centred copy: a_c of this lane's rows, [half * 4 + (r >> 2)][r & 3]
 #if MX_SCAN8_ABLATE == 1  /* scripts/scan8_ubench.hip: no scale read */
         shs = f32x4{1.0f, 1.0f, 0.0f, 0.0f};
 #else
         {
             const uint32_t sa = kRing16 * kSlot16Bytes + (ti & (kScaleRing8 - 1)) * kScale8Entry;
-            if (CEN_OK && centred)
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(shs), "=&v"(amm) : "v"(sa) : "memory");
-            else
+            if (CEN_OK && centred) {
+                // ... and with them the a_c of this lane's 2 x 16 rows -- rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each half -- in ONE
+                // batch of LDS reads behind ONE wait (three separate read-and-wait steps per tile cost 20 % of the launch)
+                const uint32_t aa = sa + 256 + (lane >> 5) * 16;
+                asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:16\n\t"
+                             "ds_read_b128 %2, %11\n\tds_read_b128 %3, %11 offset:32\n\tds_read_b128 %4, %11 offset:64\n\tds_read_b128 %5, %11 offset:96\n\t"
+                             "ds_read_b128 %6, %11 offset:128\n\tds_read_b128 %7, %11 offset:160\n\tds_read_b128 %8, %11 offset:192\n\tds_read_b128 %9, %11 offset:224\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(shs), "=&v"(amm), "=&v"(acv[0]), "=&v"(acv[1]), "=&v"(acv[2]), "=&v"(acv[3]), "=&v"(acv[4]), "=&v"(acv[5]),
+                               "=&v"(acv[6]), "=&v"(acv[7])
+                             : "v"(sa), "v"(aa)
+                             : "memory");
+            } else
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(shs) : "v"(sa) : "memory");
         }
 #endif
@@ -251,17 +266,10 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
                             const float ub = fmaf((float)mxq, ss, fmaxf(aq * (u ? amm[1] : amm[0]), aq * (u ? amm[3] : amm[2]))) + 1e-6f;
                             if (__builtin_amdgcn_ballot_w64(ub >= thr) == 0) continue;
                         }
-                        // score of row r = a_q a_c[r] + sum_r (s_h s_q); this lane's rows: (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of half u
-                        f32x4 a4[4];
-                        const uint32_t aa = kRing16 * kSlot16Bytes + (ti & (kScaleRing8 - 1)) * kScale8Entry + 256 + u * 128 + (lane >> 5) * 16;
-                        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96\n\t"
-                                     "s_waitcnt lgkmcnt(0)"
-                                     : "=&v"(a4[0]), "=&v"(a4[1]), "=&v"(a4[2]), "=&v"(a4[3])
-                                     : "v"(aa)
-                                     : "memory");
+                        // score of row r = a_q a_c[r] + sum_r (s_h s_q)
                         float v[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(aq, a4[r >> 2][r & 3], (float)ac[r] * ss);
+                        for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(aq, acv[u * 4 + (r >> 2)][r & 3], (float)ac[r] * ss);
                         float mxc = fmaxf(fmaxf(v[0], v[1]), v[2]);
 #pragma unroll
                         for (int r = 3; r < 15; r += 2) mxc = fmaxf(fmaxf(mxc, v[r]), v[r + 1]);

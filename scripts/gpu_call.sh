@@ -1,14 +1,12 @@
 #!/bin/bash
-# r6i: centred int8 copy -- the search tests, then the enc_like / cfg2 legs
-cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_centred_gpu.py tests/test_search_gpu.py tests/test_random_ops_gpu.py tests/test_cfg2_gpu.py -m gpu -x -q 2>&1 | tail -30 > gpurun_out/r6i_tests.txt
-cat gpurun_out/r6i_tests.txt
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --ingest-chunks 0 --bge-chunks 0 --short-seqs 0 --precise-chunks 0 --text-docs 0 --shard-legs 0 --sides-out gpurun_out/r6i_sides.json > gpurun_out/r6i_bench.json 2> gpurun_out/r6i_bench.err
-python - <<'P'
-import json
-d=json.load(open('gpurun_out/r6i_bench.json'))
-print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'])
-for k in ('enc_like_10M','cfg2','clustered','anisotropic'):
-    print(k, d['sides'].get(k))
-P
-tail -3 gpurun_out/r6i_bench.err
+# r6k: scan8_kernel alone: production against "half the fragment reads" (what a half-tile split of the waves would buy)
+cd /tmp && export TMPDIR=/tmp
+ROOT="$GRAFT_REPO_ROOT"
+{
+for rep in 1 2; do
+for ab in 0 2; do
+  timeout 120 $ROOT/build_ub/scan8_ub_$ab 10000000 384 200 256
+  timeout 120 $ROOT/build_ub/scan8_ub_$ab 10000000 768 100 256
+done; done
+} > $ROOT/gpurun_out/r6k_scan8_half_reads.txt 2>&1
+cat $ROOT/gpurun_out/r6k_scan8_half_reads.txt

@@ -26,9 +26,9 @@ int main(int argc, char** argv) {
   float thr = argc > 5 ? atof(argv[5]) : INFINITY;
   int kc = ds / 128; rows = rows / 64 * 64;
   float *tsc, *qsc, *theta; void *qf, *xh; float* lb; uint32_t *lc, *ovf;
-  CK(hipMalloc(&xh, rows * ds)); CK(hipMalloc(&tsc, rows / 16 * 4)); float* zq; CK(hipMalloc(&zq, 1024)); CK(hipMemset(zq, 0, 1024)); CK(hipMalloc(&qsc, 1024)); CK(hipMalloc(&theta, 1024)); CK(hipMalloc(&qf, 256 * ds));
+  CK(hipMalloc(&xh, rows * ds)); CK(hipMalloc(&tsc, rows / 64 * kTscaleFloats * 4)); float* zq; CK(hipMalloc(&zq, 1024)); CK(hipMemset(zq, 0, 1024)); CK(hipMalloc(&qsc, 1024)); CK(hipMalloc(&theta, 1024)); CK(hipMalloc(&qf, 256 * ds));
   CK(hipMalloc(&lb, (size_t)256 * 512 * kRecCap * 64)); uint32_t* lt; CK(hipMalloc(&lt, (size_t)256 * 512 * kRecCap * 4)); CK(hipMalloc(&lc, 256 * 512 * 4)); CK(hipMalloc(&ovf, 1024));
-  int sf = argc > 6 ? atoi(argv[6]) : 1; fill8<<<4096, 256>>>((unsigned*)xh, rows * ds / 4, 1, sf); fillf<<<1024, 256>>>(tsc, rows / 16, 1.0f); fillf<<<1, 256>>>(qsc, 256, 1.0f); fill8<<<64, 256>>>((unsigned*)qf, 256 * ds / 4, 3, sf);
+  int sf = argc > 6 ? atoi(argv[6]) : 1; fill8<<<4096, 256>>>((unsigned*)xh, rows * ds / 4, 1, sf); fillf<<<1024, 256>>>(tsc, rows / 64 * kTscaleFloats, 1.0f); fillf<<<1, 256>>>(qsc, 256, 1.0f); fill8<<<64, 256>>>((unsigned*)qf, 256 * ds / 4, 3, sf);
   std::vector<float> th(256, thr); CK(hipMemcpy(theta, th.data(), 1024, hipMemcpyHostToDevice));
   CK(scan8_setup());
   ScanParams p; p.x = nullptr; p.xh = xh; p.scale = nullptr; p.qfrag = qf; p.theta = theta; p.n_rows = rows; p.tile_begin = 0; p.tile_end = rows / 64; p.tile_stride = 1; p.ds = ds; p.lane_max = (float*)lc; p.lane_rec = lb; p.lane_tile = lt; p.lane_cnt = lc; p.overflow = ovf; p.tscale = tsc; p.qscale = qsc; p.qa = zq; p.qb = zq;
