@@ -284,9 +284,13 @@ typedef struct mx_encoder_cfg {
                            MX_PREC_BF16X3: every GEMM operand carried as hi + lo bf16 (three MFMA products per
                            f32 product), f32 hidden state and f32 attention -- scores BETWEEN embeddings within
                            1e-4 of the f32 CPU path (embedding.rs:109) also under checkpoint-like weights, where
-                           the bf16 path moves them by up to 1e-2; about 6x slower        */
+                           the bf16 path moves them by up to 1e-2; about 6x slower |
+                           MX_PREC_MIXED (round 6): the attention block (Q, K, V, scores, PV, out-projection) as in
+                           MX_PREC_BF16X3, the MLP's two GEMMs as TWO fp16 products per product (fp16 weights x fp16 hi + lo
+                           activations) -- scores within 1e-4 as well (profiles/r6_encoder_rounding_sim.txt: the MLP tolerates
+                           11-bit weights, the logit path does not), 20-25 % faster than MX_PREC_BF16X3                */
 } mx_encoder_cfg;
-enum { MX_PREC_BF16 = 0, MX_PREC_BF16X3 = 1 };
+enum { MX_PREC_BF16 = 0, MX_PREC_BF16X3 = 1, MX_PREC_MIXED = 2 };
 /* sizeof(mx_encoder_cfg) of the library that is loaded: the struct grew a trailing field (`precision`) and may again; a shim
  * built against an older header compares this with its own sizeof at start-up instead of letting the library read past
  * its struct (same handshake as mx_index_stats_size). */

@@ -292,7 +292,7 @@ inline PretrainedModel load_pretrained_dir_impl(const std::string &dir, int prec
 // -> configuration, f32 weight blob and tokenizer files of a sentence-transformers directory.  Throws EmbeddingError(SetupError)
 // and nothing else: whatever a damaged file provokes underneath (a bad number, an allocation the header asked for) is reported
 // as "Unable to load model", like the reference's create_model() failing (embedding.rs:99-100).
-inline PretrainedModel load_pretrained_dir(const std::string &dir, int precision = MX_PREC_BF16) {
+inline PretrainedModel load_pretrained_dir(const std::string &dir, int precision = -1 /* the loader's choice */) {
     try {
         return load_pretrained_dir_impl(dir, precision);
     } catch (const EmbeddingError &) {
@@ -354,6 +354,9 @@ inline PretrainedModel load_pretrained_dir_impl(const std::string &dir, int prec
         c.pooling = which == 0 ? MX_POOL_CLS : MX_POOL_MEAN;
         if ((int32_t)pc.number("word_embedding_dimension", c.hidden) != c.hidden) throw unsupported("pooling dimension != hidden_size");
     }
+    // precision < 0: the loader's choice -- the bf16 ingest mode, except for CLS-pooled hidden-768 models (bge-base-en), whose scores
+    // move by up to 1e-2 on bf16 operands under checkpoint-like weights (north_star: 1e-3): MX_PREC_MIXED holds 6e-5 there
+    if (precision < 0) c.precision = (c.pooling == MX_POOL_CLS && c.hidden == 768) ? MX_PREC_MIXED : MX_PREC_BF16;
     pm.max_seq_length = (size_t)std::min(512, c.max_pos - c.pos_offset);
     if (file_exists(dir + "/sentence_bert_config.json")) {
         const Json sb = read_json(dir + "/sentence_bert_config.json");
@@ -435,7 +438,7 @@ inline std::shared_ptr<Tokenizer> pretrained_tokenizer(const PretrainedModel &pm
 // SentenceEmbedder::spawn(&ModelConfig) with create_model() reading a LOCAL sentence-transformers directory
 // (embedding.rs:84-100): encoder + native tokenizer from the files the reference downloads
 inline std::pair<std::thread, std::shared_ptr<SentenceEmbedder>> spawn_pretrained(const std::string &dir, const ModelConfig &mc = ModelConfig{},
-                                                                                  int device = 0, int precision = MX_PREC_BF16) {
+                                                                                  int device = 0, int precision = -1 /* the loader's choice */) {
     PretrainedModel pm = load_pretrained_dir(dir, precision);
     std::shared_ptr<Tokenizer> tok = pretrained_tokenizer(pm);
     return SentenceEmbedder::spawn(mc, pm.cfg, std::move(pm.weights), pm.max_seq_length, device, tok);

@@ -51,6 +51,9 @@ struct Layer {
     float *bo2 = nullptr, *ln2g = nullptr, *ln2b = nullptr;
     // MX_PREC_BF16X3: the same four matrices with k tripled, [hi | hi | lo] (upload_weight3); the bf16 ones above stay null
     bf16_t *wqkv3 = nullptr, *wo3 = nullptr, *wi3 = nullptr, *wo23 = nullptr;
+    // MX_PREC_MIXED: the attention block as in MX_PREC_BF16X3 (wqkv3, wo3), the MLP's two matrices as fp16 with k DOUBLED,
+    // [w | w] against activations split as fp16 [hi | lo] (upload_weight2h); wi3 / wo23 stay null
+    bf16_t *wi2h = nullptr, *wo22h = nullptr;
 };
 
 // kernel attributes (dynamic LDS sizes) are per device: set up once on every device an encoder is created on.  The grid
@@ -77,6 +80,7 @@ struct mx_encoder {
     float *xf = nullptr, *qkvf = nullptr, *af = nullptr;
     bf16_t *xs = nullptr, *ctxs = nullptr, *hs = nullptr;
     bool precise = false;
+    bool mixed = false;       // MX_PREC_MIXED: precise, with the MLP on two fp16 products per product
     // small passes (<= kSmallRows packed rows, fused-tail models): x1 of the layer in flight, the MLP's partial products
     bf16_t *sp_x1 = nullptr;
     float *sp_part = nullptr;
@@ -138,6 +142,26 @@ int upload_weight3(mx_encoder *e, const float *src, size_t rows, size_t k, bf16_
             at(r, c) = hi;
             at(r, k + c) = hi;
             at(r, 2 * k + c) = lo;
+        }
+    MX_HIP(hipMalloc(dst, tmp.size() * sizeof(uint16_t)));
+    e->allocs.push_back(*dst);
+    MX_HIP(hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return MX_OK;
+}
+
+// the mixed mode's form of a Linear weight: ONE fp16 value per element (saturating), k doubled, [w | w] against activations
+// split as fp16 [hi | lo]: two fp16 MFMA products per product, 11 + 22 significant bits
+int upload_weight2h(mx_encoder *e, const float *src, size_t rows, size_t k, bf16_t **dst) {
+    std::vector<uint16_t> tmp(rows * 2 * k);
+    auto at = [&](size_t r, size_t c) -> uint16_t & { return tmp[((c >> 5) * rows + r) * 32 + (c & 31)]; };
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < k; ++c) {
+            const float w = std::min(std::max(src[r * k + c], -65504.0f), 65504.0f);
+            const _Float16 hv = (_Float16)w;  // round to nearest even, subnormals kept
+            uint16_t bits;
+            memcpy(&bits, &hv, 2);
+            at(r, c) = bits;
+            at(r, k + c) = bits;
         }
     MX_HIP(hipMalloc(dst, tmp.size() * sizeof(uint16_t)));
     e->allocs.push_back(*dst);
@@ -288,15 +312,18 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             o.a = e->ctxs; o.lda = 3 * H; o.w = L.wo3; o.w_rows = H; o.bias = L.bo; o.m = m_c; o.n = H; o.k = 3 * H;
             o.out_f32 = e->af; o.ldo = H;
             MX_HIP(pgemm_or_gemm(EPI_F32, o));
-            MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, m_c, H, L.ln1g, L.ln1b, c.ln_eps));
+            // the MLP: three bf16 products per product (MX_PREC_BF16X3), or two fp16 ones (MX_PREC_MIXED: x1 and gelu(..) as fp16
+            // hi + lo in the same buffers, the weights as one fp16 value)
+            const int sp = e->mixed ? 2 : 3;
+            MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, m_c, H, L.ln1g, L.ln1b, c.ln_eps, e->mixed));
             GemmParams f1{};
-            f1.a = e->xs; f1.lda = 3 * H; f1.w = L.wi3; f1.w_rows = F; f1.bias = L.bi; f1.m = m_c; f1.n = F; f1.k = 3 * H;
-            f1.out = e->hs; f1.ldo = 3 * F;
-            MX_HIP(pgemm_or_gemm(EPI_GELU_SPLIT, f1));
+            f1.a = e->xs; f1.lda = sp * H; f1.w = e->mixed ? L.wi2h : L.wi3; f1.w_rows = F; f1.bias = L.bi; f1.m = m_c; f1.n = F; f1.k = sp * H;
+            f1.out = e->hs; f1.ldo = sp * F;
+            MX_HIP(pgemm_or_gemm(e->mixed ? EPI_GELU_SPLIT_H : EPI_GELU_SPLIT, f1));
             GemmParams f2{};
-            f2.a = e->hs; f2.lda = 3 * F; f2.w = L.wo23; f2.w_rows = H; f2.bias = L.bo2; f2.m = m_c; f2.n = H; f2.k = 3 * F;
+            f2.a = e->hs; f2.lda = sp * F; f2.w = e->mixed ? L.wo22h : L.wo23; f2.w_rows = H; f2.bias = L.bo2; f2.m = m_c; f2.n = H; f2.k = sp * F;
             f2.out_f32 = e->af; f2.ldo = H;
-            MX_HIP(pgemm_or_gemm(EPI_F32, f2));
+            MX_HIP(pgemm_or_gemm(e->mixed ? EPI_F32_H : EPI_F32, f2));
             MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, m_c, H, L.ln2g, L.ln2b, c.ln_eps));
         }
         MX_HIP(launch_pool(st, nullptr, e->xf, e->cu, d_lens, B, H, c.pooling == MX_POOL_CLS, c.normalize, d_out));
@@ -463,8 +490,8 @@ int check_cfg(const mx_encoder_cfg *c) {
     if (c->pos_offset < 0 || c->pos_offset >= c->max_pos) return fail(MX_EINVAL, "pos_offset %d outside [0, max_pos)", c->pos_offset);
     if (c->pooling != MX_POOL_MEAN && c->pooling != MX_POOL_CLS) return fail(MX_EINVAL, "pooling %d", c->pooling);
     if (!(c->ln_eps >= 0.0f)) return fail(MX_EINVAL, "ln_eps");
-    if (c->precision != MX_PREC_BF16 && c->precision != MX_PREC_BF16X3) return fail(MX_EINVAL, "precision %d", c->precision);
-    if (c->precision == MX_PREC_BF16X3 && c->ffn % 192) return fail(MX_EUNSUPPORTED, "ffn %d: MX_PREC_BF16X3 needs a multiple of 192", c->ffn);
+    if (c->precision != MX_PREC_BF16 && c->precision != MX_PREC_BF16X3 && c->precision != MX_PREC_MIXED) return fail(MX_EINVAL, "precision %d", c->precision);
+    if (c->precision != MX_PREC_BF16 && c->ffn % 192) return fail(MX_EUNSUPPORTED, "ffn %d: the split-operand modes need a multiple of 192", c->ffn);
     return MX_OK;
 }
 
@@ -517,7 +544,8 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     e->device = device;
     {
         // kernel-variant keys of MEMEX_HIP_DEBUG (mx_debug.h), fixed per encoder handle
-        e->precise = cfg->precision == MX_PREC_BF16X3;
+        e->precise = cfg->precision == MX_PREC_BF16X3 || cfg->precision == MX_PREC_MIXED;
+        e->mixed = cfg->precision == MX_PREC_MIXED;
         e->fused_tail = !e->precise && tail_supported(cfg->hidden, cfg->ffn) && debug_flag("unfused_tail", 0) != 1;
         e->pgemm = debug_flag("pgemm", 1) != 0;
         e->small_pass = e->fused_tail && debug_flag("small", 1) != 0;
@@ -572,12 +600,14 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         MX_TRY(upload_f32(e, g1_src, H, &L.ln1g));
         MX_TRY(upload_f32(e, be1_src, H, &L.ln1b));
         const float *wi_src = take(F * H);
-        if (e->precise) MX_TRY(upload_weight3(e, wi_src, F, H, &L.wi3));
+        if (e->precise && !e->mixed) MX_TRY(upload_weight3(e, wi_src, F, H, &L.wi3));
+        if (e->mixed) MX_TRY(upload_weight2h(e, wi_src, F, H, &L.wi2h));
         else MX_TRY(upload_weight(e, wi_src, F, H, &L.wi));
         const float *b1_src = take(F);
         MX_TRY(upload_f32(e, b1_src, F, &L.bi));
         const float *wo2_src = take(H * F);
-        if (e->precise) MX_TRY(upload_weight3(e, wo2_src, H, F, &L.wo23));
+        if (e->precise && !e->mixed) MX_TRY(upload_weight3(e, wo2_src, H, F, &L.wo23));
+        if (e->mixed) MX_TRY(upload_weight2h(e, wo2_src, H, F, &L.wo22h));
         else MX_TRY(upload_weight(e, wo2_src, H, F, &L.wo2));
         if (e->fused_tail) MX_TRY(upload_tail_stream(e, wo_src, wi_src, wo2_src, F, &L.wf));
         const float *b2_src = take(H), *g2_src = take(H), *be2_src = take(H);

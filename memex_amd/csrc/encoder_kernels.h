@@ -27,6 +27,10 @@ enum GemmEpilogue {
     // the bf16x3 ("precise") encoder, encoder_precise.hip: operands arrive split, results leave in f32 or split again
     EPI_F32 = 6,          // out_f32 = acc + bias                              ([M, N] f32, row pitch ldo)
     EPI_GELU_SPLIT = 7,   // out = split3(gelu_erf(acc + bias))                ([M, 3N] bf16, row pitch ldo: hi | lo | hi)
+    // the mixed mode (MX_PREC_MIXED): the MLP's two GEMMs as TWO fp16 products per product -- the activation as fp16 hi + lo
+    // ([hi | lo], width 2K), the weight as ONE fp16 value ([w | w]) -- on v_mfma_f32_32x32x16_f16
+    EPI_F32_H = 8,        // EPI_F32 on fp16 operands
+    EPI_GELU_SPLIT_H = 9, // out = split2h(gelu_erf(acc + bias))               ([M, 2N] fp16, row pitch ldo: hi | lo)
 };
 
 struct GemmParams {
@@ -156,8 +160,9 @@ hipError_t launch_embed_ln_precise(hipStream_t s, const int32_t *ids, int S, con
                                    int t_pad, int hidden, const float *word, const float *pos, const float *type0,
                                    const float *gamma, const float *beta, float eps, int vocab, float *xf, bf16_t *xs);
 // xf[r] = LayerNorm(a[r] + xf[r]) in place (f32), xs[r] = split3(xf[r])
+// half2 = true: xs[r] = [hi | lo] in fp16 (2H wide) instead of the three bf16 blocks: the operand of the mixed mode's W1
 hipError_t launch_add_ln_split(hipStream_t s, const float *a, float *xf, bf16_t *xs, int rows, int hidden, const float *gamma,
-                               const float *beta, float eps);
+                               const float *beta, float eps, bool half2 = false);
 // softmax(q k^T / sqrt(d) + mask) v in f32 (v_mfma_f32_32x32x2_f32) from qkv [t_pad, 3H] f32 (q | k | v) -> ctxs [t_pad, 3H] split
 hipError_t launch_attention_f32(hipStream_t s, const float *qkv, const int32_t *cu, const int32_t *lens, int B, int S, int heads,
                                 int d_head, int hidden, bf16_t *ctxs, bool f32_mfma);

@@ -34,6 +34,17 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vector (HIP's uint4 struct defeats SROA)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+// one 32 x 32 x 16 MFMA on the fragments as they sit in LDS: bf16, or (the mixed mode's GEMMs) fp16 -- same bytes, same layout
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8 &a, const bf16x8 &b, const f32x16 &c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// fp16 hi of a value (saturating: fp16 ends at 65504) and what is left of it
+__device__ __forceinline__ _Float16 half_hi(float g) { return (_Float16)fminf(fmaxf(g, -65504.0f), 65504.0f); }
 
 // ---------------------------------------------------------------------------------------------
 // K2: GEMM  C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue)
@@ -73,8 +84,11 @@ struct GemmGeom {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <int EPI, int WM, int WN, int MI, int BK, int S>
+template <int EPI_, int WM, int WN, int MI, int BK, int S>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) {
+    // the fp16 variants (EPI_F32_H, EPI_GELU_SPLIT_H) are their bf16 namesakes with another MFMA and another split of the output
+    constexpr bool F16 = EPI_ == EPI_F32_H || EPI_ == EPI_GELU_SPLIT_H;
+    constexpr int EPI = EPI_ == EPI_F32_H ? (int)EPI_F32 : EPI_ == EPI_GELU_SPLIT_H ? (int)EPI_GELU_SPLIT : EPI_;
     using G = GemmGeom<WM, WN, MI, BK, S>;
     constexpr int NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
         // activations: row-major [M][K]; weights: K-blocked [K/32][w_rows][32] so that a weight piece
         // (16 rows x 64 B) is one contiguous KiB of full cache lines
         // (split-k launches, EPI_F32: chunk blockIdx.y starts p.k columns / p.k / 32 weight k-blocks further on)
-        const size_t kz = EPI == EPI_F32 ? (size_t)blockIdx.y : 0;
+        const size_t kz = EPI_ == EPI_F32 ? (size_t)blockIdx.y : 0;
         const bf16_t *base = row < G::BM ? p.a + (size_t)(m0 + row) * p.lda + kz * p.k
                                          : p.w + (size_t)(p.w_row0 + n0 + row - G::BM) * 32 + kz * (p.k / 32) * p.w_rows * 32;
         src[i] = reinterpret_cast<const char *>(base + c * 8);
@@ -211,13 +225,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<F16>(af[i], bf[j], acc[i][j]);
             } else {              // D^T[n][m]: lane owns row m, 4 consecutive columns n per group
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<F16>(bf[j], af[i], acc[i][j]);
             }
         }
     }
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + b4[e];
-                    *reinterpret_cast<f32x4 *>(p.out_f32 + (size_t)blockIdx.y * p.m * p.ldo + grow * p.ldo + ncol) = v;
+                    *reinterpret_cast<f32x4 *>(p.out_f32 + (F16 ? (size_t)0 : (size_t)blockIdx.y * p.m * p.ldo) + grow * p.ldo + ncol) = v;
                 }
             }
         return;
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                     }
             }
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {  // 0: hi = bf16(g), 1: lo = bf16(g - hi)
+        for (int half = 0; half < 2; ++half) {  // 0: hi = bf16(g) (fp16(g) in the mixed mode), 1: lo = g - hi rounded the same way
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -279,14 +293,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
                         const int mrow = wm * 32 * MI + i * 32 + l31;
-                        bf16x4 pk;
+                        if constexpr (F16) {
+                            f16x4 pk;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float g = acc[i][j][rg * 4 + e];
-                            const __bf16 hi = (__bf16)g;
-                            pk[e] = half == 0 ? hi : (__bf16)(g - (float)hi);
+                            for (int e = 0; e < 4; ++e) {
+                                const float g = acc[i][j][rg * 4 + e];
+                                const _Float16 hi = half_hi(g);
+                                pk[e] = half == 0 ? hi : (_Float16)(g - (float)hi);
+                            }
+                            *reinterpret_cast<f16x4 *>(smem + mrow * G::PO + nloc * 2) = pk;
+                        } else {
+                            bf16x4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float g = acc[i][j][rg * 4 + e];
+                                const __bf16 hi = (__bf16)g;
+                                pk[e] = half == 0 ? hi : (__bf16)(g - (float)hi);
+                            }
+                            *reinterpret_cast<bf16x4 *>(smem + mrow * G::PO + nloc * 2) = pk;
                         }
-                        *reinterpret_cast<bf16x4 *>(smem + mrow * G::PO + nloc * 2) = pk;
                     }
                 }
             __syncthreads();
@@ -297,7 +322,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                 bf16_t *o = p.out + (size_t)(m0 + row) * p.ldo + n0 + cc * 8;
                 if (half == 0) {
                     *reinterpret_cast<u32x4 *>(o) = v;
-                    *reinterpret_cast<u32x4 *>(o + 2 * p.n) = v;
+                    if (!F16) *reinterpret_cast<u32x4 *>(o + 2 * p.n) = v;  // (the mixed mode's image is [hi | lo])
                 } else {
                     *reinterpret_cast<u32x4 *>(o + p.n) = v;
                 }
@@ -463,6 +488,8 @@ hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
         case EPI_VT: return big_vt ? gemm_go<EPI_VT, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_VT, 2, 2, 2, 32, 4>(s, p);
         case EPI_F32: return (fits && (mask & 8)) ? gemm_go<EPI_F32, 2, 4, 4, 32, 3>(s, p) : gemm_go<EPI_F32, 2, 2, 2, 32, 4>(s, p);
         case EPI_GELU_SPLIT: return gemm_go<EPI_GELU_SPLIT, 2, 2, 2, 32, 4>(s, p);
+        case EPI_F32_H: return gemm_go<EPI_F32_H, 2, 2, 2, 32, 4>(s, p);
+        case EPI_GELU_SPLIT_H: return gemm_go<EPI_GELU_SPLIT_H, 2, 2, 2, 32, 4>(s, p);
         case EPI_BIAS_RES_LN:
             if (p.n == 384) return gemm_go<EPI_BIAS_RES_LN, 2, 4, 2, 32, 4>(s, p);
             if (p.n == 768) return gemm_go<EPI_BIAS_RES_LN, 1, 8, 2, 32, 3>(s, p);
@@ -1488,6 +1515,8 @@ hipError_t encoder_kernels_setup() {
     if ((e = gemm_attr<EPI_VT, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_F32, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_GELU_SPLIT, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_F32_H, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
+    if ((e = gemm_attr<EPI_GELU_SPLIT_H, 2, 2, 2, 32, 4>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_BIAS_GELU, 2, 4, 4, 32, 3>()) != hipSuccess) return e;
     if ((e = gemm_attr<EPI_QKV, 2, 4, 4, 32, 3>()) != hipSuccess) return e;

@@ -47,6 +47,8 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((address_space(3))) void lds_void;
 
 namespace {
@@ -65,8 +67,12 @@ constexpr uint32_t kU_ALO = 0, kU_BLO = kUnit, kU_BHI = 2 * kUnit, kU_AHI = 3 * 
 
 }  // namespace
 
-template <int EPI>
+template <int EPI_>
 __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const int skew) {
+    // the fp16 variants (EPI_F32_H, EPI_GELU_SPLIT_H: the mixed mode's MLP, two fp16 products per product) are their bf16
+    // namesakes with v_mfma_f32_32x32x16_f16 and a two-block fp16 image of the GELU output
+    constexpr bool F16 = EPI_ == EPI_F32_H || EPI_ == EPI_GELU_SPLIT_H;
+    constexpr int EPI = EPI_ == EPI_F32_H ? (int)EPI_F32 : EPI_ == EPI_GELU_SPLIT_H ? (int)EPI_GELU_SPLIT : EPI_;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool FM = (EPI == EPI_VT);  // feature-major output, swapped MFMA roles
     const int tid = threadIdx.x;
@@ -283,14 +289,25 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
                         for (int j = 0; j < 2; ++j)
 #pragma unroll
                             for (int rg = 0; rg < 4; ++rg) {
-                                bf16x4 pk;
+                                if constexpr (F16) {
+                                    f16x4 pk;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float g = acc[i][j][rg * 4 + e];
-                                    const __bf16 hi = (__bf16)g;
-                                    pk[e] = half == 0 ? hi : (__bf16)(g - (float)hi);
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float g = acc[i][j][rg * 4 + e];
+                                        const _Float16 hi = (_Float16)fminf(fmaxf(g, -65504.0f), 65504.0f);
+                                        pk[e] = half == 0 ? hi : (_Float16)(g - (float)hi);
+                                    }
+                                    *reinterpret_cast<f16x4 *>(sc + l31 * 128 + (((j * 4 + rg) ^ (l31 & 7)) << 4) + h * 8) = pk;
+                                } else {
+                                    bf16x4 pk;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float g = acc[i][j][rg * 4 + e];
+                                        const __bf16 hi = (__bf16)g;
+                                        pk[e] = half == 0 ? hi : (__bf16)(g - (float)hi);
+                                    }
+                                    *reinterpret_cast<bf16x4 *>(sc + l31 * 128 + (((j * 4 + rg) ^ (l31 & 7)) << 4) + h * 8) = pk;
                                 }
-                                *reinterpret_cast<bf16x4 *>(sc + l31 * 128 + (((j * 4 + rg) ^ (l31 & 7)) << 4) + h * 8) = pk;
                             }
 #pragma unroll
                         for (int ps = 0; ps < 4; ++ps) {
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
                             bf16_t *o = dst + (size_t)(m0 + wr * 128 + i * 32 + row) * p.ldo + ncol0 + lc * 8;
                             if (half == 0) {
                                 *reinterpret_cast<u32x4 *>(o) = v;
-                                *reinterpret_cast<u32x4 *>(o + 2 * p.n) = v;
+                                if (!F16) *reinterpret_cast<u32x4 *>(o + 2 * p.n) = v;  // (the mixed mode's image is [hi | lo])
                             } else {
                                 *reinterpret_cast<u32x4 *>(o + p.n) = v;
                             }
@@ -351,7 +368,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
     };
 
     auto mma = [&](const bf16x8 &w, const bf16x8 &a, f32x16 &c) __attribute__((always_inline)) {
-        if (FM) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, c, 0, 0, 0);
+        if constexpr (F16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+        else if (FM) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, c, 0, 0, 0);
         else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0);
     };
 #if MX_PGEMM_ABLATE & 32  /* scripts/gemm_ubench.hip: MFMA shape probe -- two k-steps' operand traffic on four v_mfma_f32_16x16x32_bf16 (values meaningless) */
@@ -576,6 +594,8 @@ hipError_t pgemm_setup() {
     if ((e = pgemm_attr<EPI_BIAS_RES>()) != hipSuccess) return e;
     if ((e = pgemm_attr<EPI_F32>()) != hipSuccess) return e;
     if ((e = pgemm_attr<EPI_GELU_SPLIT>()) != hipSuccess) return e;
+    if ((e = pgemm_attr<EPI_F32_H>()) != hipSuccess) return e;
+    if ((e = pgemm_attr<EPI_GELU_SPLIT_H>()) != hipSuccess) return e;
     int dev = 0;
     hipDeviceProp_t prop;
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
@@ -588,11 +608,11 @@ hipError_t pgemm_setup() {
 // shapes pgemm_kernel takes: whole 256 x 256 tiles, k-tiles of 64, 32-bit byte offsets, the q / k split on a wave edge
 bool pgemm_supported(int epi, const GemmParams &p) {
     if (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_QKV && epi != EPI_VT && epi != EPI_BIAS_RES && epi != EPI_F32 &&
-        epi != EPI_GELU_SPLIT)
+        epi != EPI_GELU_SPLIT && epi != EPI_F32_H && epi != EPI_GELU_SPLIT_H)
         return false;
     // whole column tiles, or for the f32-output epilogue a last tile of 128 columns (MX_PREC_BF16X3 at hidden 384: N = 1152 / 384;
     // A/B against gemm_kernel: profiles/r5_precise_partial_tile_ab.txt; the same for EPI_VT is worth +0.3 %: r5_vt_partial_tile_ab.txt)
-    const bool n_ok = p.n % kPT == 0 || (epi == EPI_F32 && p.n % kPT == kPT / 2 && p.n > kPT / 2);
+    const bool n_ok = p.n % kPT == 0 || ((epi == EPI_F32 || epi == EPI_F32_H) && p.n % kPT == kPT / 2 && p.n > kPT / 2);
     if (g_pgemm_cus < 8 || p.m % kPT || !n_ok || p.k % kPK || p.k < 2 * kPK) return false;
     if ((size_t)p.m * p.lda * 2 >= (1ull << 32) || (size_t)p.w_rows * p.k * 2 >= (1ull << 32)) return false;
     if (epi == EPI_QKV && (p.hidden % 64 || p.n != 2 * p.hidden)) return false;
@@ -609,6 +629,8 @@ hipError_t launch_pgemm(hipStream_t s, int epi, const GemmParams &p) {
         case EPI_BIAS_RES: return pgemm_go<EPI_BIAS_RES>(s, p);
         case EPI_F32: return pgemm_go<EPI_F32>(s, p);
         case EPI_GELU_SPLIT: return pgemm_go<EPI_GELU_SPLIT>(s, p);
+        case EPI_F32_H: return pgemm_go<EPI_F32_H>(s, p);
+        case EPI_GELU_SPLIT_H: return pgemm_go<EPI_GELU_SPLIT_H>(s, p);
         default: return hipErrorInvalidValue;
     }
 }

@@ -40,6 +40,18 @@ __device__ __forceinline__ void store_split4(bf16_t *o, int blk, const f32x4 v) 
     *reinterpret_cast<bf16x4 *>(o + blk) = lo;
     *reinterpret_cast<bf16x4 *>(o + 2 * blk) = hi;
 }
+// the mixed mode's two-block fp16 image: o[0..3] = fp16(v) (saturating), o[blk..] = fp16(v - hi)
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+__device__ __forceinline__ void store_split4h(bf16_t *o, int blk, const f32x4 v) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (_Float16)fminf(fmaxf(v[e], -65504.0f), 65504.0f);
+        lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    }
+    *reinterpret_cast<f16x4 *>(o) = hi;
+    *reinterpret_cast<f16x4 *>(o + blk) = lo;
+}
 
 }  // namespace
 
@@ -132,14 +144,14 @@ hipError_t launch_embed_ln_precise(hipStream_t s, const int32_t *ids, int S, con
 template <int TPR>
 __global__ __launch_bounds__(256) void add_ln_split_kernel(const float *__restrict__ a, float *__restrict__ xf, bf16_t *__restrict__ xs,
                                                             int rows, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            float eps) {
+                                                            float eps, int half2) {
     constexpr int H = 24 * TPR;
     const int l = threadIdx.x % TPR;
     const int row = (int)(blockIdx.x * (256 / TPR) + threadIdx.x / TPR);
     if (row >= rows) return;
     const float *ar = a + (size_t)row * H;
     float *xr = xf + (size_t)row * H;
-    bf16_t *sr = xs + (size_t)row * 3 * H;
+    bf16_t *sr = xs + (size_t)row * (half2 ? 2 : 3) * H;  // (half2: the mixed mode's [hi | lo] fp16 image, 2H wide)
     float y[24];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -164,16 +176,17 @@ __global__ __launch_bounds__(256) void add_ln_split_kernel(const float *__restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ln_affine(y[c * 8 + 4 * hf + e], mean, rstd, g[e], b[e]);
             *reinterpret_cast<f32x4 *>(xr + col) = o;
-            store_split4(sr + col, H, o);
+            if (half2) store_split4h(sr + col, H, o);
+            else store_split4(sr + col, H, o);
         }
 }
 
 hipError_t launch_add_ln_split(hipStream_t s, const float *a, float *xf, bf16_t *xs, int rows, int hidden, const float *gamma,
-                               const float *beta, float eps) {
+                               const float *beta, float eps, bool half2) {
     if (hidden == 768)
-        hipLaunchKernelGGL(add_ln_split_kernel<32>, dim3((rows + 7) / 8), dim3(256), 0, s, a, xf, xs, rows, gamma, beta, eps);
+        hipLaunchKernelGGL(add_ln_split_kernel<32>, dim3((rows + 7) / 8), dim3(256), 0, s, a, xf, xs, rows, gamma, beta, eps, half2 ? 1 : 0);
     else if (hidden == 384)
-        hipLaunchKernelGGL(add_ln_split_kernel<16>, dim3((rows + 15) / 16), dim3(256), 0, s, a, xf, xs, rows, gamma, beta, eps);
+        hipLaunchKernelGGL(add_ln_split_kernel<16>, dim3((rows + 15) / 16), dim3(256), 0, s, a, xf, xs, rows, gamma, beta, eps, half2 ? 1 : 0);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

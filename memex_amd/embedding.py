@@ -232,7 +232,7 @@ class SentenceEmbedder:
 
     @classmethod
     def from_pretrained_dir(cls, path: str, model_config: ModelConfig = ModelConfig(), device: int = 0,
-                            precision: str = "bf16", encoder_key: Optional[str] = None):
+                            precision: Optional[str] = None, encoder_key: Optional[str] = None):
         """``create_model()`` from a LOCAL sentence-transformers directory -- the files
         ``SentenceEmbeddingsBuilder::remote(..)`` downloads (embedding.rs:99-100): ``modules.json``, ``config.json``,
         ``sentence_bert_config.json``, ``1_Pooling/config.json``, ``model.safetensors`` / ``pytorch_model.bin``,

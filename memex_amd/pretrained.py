@@ -61,8 +61,18 @@ def _load_state(path: str) -> Dict[str, np.ndarray]:
     raise FileNotFoundError(f"{path}: no model.safetensors / pytorch_model.bin")
 
 
-def load_pretrained_dir(path: str, precision: str = "bf16") -> Tuple[EncoderConfig, Dict[str, np.ndarray], Optional[str], dict]:
-    """-> (EncoderConfig, tensors by HF name, path of vocab.txt or None, info).
+def default_precision(hidden: int, pooling: str) -> str:
+    """The precision a loader picks when the caller names none: the bf16 ingest mode -- except for CLS-pooled hidden-768
+    models (bge-base-en), where bf16 operands move the cosines BETWEEN embeddings by up to 1e-2 under checkpoint-like weights
+    (one token, twelve layers; tests/test_encoder_gpu.py) against north_star's 1e-3 on scores: those get "mixed"
+    (MX_PREC_MIXED: <= 6e-5, 2.7x slower than bf16).  Mean pooling averages the rounding noise of hundreds of tokens
+    (<= 1.3e-3 measured at hidden 384): bf16 stays."""
+    return "mixed" if pooling == "cls" and hidden == 768 else "bf16"
+
+
+def load_pretrained_dir(path: str, precision: Optional[str] = None) -> Tuple[EncoderConfig, Dict[str, np.ndarray], Optional[str], dict]:
+    """-> (EncoderConfig, tensors by HF name, path of vocab.txt or None, info).  ``precision``: "bf16" | "bf16x3" | "mixed", or
+    None = :func:`default_precision` of the model.
 
     ``info``: ``do_lower_case``, ``model_type``, ``modules`` (the pipeline's module types in order), ``bpe_files``
     (``(vocab.json, merges.txt)`` of a byte-level BPE tokenizer, or None), ``tokenizer_json`` (path of ``tokenizer.json``, or
@@ -79,7 +89,7 @@ def load_pretrained_dir(path: str, precision: str = "bf16") -> Tuple[EncoderConf
         raise ValueError(f"{path}: damaged model directory ({type(e).__name__}: {e})") from e
 
 
-def _load_pretrained_dir(path: str, precision: str):
+def _load_pretrained_dir(path: str, precision: Optional[str]):
     if not os.path.isdir(path):
         raise FileNotFoundError(path)
     modules_path = os.path.join(path, "modules.json")
@@ -135,7 +145,8 @@ def _load_pretrained_dir(path: str, precision: str):
     cfg = EncoderConfig(layers=int(hc["num_hidden_layers"]), hidden=int(hc["hidden_size"]), heads=int(hc["num_attention_heads"]),
                         ffn=int(hc["intermediate_size"]), vocab=int(hc["vocab_size"]), max_pos=int(hc["max_position_embeddings"]),
                         type_vocab=int(hc.get("type_vocab_size", 2)), ln_eps=float(hc.get("layer_norm_eps", 1e-12)),
-                        pooling=pooling, normalize=normalize, max_seq_length=max_seq, pos_offset=pos_offset, precision=precision)
+                        pooling=pooling, normalize=normalize, max_seq_length=max_seq, pos_offset=pos_offset,
+                        precision=precision if precision is not None else default_precision(int(hc["hidden_size"]), pooling))
 
     state = _load_state(tdir)
     # keep what the encoder reads (drops pooler.*, position_ids, lm heads) and check the shapes now, not at upload time

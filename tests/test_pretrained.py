@@ -76,6 +76,20 @@ def test_directory_round_trip(tmp_path, weights):
     assert load_pretrained_dir(d, precision="bf16x3")[0].precision == "bf16x3"
 
 
+def test_loaders_choose_the_bar_meeting_precision_for_cls_pooled_hidden_768(tmp_path):
+    """a CLS-pooled hidden-768 model (bge-base-en) moves its scores by up to 1e-2 on bf16 operands (north_star: 1e-3);
+    a loader that is not told otherwise picks MX_PREC_MIXED for it (<= 6e-5: tests/test_encoder_gpu.py), bf16 for everything else."""
+    from memex_amd.pretrained import default_precision, load_pretrained_dir
+    assert default_precision(768, "cls") == "mixed" and default_precision(768, "mean") == "bf16" and default_precision(384, "cls") == "bf16"
+    d = str(tmp_path / "bge")
+    make_st_dir(d, hidden=768, layers=1, pooling="cls", weights="safetensors")
+    assert load_pretrained_dir(d)[0].precision == "mixed"
+    assert load_pretrained_dir(d, precision="bf16")[0].precision == "bf16"
+    d2 = str(tmp_path / "mean768")
+    make_st_dir(d2, hidden=768, layers=1, pooling="mean", weights="safetensors")
+    assert load_pretrained_dir(d2)[0].precision == "bf16"
+
+
 def test_unsupported_models_are_refused(tmp_path):
     """What the HIP encoder does not implement must fail loudly (MX_EUNSUPPORTED's Python face), not be approximated."""
     from memex_amd.pretrained import UnsupportedModel, load_pretrained_dir
