@@ -56,9 +56,24 @@ def _load_state(path: str) -> Dict[str, np.ndarray]:
         import torch
         sd = torch.load(pb, map_location="cpu", weights_only=True)
         return {k: v.float().numpy() for k, v in sd.items()}
-    if os.path.exists(os.path.join(path, "rust_model.ot")):
-        raise UnsupportedModel(f"{path}: only rust_model.ot is present (libtorch archive); provide model.safetensors or pytorch_model.bin")
-    raise FileNotFoundError(f"{path}: no model.safetensors / pytorch_model.bin")
+    ot = os.path.join(path, "rust_model.ot")
+    if os.path.exists(ot):
+        # The file create_model() itself reads (embedding.rs:99-100): rust-bert's weights, written by tch's Tensor::save_multi =
+        # libtorch's OutputArchive -- a TorchScript archive (zip: data.pkl + data/N) whose parameters / buffers carry the
+        # checkpoint's tensor names with '.' spelled '|' (a TorchScript attribute name cannot hold a dot).  torch.jit.load reads
+        # such an archive; VERIFIED HERE only against archives torch.jit.save wrote (tests/test_pretrained.py): no rust_model.ot can
+        # be fetched offline.  Anything torch.jit.load refuses is refused with the file's name.
+        try:
+            import torch
+            mod = torch.jit.load(ot, map_location="cpu")
+            sd = {k.replace("|", "."): v.detach().float().numpy() for k, v in list(mod.named_parameters()) + list(mod.named_buffers())}
+        except Exception as e:  # noqa: BLE001
+            raise UnsupportedModel(f"{path}: rust_model.ot is not a TorchScript archive torch.jit.load reads ({type(e).__name__}); "
+                                   "provide model.safetensors or pytorch_model.bin") from e
+        if not sd:
+            raise UnsupportedModel(f"{path}: rust_model.ot holds no tensors")
+        return sd
+    raise FileNotFoundError(f"{path}: no model.safetensors / pytorch_model.bin / rust_model.ot")
 
 
 def default_precision(hidden: int, pooling: str) -> str:

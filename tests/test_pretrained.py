@@ -76,6 +76,31 @@ def test_directory_round_trip(tmp_path, weights):
     assert load_pretrained_dir(d, precision="bf16x3")[0].precision == "bf16x3"
 
 
+def test_rust_model_ot_is_read_when_it_is_a_torchscript_archive(tmp_path):
+    """The weight file create_model() itself reads (embedding.rs:99-100) is rust_model.ot: tch's save_multi = libtorch's
+    OutputArchive, a TorchScript archive whose tensors carry the checkpoint's names with '.' spelled '|'.  No such file can be
+    fetched offline, so the archive is written HERE (torch.jit.save of a module holding the same tensors under those names): the
+    loader reads it through torch.jit.load and hands out the tensors of model.safetensors bit for bit."""
+    import torch
+    from memex_amd.pretrained import load_pretrained_dir
+    d = str(tmp_path / "ot")
+    model, _ = make_st_dir(d, hidden=384, layers=2, weights="safetensors")
+    want = load_pretrained_dir(d, precision="bf16")[1]
+
+    class Holder(torch.nn.Module):
+        def forward(self):
+            return 0
+
+    holder = Holder()
+    for name, tensor in model.state_dict().items():
+        holder.register_buffer(("bert." + name).replace(".", "|"), tensor.clone())   # rust-bert's names carry the model prefix
+    torch.jit.save(torch.jit.script(holder), os.path.join(d, "rust_model.ot"))
+    os.remove(os.path.join(d, "model.safetensors"))
+    cfg, got, _, _ = load_pretrained_dir(d, precision="bf16")
+    from memex_amd.weights import pack_weights
+    np.testing.assert_array_equal(pack_weights(got, cfg), pack_weights(want, cfg))
+
+
 def test_loaders_choose_the_bar_meeting_precision_for_cls_pooled_hidden_768(tmp_path):
     """a CLS-pooled hidden-768 model (bge-base-en) moves its scores by up to 1e-2 on bf16 operands (north_star: 1e-3);
     a loader that is not told otherwise picks MX_PREC_MIXED for it (<= 6e-5: tests/test_encoder_gpu.py), bf16 for everything else."""
