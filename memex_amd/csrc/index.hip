@@ -43,6 +43,7 @@
 
 #include "index_kernels.h"
 #include "mx_common.h"
+#include "mx_debug.h"
 #include "shard_pool.h"
 
 namespace mx {
@@ -723,7 +724,7 @@ int add_device_locked(mx_index *idx, const float *d_rows, uint64_t n, uint64_t *
 // how many tiles the sample launch visits: enough that the k-th largest of 2*nwg lane maxima is a
 // useful threshold (expected survivors of the collect launch ~ k * N / sample, times the margin's
 // share) and small enough to stay a few percent of the pass
-uint32_t sample_stride(uint64_t full_tiles, int nwg, int k, bool filt8, int ds) {
+uint32_t sample_stride(uint64_t full_tiles, int nwg, int k, bool filt8, int ds, bool centred8 = false) {
     // 1/64 of the tiles for k <= 10.  Measured at 10M x 384 (B = 256): the sample launch costs 65 / 38 / 24 /
     // 17 us at 1/32, 1/64, 1/128, 1/256; a weaker threshold means more records for finish_kernel to sift
     // (62 / 63 / 72 us, and at 1/256 lanes start to overflow their 32 records), while the collect launch
@@ -732,7 +733,12 @@ uint32_t sample_stride(uint64_t full_tiles, int nwg, int k, bool filt8, int ds) 
     // more rows: 1/16 of the tiles up to 512 dims, 1/8 at 768, 1/4 at 1024 (a smaller sample makes lanes overflow
     // their 64 records and the retry pass costs a whole scan: scripts/r3_i8_sample.sh, r3_dims.sh).
     // (A tuning constant: results do not depend on it.)
-    const double div = !filt8 ? 64.0 : ds <= 512 ? 16.0 : ds <= 768 ? 8.0 : 4.0;
+    // (MEMEX_HIP_DEBUG=sample_div=N tries others: a tuning knob, results do not depend on it.)
+    // (a centred int8 copy, whose certificate is four to five times tighter again, gains nothing from a smaller sample: 1/32 against
+    // 1/16 on the enc_like leg 169.3k against 169.0k queries/s; at 1/64 lanes overflow and the copy is demoted: gpurun_out/r6m_*)
+    (void)centred8;
+    double div = !filt8 ? 64.0 : ds <= 512 ? 16.0 : ds <= 768 ? 8.0 : 4.0;
+    if (const int dv = debug_flag("sample_div", 0); dv >= 2 && dv <= 4096) div = (double)dv;
     // larger k: the sample grows like k / 640 for every copy (int8 at k = 30 / 100: 1.33 / 1.56 ms per step with
     // 1/16 / 0.16 of the tiles against 1.93 / 1.77 with three and ten times the k = 10 sample)
     const double f = std::min(0.5, std::max(1.0 / div, (double)k / 640.0));
@@ -1035,7 +1041,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
         if (tiles > 2ull * idx->nwg) {
             p.tile_begin = 0;
             p.tile_end = (uint32_t)full;
-            p.tile_stride = sample_stride(full, idx->nwg, k, filt8, idx->ds);
+            p.tile_stride = sample_stride(full, idx->nwg, k, filt8, idx->ds, centred8);
             MX_HIP(scan(false));
             MX_HIP(launch_theta(st, B, k, idx->nwg, s.lane_max, s.qa, !filt8, s.theta));
         }

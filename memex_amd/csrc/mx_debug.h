@@ -14,6 +14,7 @@
 //   attn_short_lds=0 [1]  attention_short_kernel fetches K / V^T per wave from global memory
 //   attn_pair=0|1    [per pass]  never / always two heads per item of the staged attention
 //   attn_safe=1      [0]  running-maximum softmax loop only
+//   sample_div=N          the search's sample pass visits 1/N of the scan tiles (a tuning knob: results do not depend on it)
 // Unknown keys are ignored.  Operational switches (wait mode, exchange, filter copy) are separate, documented in
 // include/memex_hip.h; there is no fault-injection switch in this library (libmemex_hip_testing.so, -DMEMEX_TESTING, has two).
 #pragma once

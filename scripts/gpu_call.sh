@@ -1,25 +1,12 @@
 #!/bin/bash
-# r6l: the mixed mode (MX_PREC_MIXED): parity tests, then throughput next to bf16x3
+# r6m: sample size of the centred int8 copy (enc_like leg), MEMEX_HIP_DEBUG=sample_div=N
 cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_encoder_gpu.py -m gpu -x -q -k "vs_oracle or checkpoint_like or split_operand" -s 2>&1 | grep -v "^$" | tail -40 > gpurun_out/r6l_tests.txt
-cat gpurun_out/r6l_tests.txt
-python - <<'P' 2>&1 | tee gpurun_out/r6l_mixed_perf.txt
-import dataclasses, time, numpy as np, torch
-from memex_amd import weights as W
-from memex_amd.encoder import Encoder
-for name, base, B in (("all-MiniLM-L6-v2", W.ALL_MINILM_L6_V2, 256), ("bge-base-en", W.BGE_BASE_EN, 256)):
-    for prec in ("bf16x3", "mixed", "bf16"):
-        cfg = dataclasses.replace(base, precision=prec)
-        enc = Encoder(cfg, W.pack_weights(W.synthetic_weights(cfg, 0), cfg))
-        g = torch.Generator(device="cuda"); g.manual_seed(3)
-        ids = torch.randint(1000, cfg.vocab, (B, 512), device="cuda", dtype=torch.int32, generator=g)
-        lens = torch.full((B,), 512, device="cuda", dtype=torch.int32)
-        emb = torch.zeros((B, cfg.hidden), device="cuda")
-        for _ in range(3): enc.encode_device(ids, lens, emb)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        n = 24 if prec != "bf16" else 60
-        for _ in range(n): enc.encode_device(ids, lens, emb)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"{name:18s} {prec:7s} {n * B / dt:9.0f} chunks/s")
-        enc.close()
+for dv in 16 32 64 128; do
+  MEMEX_HIP_DEBUG=sample_div=$dv timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --ingest-chunks 0 --bge-chunks 0 --short-seqs 0 --precise-chunks 0 --text-docs 0 --shard-legs 0 --cfg2-segments 0 --alt-steps 0 --sides-out gpurun_out/r6m_sides_$dv.json > gpurun_out/r6m_bench_$dv.json 2> /dev/null
+  python - $dv <<'P'
+import json, sys
+d=json.load(open(f'gpurun_out/r6m_bench_{sys.argv[1]}.json'))
+e=d['sides']['enc_like_10M']
+print('sample_div', sys.argv[1], 'headline', d['value'], 'cand', d['candidates_per_query'], '| enc_like', e['value'], 'ms', e['ms_per_step'], 'launch', e['ms_per_launch'], 'outside', e['ms_outside_collect_launch'], 'cand', e['candidates_per_query'], 'retry', e['retry_queries'])
 P
+done | tee gpurun_out/r6m_sample_div.txt
