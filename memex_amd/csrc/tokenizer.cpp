@@ -103,6 +103,17 @@ struct mx_tokenizer {
     bool bpe_ids = false;
     std::string byte_chr[256];                      // byte -> its printable code point, UTF-8 encoded
     std::unordered_map<uint32_t, uint8_t> chr_byte;  // code point -> byte
+    // added tokens: strings the `tokenizers` crate cuts out of the RAW text before anything else (literal "[SEP]" / "<s>" /
+    // "<mask>" in a document become that token's id, and decode(skip_special_tokens) then drops them): tokenizer.json's
+    // `added_tokens`, or the model family's five specials (finish_vocab / finish_bpe).  lstrip / rstrip: the match swallows the
+    // white space on that side (RoBERTa's <mask> has lstrip)
+    struct Added {
+        std::string s;
+        int32_t id;
+        bool lstrip, rstrip, special;
+    };
+    std::vector<Added> added;
+    bool added_from_json = false;
 };
 
 namespace {
@@ -365,10 +376,49 @@ void encode_wordpiece(const mx_tokenizer *t, const char *text, std::vector<int32
     flush();
 }
 
-std::vector<int32_t> encode_plain(const mx_tokenizer *t, const char *text) {
+std::vector<int32_t> encode_piece(const mx_tokenizer *t, const char *text) {
     if (t->kind == 1) return bpe_encode_plain(t, text);
     std::vector<int32_t> ids;
     encode_wordpiece(t, text, ids);
+    return ids;
+}
+
+inline bool ascii_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+// the raw text cut at its added tokens (leftmost match, the longest token at a position -- the crate's Aho-Corasick
+// "leftmost-longest" over the un-normalised text), the pieces between them through the model's own pipeline
+std::vector<int32_t> encode_plain(const mx_tokenizer *t, const char *text) {
+    if (t->added.empty()) return encode_piece(t, text);
+    // (every added token of the supported families starts with '[' or '<': a text without either has none)
+    const size_t n = strlen(text);
+    std::vector<int32_t> ids;
+    size_t piece0 = 0, i = 0;
+    std::string piece;
+    auto flush = [&](size_t end) {
+        if (end > piece0) {
+            piece.assign(text + piece0, end - piece0);
+            const std::vector<int32_t> v = encode_piece(t, piece.c_str());
+            ids.insert(ids.end(), v.begin(), v.end());
+        }
+    };
+    while (i < n) {
+        const mx_tokenizer::Added *hit = nullptr;
+        for (const auto &a : t->added)
+            if (a.s.size() <= n - i && text[i] == a.s[0] && memcmp(text + i, a.s.data(), a.s.size()) == 0 && (!hit || a.s.size() > hit->s.size())) hit = &a;
+        if (!hit) {
+            ++i;
+            continue;
+        }
+        size_t b = i, e = i + hit->s.size();
+        if (hit->lstrip)
+            while (b > piece0 && ascii_space(text[b - 1])) --b;
+        if (hit->rstrip)
+            while (e < n && ascii_space(text[e])) ++e;
+        flush(b);
+        ids.push_back(hit->id);
+        piece0 = i = e;
+    }
+    flush(n);
     return ids;
 }
 
@@ -380,7 +430,11 @@ std::vector<int32_t> encode_staged(const mx_tokenizer *t, const char *text) {
 }
 
 bool is_special(const mx_tokenizer *t, int32_t id) {
-    return id == t->pad || id == t->unk || id == t->cls || id == t->sep || id == t->mask;
+    if (id == t->pad || id == t->unk || id == t->cls || id == t->sep || id == t->mask) return true;
+    if (t->added_from_json)
+        for (const auto &a : t->added)
+            if (a.special && a.id == id) return true;
+    return false;
 }
 
 void replace_all(std::string &s, const std::string &a, const std::string &b) {
@@ -585,7 +639,7 @@ std::string bpe_decode_ids(const mx_tokenizer *t, const int32_t *ids, int n, boo
     for (int i = 0; i < n; ++i) {
         const int32_t id = ids[i];
         if (id < 0 || id >= (int32_t)t->vocab.size()) continue;
-        if (skip_special && (id == t->pad || id == t->unk || id == t->cls || id == t->sep || id == t->mask)) continue;
+        if (skip_special && is_special(t, id)) continue;
         bytes.append(t->dec_arena.data() + t->dec_off[(size_t)id], t->dec_off[(size_t)id + 1] - t->dec_off[(size_t)id]);
     }
     std::string out;
@@ -717,6 +771,12 @@ int finish_bpe(mx_tokenizer *t, std::istream &merges) {
     // two different strings must not share an id pair's product by accident: the id form is only used when ids and strings are
     // in bijection for everything a merge can produce (vocab.json maps distinct strings to distinct ids by construction)
     if (!t->bpe_ids) t->pair_rank.clear();
+    if (!t->added_from_json) {  // what tokenizer.json of the RoBERTa family lists as added_tokens (<mask> swallows the space before it)
+        t->added.clear();
+        for (const auto &sp : {std::make_pair("<s>", t->cls), std::make_pair("<pad>", t->pad), std::make_pair("</s>", t->sep), std::make_pair("<unk>", t->unk)})
+            if (sp.second >= 0 && t->index.count(sp.first)) t->added.push_back({sp.first, sp.second, false, false, true});
+        if (t->index.count("<mask>")) t->added.push_back({"<mask>", t->mask, true, false, true});
+    }
     return MX_OK;
 }
 
@@ -732,6 +792,12 @@ int finish_vocab(mx_tokenizer *t) {
     if (!need("[PAD]", t->pad) || !need("[UNK]", t->unk) || !need("[CLS]", t->cls) || !need("[SEP]", t->sep))
         return fail(MX_EINVAL, "vocabulary lacks [PAD]/[UNK]/[CLS]/[SEP]");
     if (!need("[MASK]", t->mask)) t->mask = -1;
+    if (!t->added_from_json) {  // what tokenizer.json of the BERT family lists as added_tokens
+        t->added.clear();
+        for (const auto &sp : {std::make_pair("[PAD]", t->pad), std::make_pair("[UNK]", t->unk), std::make_pair("[CLS]", t->cls),
+                               std::make_pair("[SEP]", t->sep), std::make_pair("[MASK]", t->mask)})
+            if (sp.second >= 0) t->added.push_back({sp.first, sp.second, false, false, true});
+    }
     std::vector<std::pair<std::string, int32_t>> all, cont;
     for (size_t i = 0; i < t->vocab.size(); ++i) {
         all.emplace_back(t->vocab[i], (int32_t)i);
@@ -899,6 +965,23 @@ int build_from_tokenizer_json(mx_tokenizer *t, const std::string &js) {
     if (type.empty()) type = merges.ok() ? "BPE" : "WordPiece";  // files written before the tag existed
     auto type_of = [&](const char *key) { const JSpan v = J.find(root, key); return J.is_null(v) ? std::string() : J.str(J.find(v, "type")); };
     const std::string norm = type_of("normalizer"), pre = type_of("pre_tokenizer"), dec = type_of("decoder");
+    {   // added_tokens: [{"id": 0, "content": "<s>", "single_word": false, "lstrip": false, "rstrip": false, "normalized": false, "special": true}, ..]
+        const JSpan at = J.find(root, "added_tokens");
+        std::vector<JSpan> items;
+        if (at.ok() && !J.is_null(at) && J.elements(at, items)) {
+            for (const JSpan &it : items) {
+                const JSpan id = J.find(it, "id"), content = J.find(it, "content");
+                if (!id.ok() || !content.ok()) return fail(MX_EINVAL, "tokenizer.json: an added token without id / content");
+                if (J.is_true(J.find(it, "single_word")) || J.is_true(J.find(it, "normalized")))
+                    return fail(MX_EUNSUPPORTED, "tokenizer.json: added token options single_word / normalized");
+                const std::string s = J.str(content);
+                if (s.empty()) continue;
+                t->added.push_back({s, (int32_t)strtol(js.c_str() + id.b, nullptr, 10), J.is_true(J.find(it, "lstrip")), J.is_true(J.find(it, "rstrip")),
+                                    !J.is_false(J.find(it, "special"))});
+            }
+            t->added_from_json = true;
+        }
+    }
     if (type == "WordPiece") {
         if (norm != "BertNormalizer") return fail(MX_EUNSUPPORTED, "tokenizer.json: normalizer '%s' (BertNormalizer only)", norm.c_str());
         if (pre != "BertPreTokenizer") return fail(MX_EUNSUPPORTED, "tokenizer.json: pre_tokenizer '%s' (BertPreTokenizer only)", pre.c_str());

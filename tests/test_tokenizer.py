@@ -52,6 +52,8 @@ TEXTS = [
     "",
     "   ",
     "it 's the tax . do not say ' no ' !",
+    # added tokens are cut out of the RAW text first, case-sensitively, whatever the normaliser does later
+    "hello [SEP] world", "[CLS]x[MASK] [mask] [PAD][PAD]", "a [UNK] b [SE P] [SEP", "[SEP][SEP]the[CLS]",
 ]
 
 

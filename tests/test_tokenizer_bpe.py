@@ -25,6 +25,8 @@ TEXTS = [
     "tokenizing   long\twords\nand don't re-embed; they've said: \"we'll do it\".", "unknownword zzzqqq the", "a" * 120 + " the",
     "中文 and the", "", "   ", " leading and trailing  ", "\n\n\nnew\n\nlines\n", "it 's the tax . do not say ' no ' !",
     "x y z　w", "I'M SHOUTING, AREN'T I? we'd've", "🙂🙂 🫠", "1e10 3.5% $100 #tag @user", "tab\t\tend\t",
+    # added tokens are cut out of the RAW text first: "<s>" is an HTML tag, and a document may hold any of these
+    "a<s>b", "x <mask> y", "x  \t<mask>y <mask>", "</s></s>", "<pad> <unk>x", "a <mas k> < mask> <MASK> <s", "<s><s>the</s>",
 ]
 
 
@@ -39,7 +41,9 @@ def toks(lib_built, tmp_path_factory):
     trainer.save_model(str(d))
     vj, mg = str(d / "vocab.json"), str(d / "merges.txt")
     hf = ByteLevelBPETokenizer(vj, mg)
-    hf.add_special_tokens(SPECIALS)
+    from tokenizers import AddedToken
+    # (as the tokenizer.json of the RoBERTa family lists them: <mask> swallows the white space in front of it)
+    hf.add_special_tokens(SPECIALS[:4] + [AddedToken("<mask>", lstrip=True, special=True)])
     hf._tokenizer.post_processor = RobertaProcessing(("</s>", hf.token_to_id("</s>")), ("<s>", hf.token_to_id("<s>")))
     return hf, ByteLevelBpeTokenizer(vj, mg), json.load(open(vj, encoding="utf-8"))
 

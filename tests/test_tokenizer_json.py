@@ -68,7 +68,10 @@ def bpe(lib_built, tmp_path_factory):
     tr.train_from_iterator(CORPUS, vocab_size=700, min_frequency=1, special_tokens=SPECIALS, show_progress=False)
     tr.save_model(str(d))
     hf = ByteLevelBPETokenizer(str(d / "vocab.json"), str(d / "merges.txt"))
-    hf.add_special_tokens(SPECIALS)
+    from tokenizers import AddedToken
+    # (as the tokenizer.json of the RoBERTa family lists them: <mask> swallows the white space in front of it -- what the handle built
+    # from vocab.json + merges.txt assumes, and what the JSON handle reads from `added_tokens`)
+    hf.add_special_tokens(SPECIALS[:4] + [AddedToken("<mask>", lstrip=True, special=True)])
     hf._tokenizer.post_processor = RobertaProcessing(("</s>", hf.token_to_id("</s>")), ("<s>", hf.token_to_id("<s>")))
     hf.save(str(d / "tokenizer.json"))
     return hf, JsonTokenizer(str(d / "tokenizer.json")), ByteLevelBpeTokenizer(str(d / "vocab.json"), str(d / "merges.txt")), d
