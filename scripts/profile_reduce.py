@@ -89,8 +89,18 @@ def main():
     bench = {}
     try:
         bench = json.loads(open(os.path.join(prof, f"{tag}_bench.json")).read())
+        # (round 6: the side legs' full reports live in a second file, bench.py --sides-out)
+        side = os.path.join(out_dir, "bench_sides.json")
+        if os.path.exists(side):
+            bench.update(json.load(open(side)))
+            with open(side) as f, open(os.path.join(prof, f"{tag}_bench_sides.json"), "w") as g:
+                g.write(f.read())
     except Exception:
         pass
+    el = find(os.path.join(out_dir, "enc_like_stats"), "_kernel_stats.csv")
+    if el:
+        with open(el) as f, open(os.path.join(prof, f"{tag}_enc_like_kernel_stats.csv"), "w") as g:
+            g.write(f.read())
     for label, want, fname, pat in (("i8", "scan8_kernel<3, 1, 1>", f"{tag}_scan8_traffic.json", "pmc_*"),
                                     ("768", "scan8_kernel<6, 1, 1>", f"{tag}_scan8_768_traffic.json", "pmc768_*"),
                                     ("bf16", "scan16_kernel<3, 1>", f"{tag}_scan16_traffic.json", "pmc_*"),

@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # (the 1.25M-row and encoder-like legs launch the same kernels at other sizes: off under the profiler, like --small-steps 0)
-BENCH="python $ROOT/bench.py --ingest-chunks 0 --bge-chunks 0 --no-cpu-baseline --shard-legs 0 --enc-like-rows 0 --text-docs 0 --precise-chunks 0"
+BENCH="python $ROOT/bench.py --ingest-chunks 0 --bge-chunks 0 --short-seqs 0 --no-cpu-baseline --shard-legs 0 --enc-like-rows 0 --text-docs 0 --precise-chunks 0 --sides-out $OUT/sides_scratch.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --steps 50 --warmup 10 --alt-steps 20 --side-steps 20 --small-steps 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats768" -- $BENCH --dim 768 --steps 30 --warmup 5 --alt-steps 0 --side-steps 0 > "$OUT/bench768_under_rocprof.json" 2> "$OUT/stats768.log"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"; do
@@ -21,7 +21,9 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WA
   D=$OUT/pmc768_$(echo $C | tr ' ' '_' | cut -c1-60)
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$D" -- $BENCH --dim 768 --steps 6 --warmup 2 --alt-steps 0 --side-steps 0 > "$D.json" 2> "$D.log"
 done
-$BENCH > "$OUT/bench.json" 2> "$OUT/bench.log"
+$BENCH --sides-out "$OUT/bench_sides.json" > "$OUT/bench.json" 2> "$OUT/bench.log"
+# the centred int8 copy (round 6): the enc_like leg alone under the kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/enc_like_stats" -- python $ROOT/scripts/gpu_enc_like.py 10000000 30 > "$OUT/enc_like.json" 2> "$OUT/enc_like_stats.log"
 # package power and shader clock while the scan kernel (and its ablations: 1 = DMA stream only,
 # 4 = fragment reads + MFMA without the DMA) runs back to back for >= 5 s
 if [ -x $ROOT/build_ub/scan8_ub_0 ]; then   # the int8-copy scan on signed Gaussian-like bytes, no records
@@ -51,7 +53,7 @@ done
 python $ROOT/scripts/profile_encoder_traffic.py "$OUT" > "$OUT/encoder_bge_traffic.txt" 2>&1
 # effective shader clock and MFMA-busy fraction of every encoder kernel (PMC pass of its own)
 timeout 300 bash $ROOT/scripts/profile_encoder_clock.sh > "$OUT/encoder_clock_mfma.txt" 2>&1
-python $ROOT/bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.log"
+python $ROOT/bench.py --sides-out "$OUT/bench_default_sides.json" > "$OUT/bench_default.json" 2> "$OUT/bench_default.log"
 python "$ROOT/scripts/profile_reduce.py" "$OUT" "$TAG"
 # the raw rocprofv3 directories are large (gpurun brings back at most 64 MiB): keep the summaries and the logs
-rm -rf "$OUT"/stats "$OUT"/stats768 "$OUT"/enc_stats "$OUT"/enc_bge_stats "$OUT"/encpmc_*/ "$OUT"/pmc_*/ "$OUT"/pmc768_*/
+rm -rf "$OUT"/enc_like_stats "$OUT"/stats "$OUT"/stats768 "$OUT"/enc_stats "$OUT"/enc_bge_stats "$OUT"/encpmc_*/ "$OUT"/pmc_*/ "$OUT"/pmc768_*/
