@@ -11,8 +11,9 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-# (the 1.25M-row and encoder-like legs launch the same kernels at other sizes: off under the profiler, like --small-steps 0)
-BENCH="python $ROOT/bench.py --ingest-chunks 0 --bge-chunks 0 --short-seqs 0 --no-cpu-baseline --shard-legs 0 --enc-like-rows 0 --text-docs 0 --precise-chunks 0 --sides-out $OUT/sides_scratch.json"
+# (the 1.25M-row, encoder-like and cfg2 legs launch the same kernels at other sizes -- cfg2 runs scan8_kernel<3,1,1> on 100k rows since
+# its copy stays int8 (round 6): off under the profiler, like --small-steps 0)
+BENCH="python $ROOT/bench.py --ingest-chunks 0 --bge-chunks 0 --short-seqs 0 --no-cpu-baseline --shard-legs 0 --enc-like-rows 0 --cfg2-segments 0 --text-docs 0 --precise-chunks 0 --sides-out $OUT/sides_scratch.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --steps 50 --warmup 10 --alt-steps 20 --side-steps 20 --small-steps 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats768" -- $BENCH --dim 768 --steps 30 --warmup 5 --alt-steps 0 --side-steps 0 > "$OUT/bench768_under_rocprof.json" 2> "$OUT/stats768.log"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"; do
