@@ -1027,7 +1027,7 @@ def run(a):
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-    if "MEMEX_HIP_SPIN" not in os.environ and "MEMEX_HIP_NO_SPIN" not in os.environ:
+    if "MEMEX_HIP_SPIN" not in os.environ:
         os.environ["MEMEX_HIP_SPIN"] = "1"  # a benchmark owns its core: poll the completion word (servers sleep by default)
 
     # ---- corpus shard in HBM (generated on device in blocks; ids are global)

@@ -86,19 +86,19 @@ struct mx_encoder {
     float *sp_part = nullptr;
     // small passes of the GEMM-by-GEMM models (hidden 768): the two Add & LayerNorm GEMMs run split over k with f32 partials and a
     // reduce + LayerNorm kernel behind them (one 64 x 768 workgroup looping over k = 3072 is an 80 us latency chain)
-    bool split_small = true;  // MEMEX_HIP_SPLITK=0: keep the fused Add & LayerNorm GEMMs at every pass size (tests, A/B)
+    bool split_small = true;  // MEMEX_HIP_DEBUG splitk=0: keep the fused Add & LayerNorm GEMMs at every pass size (tests, A/B)
     float *sk_part = nullptr; // [kSplitMax][kSplitRows][H] f32
     float *sk_zero = nullptr; // [3H] zeros: the partial GEMMs' bias (the reduce kernel adds the real one)
-    bool small_pass = true;   // MEMEX_HIP_SMALL=0: small passes take the large-pass kernels (tests, A/B)
-    bool attn_f32 = false;    // MEMEX_HIP_ATTN_F32=1: the bf16x3 mode's attention on the f32 MFMA instead of split bf16 products (tests)
-    int small_rows = kSmallRows;  // passes of at most this many packed rows take the small-pass layer (MEMEX_HIP_SMALL_ROWS)
+    bool small_pass = true;   // MEMEX_HIP_DEBUG small=0: small passes take the large-pass kernels (tests, A/B)
+    bool attn_f32 = false;    // MEMEX_HIP_DEBUG attn_f32=1: the bf16x3 mode's attention on the f32 MFMA instead of split bf16 products (tests)
+    int small_rows = kSmallRows;  // passes of at most this many packed rows take the small-pass layer (MEMEX_HIP_DEBUG small_rows=N)
     char *h_io = nullptr;     // pinned, device-mapped page of a query-sized host call: ids | lens | embeddings (mx_encoder_encode)
     int32_t *cu = nullptr, *tok_seq = nullptr, *tok_pos = nullptr, *lens_dev = nullptr, *ids_dev = nullptr;
     void *attn_plan = nullptr;  // attention work list of the pass in flight (kAttnPlanBytesPerSeq per sequence)
     float *out_dev = nullptr;
     bool profiling = false;
-    bool fused_tail = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_UNFUSED_TAIL=1 keeps the three GEMMs
-    bool pgemm = true;        // large passes run their GEMMs on pgemm_kernel (encoder_pgemm.hip); MEMEX_HIP_PGEMM=0: gemm_kernel
+    bool fused_tail = false;  // layer tail as one kernel (hidden 384); MEMEX_HIP_DEBUG unfused_tail=1 keeps the three GEMMs
+    bool pgemm = true;        // large passes run their GEMMs on pgemm_kernel (encoder_pgemm.hip); MEMEX_HIP_DEBUG pgemm=0: gemm_kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wait = nullptr, ev_done = nullptr;
     mx_encoder_stats stats{};
     std::string key;  // registry key (mx_encoder_open); empty = private

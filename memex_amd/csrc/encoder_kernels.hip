@@ -472,8 +472,8 @@ static hipError_t gemm_go(hipStream_t s, const GemmParams &p) {
 // configuration sums k in the same order.  INSIDE the encoder (scripts/r3_enc_ab.sh: same box, same process,
 // real operands, the package at its power cap) the gain is +1.2 % chunks/s for the hidden-768 models with the QK
 // projection alone on big tiles, -1.3 % at hidden 384, and the V projection loses 30 us per layer (its
-// feature-major epilogue): so the default is bit 0 (QK) for K >= 768 only.  MEMEX_HIP_GEMM_BIG=<mask> (bit 0 QK,
-// bit 1 V, bit 2 bias / GELU GEMMs) overrides for A/B runs.
+// feature-major epilogue): so the QK projection alone takes them, for K >= 768 only (the A/B mask of that measurement --
+// bit 0 QK, bit 1 V, bit 2 bias / GELU GEMMs -- is gone from the library; scripts/gemm_ubench.hip still runs every tile).
 constexpr int kBigTileRows = 32768;
 
 hipError_t launch_gemm(hipStream_t s, int epi, const GemmParams &p) {
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(bf16_t *__restrict__ x, in
                                                        const float *__restrict__ beta, float eps, int rev) {
     const int l = threadIdx.x % TPR;
     // rev: rows from the END of the matrix -- the GEMM that reads the result starts where this launch wrote last (worth 0.4 %
-    // of a hidden-768 layer: W1 664 -> 657 us, QK 283.6 -> 281; the launch itself 67 us either way); MEMEX_HIP_LN_REV=0: forward
+    // of a hidden-768 layer: W1 664 -> 657 us, QK 283.6 -> 281; the launch itself 67 us either way)
     const int row = rev ? rows - 1 - (int)(blockIdx.x * (256 / TPR) + threadIdx.x / TPR) : (int)(blockIdx.x * (256 / TPR) + threadIdx.x / TPR);
     if (row >= rows || row < 0) return;
     bf16_t *xr = x + (size_t)row * ld;
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int pitch = hidden * 2;
-    // MEMEX_HIP_ATTN_SAFE=2 .. 6 (measurement only): 2, 3, 4 no key loop; 3: no q loads and no ctx stores either; 4: no ctx
+    // MEMEX_HIP_DEBUG attn_safe=2 .. 6 (measurement only): 2, 3, 4 no key loop; 3: no q loads and no ctx stores either; 4: no ctx
     // stores; 5: key loop only (no DMA traffic, no q loads, no ctx stores); 6: everything but the ctx stores
     const bool no_keys = mode >= 2 && mode <= 4;
     const bool q_live = mode != 3 && mode != 5, c_live = mode < 3, kv_live = mode != 5;
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(kAttnWaves * 64, 4) void attention_kernel(const bf1
 
     const uint64_t all = n_my >= 64 ? ~0ull : (1ull << n_my) - 1ull;
     if (mode != 1) pass(std::false_type{}, all, all);
-    else my_redo = all;  // MEMEX_HIP_ATTN_SAFE=1: everything through the running-maximum loop
+    else my_redo = all;  // MEMEX_HIP_DEBUG attn_safe=1: everything through the running-maximum loop
     if (mode >= 2) return;
     // items some wave of this workgroup has to redo (rare): staged again by everybody, computed by the waves that asked
     if (my_redo != 0ull && (tid & 63) == 0) __hip_atomic_fetch_or(wg_redo, my_redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1378,7 +1378,7 @@ static size_t attn_lds(int d) { return (size_t)2 * 2 * kAttnStage * d * 2 + 16; 
 // Short sequences are bound by the per-item cost instead -- 134 us per 131k tokens at 128-token sequences, 208 at 64, against
 // 164 at 512 (profiles/r5_encoder_short_windows.txt) -- and pairs win: +0.8 % per pass at 256 tokens, +3.2 % at 128, +4.5 % at
 // ragged U[32, 128], +7 % at 64 (profiles/r5_attention_pairs_short_windows.txt).  So the pass decides: pairs when its longest
-// sequence has <= 256 tokens.  MEMEX_HIP_ATTN_PAIR=1 / 0: always / never (tests, A/B).  Same arithmetic per head either way.
+// sequence has <= 256 tokens.  MEMEX_HIP_DEBUG attn_pair=1 / 0: always / never (tests, A/B).  Same arithmetic per head either way.
 constexpr int kAttnPairMaxLen = 256;
 // ... and attention_short_kernel (above) takes every pass whose longest sequence has <= 128 tokens (same box, full passes,
 // profiles/r5_attention_short_kernel_ab.txt): 126.6k -> 130.4k sequences/s at 128 tokens, 170.7k -> 181.9k at U[32, 128],
@@ -1386,7 +1386,7 @@ constexpr int kAttnPairMaxLen = 256;
 // query 0.255 -> 0.240 ms (all-MiniLM-L6-v2), 0.486 -> 0.453 (L12): a plain grid of one workgroup per item beats sixteen-wave
 // workgroups walking a list at every size.  (Its first two forms did not: fragments fetched per wave from global memory,
 // 117.8k at 128 tokens; all fragments read from LDS up front and held in registers, 144 VGPRs, 125.5k.)
-// MEMEX_HIP_ATTN_SHORT=0 / 1: never / as the rule says (tests, A/B); MEMEX_HIP_ATTN_SHORT_LDS=0: the per-wave global form.
+// MEMEX_HIP_DEBUG attn_short=0 / 1: never / as the rule says (tests, A/B); attn_short_lds=0: the per-wave global form.
 constexpr int kAttnShortMaxLen = 128;
 enum { ATTN_ONE = 0, ATTN_PAIR = 1, ATTN_SHORT = 2 };
 static int attn_form(int heads, int d_head, int max_len, int B) {
@@ -1412,7 +1412,7 @@ hipError_t launch_attention(hipStream_t s, const bf16_t *q, const bf16_t *k, con
     const bool pair = form == ATTN_PAIR;
     const int n_items = B * attention_groups(heads, d_head, max_len, B);
     const size_t lds = attn_lds(pair ? 64 : d_head);
-    // MEMEX_HIP_ATTN_SAFE=1: running-maximum loop only (tests compare it with the default fast path); 2 .. 6: measurement modes
+    // MEMEX_HIP_DEBUG attn_safe=1: running-maximum loop only (tests compare it with the default fast path); 2 .. 6: measurement modes
     // (no key loop / no loads / no stores: wrong results)
     const int mode = [] {
         const int m = debug_flag("attn_safe", 0);

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restr
 //     that lane to supply key slots 8 h .. 8 h + 7, so slot s of a k-step holds key s with bits 2 and 3 swapped (V^T is
 //     staged in that order) and the lane's P registers 8 t .. 8 t + 7 ARE its B operand of k-step t, split hi / lo in place;
 //   * q is split once per lane (registers), scaled first.
-// Dropped: the lo x lo products (2^-18 relative), as in the GEMMs.  MEMEX_HIP_ATTN_F32=1 (read when an encoder is created) keeps the f32-MFMA kernel
+// Dropped: the lo x lo products (2^-18 relative), as in the GEMMs.  MEMEX_HIP_DEBUG attn_f32=1 (read when an encoder is created) keeps the f32-MFMA kernel
 // (tests hold the two against each other).
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8p;

@@ -923,7 +923,6 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     fp.dists = d_dists;
     fp.n_found = d_nfound;
     fp.max_err = idx->profiling ? s.max_err : nullptr;
-    fp.debug_stop = 0;  // (stage timing of finish_kernel: scripts/r2_finish_probe.sh set it from the environment)
     fp.done_ctr = s.done_ctr;
     fp.dev_flags = s.dev_flags;
     fp.host_flags = s.host_sum;
@@ -932,7 +931,7 @@ int search_batch(mx_index *idx, const float *d_q, int B, int k, uint64_t *d_ids,
     // finish + completion: the kernel's last workgroup writes the batch summary into pinned host memory and
     // stores the launch's sequence number behind it; the host spins on that word (no D2H copy command and no
     // memset between batches: the host gap between two batches drops from 45 to 22 us, the kernel grows by
-    // 8: scripts/r2_step_gaps.sh; waiting in hipStreamSynchronize is as fast, see MEMEX_HIP_NO_SPIN below).  A kernel that never signals (fault) is
+    // 8: scripts/r2_step_gaps.sh; waiting in hipStreamSynchronize is as fast, see MEMEX_HIP_SPIN below).  A kernel that never signals (fault) is
     // caught by the synchronize after the spin budget.  -> the summary's overflow code
     auto finish_and_wait = [&]() -> int {
         fp.seq = ++s.flag_seq;

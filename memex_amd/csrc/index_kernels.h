@@ -212,7 +212,6 @@ struct FinishParams {
     float *scores, *dists;
     int32_t *n_found;
     float *max_err;             // null unless profiling
-    int debug_stop;             // 0; 1..8 = return after that stage (MEMEX_HIP_FINISH_STOP: timing probes only, results are garbage)
     // completion signal: the LAST workgroup of the launch writes a 4-word summary of the batch's flag block
     // (dev_flags: [overflow 256 | cand_cnt 256 | e1 256 | qbad 256]) into host-mapped memory and then stores
     // seq behind it (system scope) -- the host polls that word instead of queueing a D2H copy (and a flag memset) and waiting in

@@ -602,7 +602,6 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     if (p.todo && !p.todo[q]) return;
-    if (p.debug_stop == 8) return;
     const int k = p.k, ds = p.ds;
     const uint64_t want64 = p.n_rows < (uint64_t)k ? p.n_rows : (uint64_t)k;
     const int want = (int)want64;
@@ -672,7 +671,6 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     if (tid <= 2 * nwg) s_off[tid] = tid < 2 * nwg ? roff : R;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    if (p.debug_stop == 5) return;
     // (b) one record per thread and trip (all of a query's records are in flight together): find its
     // lane buffer by binary search in the scanned counts, test the 16 scores, append the passing rows
     auto put = [&](uint32_t at, float sc, uint32_t row) {
@@ -734,7 +732,6 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     for (uint32_t z = tid; z < nz; z += kFinThreads)
         if ((uint64_t)p.zero_rows[z] < p.n_rows) put(atomicAdd(&s_cnt, 1u), 1.0f, p.zero_rows[z]);
     __syncthreads();
-    if (p.debug_stop == 6) return;
     uint32_t M = s_cnt;
     const bool too_many = M > (uint32_t)kCandCap;  // more than the block can hold: keep what fits (any subset yields a
                                                     // valid rescan threshold) and flag the query for the rescan
@@ -764,7 +761,6 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     }
     {
         const uint32_t kth = block_kth_largest<kFinPer>(key, valid, (uint32_t)want, s_hist, s_pick);
-        if (p.debug_stop == 7) return;
         const float L1 = key_f32(kth);
         if (tid == 0) s_cnt = 0;
         __syncthreads();  // also: every thread has its entries in registers, ent[] may be overwritten
@@ -789,7 +785,6 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
     }
     const uint32_t m1 = s_cnt;
     if (tid == 0) p.cand_cnt[q] = m1;
-    if (p.debug_stop == 1) return;
 
     // ---- stage 2: f32 rescoring of the m1 survivors (one wave per row, 4 rows in flight per wave):
     // s2 = sum fma(q_i/|q|, c_i/|c|), |s2 - cos| <= e2 (any summation order)
@@ -860,7 +855,6 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
         if (lane == 0 && err > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(p.max_err), __float_as_uint(err));
     }
     __syncthreads();
-    if (p.debug_stop == 2) return;
 
     // ---- k-th best f32 score L; keep [L - 2*e2, +inf); publish the retry threshold
 #pragma unroll
@@ -922,7 +916,6 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
         __syncthreads();
     }
     const uint32_t m2 = s_cnt;
-    if (p.debug_stop == 3) return;
 
     // ---- stage 3: exact DistCosine: sequential f64 chain, one thread per row, key = (dist_bits << 32 |
     // row).  Up to kStageRows survivors (the usual case: k plus a few) are first copied to LDS by the
@@ -968,7 +961,6 @@ __device__ __forceinline__ void finish_query(const FinishParams &p) {
         }
     }
     __syncthreads();
-    if (p.debug_stop == 4) return;
 
     // ---- order by (dist, row) and emit the first `want`
     uint64_t lim = ~0ull;  // keys above the want-th smallest need no rank

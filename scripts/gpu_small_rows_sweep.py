@@ -1,5 +1,5 @@
 """Where the small-pass layer should hand over to the bulk kernels: per-call time of mx_encoder_encode for B windows of S tokens
-under the threshold given by MEMEX_HIP_SMALL_ROWS (read at encoder creation).  usage: gpu_small_rows_sweep.py [l6|l12] [S]"""
+under the threshold given by MEMEX_HIP_DEBUG=small_rows=N (read at encoder creation).  usage: gpu_small_rows_sweep.py [l6|l12] [S]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,4 +17,4 @@ for B in (2, 4, 8, 16, 24, 32, 48, 64, 96, 128):
     t0 = time.perf_counter()
     for _ in range(40): enc.encode(ids, lens)
     out.append(f"{B * S}:{(time.perf_counter() - t0) / 40 * 1e3:.3f}")
-print(f"SMALL_ROWS={os.environ.get('MEMEX_HIP_SMALL_ROWS', 'default')} S={S} rows:ms  " + "  ".join(out))
+print(f"DEBUG={os.environ.get('MEMEX_HIP_DEBUG', 'default')} S={S} rows:ms  " + "  ".join(out))

@@ -6,7 +6,7 @@ from memex_amd.encoder import Encoder
 from memex_amd import weights as W
 
 def run(cfg, B, S, unfused, reps=5):
-    os.environ["MEMEX_HIP_UNFUSED_TAIL"] = "1" if unfused else "0"
+    os.environ["MEMEX_HIP_DEBUG"] = "unfused_tail=1" if unfused else ""
     enc = Encoder(cfg, W.synthetic_weights(cfg, 0))
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     ids = torch.randint(1000, cfg.vocab, (B, S), device="cuda", dtype=torch.int32, generator=g)

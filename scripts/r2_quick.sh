@@ -9,7 +9,7 @@ cd $ROOT
 python -m pytest tests/test_search_gpu.py tests/test_sharded_gpu.py -x -q 2>&1 | tail -15 > "$OUT/pytest.log"
 cd /tmp && export TMPDIR=/tmp
 for DIV in ${DIVS:-64}; do
-  export MEMEX_HIP_SAMPLE_DIV=$DIV
+  export MEMEX_HIP_DEBUG=sample_div=$DIV
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$DIV" -- python $ROOT/bench.py --ingest-chunks 0 --no-cpu-baseline --steps 40 --warmup 5 --alt-steps 0 --side-steps ${SIDE:-0} > "$OUT/bench_$DIV.json" 2> "$OUT/bench_$DIV.err"
   python - "$OUT/stats_$DIV" <<'PY'
 import csv, glob, sys, os

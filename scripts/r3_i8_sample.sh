@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3: int8 filter copy, sample size sweep (MEMEX_HIP_SAMPLE_DIV): step time, collect launch, candidates, retries
+# round 3: int8 filter copy, sample size sweep (MEMEX_HIP_DEBUG sample_div=N): step time, collect launch, candidates, retries
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/i8s
 for DIV in ${DIVS:-64 32 16 8 4}; do
-  MEMEX_HIP_SAMPLE_DIV=$DIV timeout 600 python bench.py --scan ${SCAN:-i8} --steps 20 --warmup 5 --ingest-chunks 0 --no-cpu-baseline --alt-steps 0 --side-steps 0 > gpurun_out/i8s/b_$DIV.json 2> gpurun_out/i8s/b_$DIV.err
+  MEMEX_HIP_DEBUG=sample_div=$DIV timeout 600 python bench.py --scan ${SCAN:-i8} --steps 20 --warmup 5 --ingest-chunks 0 --no-cpu-baseline --alt-steps 0 --side-steps 0 > gpurun_out/i8s/b_$DIV.json 2> gpurun_out/i8s/b_$DIV.err
   python - gpurun_out/i8s/b_$DIV.json $DIV <<'PY'
 import json, sys
 for ln in open(sys.argv[1]):

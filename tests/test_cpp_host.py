@@ -41,6 +41,15 @@ def test_shard_pool_hand_off(tmp_path):
     assert r.returncode == 0 and "OK shard pool" in r.stdout, r.stdout + r.stderr
 
 
+def test_debug_flag_parser(tmp_path):
+    """MEMEX_HIP_DEBUG (memex_amd/csrc/mx_debug.h), the library's one kernel-variant switch: re-read when the string
+    changes, defaults for absent keys, malformed items ignored, safe from several threads."""
+    exe = str(tmp_path / "test_debug_flag")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_debug_flag.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK debug flag" in r.stdout, r.stdout + r.stderr
+
+
 def test_cpp_tokenizer_class_matches_the_tokenizers_package(tmp_path, lib_built):
     """memex::Tokenizer (the C++ host's face of mx_tokenizer_*): ids, decoded text and segment_text windows of a few
     documents equal the `tokenizers` package's (the crate the reference calls, embedding.rs:163-195)."""
