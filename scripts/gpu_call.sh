@@ -1,9 +1,16 @@
 #!/bin/bash
-# r6p: kernel stats of the headline command without the legs that launch the same kernel at other sizes
-cd /tmp && export TMPDIR=/tmp
-ROOT="$GRAFT_REPO_ROOT"; OUT=$ROOT/gpurun_out/r6p; rm -rf $OUT; mkdir -p $OUT
-BENCH="python $ROOT/bench.py --ingest-chunks 0 --bge-chunks 0 --short-seqs 0 --no-cpu-baseline --shard-legs 0 --enc-like-rows 0 --cfg2-segments 0 --text-docs 0 --precise-chunks 0 --sides-out $OUT/sides.json"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --steps 50 --warmup 10 --alt-steps 20 --side-steps 20 --small-steps 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
-f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); cp "$f" $ROOT/gpurun_out/r6p_bench_kernel_stats.csv
-head -8 $ROOT/gpurun_out/r6p_bench_kernel_stats.csv | cut -c1-160
-tail -c 600 "$OUT/bench_under_rocprof.json" > /dev/null; cp "$OUT/bench_under_rocprof.json" $ROOT/gpurun_out/r6p_bench_under_rocprof.json; rm -rf $OUT/stats
+# round 6: full GPU suite + smoke + the default bench line at HEAD
+mkdir -p gpurun_out
+cd $GRAFT_REPO_ROOT
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r6h_tests.txt 2>&1; echo "tests rc=$?" | tee -a gpurun_out/r6h_tests.txt
+tail -3 gpurun_out/r6h_tests.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r6h_smoke.txt 2>&1; tail -2 gpurun_out/r6h_smoke.txt
+timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 --sides-out gpurun_out/r6h_bench_sides.json > gpurun_out/r6h_bench.json 2> gpurun_out/r6h_bench.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+r = json.loads(open('gpurun_out/r6h_bench.json').read().strip().splitlines()[-1])
+print(r['value'], r['ms_per_step'], r['roofline']['frac'], r['roofline'].get('traffic_source'))
+for k in ('encoder_minilm', 'encoder_bge', 'encoder_minilm_128tok'):
+    print(k, r['roofline'].get(k))
+print(json.dumps(r.get('sides'))[:1500])
+PY
