@@ -91,7 +91,7 @@ struct ScanParams {
     float *lane_max;         // [512][nwg] sample mode: running maximum of each lane
     uint32_t *overflow;      // [256]
     // 8-bit filter copy (scan8_kernel): xh holds int8 fragments, tiles are 64 rows
-    const float *tscale = nullptr;  // [cap_rows / 64][kTscaleFloats]: quantisation steps of a tile's two halves, their residual bounds, max / min a_c
+    const float *tscale = nullptr;  // [cap_rows / 64][kTscaleFloats]: quantisation steps of a tile's two halves, their residual bounds, 1 / step of a centred copy
     const float *qscale = nullptr;  // [256] quantisation step of each query
     const float *qa = nullptr, *qb = nullptr;  // [256] a row's bound is qa + qb * residual (launch_prep_queries)
     // centred bf16 copy (scan16_kernel, launch_shadow): the copy holds r_c = c/|c| - a_c m for a fixed unit direction m (the
@@ -109,7 +109,8 @@ hipError_t launch_scan(hipStream_t s, int kc, bool collect, int nwg, const ScanP
 hipError_t launch_scan16(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p);
 // scan over the 8-bit filter copy: kc = ds / 128 in 1 .. 12, tile_begin / tile_end / tile_stride count 64-row tiles
 constexpr int kTile8Rows = 64;
-constexpr int kTscaleFloats = 8;  // per 64-row tile: steps of its two halves | residual bounds | largest a_c | smallest a_c (centred copy, else 0)
+constexpr int kTscaleFloats = 8;  // per 64-row tile: steps of its two halves | residual bounds | 1 / step (centred copy, else 0) | 0
+constexpr float kMinStep8 = 1.0f / 32768.0f;  // smallest quantisation step of a CENTRED int8 copy and of its queries (scan8.hip: |a_q a_c / (s_h s_q)| < 2^30)
 constexpr int kScaleRing8 = 32;  // tiles whose scales can be in flight (15 slots ahead at one slot per tile, + the tile being multiplied)
 constexpr int kScale8Entry = 512;  // per tile: [0, 16) the steps and residual bounds of its halves | [256, 512) a_c of its 64 rows (centred copy)
 constexpr int kScan8LdsBytes = kRing16 * kSlot16Bytes + kScaleRing8 * kScale8Entry + 256;  // ... | 256 B that absorb the empty a_c operations
@@ -118,7 +119,7 @@ hipError_t launch_scan8(hipStream_t s, int kc, bool collect, int nwg, const Scan
 // (re)build half tiles [half0, half1) (32 rows each) of the 8-bit filter copy from the padded f32 store: per half
 // tile one quantisation step = max |c_i/|c|| / 127 over its rows below row_hi (rows at or above row_hi, and zero-norm
 // rows, are stored as zeros) and one residual bound = 1.01 * max_rows |c/|c| - step * c8| + 1e-6; both go to
-// tscale[kTscaleFloats * (h / 2) + (h & 1)] and [.. + 2] (then the half tiles' largest / smallest a_c): the 32 bytes of a 64-row scan tile;
+// tscale[kTscaleFloats * (h / 2) + (h & 1)] and [.. + 2] (then 1 / step of the halves of a centred copy): the 32 bytes of a 64-row scan tile;
 // ec_max as launch_shadow.
 // Centred form (mean != nullptr, f32 corpora up to kMaxKC slots): the quantiser sees r_c = c/|c| - a_c mean, amean[row] = a_c
 // (f32; zero for the zero rows), steps and residual bounds are those of the shorter vectors, rc_max (device word, atomicMax'ed

@@ -283,7 +283,10 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
         __syncthreads();
         mx = fmaxf(fmaxf(__uint_as_float(s_red[0]), __uint_as_float(s_red[1])), fmaxf(__uint_as_float(s_red[2]), __uint_as_float(s_red[3])));
         __syncthreads();  // s_red is reused for the residual below
-        const float sq = mx / 127.0f, qinv = mx > 0.0f ? 127.0f / mx : 0.0f;
+        // (centred copy: the step stays at or above kMinStep8, as the rows' does -- scan8.hip's accumulator start a_q a_c / (s_h s_q)
+        // must fit an int32; a query whose residual is that short loses nothing it can measure: r2 below is its actual residual)
+        const float sq = (mean && mx > 0.0f) ? fmaxf(mx / 127.0f, kMinStep8) : mx / 127.0f;
+        const float qinv = mx > 0.0f ? (mean ? 1.0f / sq : 127.0f / mx) : 0.0f;
         if (tid == 0) qscale[b] = sq;
         const int ksteps = ds / 32;
         int8_t *q8 = reinterpret_cast<int8_t *>(qfrag);

@@ -86,15 +86,22 @@ static_assert(ops_after<1>(2, 14) == 39 && ops_after<12>(2, 14) == 15 && ops_aft
 // QG = query groups (of 32) per wave: 1 = a pass of 256 queries (the kernel every batch size up to 256 runs);
 // 2 = a pass of 512 (each fragment read feeds two MFMAs; wave w holds the "virtual waves" 2w and 2w+1 of
 // theta_kernel's / finish_kernel's lane numbering; up to 512 dims)
-template <int KC, int MODE, int QG>
+// CEN = the centred copy (KC <= kMaxKC, one query group): see below
+template <int KC, int MODE, int QG, bool CEN>
 __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams p) {
+    static_assert(!CEN || (KC <= kMaxKC && QG == 1), "the centred form exists up to kMaxKC slots with one query group");
     constexpr int R = QG == 2 ? (KC <= 3 ? 8 : 4) : KC <= 8 ? 8 : KC <= 10 ? 4 : 2;  // fragment ring: what the 256 VGPRs leave next to qf
     extern __shared__ __attribute__((aligned(16))) char smem[];  // slot ring | per-tile ring [kScaleRing8] x kScale8Entry B
-    // Centred copy (ScanParams::amean, section 3.2c of DESIGN.md carried over to int8; up to kMaxKC slots, one query group): the
-    // copy holds the quantised r_c = c/|c| - a_c m, amean[row] = a_c, the query fragments the quantised r_q, qmean[q] = a_q;
-    // a row's score is a_q a_c + s_h s_q sum, evaluated per row in the tile epilogue
-    constexpr bool CEN_OK = KC <= kMaxKC && QG == 1;
-    const bool centred = CEN_OK && p.amean != nullptr;
+    // Centred copy (ScanParams::amean, section 3.2c of DESIGN.md carried over to int8): the copy holds the quantised
+    // r_c = c/|c| - a_c m, amean[row] = a_c, the query fragments the quantised r_q, qmean[q] = a_q; a row's score is
+    // a_q a_c + s_h s_q sum.  The a_q a_c term enters as the ACCUMULATOR'S INITIAL VALUE, I = trunc(a_c (a_q / s_q) (1 / s_h)) in
+    // units of the half tile's s_h s_q -- an int32 the MFMAs add the sum to -- so the tile epilogue is the plain copy's: one
+    // maximum tree over 16 integers, one conversion, two multiplications.  (Evaluating a_q a_c + s_h s_q sum per row in the
+    // epilogue -- the first form of this round -- ran on EVERY half tile of an encoder-shaped corpus: the quick upper-bound test in
+    // front of it never stopped one, profiles/r6_centred_int8_accumulator_init.txt.)  |I| < 2^30 + 1100 because the builder and
+    // prep_queries_kernel keep both steps of a centred copy at or above kMinStep8 = 2^-15; what the truncation and the f32
+    // roundings of I cost a score (<= s_h s_q + 5e-7) is inside kAccSlack.
+    constexpr bool centred = CEN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -118,11 +125,12 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
 #pragma unroll
         for (int i = 0; i < KC * 4; ++i) qf[g * KC * 4 + i] = src[(size_t)i * 64];
         theta[g] = MODE == 1 ? p.theta[vw * 32 + m] : 0.0f;
-        if (CEN_OK && g == 0) aq = centred ? p.qmean[vw * 32 + m] : 0.0f;
+        if (CEN && g == 0) aq = p.qmean[vw * 32 + m];
         qa[g] = MODE == 0 ? p.qa[vw * 32 + m] : 0.0f;
         qb[g] = p.qb[vw * 32 + m];
         sq[g] = p.qscale[vw * 32 + m];  // 0 for an unusable (zero / padded) query
     }
+    const float kq = CEN && sq[0] > 0.0f ? aq / sq[0] : 0.0f;  // a_q in units of the query's step
 
     // ---- 64-row tiles of this workgroup: tile_begin + (blockIdx + i*grid) * tile_stride
     const uint32_t grid = gridDim.x;
@@ -141,20 +149,29 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
     // (same 16 bytes, same LDS address: the waits below stay wave-uniform arithmetic).
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t is_ti = 0;
-    auto open_tile = [&]() {
-        const uint32_t tile = t0 + is_ti * tstep;
-        const bool live_tile = is_ti < nT;
+    // The per-tile operations of tile i ride one tile AHEAD of its slots (with the first slot of tile i-1; tile 0's before everything):
+    // they have landed -- and every wave has passed a barrier behind the wait that says so -- from position 0 of tile i-1 on, so the
+    // centred form can read tile i's a_c while tile i-1 is still in flight.  Two operations per tile start, as before: the wait
+    // schedule below does not change.
+    auto tile_ops = [&](uint32_t it) {
+        const uint32_t tile = t0 + it * tstep;
+        const bool live_tile = it < nT;
         __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.tscale + kTscaleFloats * (size_t)tile), 0, live_tile ? (uint32_t)(kTscaleFloats * 4) : 0u, 0x00020000);
-        char *sdst = smem + __builtin_amdgcn_readfirstlane(kRing16 * kSlot16Bytes + (is_ti & (kScaleRing8 - 1)) * kScale8Entry);
+        char *sdst = smem + __builtin_amdgcn_readfirstlane(kRing16 * kSlot16Bytes + (it & (kScaleRing8 - 1)) * kScale8Entry);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_void *)sdst, 4, lane4, 0, 0, 0);
         // a_c of the tile's 64 rows: 256 bytes behind the scales, fetched by ONE wave of the eight.  The others, and every wave of a
         // plain copy, issue the same operation on an empty descriptor (one wait schedule, no memory read) -- into a dump area of
         // their own: an out-of-range LDS-DMA lane still WRITES (zeros), and must not land on the values another wave fetched
         const float *abase = centred ? p.amean + (size_t)kTile8Rows * tile : p.tscale;
-        const bool mine = live_tile && centred && (int)(is_ti & 7u) == wave;
+        const bool mine = live_tile && centred && (int)(it & 7u) == wave;
         __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)abase, 0, mine ? (uint32_t)(kTile8Rows * 4) : 0u, 0x00020000);
         char *adst = mine ? sdst + 256 : smem + kRing16 * kSlot16Bytes + kScaleRing8 * kScale8Entry;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_void *)adst, 4, lane4, 0, 0, 0);
+    };
+    auto open_tile = [&]() {
+        const uint32_t tile = t0 + is_ti * tstep;
+        const bool live_tile = is_ti < nT;
+        tile_ops(is_ti + 1);
         const char *base = reinterpret_cast<const char *>(p.xh) + (size_t)tile * tilebytes;
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live_tile ? tilebytes : 0u, 0x00020000);
         ++is_ti;
@@ -171,6 +188,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
 #pragma unroll
     for (int g = 0; g < QG; ++g) cnt[g] = 0, best[g] = -INFINITY;
 
+    tile_ops(0);
 #pragma unroll
     for (int i = 0; i < kRing16 - 1; ++i) issue(i % KC, (uint32_t)i);
 
@@ -180,15 +198,49 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
 #pragma unroll
     for (int f = 0; f < R; ++f) a[f] = *reinterpret_cast<const i32x4 *>(smem + lane16 + f * 1024);
 
+    // ---- centred copy: init[u][r] = trunc(a_c[row] * (a_q / s_q) * (1 / s_h)), what the first MFMA of each half tile takes as C.
+    // All LDS reads of scales and a_c are inline asm (hipcc puts s_waitcnt vmcnt(0) in front of a plain LDS load that it thinks an
+    // LDS-DMA may have written, which would drain the ring once per tile).  Tile 0's values are computed here; tile i+1's behind
+    // tile i's epilogue: ten reads issued in front of the epilogue, one wait and 16 packed multiplications + 32 conversions behind
+    // it.  (Spreading that work over the tile's MFMA slots -- eight groups of 4 rows, each read a ring depth ahead of its use -- was
+    // built and measured: 4.5 % SLOWER on the same box, profiles/r6_centred_int8_accumulator_init.txt.)
+    f32x4 shs_c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // (s_h0, s_h1, e_h0, e_h1) of the tile in flight
+    f32x4 shs_n = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // ... of the next one
+    f32x4 inv_n = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // (1/s_h0, 1/s_h1, -, -) of the tile whose initial values are being computed
+    f32x4 acv[CEN ? 8 : 1];                        // a_c of this lane's rows, group j = half * 4 + (r >> 2): [j][r & 3]
+    i32x16 init[CEN ? 2 : 1];                      // [half tile]
+    i32x16 acc[QG * 2];                            // [query group][half tile]
+    auto entry_of = [&](uint32_t it) { return (uint32_t)(kRing16 * kSlot16Bytes) + (it & (kScaleRing8 - 1)) * (uint32_t)kScale8Entry; };
+    auto group_values = [&](int j) {
+        const float ku = kq * ((j >> 2) ? inv_n[1] : inv_n[0]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) init[j >> 2][(j & 3) * 4 + i] = (int)(acv[j][i] * ku);
+    };
+    if constexpr (CEN) {
+        if (live) {
+            const uint32_t sa = entry_of(0), aa = sa + 256 + (lane >> 5) * 16;
+            asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:16\n\t"
+                         "ds_read_b128 %2, %11\n\tds_read_b128 %3, %11 offset:32\n\tds_read_b128 %4, %11 offset:64\n\tds_read_b128 %5, %11 offset:96\n\t"
+                         "ds_read_b128 %6, %11 offset:128\n\tds_read_b128 %7, %11 offset:160\n\tds_read_b128 %8, %11 offset:192\n\tds_read_b128 %9, %11 offset:224\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(shs_c), "=&v"(inv_n), "=&v"(acv[0]), "=&v"(acv[1]), "=&v"(acv[2]), "=&v"(acv[3]), "=&v"(acv[4]), "=&v"(acv[5]),
+                           "=&v"(acv[6]), "=&v"(acv[7])
+                         : "v"(sa), "v"(aa)
+                         : "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) group_values(j);
+        }
+    }
     uint32_t rp = 0;
 #pragma unroll 1
     for (uint32_t ti = 0; ti < nT; ++ti) {
         const uint32_t tile = t0 + ti * tstep;
-        i32x16 acc[QG * 2];  // [query group][half tile]
+        if constexpr (!CEN) {
 #pragma unroll
-        for (int g = 0; g < QG * 2; ++g)
+            for (int g = 0; g < QG * 2; ++g)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][r] = 0;
+                for (int r = 0; r < 16; ++r) acc[g][r] = 0;
+        }
 
         static_for<0, KC>([&](auto kct) __attribute__((always_inline)) {
             constexpr int kc = decltype(kct)::value;
@@ -199,18 +251,19 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
             __builtin_amdgcn_s_barrier();  // ... for every wave; slot j-1 is free for slot j+15
             const uint32_t fb0 = rp * kSlot16Bytes + lane16, fb1 = rp1 * kSlot16Bytes + lane16;
             if (live) {
-#pragma unroll
-                for (int f = 0; f < 8; ++f) {
+                static_for<0, 8>([&](auto ft) __attribute__((always_inline)) {
+                    constexpr int f = decltype(ft)::value;
 #pragma unroll
                     for (int g = 0; g < QG; ++g)
-                        acc[g * 2 + (f & 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[g * KC * 4 + kc * 4 + (f >> 1)], acc[g * 2 + (f & 1)], 0, 0, 0);
+                        acc[g * 2 + (f & 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[f % R], qf[g * KC * 4 + kc * 4 + (f >> 1)],
+                                                                                      CEN && kc == 0 && f < 2 ? init[CEN ? (f & 1) : 0] : acc[g * 2 + (f & 1)], 0, 0, 0);
 #if MX_SCAN8_ABLATE == 2  /* scripts/scan8_ubench.hip: what would HALF the fragment reads buy (every read feeding two MFMAs; results meaningless) */
                     if ((f & 1) == 0)
 #endif
                     a[f % R] = *reinterpret_cast<const i32x4 *>(smem + (f + R < 8 ? fb0 : fb1) + ((f + R) & 7) * 1024);
                     if (f == 1) issue((kc + kRing16 - 1) % KC, rpi);
                     __builtin_amdgcn_sched_barrier(0);
-                }
+                });
             } else {
                 issue((kc + kRing16 - 1) % KC, rpi);
             }
@@ -222,27 +275,24 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
         // (read with inline asm: hipcc puts s_waitcnt vmcnt(0) in front of a plain LDS load that it thinks an LDS-DMA
         // may have written, which would drain the ring once per tile; the scales landed with the tile's first slot)
         f32x4 shs;  // steps of the two halves, residual bounds of the two halves
-        f32x4 amm = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // centred copy: largest a_c of the two halves, smallest a_c of the two halves
-        f32x4 acv[CEN_OK ? 8 : 1];                  // centred copy: a_c of this lane's rows, [half * 4 + (r >> 2)][r & 3]
 #if MX_SCAN8_ABLATE == 1  /* scripts/scan8_ubench.hip: no scale read */
         shs = f32x4{1.0f, 1.0f, 0.0f, 0.0f};
 #else
-        {
-            const uint32_t sa = kRing16 * kSlot16Bytes + (ti & (kScaleRing8 - 1)) * kScale8Entry;
-            if (CEN_OK && centred) {
-                // ... and with them the a_c of this lane's 2 x 16 rows -- rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each half -- in ONE
-                // batch of LDS reads behind ONE wait (three separate read-and-wait steps per tile cost 20 % of the launch)
-                const uint32_t aa = sa + 256 + (lane >> 5) * 16;
+        if constexpr (CEN) {
+            shs = shs_c;  // read with this tile's initial values, a tile ago
+            {  // the next tile's scales and a_c: reads issued here, consumed behind this tile's epilogue
+                const uint32_t sa = entry_of(ti + 1), aa = sa + 256 + (lane >> 5) * 16;
                 asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:16\n\t"
                              "ds_read_b128 %2, %11\n\tds_read_b128 %3, %11 offset:32\n\tds_read_b128 %4, %11 offset:64\n\tds_read_b128 %5, %11 offset:96\n\t"
-                             "ds_read_b128 %6, %11 offset:128\n\tds_read_b128 %7, %11 offset:160\n\tds_read_b128 %8, %11 offset:192\n\tds_read_b128 %9, %11 offset:224\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(shs), "=&v"(amm), "=&v"(acv[0]), "=&v"(acv[1]), "=&v"(acv[2]), "=&v"(acv[3]), "=&v"(acv[4]), "=&v"(acv[5]),
+                             "ds_read_b128 %6, %11 offset:128\n\tds_read_b128 %7, %11 offset:160\n\tds_read_b128 %8, %11 offset:192\n\tds_read_b128 %9, %11 offset:224"
+                             : "=&v"(shs_n), "=&v"(inv_n), "=&v"(acv[0]), "=&v"(acv[1]), "=&v"(acv[2]), "=&v"(acv[3]), "=&v"(acv[4]), "=&v"(acv[5]),
                                "=&v"(acv[6]), "=&v"(acv[7])
                              : "v"(sa), "v"(aa)
                              : "memory");
-            } else
-                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(shs) : "v"(sa) : "memory");
+            }
+        } else {
+            const uint32_t sa = kRing16 * kSlot16Bytes + (ti & (kScaleRing8 - 1)) * kScale8Entry;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(shs) : "v"(sa) : "memory");
         }
 #endif
 #pragma unroll
@@ -251,50 +301,6 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
             for (int u = 0; u < 2; ++u) {
                 const i32x16 &ac = acc[g * 2 + u];
                 const float sh = u ? shs[1] : shs[0], er = u ? shs[3] : shs[2];
-                if constexpr (CEN_OK) {
-                    if (centred) {
-                        const float ss = sh * sq[g];
-                        const float thr = fmaf(-qb[g], er, theta[g]);
-                        if (MODE == 1) {
-                            // collect pass: an upper bound of the lane's 16 scores first -- the largest sum with the half tile's
-                            // largest a_q a_c (+ 1e-6: the per-row evaluation below rounds differently); in a cone the a_c of a half
-                            // tile differ by ~0.01, so nine half tiles in ten stop here and cost what a plain copy's do
-                            int mxq = max(max(ac[0], ac[1]), ac[2]);
-#pragma unroll
-                            for (int r = 3; r < 15; r += 2) mxq = max(max(mxq, ac[r]), ac[r + 1]);
-                            mxq = max(mxq, ac[15]);
-                            const float ub = fmaf((float)mxq, ss, fmaxf(aq * (u ? amm[1] : amm[0]), aq * (u ? amm[3] : amm[2]))) + 1e-6f;
-                            if (__builtin_amdgcn_ballot_w64(ub >= thr) == 0) continue;
-                        }
-                        // score of row r = a_q a_c[r] + sum_r (s_h s_q)
-                        float v[16];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(aq, acv[u * 4 + (r >> 2)][r & 3], (float)ac[r] * ss);
-                        float mxc = fmaxf(fmaxf(v[0], v[1]), v[2]);
-#pragma unroll
-                        for (int r = 3; r < 15; r += 2) mxc = fmaxf(fmaxf(mxc, v[r]), v[r + 1]);
-                        mxc = fmaxf(mxc, v[15]);
-                        // (an unusable query -- s_q = 0: zero or padded -- has theta = +inf in the collect pass; in the sample pass its
-                        // maxima are never read)
-                        if (MODE == 0) {
-                            best[g] = fmaxf(best[g], mxc - fmaf(qb[g], er, qa[g]));
-                        } else if (__builtin_amdgcn_ballot_w64(mxc >= thr) != 0) {
-                            if (mxc >= thr) {
-                                if ((cnt[g] & 0x7fffffffu) < (uint32_t)kRecCap) {
-                                    const size_t at = (size_t)mylane(g) * kRecCap + (cnt[g] & 0x7fffffffu);
-                                    f32x4 *dst = reinterpret_cast<f32x4 *>(p.lane_rec + at * 16);
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) dst[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-                                    p.lane_tile[at] = 2 * tile + u;
-                                    ++cnt[g];
-                                } else {
-                                    cnt[g] |= 0x80000000u;
-                                }
-                            }
-                        }
-                        continue;
-                    }
-                }
                 int mxi = max(max(ac[0], ac[1]), ac[2]);
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) mxi = max(max(mxi, ac[r]), ac[r + 1]);
@@ -322,6 +328,15 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan8_kernel(const ScanParams
                     }
                 }
             }
+        }
+        if constexpr (CEN) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(shs_n), "+v"(inv_n), "+v"(acv[0]), "+v"(acv[1]), "+v"(acv[2]), "+v"(acv[3]), "+v"(acv[4]), "+v"(acv[5]), "+v"(acv[6]), "+v"(acv[7])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) group_values(j);
+            shs_c = shs_n;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // dead DMA ops must not outlive the workgroup's LDS
@@ -409,7 +424,10 @@ __global__ __launch_bounds__(256) void shadow8_kernel(const float *__restrict__ 
         if (lane == 0) s_red[wave] = mx;
         __syncthreads();
         mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        const float sh = mx / 127.0f, inv = mx > 0.0f ? 127.0f / mx : 0.0f;
+        // (centred form: the step stays at or above kMinStep8, so that the scan's a_q a_c / (s_h s_q) fits an int32 -- a floor
+        // only a half tile of residuals shorter than 0.004 ever meets, and what it costs them is inside their measured residual)
+        const float sh = mean ? fmaxf(mx / 127.0f, kMinStep8) : mx / 127.0f;
+        const float inv = mean ? 1.0f / sh : (mx > 0.0f ? 127.0f / mx : 0.0f);
         // ---- pass 2: quantise, residual per row, int8 rows staged in LDS
         for (int r = wave; r < kTileRows; r += 4) {
             float r2 = 0.0f;
@@ -440,15 +458,11 @@ __global__ __launch_bounds__(256) void shadow8_kernel(const float *__restrict__ 
         float hw = tid < kTileRows ? sqrtf(s_r2[tid]) : 0.0f;  // worst residual of THIS half tile (waves 1-3 hold zeros)
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) hw = fmaxf(hw, __shfl_xor(hw, o));
-        // centred form: the largest and smallest a_c of the half tile (the scan's quick upper bound of a lane's 16 scores)
-        float amx = mean && tid < kTileRows ? s_ac[tid] : 0.0f, amn = amx;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o)), amn = fminf(amn, __shfl_xor(amn, o));
         if (tid == 0) {
             tscale[kTscaleFloats * (size_t)T + u] = sh;
             tscale[kTscaleFloats * (size_t)T + 2 + u] = hw * 1.01f + 1e-6f;
-            tscale[kTscaleFloats * (size_t)T + 4 + u] = amx;
-            tscale[kTscaleFloats * (size_t)T + 6 + u] = amn;
+            tscale[kTscaleFloats * (size_t)T + 4 + u] = mean ? 1.0f / sh : 0.0f;  // what the scan multiplies a_c (a_q / s_q) by
+            tscale[kTscaleFloats * (size_t)T + 6 + u] = 0.0f;
         }
         if (tid < kTileRows) worst = fmaxf(worst, hw);
         __syncthreads();
@@ -476,9 +490,9 @@ hipError_t launch_shadow8(hipStream_t s, const float *x, const float *scale, int
     return hipGetLastError();
 }
 
-template <int KC, int MODE, int QG>
+template <int KC, int MODE, int QG, bool CEN = false>
 static hipError_t setup8_one() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&scan8_kernel<KC, MODE, QG>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&scan8_kernel<KC, MODE, QG, CEN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kScan8LdsBytes);
 }
 
@@ -498,25 +512,43 @@ hipError_t scan8_setup() {
     if ((e = setup8_one<KC, 1, 2>()) != hipSuccess) return e;
     MX_SETUP(1) MX_SETUP(2) MX_SETUP(3) MX_SETUP(4)
 #undef MX_SETUP
+#define MX_SETUP(KC)                                                   \
+    if ((e = setup8_one<KC, 0, 1, true>()) != hipSuccess) return e;    \
+    if ((e = setup8_one<KC, 1, 1, true>()) != hipSuccess) return e;
+    MX_SETUP(1) MX_SETUP(2) MX_SETUP(3) MX_SETUP(4) MX_SETUP(5) MX_SETUP(6)  // the centred forms: up to kMaxKC slots
+#undef MX_SETUP
+    static_assert(kMaxKC == 6, "one centred scan8_kernel per slot count up to kMaxKC");
     return hipSuccess;
 }
 
-template <int KC, int QG>
+template <int KC, int QG, bool CEN = false>
 static hipError_t launch8_kc(hipStream_t s, bool collect, int nwg, const ScanParams &p) {
     if (collect)
-        hipLaunchKernelGGL((scan8_kernel<KC, 1, QG>), dim3(nwg), dim3(kScanThreads), kScan8LdsBytes, s, p);
+        hipLaunchKernelGGL((scan8_kernel<KC, 1, QG, CEN>), dim3(nwg), dim3(kScanThreads), kScan8LdsBytes, s, p);
     else
-        hipLaunchKernelGGL((scan8_kernel<KC, 0, QG>), dim3(nwg), dim3(kScanThreads), kScan8LdsBytes, s, p);
+        hipLaunchKernelGGL((scan8_kernel<KC, 0, QG, CEN>), dim3(nwg), dim3(kScanThreads), kScan8LdsBytes, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_scan8(hipStream_t s, int kc, bool collect, int nwg, const ScanParams &p, bool two_groups) {
     if (two_groups) {  // 512 queries per pass: up to 512 dims (kMaxKC8x2)
+        if (p.amean) return hipErrorInvalidValue;
         switch (kc) {
             case 1: return launch8_kc<1, 2>(s, collect, nwg, p);
             case 2: return launch8_kc<2, 2>(s, collect, nwg, p);
             case 3: return launch8_kc<3, 2>(s, collect, nwg, p);
             case 4: return launch8_kc<4, 2>(s, collect, nwg, p);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (p.amean) {  // centred copy: one query group, up to kMaxKC slots (index.hip builds no other)
+        switch (kc) {
+            case 1: return launch8_kc<1, 1, true>(s, collect, nwg, p);
+            case 2: return launch8_kc<2, 1, true>(s, collect, nwg, p);
+            case 3: return launch8_kc<3, 1, true>(s, collect, nwg, p);
+            case 4: return launch8_kc<4, 1, true>(s, collect, nwg, p);
+            case 5: return launch8_kc<5, 1, true>(s, collect, nwg, p);
+            case 6: return launch8_kc<6, 1, true>(s, collect, nwg, p);
             default: return hipErrorInvalidValue;
         }
     }
