@@ -1,6 +1,8 @@
 """How often scan8_kernel's centred collect pass gets past its quick test (an instrumented build of scan8.hip, build_ub/ only:
 counters per wave and half tile -- tested, past the quick test, past the per-row test, groups of 4 rows a per-group bound would pass).
-usage: gpu_scan8_pass_rates.py [rows] [steps]   (the library in memex_amd/ must be the instrumented one)"""
+usage: gpu_scan8_pass_rates.py [rows] [steps]   (the library in memex_amd/ must be the instrumented one: scripts/scan8_pass_rates.patch,
+which applies to memex_amd/csrc/scan8.hip of commit c819cbd -- the per-row epilogue it counts was replaced by accumulator initial values
+in the commit after; profiles/r6_centred_int8_accumulator_init.txt holds what it measured)"""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MEMEX_HIP_SPIN", "1")
