@@ -824,7 +824,7 @@ def roofline_of(st, scan: str, dim: int, batch: int, rows_total: int, world: int
     kc = (dim + 127) // 128
     return {
         "bound": "hbm",
-        "kernel": f"mx::scan8_kernel<{kc},1,{2 if batch > 256 else 1}> (int8 filter copy, collect launch)" if scan == "i8"
+        "kernel": f"mx::scan8_kernel<{kc}, 1, {2 if batch > 256 else 1}, false> (int8 filter copy, collect launch; <..., true> on a centred copy)" if scan == "i8"
                   else f"mx::scan16_kernel<{kc},1> (bf16 filter copy, collect launch)" if scan == "bf16"
                   else f"mx::scan_kernel<{kc},1> (f32 rows, collect launch)",
         "achieved": achieved,

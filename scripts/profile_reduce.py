@@ -101,8 +101,8 @@ def main():
     if el:
         with open(el) as f, open(os.path.join(prof, f"{tag}_enc_like_kernel_stats.csv"), "w") as g:
             g.write(f.read())
-    for label, want, fname, pat in (("i8", "scan8_kernel<3, 1, 1>", f"{tag}_scan8_traffic.json", "pmc_*"),
-                                    ("768", "scan8_kernel<6, 1, 1>", f"{tag}_scan8_768_traffic.json", "pmc768_*"),
+    for label, want, fname, pat in (("i8", "scan8_kernel<3, 1, 1, false>", f"{tag}_scan8_traffic.json", "pmc_*"),
+                                    ("768", "scan8_kernel<6, 1, 1, false>", f"{tag}_scan8_768_traffic.json", "pmc768_*"),
                                     ("bf16", "scan16_kernel<3, 1>", f"{tag}_scan16_traffic.json", "pmc_*"),
                                     ("f32", "scan_kernel<3, 1>", f"{tag}_scan_traffic.json", "pmc_*"),
                                     ("768", "scan16_kernel<6, 1>", f"{tag}_scan16_768_traffic.json", "pmc768_*")):
