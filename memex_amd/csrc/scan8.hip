@@ -23,11 +23,13 @@
 // Layout.  A scan tile is 64 rows = two half tiles u = 0, 1; slot s of tile T (8 KiB, 128 dims) holds the
 // eight 1-KiB A operands f = 2j + u of k-step j (32 dims) and half u: lane l -> 16 int8 = row
 // 64T + 32u + (l & 31), dims 128s + 32j + 16(l >> 5) .. + 15 (A and B use the same k order, which is all
-// the dot product needs).  tscale[T] = (s_h0, s_h1, e_h0, e_h1): 16 bytes per tile, fetched by one more DMA
-// operation right before the tile's first slot.  The kernel is scan16_kernel with two accumulators (one per
+// the dot product needs).  tscale[T] = (s_h0, s_h1, e_h0, e_h1, 1/s_h0, 1/s_h1, -, -): 32 bytes per tile, fetched by one
+// more DMA operation one tile ahead of the tile's first slot -- and a second one for the a_c of a CENTRED copy (the rows
+// stored minus their component along the corpus mean direction; a_q a_c comes back as the accumulators' initial value:
+// scan8_kernel<..., CEN = true>).  The kernel is scan16_kernel with two accumulators (one per
 // half) fed alternately: one persistent 512-thread workgroup per CU, one 1 KiB LDS-DMA per wave and slot, 15
 // slots in flight, one s_waitcnt vmcnt(N) + s_barrier per slot (N counts the operations issued after the slot
-// being waited for: 13 slots plus the scale operations among them, a compile-time constant per position in the
+// being waited for: 13 slots plus the per-tile operations among them, a compile-time constant per position in the
 // tile), 8 MFMAs per slot each followed by the ds_read_b128 that refills the fragment register it consumed.
 // The query fragments take dim_pad/8 VGPRs (48 at 384 dims, 192 at 1536), so one launch serves 256 queries at
 // every supported width -- 512 up to 512 dims, with two query groups per wave (QG = 2).  A wave none of whose
