@@ -958,8 +958,11 @@ def _encoder_claim(leg, tokens: int):
     if not leg or "value" not in leg:
         return leg
     g = leg["gflop_per_chunk"]
+    rep = max(1, int(leg.get("replicas", 1)))  # N > 1: `chunks_per_s` is the sum over the replicas, `frac_wall` divides by their summed peak;
+    #                                            `achieved` / `frac` / `gpu_only_chunks_per_s` are ONE replica's (rank 0, HIP events on its stream)
     return {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS, "achieved": leg["roofline"]["achieved"], "frac": leg["roofline"]["frac"],
-            "chunks_per_s": leg["value"], "tokens_per_chunk": tokens, "gflop_per_chunk": g, "frac_wall": leg["value"] * g / 1e3 / MFMA_PEAK_TFLOPS,
+            "chunks_per_s": leg["value"], "replicas": rep, "tokens_per_chunk": tokens, "gflop_per_chunk": g,
+            "frac_wall": leg["value"] * g / 1e3 / (MFMA_PEAK_TFLOPS * rep),
             "gpu_only_chunks_per_s": leg["gpu_only_chunks_per_s"], "chunks": leg["chunks_per_gpu"],
             "ragged_frac": (leg.get("ragged") or {}).get("frac")}
 
