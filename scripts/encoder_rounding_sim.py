@@ -102,19 +102,20 @@ if __name__ == "__main__":
     ALL = ['res','gout','x_qk','w_qk','qk','x_v','w_v','v','p','ctx','w_o','x_f','w_1','h','w_2','final']
     def allof(fn, **over):
         d = {k: fn for k in ALL}; d.update(over); return d
-    report("all bf16", run(w, cfg, ids, lens, allof(bf)), ref)
-    report("all 16-bit split (res/gout/final f32)", run(w, cfg, ids, lens, allof(r16, res=ident, gout=ident, final=ident)), ref)
-    report("bf16 but logits path 16-bit (x_qk,w_qk,qk)", run(w, cfg, ids, lens, allof(bf, x_qk=r16, w_qk=r16, qk=r16)), ref)
-    report("  + res/gout/final f32", run(w, cfg, ids, lens, allof(bf, x_qk=r16, w_qk=r16, qk=r16, res=ident, gout=ident, final=ident)), ref)
-    report("bf16 but qk stored 16-bit only", run(w, cfg, ids, lens, allof(bf, qk=r16)), ref)
-    report("logits path bf16, everything else 16-bit", run(w, cfg, ids, lens, allof(r16, x_qk=bf, w_qk=bf, qk=bf, res=ident, gout=ident, final=ident)), ref)
-    report("weights bf16, all acts 16-bit/f32", run(w, cfg, ids, lens, allof(r16, w_qk=bf, w_v=bf, w_o=bf, w_1=bf, w_2=bf, res=ident, gout=ident, final=ident)), ref)
-    report("acts bf16, weights 16-bit, res f32", run(w, cfg, ids, lens, allof(bf, w_qk=r16, w_v=r16, w_o=r16, w_1=r16, w_2=r16, res=ident, gout=ident, final=ident)), ref)
-    report("bf16 ops, f32 residual / gemm out / final", run(w, cfg, ids, lens, allof(bf, res=ident, gout=ident, final=ident)), ref)
-    report("bf16 ops, f32 residual only", run(w, cfg, ids, lens, allof(bf, res=ident, final=ident)), ref)
-    report("all fp16", run(w, cfg, ids, lens, allof(hf)), ref)
-    report("fp16 ops, f32 residual / gemm out / final", run(w, cfg, ids, lens, allof(hf, res=ident, gout=ident, final=ident)), ref)
-    report("all f32 (numpy f32 products)", run(w, cfg, ids, lens, allof(ident)), ref)
+    R6B = len(sys.argv) > 5 and sys.argv[5] == "r6b"
+    if not R6B: report("all bf16", run(w, cfg, ids, lens, allof(bf)), ref)
+    if not R6B: report("all 16-bit split (res/gout/final f32)", run(w, cfg, ids, lens, allof(r16, res=ident, gout=ident, final=ident)), ref)
+    if not R6B: report("bf16 but logits path 16-bit (x_qk,w_qk,qk)", run(w, cfg, ids, lens, allof(bf, x_qk=r16, w_qk=r16, qk=r16)), ref)
+    if not R6B: report("  + res/gout/final f32", run(w, cfg, ids, lens, allof(bf, x_qk=r16, w_qk=r16, qk=r16, res=ident, gout=ident, final=ident)), ref)
+    if not R6B: report("bf16 but qk stored 16-bit only", run(w, cfg, ids, lens, allof(bf, qk=r16)), ref)
+    if not R6B: report("logits path bf16, everything else 16-bit", run(w, cfg, ids, lens, allof(r16, x_qk=bf, w_qk=bf, qk=bf, res=ident, gout=ident, final=ident)), ref)
+    if not R6B: report("weights bf16, all acts 16-bit/f32", run(w, cfg, ids, lens, allof(r16, w_qk=bf, w_v=bf, w_o=bf, w_1=bf, w_2=bf, res=ident, gout=ident, final=ident)), ref)
+    if not R6B: report("acts bf16, weights 16-bit, res f32", run(w, cfg, ids, lens, allof(bf, w_qk=r16, w_v=r16, w_o=r16, w_1=r16, w_2=r16, res=ident, gout=ident, final=ident)), ref)
+    if not R6B: report("bf16 ops, f32 residual / gemm out / final", run(w, cfg, ids, lens, allof(bf, res=ident, gout=ident, final=ident)), ref)
+    if not R6B: report("bf16 ops, f32 residual only", run(w, cfg, ids, lens, allof(bf, res=ident, final=ident)), ref)
+    if not R6B: report("all fp16", run(w, cfg, ids, lens, allof(hf)), ref)
+    if not R6B: report("fp16 ops, f32 residual / gemm out / final", run(w, cfg, ids, lens, allof(hf, res=ident, gout=ident, final=ident)), ref)
+    if not R6B: report("all f32 (numpy f32 products)", run(w, cfg, ids, lens, allof(ident)), ref)
     # ---- round 6: the TWO-product candidates: one operand of every product carried as a 16-bit pair, the other as
     # ONE 16-bit value; hidden state / GEMM results / output in f32 throughout
     F32 = dict(res=ident, gout=ident, final=ident)
@@ -122,12 +123,32 @@ if __name__ == "__main__":
     ACTS = ['x_qk', 'x_v', 'ctx', 'x_f', 'h']
     def mode(wfn, afn, **attn):
         d = dict(F32); d.update({k: wfn for k in WEIGHTS}); d.update({k: afn for k in ACTS}); d.update(attn); return d
-    report("r6 fp16 w x split-fp16 a; attention 16-bit x3", run(w, cfg, ids, lens, mode(hf, r22, qk=r16, p=r16, v=r16)), ref)
-    report("r6 fp16 w x split-fp16 a; attention q split-fp16, k/v/p fp16", run(w, cfg, ids, lens, mode(hf, r22, q=r22, k=hf, p=hf, v=hf)), ref)
-    report("r6 fp16 w x split-fp16 a; attention all fp16", run(w, cfg, ids, lens, mode(hf, r22, qk=hf, p=hf, v=hf)), ref)
-    report("r6 bf16-hi/lo w x fp16 a; attention 16-bit x3", run(w, cfg, ids, lens, mode(r16, hf, qk=r16, p=r16, v=r16)), ref)
-    report("r6 bf16-hi/lo w x fp16 a; attention all fp16", run(w, cfg, ids, lens, mode(r16, hf, qk=hf, p=hf, v=hf)), ref)
-    report("r6 bf16 w x bf16-hi/lo a; attention 16-bit x3", run(w, cfg, ids, lens, mode(bf, r16, qk=r16, p=r16, v=r16)), ref)
-    report("r6 x3 everywhere but 2 products (fp16 w) in W1/W2", run(w, cfg, ids, lens, mode(r16, r16, qk=r16, p=r16, v=r16, w_1=hf, w_2=hf, x_f=r22, h=r22)), ref)
-    report("r6 x3 on the logit path + attention, fp16 w x split-fp16 a elsewhere", run(w, cfg, ids, lens, mode(hf, r22, w_qk=r16, x_qk=r16, qk=r16, p=r16, v=r16)), ref)
-    report("r6 fp16 w x fp16 a (ONE product), f32 state; attention 16-bit x3", run(w, cfg, ids, lens, mode(hf, hf, qk=r16, p=r16, v=r16)), ref)
+    if not R6B: report("r6 fp16 w x split-fp16 a; attention 16-bit x3", run(w, cfg, ids, lens, mode(hf, r22, qk=r16, p=r16, v=r16)), ref)
+    if not R6B: report("r6 fp16 w x split-fp16 a; attention q split-fp16, k/v/p fp16", run(w, cfg, ids, lens, mode(hf, r22, q=r22, k=hf, p=hf, v=hf)), ref)
+    if not R6B: report("r6 fp16 w x split-fp16 a; attention all fp16", run(w, cfg, ids, lens, mode(hf, r22, qk=hf, p=hf, v=hf)), ref)
+    if not R6B: report("r6 bf16-hi/lo w x fp16 a; attention 16-bit x3", run(w, cfg, ids, lens, mode(r16, hf, qk=r16, p=r16, v=r16)), ref)
+    if not R6B: report("r6 bf16-hi/lo w x fp16 a; attention all fp16", run(w, cfg, ids, lens, mode(r16, hf, qk=hf, p=hf, v=hf)), ref)
+    if not R6B: report("r6 bf16 w x bf16-hi/lo a; attention 16-bit x3", run(w, cfg, ids, lens, mode(bf, r16, qk=r16, p=r16, v=r16)), ref)
+    if not R6B: report("r6 x3 everywhere but 2 products (fp16 w) in W1/W2", run(w, cfg, ids, lens, mode(r16, r16, qk=r16, p=r16, v=r16, w_1=hf, w_2=hf, x_f=r22, h=r22)), ref)
+    if not R6B: report("r6 x3 on the logit path + attention, fp16 w x split-fp16 a elsewhere", run(w, cfg, ids, lens, mode(hf, r22, w_qk=r16, x_qk=r16, qk=r16, p=r16, v=r16)), ref)
+    if not R6B: report("r6 fp16 w x fp16 a (ONE product), f32 state; attention 16-bit x3", run(w, cfg, ids, lens, mode(hf, hf, qk=r16, p=r16, v=r16)), ref)
+
+    # ---- round 6, second pass: inside MX_PREC_MIXED as built (three products on the attention block, two in the MLP), which products
+    # could drop to ONE?  (`python scripts/encoder_rounding_sim.py <pooling> <hidden> <layers> <seed> r6b` prints only these)
+    MIXED = dict(qk=r16, p=r16, v=r16, w_1=hf, w_2=hf, x_f=r22, h=r22)
+    def mixed(**over):
+        d = mode(r16, r16, **MIXED); d.update(over); return d
+    if R6B:
+        print("-- r6b: single products inside MX_PREC_MIXED")
+        report("r6b MX_PREC_MIXED as built", run(w, cfg, ids, lens, mixed()), ref)
+        report("r6b  + P.V as ONE fp16 product (p, v fp16)", run(w, cfg, ids, lens, mixed(p=hf, v=hf)), ref)
+        report("r6b  + P.V as two products (p fp16, v 16-bit pair)", run(w, cfg, ids, lens, mixed(p=hf)), ref)
+        report("r6b  + P.V as two products (p 16-bit pair, v fp16)", run(w, cfg, ids, lens, mixed(v=hf)), ref)
+        report("r6b  + P bf16, V 16-bit pair", run(w, cfg, ids, lens, mixed(p=bf)), ref)
+        report("r6b  + V / out projections on two products", run(w, cfg, ids, lens, mixed(w_v=hf, x_v=r22, w_o=hf, ctx=r22)), ref)
+        report("r6b  + V / out projections on two products, P.V one fp16 product", run(w, cfg, ids, lens, mixed(w_v=hf, x_v=r22, w_o=hf, ctx=r22, p=hf, v=hf)), ref)
+        report("r6b  + MLP on ONE fp16 product (w, x_f, h fp16)", run(w, cfg, ids, lens, mixed(x_f=hf, h=hf)), ref)
+        report("r6b  + W2 on ONE fp16 product (h fp16), W1 two", run(w, cfg, ids, lens, mixed(h=hf)), ref)
+        report("r6b  + W1 on ONE fp16 product (x_f fp16), W2 two", run(w, cfg, ids, lens, mixed(x_f=hf)), ref)
+        report("r6b  + QK^T as two products (q 16-bit pair, k fp16)", run(w, cfg, ids, lens, mixed(k=hf)), ref)
+        report("r6b  + QK^T as two products (q fp16 pair r22, k fp16)", run(w, cfg, ids, lens, mixed(q=r22, k=hf)), ref)
