@@ -285,10 +285,11 @@ typedef struct mx_encoder_cfg {
                            f32 product), f32 hidden state and f32 attention -- scores BETWEEN embeddings within
                            1e-4 of the f32 CPU path (embedding.rs:109) also under checkpoint-like weights, where
                            the bf16 path moves them by up to 1e-2; about 6x slower |
-                           MX_PREC_MIXED (round 6): the attention block (Q, K, V, scores, PV, out-projection) as in
-                           MX_PREC_BF16X3, the MLP's two GEMMs as TWO fp16 products per product (fp16 weights x fp16 hi + lo
-                           activations) -- scores within 1e-4 as well (profiles/r6_encoder_rounding_sim.txt: the MLP tolerates
-                           11-bit weights, the logit path does not), 20-25 % faster than MX_PREC_BF16X3                */
+                           MX_PREC_MIXED (round 6): the attention block (Q, K, V, scores, out-projection) as in
+                           MX_PREC_BF16X3 except that P enters P.V as ONE bf16 value against V's pair; the MLP's two GEMMs as
+                           TWO fp16 products per product (fp16 weights x fp16 hi + lo activations) -- scores within 1e-4 as well
+                           (profiles/r6_encoder_rounding_sim.txt: the MLP tolerates 11-bit weights and P.V an 8-bit P, the
+                           logit path neither), 15-17 % faster than MX_PREC_BF16X3                                      */
 } mx_encoder_cfg;
 enum { MX_PREC_BF16 = 0, MX_PREC_BF16X3 = 1, MX_PREC_MIXED = 2 };
 /* sizeof(mx_encoder_cfg) of the library that is loaded: the struct grew a trailing field (`precision`) and may again; a shim

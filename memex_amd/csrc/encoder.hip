@@ -307,7 +307,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             g.a = e->xs; g.lda = 3 * H; g.w = L.wqkv3; g.w_rows = 3 * H; g.bias = L.bqkv; g.m = m_c; g.n = 3 * H; g.k = 3 * H;
             g.out_f32 = e->qkvf; g.ldo = 3 * H;
             MX_HIP(pgemm_or_gemm(EPI_F32, g));
-            MX_HIP(launch_attention_f32(st, e->qkvf, e->cu, d_lens, B, max_len, heads, dh, H, e->ctxs, e->attn_f32));
+            MX_HIP(launch_attention_f32(st, e->qkvf, e->cu, d_lens, B, max_len, heads, dh, H, e->ctxs, e->attn_f32, e->mixed));
             GemmParams o{};
             o.a = e->ctxs; o.lda = 3 * H; o.w = L.wo3; o.w_rows = H; o.bias = L.bo; o.m = m_c; o.n = H; o.k = 3 * H;
             o.out_f32 = e->af; o.ldo = H;

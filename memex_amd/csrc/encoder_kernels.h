@@ -165,6 +165,6 @@ hipError_t launch_add_ln_split(hipStream_t s, const float *a, float *xf, bf16_t 
                                const float *beta, float eps, bool half2 = false);
 // softmax(q k^T / sqrt(d) + mask) v in f32 (v_mfma_f32_32x32x2_f32) from qkv [t_pad, 3H] f32 (q | k | v) -> ctxs [t_pad, 3H] split
 hipError_t launch_attention_f32(hipStream_t s, const float *qkv, const int32_t *cu, const int32_t *lens, int B, int S, int heads,
-                                int d_head, int hidden, bf16_t *ctxs, bool f32_mfma);
+                                int d_head, int hidden, bf16_t *ctxs, bool f32_mfma, bool p_single);
 
 }  // namespace mx

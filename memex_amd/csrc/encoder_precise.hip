@@ -314,7 +314,10 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restr
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8p;
 
-template <int DH>
+// P1 (MX_PREC_MIXED): P enters the PV product as ONE bf16 value against V's pair -- two products, no split of P in the loop.  The
+// rounding simulator puts that within 1.0e-4 of the f64 evaluation on scores (profiles/r6_encoder_rounding_sim.txt, "r6b": P bf16, V
+// 16-bit pair); QK^T keeps its three products in every mode (one 16-bit value on either side costs 3e-4 ... 8e-3).
+template <int DH, bool P1>
 __global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restrict__ qkv, int hidden, const int32_t *__restrict__ cu,
                                                             const int32_t *__restrict__ lens, int S, float qscale,
                                                             bf16_t *__restrict__ ctxs) {
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restri
             for (int e = 0; e < 8; ++e) {
                 const float pv = sc[8 * t2 + e];
                 ph[e] = (__bf16)pv;
-                pl[e] = (__bf16)(pv - (float)ph[e]);
+                if constexpr (!P1) pl[e] = (__bf16)(pv - (float)ph[e]);
             }
 #pragma unroll
             for (int t = 0; t < DH / 32; ++t) {
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restri
                 const bf16x8p vl = *reinterpret_cast<const bf16x8p *>(Vl + (32 * t + l31) * VP + 16 * t2 + 8 * h);
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[t], 0, 0, 0);
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[t], 0, 0, 0);
+                if constexpr (!P1) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[t], 0, 0, 0);
             }
         }
     }
@@ -469,15 +472,19 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restri
 }
 
 hipError_t launch_attention_f32(hipStream_t s, const float *qkv, const int32_t *cu, const int32_t *lens, int B, int S, int heads,
-                                int d_head, int hidden, bf16_t *ctxs, bool f32_mfma) {
+                                int d_head, int hidden, bf16_t *ctxs, bool f32_mfma, bool p_single) {
     if (B < 1 || S < 1 || S > 512 || heads * d_head != hidden) return hipErrorInvalidValue;
     const float qscale = (float)(1.4426950408889634 / sqrt((double)d_head));
     const dim3 grid((S + 127) / 128, heads, B);
     if (!f32_mfma) {
-        if (d_head == 32)
-            hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
+        if (d_head == 32 && p_single)
+            hipLaunchKernelGGL((attention_x3_kernel<32, true>), grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
+        else if (d_head == 32)
+            hipLaunchKernelGGL((attention_x3_kernel<32, false>), grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
+        else if (d_head == 64 && p_single)
+            hipLaunchKernelGGL((attention_x3_kernel<64, true>), grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
         else if (d_head == 64)
-            hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
+            hipLaunchKernelGGL((attention_x3_kernel<64, false>), grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
         else
             return hipErrorInvalidValue;
         return hipGetLastError();

@@ -1,4 +1,4 @@
-"""MX_PREC_BF16X3 throughput probe (not a test): chunks/s of the split-operand mode next to the bf16 default."""
+"""MX_PREC_BF16X3 / MX_PREC_MIXED throughput probe (not a test): chunks/s of the split-operand modes next to the bf16 default."""
 import dataclasses, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,7 +7,7 @@ from memex_amd import weights as W
 
 def run(cfg, B, S, reps=3):
     w = W.pack_weights(W.synthetic_weights(cfg, 0), cfg)
-    for prec in ("bf16", "bf16x3"):
+    for prec in ("bf16", "bf16x3", "mixed"):
         c = dataclasses.replace(cfg, precision=prec)
         enc = Encoder(c, w)
         g = torch.Generator(device="cuda"); g.manual_seed(1)
