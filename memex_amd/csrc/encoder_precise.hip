@@ -317,24 +317,29 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8p;
 // P1 (MX_PREC_MIXED): P enters the PV product as ONE bf16 value against V's pair -- two products, no split of P in the loop.  The
 // rounding simulator puts that within 1.0e-4 of the f64 evaluation on scores (profiles/r6_encoder_rounding_sim.txt, "r6b": P bf16, V
 // 16-bit pair); QK^T keeps its three products in every mode (one 16-bit value on either side costs 3e-4 ... 8e-3).
-template <int DH, bool P1>
-__global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restrict__ qkv, int hidden, const int32_t *__restrict__ cu,
-                                                            const int32_t *__restrict__ lens, int S, float qscale,
-                                                            bf16_t *__restrict__ ctxs) {
+// NW waves per workgroup = 32 NW queries of one (sequence, head); key blocks of KB = 32 or 64 keys (two barriers per block).  With 16
+// waves a 512-token sequence's K and V are split and staged once instead of once per 128 queries.
+template <int DH, bool P1, int NW, int KB>
+__global__ __launch_bounds__(64 * NW) void attention_x3_kernel(const float *__restrict__ qkv, int hidden, const int32_t *__restrict__ cu,
+                                                                const int32_t *__restrict__ lens, int S, float qscale,
+                                                                bf16_t *__restrict__ ctxs) {
+    constexpr int NT = 64 * NW;  // threads
+    constexpr int NH = KB / 32;  // halves of a key block (KB = 64, or 32 where 16 waves leave no register for 64)
     constexpr int KP = DH + 8;   // K tile pitch (bf16): rows 16 bytes apart modulo 128 -> conflict-free ds_read_b128
-    constexpr int VP = 32 + 8;   // V^T tile pitch (bf16)
-    __shared__ __attribute__((aligned(16))) __bf16 Kh[32 * KP], Kl[32 * KP];
+    constexpr int VP = KB + 8;   // V^T tile pitch (bf16)
+    __shared__ __attribute__((aligned(16))) __bf16 Kh[KB * KP], Kl[KB * KP];
     __shared__ __attribute__((aligned(16))) __bf16 Vh[DH * VP], Vl[DH * VP];
     const int b = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
     int len = lens[b];
     len = len < 1 ? 1 : (len > S ? S : len);
-    if (qb * 128 >= len) return;  // workgroup-uniform
+    if (qb * 32 * NW >= len) return;  // workgroup-uniform
     const int tok0 = cu[b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int ld = 3 * hidden;
-    const int qi = qb * 128 + wave * 32 + l31;  // this lane's query
+    const int qi = qb * 32 * NW + wave * 32 + l31;  // this lane's query
     const bool q_ok = qi < len;
+    const bool wave_ok = qb * 32 * NW + wave * 32 < len;  // a wave past the sequence's end only stages and keeps the barriers
     const float *qrow = qkv + (size_t)(tok0 + (q_ok ? qi : 0)) * ld + head * DH;
     // B operand of the scores: lane (query, h) holds q[16 s + 8 h .. + 7] of k-step s, hi and lo
     bf16x8p qh[DH / 16], ql[DH / 16];
@@ -353,23 +358,21 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restri
         for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
     float m_run = -1e30f, l_run = 0.0f;
     const float *kbase = qkv + (size_t)tok0 * ld + hidden + head * DH;
-    const float *vbase = kbase + hidden;
-    const int nkb = (len + 31) / 32;
-    // this thread's float4s of a key block's K and V rows (zeros past the sequence's end); block kb + 1 is fetched while
-    // block kb is multiplied
-    constexpr int NP = 32 * DH / 4 / 256;
-    f32x4 kpre[NP], vpre[NP];
+    const int nkb = (len + KB - 1) / KB;
+    // this thread's float4s of a key block's K rows (index < KB * DH / 4) and V rows (the rest); zeros past the sequence's end;
+    // block kb + 1 is fetched while block kb is multiplied.  (V goes into LDS transposed, one 16-bit write per element with the
+    // lanes running over the dims.  Lanes over key PAIRS and packed 32-bit writes -- no bank conflict -- was measured 18-40 % slower:
+    // the global reads of a wave then touch 128 rows instead of 4.)
+    constexpr int NF = KB * DH / 4;          // float4s of K (and of V) per block
+    constexpr int NP = (2 * NF + NT - 1) / NT;  // float4s per thread
+    f32x4 pre[NP];
     auto fetch = [&](int kb) {
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            const int i = tid + 256 * u, r = i / (DH / 4), c4 = i % (DH / 4);
-            const int key = kb * 32 + r;
-            kpre[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            vpre[u] = kpre[u];
-            if (key < len) {
-                kpre[u] = *reinterpret_cast<const f32x4 *>(kbase + (size_t)key * ld + 4 * c4);
-                vpre[u] = *reinterpret_cast<const f32x4 *>(vbase + (size_t)key * ld + 4 * c4);
-            }
+            const int i = tid + NT * u, isv = i >= NF ? 1 : 0, ii = i - isv * NF, r = ii / (DH / 4), c4 = ii % (DH / 4);
+            const int key = kb * KB + r;
+            pre[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < 2 * NF && key < len) pre[u] = *reinterpret_cast<const f32x4 *>(kbase + (size_t)key * ld + isv * hidden + 4 * c4);
         }
     };
     fetch(0);
@@ -377,45 +380,54 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restri
         __syncthreads();  // everybody is done with the previous block's tiles
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            const int i = tid + 256 * u, r = i / (DH / 4), c4 = i % (DH / 4);
-            const f32x4 kv = kpre[u], vv = vpre[u];
-            bf16x4 khi, klo;
+            const int i = tid + NT * u, isv = i >= NF ? 1 : 0, ii = i - isv * NF, r = ii / (DH / 4), c4 = ii % (DH / 4);
+            if (i >= 2 * NF) continue;
+            const f32x4 x = pre[u];
+            bf16x4 xhi, xlo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                khi[e] = (__bf16)kv[e];
-                klo[e] = (__bf16)(kv[e] - (float)khi[e]);
+                xhi[e] = (__bf16)x[e];
+                xlo[e] = (__bf16)(x[e] - (float)xhi[e]);
             }
-            *reinterpret_cast<bf16x4 *>(Kh + r * KP + 4 * c4) = khi;
-            *reinterpret_cast<bf16x4 *>(Kl + r * KP + 4 * c4) = klo;
-            // key r of the block sits in slot (r with bits 2 and 3 swapped) of its 16-key k-step
-            const int slot = (r & 16) | (r & 3) | ((r & 8) >> 1) | ((r & 4) << 1);
+            if (!isv) {
+                *reinterpret_cast<bf16x4 *>(Kh + r * KP + 4 * c4) = xhi;
+                *reinterpret_cast<bf16x4 *>(Kl + r * KP + 4 * c4) = xlo;
+            } else {
+                // key r of the block sits in slot (r with bits 2 and 3 swapped) of its 16-key k-step
+                const int slot = (r & 48) | (r & 3) | ((r & 8) >> 1) | ((r & 4) << 1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const __bf16 vh = (__bf16)vv[e];
-                Vh[(4 * c4 + e) * VP + slot] = vh;
-                Vl[(4 * c4 + e) * VP + slot] = (__bf16)(vv[e] - (float)vh);
+                for (int e = 0; e < 4; ++e) {
+                    Vh[(4 * c4 + e) * VP + slot] = xhi[e];
+                    Vl[(4 * c4 + e) * VP + slot] = xlo[e];
+                }
             }
         }
         if (kb + 1 < nkb) fetch(kb + 1);
         __syncthreads();
-        f32x16 sc;
+        if (!wave_ok) continue;
+        f32x16 sc[NH];  // [half of the block]: lane (query, h) holds keys 32 hb + (r & 3) + 8 (r >> 2) + 4 h
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+        for (int hb = 0; hb < NH; ++hb) {
 #pragma unroll
-        for (int s = 0; s < DH / 16; ++s) {
-            const bf16x8p ah = *reinterpret_cast<const bf16x8p *>(Kh + l31 * KP + 16 * s + 8 * h);
-            const bf16x8p al = *reinterpret_cast<const bf16x8p *>(Kl + l31 * KP + 16 * s + 8 * h);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[s], sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[s], sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[s], sc, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) sc[hb][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < DH / 16; ++s) {
+                const bf16x8p ah = *reinterpret_cast<const bf16x8p *>(Kh + (32 * hb + l31) * KP + 16 * s + 8 * h);
+                const bf16x8p al = *reinterpret_cast<const bf16x8p *>(Kl + (32 * hb + l31) * KP + 16 * s + 8 * h);
+                sc[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[s], sc[hb], 0, 0, 0);
+                sc[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[s], sc[hb], 0, 0, 0);
+                sc[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[s], sc[hb], 0, 0, 0);
+            }
         }
         float bm = -1e30f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            sc[r] = key < len ? sc[r] : -1e30f;
-            bm = fmaxf(bm, sc[r]);
-        }
+        for (int hb = 0; hb < NH; ++hb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * KB + 32 * hb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                sc[hb][r] = key < len ? sc[hb][r] : -1e30f;
+                bm = fmaxf(bm, sc[hb][r]);
+            }
         bm = fmaxf(bm, __shfl_xor(bm, 32));
         const float m_new = fmaxf(m_run, bm);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // (arguments <= 0: the raw v_exp_f32 is all there is to do)
@@ -423,11 +435,13 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restri
         m_run = m_new;
         float ps = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            sc[r] = key < len ? __builtin_amdgcn_exp2f(sc[r] - m_new) : 0.0f;
-            ps += sc[r];
-        }
+        for (int hb = 0; hb < NH; ++hb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * KB + 32 * hb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                sc[hb][r] = key < len ? __builtin_amdgcn_exp2f(sc[hb][r] - m_new) : 0.0f;
+                ps += sc[hb][r];
+            }
         l_run = l_run * alpha + ps;
         if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // after the first blocks a row's maximum rarely moves: alpha = 1 for the whole wave
 #pragma unroll
@@ -435,14 +449,14 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
         }
-        // k-step t of O^T += V^T P^T: keys 16 t .. 16 t + 15 in slot order; this lane's registers 8 t .. 8 t + 7 are the keys
-        // 16 t + {0..3, 8..11} + 4 h = the slots 8 h .. 8 h + 7
+        // k-step t2 of O^T += V^T P^T: keys 16 t2 .. 16 t2 + 15 of the block in slot order; this lane's registers 8 (t2 & 1) .. + 7 of
+        // half t2 >> 1 are the keys 16 t2 + {0..3, 8..11} + 4 h = the slots 8 h .. 8 h + 7
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
+        for (int t2 = 0; t2 < KB / 16; ++t2) {
             bf16x8p ph, pl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float pv = sc[8 * t2 + e];
+                const float pv = sc[t2 >> 1][8 * (t2 & 1) + e];
                 ph[e] = (__bf16)pv;
                 if constexpr (!P1) pl[e] = (__bf16)(pv - (float)ph[e]);
             }
@@ -471,22 +485,29 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float *__restri
         }
 }
 
+// Geometry by sweep (profiles/r6_attention_x3_geometry.txt: 4 / 8 / 16 waves x 32 / 64 keys, all within 3 % of each other -- the loop is
+// bound by its VALU work per score, not by staging): 16 waves at d_head 64 and 8 at d_head 32 for long sequences, 32-key blocks.
+template <int DH, bool P1>
+static void launch_x3(hipStream_t s, int B, int S, int heads, const float *qkv, int hidden, const int32_t *cu, const int32_t *lens,
+                      float qscale, bf16_t *ctxs) {
+#define MX_X3(NW) hipLaunchKernelGGL((attention_x3_kernel<DH, P1, NW, 32>), dim3((S + 32 * NW - 1) / (32 * NW), heads, B), dim3(64 * NW), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs)
+    if (S > 256 && DH > 32) MX_X3(16);
+    else if (S > 128) MX_X3(8);
+    else MX_X3(4);
+#undef MX_X3
+}
+
 hipError_t launch_attention_f32(hipStream_t s, const float *qkv, const int32_t *cu, const int32_t *lens, int B, int S, int heads,
                                 int d_head, int hidden, bf16_t *ctxs, bool f32_mfma, bool p_single) {
     if (B < 1 || S < 1 || S > 512 || heads * d_head != hidden) return hipErrorInvalidValue;
     const float qscale = (float)(1.4426950408889634 / sqrt((double)d_head));
     const dim3 grid((S + 127) / 128, heads, B);
     if (!f32_mfma) {
-        if (d_head == 32 && p_single)
-            hipLaunchKernelGGL((attention_x3_kernel<32, true>), grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
-        else if (d_head == 32)
-            hipLaunchKernelGGL((attention_x3_kernel<32, false>), grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
-        else if (d_head == 64 && p_single)
-            hipLaunchKernelGGL((attention_x3_kernel<64, true>), grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
-        else if (d_head == 64)
-            hipLaunchKernelGGL((attention_x3_kernel<64, false>), grid, dim3(256), 0, s, qkv, hidden, cu, lens, S, qscale, ctxs);
-        else
-            return hipErrorInvalidValue;
+        if (d_head == 32 && p_single) launch_x3<32, true>(s, B, S, heads, qkv, hidden, cu, lens, qscale, ctxs);
+        else if (d_head == 32) launch_x3<32, false>(s, B, S, heads, qkv, hidden, cu, lens, qscale, ctxs);
+        else if (d_head == 64 && p_single) launch_x3<64, true>(s, B, S, heads, qkv, hidden, cu, lens, qscale, ctxs);
+        else if (d_head == 64) launch_x3<64, false>(s, B, S, heads, qkv, hidden, cu, lens, qscale, ctxs);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     if (d_head == 32)
