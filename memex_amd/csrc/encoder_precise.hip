@@ -419,15 +419,23 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(const float *__re
                 sc[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[s], sc[hb], 0, 0, 0);
             }
         }
+        // only the sequence's last key block can hold keys past its end: every other block skips the two selects per score
+        // (the loop is bound by its VALU work per score, profiles/r6_attention_x3_geometry.txt)
+        const bool ragged = (kb + 1) * KB > len;  // workgroup-uniform
         float bm = -1e30f;
+        if (ragged) {
+#pragma unroll
+            for (int hb = 0; hb < NH; ++hb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * KB + 32 * hb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    sc[hb][r] = key < len ? sc[hb][r] : -1e30f;
+                }
+        }
 #pragma unroll
         for (int hb = 0; hb < NH; ++hb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb * KB + 32 * hb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                sc[hb][r] = key < len ? sc[hb][r] : -1e30f;
-                bm = fmaxf(bm, sc[hb][r]);
-            }
+            for (int r = 0; r < 16; ++r) bm = fmaxf(bm, sc[hb][r]);
         bm = fmaxf(bm, __shfl_xor(bm, 32));
         const float m_new = fmaxf(m_run, bm);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // (arguments <= 0: the raw v_exp_f32 is all there is to do)
@@ -438,8 +446,8 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(const float *__re
         for (int hb = 0; hb < NH; ++hb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kb * KB + 32 * hb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                sc[hb][r] = key < len ? __builtin_amdgcn_exp2f(sc[hb][r] - m_new) : 0.0f;
+                // (a masked score is -1e30: exp2 of it minus a finite maximum is exactly 0, the value the select used to supply)
+                sc[hb][r] = __builtin_amdgcn_exp2f(sc[hb][r] - m_new);
                 ps += sc[hb][r];
             }
         l_run = l_run * alpha + ps;
