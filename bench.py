@@ -392,9 +392,10 @@ def precise_ingest_leg(chunks_l6: int, chunks_bge: int):
             st = enc.stats()
             enc.close()
             tf = st.flops / (st.gpu_ms / 1e3) / 1e12 if st.gpu_ms > 0 else 0.0
-            # MFMA products per algorithmic product: 3 everywhere (bf16x3); 3 in the attention block and 2 in the MLP (mixed)
+            # MFMA products per algorithmic product: 3 everywhere (bf16x3); mixed: 3 in the projections of the attention block and in
+            # QK^T, 2 in P.V (P as one bf16 value) and in the MLP
             gemm, attn = 8.0 * H * H + 4.0 * H * F, 4.0 * 512 * H
-            mult = 3.0 if prec == "bf16x3" else (3.0 * (8.0 * H * H + attn) + 2.0 * 4.0 * H * F) / (gemm + attn)
+            mult = 3.0 if prec == "bf16x3" else (3.0 * (8.0 * H * H + 0.5 * attn) + 2.0 * (4.0 * H * F + 0.5 * attn)) / (gemm + attn)
             out[name][prec] = {"value": st.sequences / dt, "unit": "chunks/s", "chunks": int(st.sequences), "algorithmic_tflops": tf,
                                "mfma_products_per_product": mult, "mfma_frac": mult * tf / MFMA_PEAK_TFLOPS}
             del ids, lens, emb
