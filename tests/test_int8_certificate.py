@@ -68,3 +68,42 @@ def test_measured_residuals_bound_the_filter_score(seed):
     # what the certificate costs: on dense rows the worst half tile of a big corpus is ~0.014, a query ~0.007-0.009
     _, _, _, ec = _quantise_half_tiles(rng.standard_normal((4096, 384)).astype(np.float32))
     assert 0.007 < ec.max() < 0.016 and 0.007 < np.median(ec) < 0.011
+
+
+def test_centred_copy_accumulator_initial_value():
+    """The centred int8 copy (scan8_kernel<..., CEN = true>): a_q a_c enters as the int32 the MFMA accumulators
+    start from, I = trunc(f32(a_c * f32(f32(a_q / s_q) * f32(1 / s_h)))), and the score is ((float)(I + sum) * s_h) * s_q.  Restated
+    in numpy with the kernel's f32 roundings: for steps at or above kMinStep8 = 2^-15 (what the builder and prep_queries_kernel keep)
+    the integer never leaves int32, and the score differs from a_q a_c + s_h s_q sum by at most s_h s_q + 5e-7 -- inside the
+    2.7e-4 the certificate carries as slack."""
+    f = np.float32
+    rng = np.random.default_rng(3)
+    k_min = f(2.0 ** -15)
+    n = 200_000
+    a_c = rng.uniform(-1.0, 1.0, n).astype(f)
+    a_c[:8] = f(1.0) + f(1e-6), f(-1.0) - f(1e-6), 0.0, 1e-30, 0.98, -0.98, 1.0, -1.0      # the extremes a unit row can reach
+    a_q = rng.uniform(-1.0, 1.0, n).astype(f)
+    a_q[:8] = 1.0, 1.0, 1.0, 1.0, -1.0, 0.97, f(1.0) + f(1e-6), f(-1.0) - f(1e-6)
+    # steps from the floor up to a plain unit vector's (1/127), log-uniform; the first entries sit ON the floor
+    s_h = np.exp(rng.uniform(np.log(float(k_min)), np.log(1.0 / 127.0), n)).astype(f)
+    s_q = np.exp(rng.uniform(np.log(float(k_min)), np.log(1.0 / 127.0), n)).astype(f)
+    s_h[:16] = k_min
+    s_q[:16] = k_min
+    inv_sh = (f(1.0) / s_h).astype(f)
+    kq = (a_q / s_q).astype(f)
+    ku = (kq * inv_sh).astype(f)
+    t = (a_c * ku).astype(f)
+    assert np.abs(t.astype(np.float64)).max() < 2.0 ** 30 * (1 + 4e-6)                       # |a| <= 1 + 1e-6 on both sides
+    init = np.trunc(t.astype(np.float64)).astype(np.int64)
+    # integer sums: what two residual vectors no longer than a unit vector can produce (|s_h s_q sum| <= 1.05), capped at the widest row
+    lim = np.minimum(127.0 * 127.0 * 1536.0, 1.05 / (s_h.astype(np.float64) * s_q.astype(np.float64)))
+    sums = np.rint(rng.uniform(-1.0, 1.0, n) * lim).astype(np.int64)
+    sums[:4] = np.rint(lim[:4]).astype(np.int64)                                             # steps on the floor: 2^30 + the largest sum
+    total = init + sums
+    assert np.abs(total).max() < 2 ** 31                                                     # the MFMA accumulates in int32
+    score = ((total.astype(f) * s_h).astype(f) * s_q).astype(f).astype(np.float64)
+    exact = a_q.astype(np.float64) * a_c.astype(np.float64) + s_h.astype(np.float64) * s_q.astype(np.float64) * sums
+    err = np.abs(score - exact)
+    bound = s_h.astype(np.float64) * s_q.astype(np.float64) + 5e-7 * np.maximum(1.0, np.abs(exact))
+    assert (err <= bound).all(), (err.max(), (err / bound).max())
+    assert err.max() < 2.7e-4 / 4      # (the truncation costs up to one unit s_h s_q: 6.2e-5 when both steps are a plain unit vector's)
