@@ -372,7 +372,7 @@ def precise_ingest_leg(chunks_l6: int, chunks_bge: int):
             continue
         out[name] = {}
         H, F = base.hidden, base.ffn
-        for prec in ("bf16x3", "mixed"):
+        for prec in ("bf16x3", "mixed", "mixed1"):
             cfg = dataclasses.replace(base, precision=prec)
             enc = Encoder(cfg, W.pack_weights(W.synthetic_weights(cfg, 0), cfg))
             g = torch.Generator(device="cuda")
@@ -395,7 +395,8 @@ def precise_ingest_leg(chunks_l6: int, chunks_bge: int):
             # MFMA products per algorithmic product: 3 everywhere (bf16x3); mixed: 3 in the projections of the attention block and in
             # QK^T, 2 in P.V (P as one bf16 value) and in the MLP
             gemm, attn = 8.0 * H * H + 4.0 * H * F, 4.0 * 512 * H
-            mult = 3.0 if prec == "bf16x3" else (3.0 * (8.0 * H * H + 0.5 * attn) + 2.0 * (4.0 * H * F + 0.5 * attn)) / (gemm + attn)
+            mlp = {"mixed": 2.0, "mixed1": 1.0}.get(prec, 3.0)
+            mult = 3.0 if prec == "bf16x3" else (3.0 * (8.0 * H * H + 0.5 * attn) + mlp * 4.0 * H * F + 2.0 * 0.5 * attn) / (gemm + attn)
             out[name][prec] = {"value": st.sequences / dt, "unit": "chunks/s", "chunks": int(st.sequences), "algorithmic_tflops": tf,
                                "mfma_products_per_product": mult, "mfma_frac": mult * tf / MFMA_PEAK_TFLOPS}
             del ids, lens, emb
@@ -410,14 +411,15 @@ def precise_ingest_leg(chunks_l6: int, chunks_bge: int):
             cid = rng.integers(0, small.vocab, (8, 200)).astype(np.int32)
             cln = rng.integers(100, 201, 8).astype(np.int32)
             embs = {}
-            for prec in ("bf16", "mixed", "bf16x3"):
+            for prec in ("bf16", "mixed", "mixed1", "bf16x3"):
                 c2 = dataclasses.replace(small, precision=prec)
                 with Encoder(c2, W.pack_weights(wck, c2)) as e2:
                     v = e2.encode(cid, cln).astype(np.float64)
                 embs[prec] = v / np.linalg.norm(v, axis=1, keepdims=True)
             ref = embs["bf16x3"] @ embs["bf16x3"].T
             out[name]["score_error_vs_bf16x3"] = {"bf16": float(np.abs(embs["bf16"] @ embs["bf16"].T - ref).max()),
-                                                  "mixed": float(np.abs(embs["mixed"] @ embs["mixed"].T - ref).max())}
+                                                  "mixed": float(np.abs(embs["mixed"] @ embs["mixed"].T - ref).max()),
+                                                  "mixed1": float(np.abs(embs["mixed1"] @ embs["mixed1"].T - ref).max())}
             out[name]["score_error_note"] = ("max |cos(e_i, e_j)| difference to the bf16x3 mode, 8 x 200 tokens, checkpoint_like_weights "
                                              "(north_star bar on scores: 1e-3)")
         except Exception as e:  # noqa: BLE001

@@ -289,9 +289,13 @@ typedef struct mx_encoder_cfg {
                            MX_PREC_BF16X3 except that P enters P.V as ONE bf16 value against V's pair; the MLP's two GEMMs as
                            TWO fp16 products per product (fp16 weights x fp16 hi + lo activations) -- scores within 1e-4 as well
                            (profiles/r6_encoder_rounding_sim.txt: the MLP tolerates 11-bit weights and P.V an 8-bit P, the
-                           logit path neither), 15-17 % faster than MX_PREC_BF16X3                                      */
+                           logit path neither), 15-17 % faster than MX_PREC_BF16X3 |
+                           MX_PREC_MIXED1 (round 6): MX_PREC_MIXED with the MLP on ONE fp16 product per product (weights, LayerNorm
+                           output and GELU output one fp16 value each; residual stream, GEMM results and LayerNorm stay f32):
+                           scores within 3.5e-4 in the simulator (a 3 x margin to 1e-3 where MX_PREC_MIXED has 5-25 x) --
+                           opt-in, no loader picks it                                                                  */
 } mx_encoder_cfg;
-enum { MX_PREC_BF16 = 0, MX_PREC_BF16X3 = 1, MX_PREC_MIXED = 2 };
+enum { MX_PREC_BF16 = 0, MX_PREC_BF16X3 = 1, MX_PREC_MIXED = 2, MX_PREC_MIXED1 = 3 };
 /* sizeof(mx_encoder_cfg) of the library that is loaded: the struct grew a trailing field (`precision`) and may again; a shim
  * built against an older header compares this with its own sizeof at start-up instead of letting the library read past
  * its struct (same handshake as mx_index_stats_size). */

@@ -22,7 +22,7 @@ MX_EINVAL, MX_EDEVICE, MX_EINSERT, MX_ESEARCH, MX_EIO, MX_EUNSUPPORTED, MX_ENOME
 MX_SEARCH_AUTO, MX_SEARCH_EXACT = 0, 1
 MX_CORPUS_F32, MX_CORPUS_BF16 = 0, 1
 MX_POOL_MEAN, MX_POOL_CLS = 0, 1
-MX_PREC_BF16, MX_PREC_BF16X3, MX_PREC_MIXED = 0, 1, 2
+MX_PREC_BF16, MX_PREC_BF16X3, MX_PREC_MIXED, MX_PREC_MIXED1 = 0, 1, 2, 3
 
 # every symbol include/memex_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [

@@ -80,7 +80,8 @@ struct mx_encoder {
     float *xf = nullptr, *qkvf = nullptr, *af = nullptr;
     bf16_t *xs = nullptr, *ctxs = nullptr, *hs = nullptr;
     bool precise = false;
-    bool mixed = false;       // MX_PREC_MIXED: precise, with the MLP on two fp16 products per product
+    bool mixed = false;       // MX_PREC_MIXED / MX_PREC_MIXED1: precise, with the MLP on fp16 products (and P as one bf16 value in P.V)
+    bool mlp1 = false;        // MX_PREC_MIXED1: ... ONE fp16 product per product in the MLP (weights, input and GELU output one fp16 value each)
     // small passes (<= kSmallRows packed rows, fused-tail models): x1 of the layer in flight, the MLP's partial products
     bf16_t *sp_x1 = nullptr;
     float *sp_part = nullptr;
@@ -149,10 +150,11 @@ int upload_weight3(mx_encoder *e, const float *src, size_t rows, size_t k, bf16_
     return MX_OK;
 }
 
-// the mixed mode's form of a Linear weight: ONE fp16 value per element (saturating), k doubled, [w | w] against activations
-// split as fp16 [hi | lo]: two fp16 MFMA products per product, 11 + 22 significant bits
-int upload_weight2h(mx_encoder *e, const float *src, size_t rows, size_t k, bf16_t **dst) {
-    std::vector<uint16_t> tmp(rows * 2 * k);
+// the mixed modes' form of a Linear weight: ONE fp16 value per element (saturating).  copies = 2 (MX_PREC_MIXED): k doubled, [w | w]
+// against activations split as fp16 [hi | lo] -- two fp16 MFMA products per product, 11 + 22 significant bits; copies = 1
+// (MX_PREC_MIXED1): [w] against ONE fp16 value per activation
+int upload_weight2h(mx_encoder *e, const float *src, size_t rows, size_t k, bf16_t **dst, int copies = 2) {
+    std::vector<uint16_t> tmp(rows * (size_t)copies * k);
     auto at = [&](size_t r, size_t c) -> uint16_t & { return tmp[((c >> 5) * rows + r) * 32 + (c & 31)]; };
     for (size_t r = 0; r < rows; ++r)
         for (size_t c = 0; c < k; ++c) {
@@ -161,7 +163,7 @@ int upload_weight2h(mx_encoder *e, const float *src, size_t rows, size_t k, bf16
             uint16_t bits;
             memcpy(&bits, &hv, 2);
             at(r, c) = bits;
-            at(r, k + c) = bits;
+            if (copies == 2) at(r, k + c) = bits;
         }
     MX_HIP(hipMalloc(dst, tmp.size() * sizeof(uint16_t)));
     e->allocs.push_back(*dst);
@@ -314,11 +316,11 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             MX_HIP(pgemm_or_gemm(EPI_F32, o));
             // the MLP: three bf16 products per product (MX_PREC_BF16X3), or two fp16 ones (MX_PREC_MIXED: x1 and gelu(..) as fp16
             // hi + lo in the same buffers, the weights as one fp16 value)
-            const int sp = e->mixed ? 2 : 3;
-            MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, m_c, H, L.ln1g, L.ln1b, c.ln_eps, e->mixed));
+            const int sp = e->mlp1 ? 1 : e->mixed ? 2 : 3;
+            MX_HIP(launch_add_ln_split(st, e->af, e->xf, e->xs, m_c, H, L.ln1g, L.ln1b, c.ln_eps, e->mlp1 ? 2 : e->mixed ? 1 : 0));
             GemmParams f1{};
             f1.a = e->xs; f1.lda = sp * H; f1.w = e->mixed ? L.wi2h : L.wi3; f1.w_rows = F; f1.bias = L.bi; f1.m = m_c; f1.n = F; f1.k = sp * H;
-            f1.out = e->hs; f1.ldo = sp * F;
+            f1.out = e->hs; f1.ldo = sp * F; f1.single = e->mlp1 ? 1 : 0;
             MX_HIP(pgemm_or_gemm(e->mixed ? EPI_GELU_SPLIT_H : EPI_GELU_SPLIT, f1));
             GemmParams f2{};
             f2.a = e->hs; f2.lda = sp * F; f2.w = e->mixed ? L.wo22h : L.wo23; f2.w_rows = H; f2.bias = L.bo2; f2.m = m_c; f2.n = H; f2.k = sp * F;
@@ -490,7 +492,8 @@ int check_cfg(const mx_encoder_cfg *c) {
     if (c->pos_offset < 0 || c->pos_offset >= c->max_pos) return fail(MX_EINVAL, "pos_offset %d outside [0, max_pos)", c->pos_offset);
     if (c->pooling != MX_POOL_MEAN && c->pooling != MX_POOL_CLS) return fail(MX_EINVAL, "pooling %d", c->pooling);
     if (!(c->ln_eps >= 0.0f)) return fail(MX_EINVAL, "ln_eps");
-    if (c->precision != MX_PREC_BF16 && c->precision != MX_PREC_BF16X3 && c->precision != MX_PREC_MIXED) return fail(MX_EINVAL, "precision %d", c->precision);
+    if (c->precision != MX_PREC_BF16 && c->precision != MX_PREC_BF16X3 && c->precision != MX_PREC_MIXED && c->precision != MX_PREC_MIXED1)
+        return fail(MX_EINVAL, "precision %d", c->precision);
     if (c->precision != MX_PREC_BF16 && c->ffn % 192) return fail(MX_EUNSUPPORTED, "ffn %d: the split-operand modes need a multiple of 192", c->ffn);
     return MX_OK;
 }
@@ -544,8 +547,9 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
     e->device = device;
     {
         // kernel-variant keys of MEMEX_HIP_DEBUG (mx_debug.h), fixed per encoder handle
-        e->precise = cfg->precision == MX_PREC_BF16X3 || cfg->precision == MX_PREC_MIXED;
-        e->mixed = cfg->precision == MX_PREC_MIXED;
+        e->precise = cfg->precision != MX_PREC_BF16;
+        e->mixed = cfg->precision == MX_PREC_MIXED || cfg->precision == MX_PREC_MIXED1;
+        e->mlp1 = cfg->precision == MX_PREC_MIXED1;
         e->fused_tail = !e->precise && tail_supported(cfg->hidden, cfg->ffn) && debug_flag("unfused_tail", 0) != 1;
         e->pgemm = debug_flag("pgemm", 1) != 0;
         e->small_pass = e->fused_tail && debug_flag("small", 1) != 0;
@@ -601,13 +605,13 @@ int mx_encoder_create(const mx_encoder_cfg *cfg, const void *weights, size_t nby
         MX_TRY(upload_f32(e, be1_src, H, &L.ln1b));
         const float *wi_src = take(F * H);
         if (e->precise && !e->mixed) MX_TRY(upload_weight3(e, wi_src, F, H, &L.wi3));
-        if (e->mixed) MX_TRY(upload_weight2h(e, wi_src, F, H, &L.wi2h));
+        if (e->mixed) MX_TRY(upload_weight2h(e, wi_src, F, H, &L.wi2h, e->mlp1 ? 1 : 2));
         else MX_TRY(upload_weight(e, wi_src, F, H, &L.wi));
         const float *b1_src = take(F);
         MX_TRY(upload_f32(e, b1_src, F, &L.bi));
         const float *wo2_src = take(H * F);
         if (e->precise && !e->mixed) MX_TRY(upload_weight3(e, wo2_src, H, F, &L.wo23));
-        if (e->mixed) MX_TRY(upload_weight2h(e, wo2_src, H, F, &L.wo22h));
+        if (e->mixed) MX_TRY(upload_weight2h(e, wo2_src, H, F, &L.wo22h, e->mlp1 ? 1 : 2));
         else MX_TRY(upload_weight(e, wo2_src, H, F, &L.wo2));
         if (e->fused_tail) MX_TRY(upload_tail_stream(e, wo_src, wi_src, wo2_src, F, &L.wf));
         const float *b2_src = take(H), *g2_src = take(H), *be2_src = take(H);

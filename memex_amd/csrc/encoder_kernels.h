@@ -54,6 +54,7 @@ struct GemmParams {
     const float *beta;
     float eps;
     float *out_f32;       // EPI_F32
+    int single;           // EPI_GELU_SPLIT_H only: 1 = the output is ONE fp16 value per element (no lo block: MX_PREC_MIXED1), 0 = [hi | lo]
     int ksplit;           // EPI_F32 only, 0 / 1 = off: the launch has `ksplit` k-chunks of p.k columns each (blockIdx.y = chunk): chunk z reads
                           // a + z k and the weights' k-blocks from z k / 32 on, and writes its partial product to out_f32 + z m ldo
 };
@@ -160,9 +161,10 @@ hipError_t launch_embed_ln_precise(hipStream_t s, const int32_t *ids, int S, con
                                    int t_pad, int hidden, const float *word, const float *pos, const float *type0,
                                    const float *gamma, const float *beta, float eps, int vocab, float *xf, bf16_t *xs);
 // xf[r] = LayerNorm(a[r] + xf[r]) in place (f32), xs[r] = split3(xf[r])
-// half2 = true: xs[r] = [hi | lo] in fp16 (2H wide) instead of the three bf16 blocks: the operand of the mixed mode's W1
+// half2 = 1: xs[r] = [hi | lo] in fp16 (2H wide) instead of the three bf16 blocks: the operand of the mixed mode's W1; 2: ONE fp16
+// value per element (H wide): MX_PREC_MIXED1
 hipError_t launch_add_ln_split(hipStream_t s, const float *a, float *xf, bf16_t *xs, int rows, int hidden, const float *gamma,
-                               const float *beta, float eps, bool half2 = false);
+                               const float *beta, float eps, int half2 = 0);
 // softmax(q k^T / sqrt(d) + mask) v in f32 (v_mfma_f32_32x32x2_f32) from qkv [t_pad, 3H] f32 (q | k | v) -> ctxs [t_pad, 3H] split
 hipError_t launch_attention_f32(hipStream_t s, const float *qkv, const int32_t *cu, const int32_t *lens, int B, int S, int heads,
                                 int d_head, int hidden, bf16_t *ctxs, bool f32_mfma, bool p_single);

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                     }
             }
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {  // 0: hi = bf16(g) (fp16(g) in the mixed mode), 1: lo = g - hi rounded the same way
+        for (int half = 0; half < 2; ++half) {  // 0: hi = bf16(g) (fp16(g) in the mixed modes), 1: lo = g - hi rounded the same way
+            if (F16 && half == 1 && p.single) break;  // MX_PREC_MIXED1: one fp16 value per element (uniform over the launch)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll

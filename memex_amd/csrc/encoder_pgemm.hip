@@ -285,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const GemmParams p, const
                         }
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
+                        if (F16 && half == 1 && p.single) break;  // MX_PREC_MIXED1: one fp16 value per element (uniform over the launch)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
 #pragma unroll

@@ -52,6 +52,13 @@ __device__ __forceinline__ void store_split4h(bf16_t *o, int blk, const f32x4 v)
     *reinterpret_cast<f16x4 *>(o) = hi;
     *reinterpret_cast<f16x4 *>(o + blk) = lo;
 }
+// MX_PREC_MIXED1: ONE fp16 value per element (saturating)
+__device__ __forceinline__ void store_half4(bf16_t *o, const f32x4 v) {
+    f16x4 hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hi[e] = (_Float16)fminf(fmaxf(v[e], -65504.0f), 65504.0f);
+    *reinterpret_cast<f16x4 *>(o) = hi;
+}
 
 }  // namespace
 
@@ -151,7 +158,8 @@ __global__ __launch_bounds__(256) void add_ln_split_kernel(const float *__restri
     if (row >= rows) return;
     const float *ar = a + (size_t)row * H;
     float *xr = xf + (size_t)row * H;
-    bf16_t *sr = xs + (size_t)row * (half2 ? 2 : 3) * H;  // (half2: the mixed mode's [hi | lo] fp16 image, 2H wide)
+    // half2 = 1: the mixed mode's [hi | lo] fp16 image, 2H wide; 2: MX_PREC_MIXED1's single fp16 value, H wide
+    bf16_t *sr = xs + (size_t)row * (half2 == 2 ? 1 : half2 ? 2 : 3) * H;
     float y[24];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -176,17 +184,18 @@ __global__ __launch_bounds__(256) void add_ln_split_kernel(const float *__restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ln_affine(y[c * 8 + 4 * hf + e], mean, rstd, g[e], b[e]);
             *reinterpret_cast<f32x4 *>(xr + col) = o;
-            if (half2) store_split4h(sr + col, H, o);
+            if (half2 == 2) store_half4(sr + col, o);
+            else if (half2) store_split4h(sr + col, H, o);
             else store_split4(sr + col, H, o);
         }
 }
 
 hipError_t launch_add_ln_split(hipStream_t s, const float *a, float *xf, bf16_t *xs, int rows, int hidden, const float *gamma,
-                               const float *beta, float eps, bool half2) {
+                               const float *beta, float eps, int half2) {
     if (hidden == 768)
-        hipLaunchKernelGGL(add_ln_split_kernel<32>, dim3((rows + 7) / 8), dim3(256), 0, s, a, xf, xs, rows, gamma, beta, eps, half2 ? 1 : 0);
+        hipLaunchKernelGGL(add_ln_split_kernel<32>, dim3((rows + 7) / 8), dim3(256), 0, s, a, xf, xs, rows, gamma, beta, eps, half2);
     else if (hidden == 384)
-        hipLaunchKernelGGL(add_ln_split_kernel<16>, dim3((rows + 15) / 16), dim3(256), 0, s, a, xf, xs, rows, gamma, beta, eps, half2 ? 1 : 0);
+        hipLaunchKernelGGL(add_ln_split_kernel<16>, dim3((rows + 15) / 16), dim3(256), 0, s, a, xf, xs, rows, gamma, beta, eps, half2);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -16,7 +16,8 @@ def _cfg_struct(cfg: EncoderConfig) -> EncoderCfg:
     return EncoderCfg(cfg.layers, cfg.hidden, cfg.heads, cfg.ffn, cfg.vocab, cfg.max_pos, cfg.type_vocab,
                       cfg.ln_eps, _lib.MX_POOL_CLS if cfg.pooling == "cls" else _lib.MX_POOL_MEAN,
                       1 if cfg.normalize else 0, cfg.pos_offset,
-                      {"bf16": _lib.MX_PREC_BF16, "bf16x3": _lib.MX_PREC_BF16X3, "mixed": _lib.MX_PREC_MIXED}[cfg.precision])
+                      {"bf16": _lib.MX_PREC_BF16, "bf16x3": _lib.MX_PREC_BF16X3, "mixed": _lib.MX_PREC_MIXED,
+                       "mixed1": _lib.MX_PREC_MIXED1}[cfg.precision])
 
 
 class Encoder:

@@ -86,7 +86,7 @@ def default_precision(hidden: int, pooling: str) -> str:
 
 
 def load_pretrained_dir(path: str, precision: Optional[str] = None) -> Tuple[EncoderConfig, Dict[str, np.ndarray], Optional[str], dict]:
-    """-> (EncoderConfig, tensors by HF name, path of vocab.txt or None, info).  ``precision``: "bf16" | "bf16x3" | "mixed", or
+    """-> (EncoderConfig, tensors by HF name, path of vocab.txt or None, info).  ``precision``: "bf16" | "bf16x3" | "mixed" | "mixed1", or
     None = :func:`default_precision` of the model.
 
     ``info``: ``do_lower_case``, ``model_type``, ``modules`` (the pipeline's module types in order), ``bpe_files``

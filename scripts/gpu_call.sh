@@ -1,16 +1,6 @@
 #!/bin/bash
-# round 6: full GPU suite + smoke + default bench at HEAD
+# round 6: MX_PREC_MIXED1 (the MLP on one fp16 product): encoder parity tests with printed errors, throughput
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r6f_tests.txt 2>&1; echo "tests rc=$?" | tee -a gpurun_out/r6f_tests.txt
-grep -E "passed|failed" gpurun_out/r6f_tests.txt | tail -2
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r6f_smoke.txt 2>&1; tail -2 gpurun_out/r6f_smoke.txt
-timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 --sides-out gpurun_out/r6f_bench_sides.json > gpurun_out/r6f_bench.json 2> gpurun_out/r6f_bench.err; echo "bench rc=$?"
-python - <<'PY'
-import json
-r = json.loads(open('gpurun_out/r6f_bench.json').read().strip().splitlines()[-1])
-print(r['value'], r['ms_per_step'], r['roofline']['frac'])
-for k in ('encoder_minilm', 'encoder_bge', 'encoder_minilm_128tok', 'encoder_split_modes'):
-    print(k, json.dumps(r['roofline'].get(k))[:700])
-print(json.dumps(r['sides'].get('enc_like_10M')))
-PY
+timeout 1800 python -m pytest tests/test_encoder_gpu.py tests/test_abi.py -m gpu -x -q -s 2>&1 | grep -E "checkpoint-like weights|pgemm_kernel, hidden|passed|failed|Error|error" | tee gpurun_out/r6aa_tests.txt | tail -24
+timeout 900 python scripts/gpu_encoder_precise.py 2>&1 | grep "chunks/s" | tee gpurun_out/r6aa_precise.txt

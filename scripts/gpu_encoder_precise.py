@@ -7,7 +7,7 @@ from memex_amd import weights as W
 
 def run(cfg, B, S, reps=3):
     w = W.pack_weights(W.synthetic_weights(cfg, 0), cfg)
-    for prec in ("bf16", "bf16x3", "mixed"):
+    for prec in ("bf16", "bf16x3", "mixed", "mixed1"):
         c = dataclasses.replace(cfg, precision=prec)
         enc = Encoder(c, w)
         g = torch.Generator(device="cuda"); g.manual_seed(1)

@@ -66,6 +66,8 @@ def test_encoder_vs_transformers_golden(lib_built):
     (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000, precision="mixed"), 6, 256, 1),    # the mixed mode: MLP on two fp16 products
     (dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls", precision="mixed"), 3, 160, 4),
     (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000, normalize=False, precision="mixed"), 5, 512, 8),
+    (dict(layers=6, hidden=384, heads=12, ffn=1536, vocab=3000, precision="mixed1"), 6, 256, 1),   # ... on ONE fp16 product
+    (dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls", precision="mixed1"), 3, 160, 4),
 ])
 def test_encoder_vs_oracle(kw, B, S, seed, lib_built):
     from memex_amd.encoder import Encoder
@@ -82,8 +84,8 @@ def test_encoder_vs_oracle(kw, B, S, seed, lib_built):
         again = enc.encode(ids, lens)
     ref = bert_oracle.encode(w, cfg.as_dict(), ids, lens)
     assert np.isfinite(out).all()
-    precise = cfg.precision in ("bf16x3", "mixed")
-    assert (1.0 - _cos(out.astype(np.float64), ref)).max() <= ({"bf16x3": 1e-7, "mixed": 1e-6}[cfg.precision] if precise else TOL)
+    precise = cfg.precision in ("bf16x3", "mixed", "mixed1")
+    assert (1.0 - _cos(out.astype(np.float64), ref)).max() <= ({"bf16x3": 1e-7, "mixed": 1e-6, "mixed1": 1e-5}[cfg.precision] if precise else TOL)
     if not cfg.normalize:
         np.testing.assert_allclose(np.linalg.norm(out, axis=1), np.linalg.norm(ref, axis=1), rtol=1e-4 if precise else 2e-2)
     np.testing.assert_array_equal(out, again)                      # deterministic
@@ -354,7 +356,7 @@ def test_a_row_across_the_pass_size_regimes(lib_built):
     (dict(layers=4, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls"), 80, 512, 53),     # bge-base layers, 41k rows: pgemm_kernel + ln_rows_kernel
     (dict(layers=4, hidden=384, heads=12, ffn=1536, vocab=3000), 96, 512, 54),                    # MiniLM layers, large pass
 ])
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "mixed"])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "mixed", "mixed1"])
 def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, precision, lib_built):
     """Trained checkpoints carry what random weights do not: outlier hidden dimensions (LayerNorm gains ~20, biases
     +-30 on a handful of dimensions in every layer) and attention logits of +-60.  Those are the bf16 hazards --
@@ -377,7 +379,7 @@ def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, precision
     sub = slice(0, min(B, 8))
     ref = bert_oracle.encode_many(w, cfg.as_dict(), ids[sub], lens[sub])
     cos = _cos(out[sub].astype(np.float64), ref)
-    assert (1.0 - cos).max() <= {"bf16": TOL, "bf16x3": 1e-6, "mixed": 1e-5}[precision], (kw, cos)
+    assert (1.0 - cos).max() <= {"bf16": TOL, "bf16x3": 1e-6, "mixed": 1e-5, "mixed1": 1e-4}[precision], (kw, cos)
     # what the search sees: the cosines BETWEEN embeddings.  These weights put a large common component into every
     # embedding (pairwise cosines ~0.96) and most of its energy into five dimensions of magnitude 20-60, where a bf16 step
     # is 0.125-0.25: the row-wise cosine above is the easy half.  Measured (round 4): the pairwise cosines move by up to
@@ -395,10 +397,11 @@ def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, precision
     pair = np.abs(o @ o.T - r @ r.T).max()
     print(f"checkpoint-like weights {kw['layers']}x{kw['hidden']} B={B} S={S} {precision}: max(1 - cos) = {(1.0 - cos).max():.2e}, "
           f"max |pairwise cosine error| = {pair:.2e}")
-    if precision in ("bf16x3", "mixed"):
+    if precision in ("bf16x3", "mixed", "mixed1"):
         # north_star: cosine scores within 1e-3 -- with the margin the rounding simulator promised (profiles/r6_encoder_rounding_sim.txt:
-        # bf16x3 <= 4.7e-5, the mixed mode's MLP on fp16 weights x fp16 hi + lo activations <= 3.6e-5)
-        assert pair <= (1e-4 if precision == "bf16x3" else 2.5e-4), (kw, pair)
+        # bf16x3 <= 4.7e-5, the mixed mode's MLP on fp16 weights x fp16 hi + lo activations <= 3.6e-5; its MLP on ONE fp16 product
+        # <= 3.3e-4: mixed1 is asserted against the bar itself with a factor of two)
+        assert pair <= {"bf16x3": 1e-4, "mixed": 2.5e-4, "mixed1": 5e-4}[precision], (kw, pair)
     else:
         assert pair <= (2.5e-2 if cfg.pooling == "cls" else 2.5e-3), (kw, pair)   # bf16 operands: measured, not the bar
 
@@ -553,7 +556,9 @@ def test_split_bf16_attention_matches_the_f32_mfma_attention(kw, B, S, lib_built
     (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls", precision="bf16x3"), 80, 512, 61),   # every GEMM on pgemm_kernel
     (dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000, precision="bf16x3"), 96, 512, 62),                # W1 (N = 1536) only: 1152 and 384 are no multiples of 256
     (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls", precision="mixed"), 80, 512, 63),   # the fp16 two-product GEMMs of the mixed mode
-    (dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000, precision="mixed"), 96, 512, 64)])
+    (dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000, precision="mixed"), 96, 512, 64),
+    (dict(layers=2, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls", precision="mixed1"), 80, 512, 65),  # ... and the one-product ones
+    (dict(layers=2, hidden=384, heads=12, ffn=1536, vocab=3000, precision="mixed1"), 96, 512, 66)])
 def test_split_operand_mode_on_pgemm_kernel(kw, B, S, seed, lib_built, monkeypatch):
     """MX_PREC_BF16X3 in large passes: its GEMMs run on pgemm_kernel where the shape allows (EPI_F32 / EPI_GELU_SPLIT through the
     wave-private scratch tile).  Same k order, same products, f32 sums in the same order as gemm_kernel: bit-identical
@@ -578,7 +583,7 @@ def test_split_operand_mode_on_pgemm_kernel(kw, B, S, seed, lib_built, monkeypat
     d = (1.0 - _cos(outs[1][sub].astype(np.float64), ref)).max()
     pair = np.abs(outs[1][sub].astype(np.float64) @ outs[1][sub].astype(np.float64).T - ref @ ref.T).max()
     print(f"bf16x3 on pgemm_kernel, hidden {cfg.hidden}: 1 - cos = {d:.2e}, pairwise {pair:.2e}")
-    assert d <= (1e-5 if cfg.precision == "mixed" else 1e-6) and pair <= 1e-3, (d, pair)
+    assert d <= {"bf16x3": 1e-6, "mixed": 1e-5, "mixed1": 1e-4}[cfg.precision] and pair <= 1e-3, (d, pair)
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
