@@ -150,5 +150,7 @@ if __name__ == "__main__":
         report("r6b  + MLP on ONE fp16 product (w, x_f, h fp16)", run(w, cfg, ids, lens, mixed(x_f=hf, h=hf)), ref)
         report("r6b  + W2 on ONE fp16 product (h fp16), W1 two", run(w, cfg, ids, lens, mixed(h=hf)), ref)
         report("r6b  + W1 on ONE fp16 product (x_f fp16), W2 two", run(w, cfg, ids, lens, mixed(x_f=hf)), ref)
+        report("r6b AS BUILT: MX_PREC_MIXED (P one bf16 value)", run(w, cfg, ids, lens, mixed(p=bf)), ref)
+        report("r6b AS BUILT: MX_PREC_MIXED1 (P one bf16 value, MLP one fp16 product)", run(w, cfg, ids, lens, mixed(p=bf, x_f=hf, h=hf)), ref)
         report("r6b  + QK^T as two products (q 16-bit pair, k fp16)", run(w, cfg, ids, lens, mixed(k=hf)), ref)
         report("r6b  + QK^T as two products (q fp16 pair r22, k fp16)", run(w, cfg, ids, lens, mixed(q=r22, k=hf)), ref)
