@@ -152,5 +152,11 @@ if __name__ == "__main__":
         report("r6b  + W1 on ONE fp16 product (x_f fp16), W2 two", run(w, cfg, ids, lens, mixed(x_f=hf)), ref)
         report("r6b AS BUILT: MX_PREC_MIXED (P one bf16 value)", run(w, cfg, ids, lens, mixed(p=bf)), ref)
         report("r6b AS BUILT: MX_PREC_MIXED1 (P one bf16 value, MLP one fp16 product)", run(w, cfg, ids, lens, mixed(p=bf, x_f=hf, h=hf)), ref)
+        M1 = dict(p=bf, x_f=hf, h=hf)
+        report("r6c MIXED1 + V / out projections on two products (fp16 w x fp16 pair)", run(w, cfg, ids, lens, mixed(**M1, w_v=hf, x_v=r22, w_o=hf, ctx=r22)), ref)
+        report("r6c MIXED1 + V / out projections on ONE fp16 product", run(w, cfg, ids, lens, mixed(**M1, w_v=hf, x_v=hf, w_o=hf, ctx=hf)), ref)
+        report("r6c MIXED1 + V / out on ONE fp16 product, V one fp16 value in P.V", run(w, cfg, ids, lens, mixed(**M1, w_v=hf, x_v=hf, w_o=hf, ctx=hf, v=hf)), ref)
+        report("r6c MIXED1 + out projection alone on ONE fp16 product", run(w, cfg, ids, lens, mixed(**M1, w_o=hf, ctx=hf)), ref)
+        report("r6c MIXED1 + V projection alone on ONE fp16 product", run(w, cfg, ids, lens, mixed(**M1, w_v=hf, x_v=hf)), ref)
         report("r6b  + QK^T as two products (q 16-bit pair, k fp16)", run(w, cfg, ids, lens, mixed(k=hf)), ref)
         report("r6b  + QK^T as two products (q fp16 pair r22, k fp16)", run(w, cfg, ids, lens, mixed(q=r22, k=hf)), ref)
