@@ -283,17 +283,19 @@ typedef struct mx_encoder_cfg {
     int32_t precision;  /* MX_PREC_BF16 (0, the default: bf16 operands, f32 accumulation -- the ingest path) |
                            MX_PREC_BF16X3: every GEMM operand carried as hi + lo bf16 (three MFMA products per
                            f32 product), f32 hidden state and f32 attention -- scores BETWEEN embeddings within
-                           1e-4 of the f32 CPU path (embedding.rs:109) also under checkpoint-like weights, where
-                           the bf16 path moves them by up to 1e-2; about 6x slower |
-                           MX_PREC_MIXED (round 6): the attention block (Q, K, V, scores, out-projection) as in
-                           MX_PREC_BF16X3 except that P enters P.V as ONE bf16 value against V's pair; the MLP's two GEMMs as
-                           TWO fp16 products per product (fp16 weights x fp16 hi + lo activations) -- scores within 1e-4 as well
-                           (profiles/r6_encoder_rounding_sim.txt: the MLP tolerates 11-bit weights and P.V an 8-bit P, the
-                           logit path neither), 15-17 % faster than MX_PREC_BF16X3 |
+                           1e-3 of the f64 evaluation of the f32 CPU path (embedding.rs:109) on every draw of
+                           checkpoint-like weights tried (2e-5 typical, 6e-4 at worst), where the bf16 path moves
+                           them by 1e-2 ... 4e-2; about 3.2x slower.  What the loaders pick
+                           for CLS-pooled hidden-768 models |
+                           MX_PREC_MIXED (round 6): the attention block (Q, K, V, scores, PV, out-projection) as in
+                           MX_PREC_BF16X3, the MLP's two GEMMs as TWO fp16 products per product (fp16 weights x fp16 hi + lo
+                           activations): 15-17 % faster than MX_PREC_BF16X3; scores within 2.3e-4 on ten of twelve draws of
+                           checkpoint-like weights, 1.1e-3 on the other two, where MX_PREC_BF16X3 has 6e-4
+                           (profiles/r6_precision_modes_over_seeds.txt) -- "about 1e-3 at worst", opt-in |
                            MX_PREC_MIXED1 (round 6): MX_PREC_MIXED with the MLP on ONE fp16 product per product (weights, LayerNorm
-                           output and GELU output one fp16 value each; residual stream, GEMM results and LayerNorm stay f32):
-                           scores within 3.5e-4 in the simulator (a 3 x margin to 1e-3 where MX_PREC_MIXED has 5-25 x) --
-                           opt-in, no loader picks it                                                                  */
+                           output and GELU output one fp16 value each; residual stream, GEMM results and LayerNorm stay f32) and P
+                           as one bf16 value in P.V: 0.39 / 0.48 of the bf16 rate, scores 1.5e-5 ... 2e-2 by draw -- an order
+                           of magnitude better than bf16, NOT a mode that holds 1e-3; opt-in                           */
 } mx_encoder_cfg;
 enum { MX_PREC_BF16 = 0, MX_PREC_BF16X3 = 1, MX_PREC_MIXED = 2, MX_PREC_MIXED1 = 3 };
 /* sizeof(mx_encoder_cfg) of the library that is loaded: the struct grew a trailing field (`precision`) and may again; a shim

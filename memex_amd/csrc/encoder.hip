@@ -80,8 +80,9 @@ struct mx_encoder {
     float *xf = nullptr, *qkvf = nullptr, *af = nullptr;
     bf16_t *xs = nullptr, *ctxs = nullptr, *hs = nullptr;
     bool precise = false;
-    bool mixed = false;       // MX_PREC_MIXED / MX_PREC_MIXED1: precise, with the MLP on fp16 products (and P as one bf16 value in P.V)
-    bool mlp1 = false;        // MX_PREC_MIXED1: ... ONE fp16 product per product in the MLP (weights, input and GELU output one fp16 value each)
+    bool mixed = false;       // MX_PREC_MIXED / MX_PREC_MIXED1: precise, with the MLP on fp16 products
+    bool mlp1 = false;        // MX_PREC_MIXED1: ... ONE fp16 product per product in the MLP (weights, input and GELU output one fp16 value each),
+                              // and P as one bf16 value in P.V
     // small passes (<= kSmallRows packed rows, fused-tail models): x1 of the layer in flight, the MLP's partial products
     bf16_t *sp_x1 = nullptr;
     float *sp_part = nullptr;
@@ -309,7 +310,7 @@ int encode_pass(mx_encoder *e, const int32_t *d_ids, const int32_t *h_lens, cons
             g.a = e->xs; g.lda = 3 * H; g.w = L.wqkv3; g.w_rows = 3 * H; g.bias = L.bqkv; g.m = m_c; g.n = 3 * H; g.k = 3 * H;
             g.out_f32 = e->qkvf; g.ldo = 3 * H;
             MX_HIP(pgemm_or_gemm(EPI_F32, g));
-            MX_HIP(launch_attention_f32(st, e->qkvf, e->cu, d_lens, B, max_len, heads, dh, H, e->ctxs, e->attn_f32, e->mixed));
+            MX_HIP(launch_attention_f32(st, e->qkvf, e->cu, d_lens, B, max_len, heads, dh, H, e->ctxs, e->attn_f32, e->mlp1));
             GemmParams o{};
             o.a = e->ctxs; o.lda = 3 * H; o.w = L.wo3; o.w_rows = H; o.bias = L.bo; o.m = m_c; o.n = H; o.k = 3 * H;
             o.out_f32 = e->af; o.ldo = H;

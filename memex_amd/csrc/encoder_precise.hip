@@ -323,9 +323,10 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restr
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8p;
 
-// P1 (MX_PREC_MIXED): P enters the PV product as ONE bf16 value against V's pair -- two products, no split of P in the loop.  The
+// P1 (MX_PREC_MIXED1): P enters the PV product as ONE bf16 value against V's pair -- two products, no split of P in the loop.  The
 // rounding simulator puts that within 1.0e-4 of the f64 evaluation on scores (profiles/r6_encoder_rounding_sim.txt, "r6b": P bf16, V
-// 16-bit pair); QK^T keeps its three products in every mode (one 16-bit value on either side costs 3e-4 ... 8e-3).
+// 16-bit pair; on the bench's bge-base sample it tripled MX_PREC_MIXED's error, 6.2e-5 -> 1.8e-4, for 1-2 % of its time: that mode went
+// back to three products); QK^T keeps its three products in every mode (one 16-bit value on either side costs 3e-4 ... 8e-3).
 // NW waves per workgroup = 32 NW queries of one (sequence, head); key blocks of KB = 32 or 64 keys (two barriers per block).  With 16
 // waves a 512-token sequence's K and V are split and staged once instead of once per 128 queries.
 template <int DH, bool P1, int NW, int KB>

@@ -33,8 +33,8 @@ class EncoderConfig:
     pos_offset: int = 0        # 0 = BERT; 2 = RoBERTa-style (position ids start at padding_idx + 1)
     precision: str = "bf16"    # "bf16" (default: bf16 operands, the ingest path) | "bf16x3" (split operands, f32 hidden state
                                # and attention: f32-grade scores at ~1/3 of the speed; include/memex_hip.h MX_PREC_BF16X3) |
-                               # "mixed" (MX_PREC_MIXED: bf16x3 with the MLP on two fp16 products: the same grade, 15-17 % faster) |
-                               # "mixed1" (MX_PREC_MIXED1: ... on ONE fp16 product: scores within ~3e-4, another ~20 % faster; opt-in)
+                               # "mixed" (MX_PREC_MIXED: bf16x3 with the MLP on two fp16 products: 15-17 % faster, scores ~1e-3 at worst) |
+                               # "mixed1" (MX_PREC_MIXED1: ... on ONE fp16 product: another ~20 % faster, scores 1e-5 ... 2e-2 by checkpoint; opt-in)
 
     def as_dict(self) -> dict:
         return asdict(self)

@@ -406,6 +406,39 @@ def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, precision
         assert pair <= (2.5e-2 if cfg.pooling == "cls" else 2.5e-3), (kw, pair)   # bf16 operands: measured, not the bar
 
 
+@pytest.mark.parametrize("seed", [1, 4, 5])
+def test_precision_modes_over_weight_seeds(seed, lib_built):
+    """The four cases above are four draws of `checkpoint_like_weights`.  Other seeds of the same generator are harsher on the bge-base
+    shape (12 x 768, CLS): seeds 1 and 4 put the all-f32 evaluation at 1.5e-5 / 4.0e-5 from the f64 oracle on pairwise scores where
+    seed 52 has 1.5e-6, and the numpy emulation (scripts/encoder_rounding_sim.py) then says 3.4e-4 for three bf16 products
+    everywhere, 1.2-1.3e-3 for the mixed mode, 2e-2 for mixed1 and 3e-2 for bf16 (profiles/r6_precision_modes_over_seeds.txt).
+    So: MX_PREC_BF16X3 -- the mode the loaders pick for CLS-pooled hidden-768 models -- must hold north_star's 1e-3 on the scores on
+    every seed; the cheaper modes are measured and labelled, not promised."""
+    from memex_amd.encoder import Encoder
+    from memex_amd.weights import EncoderConfig, checkpoint_like_weights
+    from oracle import bert_oracle
+    kw = dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=3000, pooling="cls")
+    B, S = 6, 200
+    base = EncoderConfig(**kw)
+    w = checkpoint_like_weights(base, seed)
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(0, base.vocab, (B, S)).astype(np.int32)
+    lens = rng.integers(S // 2, S + 1, B).astype(np.int32)
+    lens[0] = S
+    ref = bert_oracle.encode_many(w, base.as_dict(), ids, lens)
+    r = ref / np.linalg.norm(ref, axis=1, keepdims=True)
+    pair = {}
+    for precision in ("bf16x3", "mixed", "mixed1", "bf16"):
+        with Encoder(EncoderConfig(**kw, precision=precision), w) as enc:
+            o = enc.encode(ids, lens).astype(np.float64)
+        assert np.isfinite(o).all()
+        o /= np.linalg.norm(o, axis=1, keepdims=True)
+        pair[precision] = float(np.abs(o @ o.T - r @ r.T).max())
+    print(f"checkpoint-like weights 12x768 CLS seed {seed}: pairwise score error " + "  ".join(f"{k} {v:.2e}" for k, v in pair.items()))
+    assert pair["bf16x3"] <= 1e-3, pair                     # the bar, for the mode the loaders default to on this shape
+    assert pair["mixed"] <= 5e-3 and pair["mixed1"] <= 6e-2 and pair["bf16"] <= 2e-1, pair   # measured, not the bar
+
+
 def test_attention_fast_path_and_its_fallback(lib_built, monkeypatch):
     """attention_kernel's fast path applies no softmax shift (P = exp2(score)) and only falls back to the
     running maximum when a row sum says an exp2 may have overflowed or a row underflowed.  (a) ordinary

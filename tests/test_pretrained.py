@@ -105,10 +105,10 @@ def test_loaders_choose_the_bar_meeting_precision_for_cls_pooled_hidden_768(tmp_
     """a CLS-pooled hidden-768 model (bge-base-en) moves its scores by up to 1e-2 on bf16 operands (north_star: 1e-3);
     a loader that is not told otherwise picks MX_PREC_MIXED for it (<= 6e-5: tests/test_encoder_gpu.py), bf16 for everything else."""
     from memex_amd.pretrained import default_precision, load_pretrained_dir
-    assert default_precision(768, "cls") == "mixed" and default_precision(768, "mean") == "bf16" and default_precision(384, "cls") == "bf16"
+    assert default_precision(768, "cls") == "bf16x3" and default_precision(768, "mean") == "bf16" and default_precision(384, "cls") == "bf16"
     d = str(tmp_path / "bge")
     make_st_dir(d, hidden=768, layers=1, pooling="cls", weights="safetensors")
-    assert load_pretrained_dir(d)[0].precision == "mixed"
+    assert load_pretrained_dir(d)[0].precision == "bf16x3"
     assert load_pretrained_dir(d, precision="bf16")[0].precision == "bf16"
     d2 = str(tmp_path / "mean768")
     make_st_dir(d2, hidden=768, layers=1, pooling="mean", weights="safetensors")
