@@ -406,7 +406,7 @@ def test_checkpoint_like_weights_stay_within_tolerance(kw, B, S, seed, precision
         assert pair <= (2.5e-2 if cfg.pooling == "cls" else 2.5e-3), (kw, pair)   # bf16 operands: measured, not the bar
 
 
-@pytest.mark.parametrize("seed", [1, 4, 5])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7])
 def test_precision_modes_over_weight_seeds(seed, lib_built):
     """The four cases above are four draws of `checkpoint_like_weights`.  Other seeds of the same generator are harsher on the bge-base
     shape (12 x 768, CLS): seeds 1 and 4 put the all-f32 evaluation at 1.5e-5 / 4.0e-5 from the f64 oracle on pairwise scores where
@@ -427,14 +427,17 @@ def test_precision_modes_over_weight_seeds(seed, lib_built):
     lens[0] = S
     ref = bert_oracle.encode_many(w, base.as_dict(), ids, lens)
     r = ref / np.linalg.norm(ref, axis=1, keepdims=True)
-    pair = {}
+    pair, row = {}, {}
     for precision in ("bf16x3", "mixed", "mixed1", "bf16"):
         with Encoder(EncoderConfig(**kw, precision=precision), w) as enc:
             o = enc.encode(ids, lens).astype(np.float64)
         assert np.isfinite(o).all()
         o /= np.linalg.norm(o, axis=1, keepdims=True)
         pair[precision] = float(np.abs(o @ o.T - r @ r.T).max())
-    print(f"checkpoint-like weights 12x768 CLS seed {seed}: pairwise score error " + "  ".join(f"{k} {v:.2e}" for k, v in pair.items()))
+        row[precision] = float((1.0 - (o * r).sum(1)).max())
+    print(f"checkpoint-like weights 12x768 CLS seed {seed}: pairwise score error " + "  ".join(f"{k} {v:.2e}" for k, v in pair.items())
+          + " | row-wise 1 - cos " + "  ".join(f"{k} {v:.2e}" for k, v in row.items()))
+    assert row["bf16"] <= TOL, row                          # the parity bar of the ingest mode: each embedding against the oracle's
     assert pair["bf16x3"] <= 1e-3, pair                     # the bar, for the mode the loaders default to on this shape
     assert pair["mixed"] <= 5e-3 and pair["mixed1"] <= 6e-2 and pair["bf16"] <= 2e-1, pair   # measured, not the bar
 
