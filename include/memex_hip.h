@@ -289,7 +289,7 @@ typedef struct mx_encoder_cfg {
                            for CLS-pooled hidden-768 models |
                            MX_PREC_MIXED (round 6): the attention block (Q, K, V, scores, PV, out-projection) as in
                            MX_PREC_BF16X3, the MLP's two GEMMs as TWO fp16 products per product (fp16 weights x fp16 hi + lo
-                           activations): 15-17 % faster than MX_PREC_BF16X3; scores within 2.3e-4 on ten of twelve draws of
+                           activations): 15-17 % faster than MX_PREC_BF16X3; scores within 5.3e-4 on nine of eleven draws of
                            checkpoint-like weights, 1.1e-3 on the other two, where MX_PREC_BF16X3 has 6e-4
                            (profiles/r6_precision_modes_over_seeds.txt) -- "about 1e-3 at worst", opt-in |
                            MX_PREC_MIXED1 (round 6): MX_PREC_MIXED with the MLP on ONE fp16 product per product (weights, LayerNorm

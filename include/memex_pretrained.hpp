@@ -356,7 +356,7 @@ inline PretrainedModel load_pretrained_dir_impl(const std::string &dir, int prec
     }
     // precision < 0: the loader's choice -- the bf16 ingest mode, except for CLS-pooled hidden-768 models (bge-base-en), whose scores
     // move by 1e-2 ... 4e-2 on bf16 operands under checkpoint-like weights (north_star: 1e-3): MX_PREC_BF16X3 is the one mode that held
-    // the bar on every draw of such weights tried (<= 6e-4; MX_PREC_MIXED reaches 1.1e-3 on two of twelve: profiles/r6_precision_modes_over_seeds.txt)
+    // the bar on every draw of such weights tried (<= 6e-4; MX_PREC_MIXED reaches 1.1e-3 on two of eleven: profiles/r6_precision_modes_over_seeds.txt)
     if (precision < 0) c.precision = (c.pooling == MX_POOL_CLS && c.hidden == 768) ? MX_PREC_BF16X3 : MX_PREC_BF16;
     pm.max_seq_length = (size_t)std::min(512, c.max_pos - c.pos_offset);
     if (file_exists(dir + "/sentence_bert_config.json")) {

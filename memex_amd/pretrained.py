@@ -81,7 +81,7 @@ def default_precision(hidden: int, pooling: str) -> str:
     models (bge-base-en), whose scores BETWEEN embeddings move by 1e-2 ... 4e-2 on bf16 operands under checkpoint-like weights
     (one token, twelve layers; tests/test_encoder_gpu.py) against north_star's 1e-3 on scores: those get "bf16x3"
     (MX_PREC_BF16X3), the one mode that held the bar on every draw of such weights that was tried (<= 6e-4; the cheaper
-    "mixed" reaches 1.1e-3 on two of twelve, profiles/r6_precision_modes_over_seeds.txt).  Mean pooling averages the rounding
+    "mixed" reaches 1.1e-3 on two of eleven, profiles/r6_precision_modes_over_seeds.txt).  Mean pooling averages the rounding
     noise of hundreds of tokens (1.3e-3 at worst on the MiniLM shapes) and keeps bf16."""
     return "bf16x3" if pooling == "cls" and hidden == 768 else "bf16"
 
