@@ -64,7 +64,8 @@ def test_centred_copy_certificate_and_parity(n, d, B, seed, oracle, lib_built):
         assert idx.stats().filter_centred == 0
 
 
-@pytest.mark.parametrize("n,d,B,seed", [(50000, 384, 64, 21), (40000, 768, 256, 22), (20000, 100, 33, 23), (40000, 512, 300, 24)])   # (768: > 2 x 256 scan tiles, so that the sample pass runs)
+@pytest.mark.parametrize("n,d,B,seed", [(50000, 384, 64, 21), (40000, 768, 256, 22), (20000, 100, 33, 23), (40000, 512, 300, 24),
+                                        (40000, 256, 50, 25), (40000, 640, 128, 26)])   # (768: > 2 x 256 scan tiles, so that the sample pass runs; 256 / 640 dims: the two-slot and five-slot centred kernels)
 def test_centred_int8_copy_certificate_and_parity(n, d, B, seed, oracle, lib_built):
     """Round 6: the same split for the int8 copy.  shadow8_kernel quantises r_c = c/|c| - a_c m (its step and its
     residual bound shrink with the vector), a_c rides in scan8_kernel's DMA stream (256 bytes per 64-row tile), the tile epilogue
