@@ -271,3 +271,40 @@ def test_a_pinned_bf16_copy_that_started_small_is_centred_once_the_collection_ha
         idx.add(G[300:])                               # doubled: looked at again, still plain
         assert idx.stats().filter_centred == 0 and idx.stats().filter_kind == 3
         _equal(idx, G, rng.standard_normal((9, d), dtype=np.float32), 10, oracle)
+
+
+@pytest.mark.parametrize("seed", list(range(40, 52)))
+def test_centred_int8_copy_random_cones(seed, oracle, lib_built):
+    """Random cone geometry against the oracle, bit for bit: row width (every centred kernel, 1 .. 6 slots of 128 dims), cone tightness
+    from 0.02 (residual steps near the floor kMinStep8) to 1.0 (hardly a cone), batch size, queries inside the cone, off it, and on
+    its FAR side (a_q < 0: the accumulators' initial values are negative and truncate toward zero), rows that are exactly the axis
+    (zero residual), duplicates, a zero row, k = 10 and k = 64.  Whatever the certificate does with such a corpus -- first pass, retry,
+    demotion -- the answers are the oracle's."""
+    from memex_amd.index import FlatIndex
+    rng = np.random.default_rng(seed)
+    d = int(rng.choice([64, 128, 200, 256, 384, 448, 512, 600, 640, 768]))
+    n = int(rng.integers(12000, 30000))
+    B = int(rng.integers(1, 200))
+    spread = float(np.exp(rng.uniform(np.log(0.02), np.log(1.0))))
+    X = cone_rows(rng, n, d, spread=spread, axis_seed=seed)
+    axis = np.random.default_rng(seed).standard_normal(d).astype(np.float32)
+    axis /= np.linalg.norm(axis)
+    X[5] = 0.0
+    X[6:12] = axis * 3.0                                   # rows ON the axis: zero residual
+    X[200:230] = X[199]
+    Q = cone_rows(rng, B, d, spread=spread, axis_seed=seed)
+    if B > 1:
+        Q[1] = -Q[1]                                       # the far side of the cone: a_q ~ -1
+    if B > 2:
+        Q[2] = rng.standard_normal(d).astype(np.float32)   # off the cone
+    if B > 3:
+        Q[3] = axis                                        # the axis itself
+    with FlatIndex(d) as idx:
+        idx.add(X)
+        idx.set_filter_copy("bf16")
+        idx.set_filter_copy("i8")                          # rebuilt from the resident rows: centred when they sit in a cone
+        _equal(idx, X, Q, 10, oracle)
+        _equal(idx, X, Q[: min(B, 8)], 64, oracle)
+        more = cone_rows(rng, 3000, d, spread=spread, axis_seed=seed)
+        idx.add(more)
+        _equal(idx, np.concatenate([X, more]), Q[: min(B, 32)], 10, oracle)
