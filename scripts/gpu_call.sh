@@ -1,7 +1,4 @@
 #!/bin/bash
-# round 6: full GPU suite + smoke at HEAD (the last one of the round)
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r6f_tests.txt 2>&1; echo "tests rc=$?" | tee -a gpurun_out/r6f_tests.txt
-grep -E "passed|failed" gpurun_out/r6f_tests.txt | tail -2
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r6f_smoke.txt 2>&1; tail -2 gpurun_out/r6f_smoke.txt
+bash scripts/r6_centred_traffic.sh 2>&1 | tee gpurun_out/r6_scan8_centred_traffic.json
